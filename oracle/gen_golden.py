@@ -1,0 +1,249 @@
+"""Generate the golden fixtures under ``tests/golden/`` from the REAL reference.
+
+Run in the build container only (needs ``/root/reference``)::
+
+    python -m oracle.gen_golden            # writes tests/golden/*.npz
+
+Every fixture holds plain arrays: the outputs of the unmodified reference on
+inputs that both sides regenerate from seeds (``inputs`` below), never the
+reference's objects, source or bytecode.  The reference's own 18 known-answer
+scalars (test/test_convenience_wrappers.py:10-12,37-39) are re-derived by
+``tests/test_oracle_golden.py`` from the ``toy`` fixture and compared with the
+literal numbers quoted in BASELINE.md.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import refshim  # noqa: E402
+from oracle.inputs import (  # noqa: E402
+    toy_system, lap2d_system, minres_jacobi_system, dense_spd_system, lap3d_system,
+    kernel_panel,
+)
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def meta():
+    return dict(numpy_version=np.__version__, scipy_version=scipy.__version__)
+
+
+def save(name, **arrays):
+    arrays.update(meta())
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-40s %8.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def col_checks(V, stride=997):
+    """Per-column checksums used instead of a full basis: sum, sum|.|, strided sample."""
+    return (V.sum(axis=0), np.abs(V).sum(axis=0), np.ascontiguousarray(V[::stride, :]))
+
+
+def gen_toy(krypy):
+    A, b = toy_system()
+    out = {}
+    for name, fn in (("cg", krypy.cg), ("minres", krypy.minres), ("gmres", krypy.gmres)):
+        x, sol = fn(A, b)
+        out[name + "_x"] = x
+        out[name + "_resnorms"] = np.array(sol.resnorms)
+        out[name + "_iter"] = sol.iter
+        U = np.zeros(100)
+        U[0] = 1.0
+        x, sol = fn(A, b, U=U)
+        out[name + "_defl_x"] = x
+        out[name + "_defl_resnorms"] = np.array(sol.resnorms)
+        out[name + "_defl_E"] = sol.E
+    x, sol = krypy.gmres(A, b, store_arnoldi=True)
+    out["gmres_H"] = sol.H
+    out["gmres_R"] = sol.R
+    out["gmres_V"] = sol.V
+    # ConvergenceError semantics
+    try:
+        krypy.gmres(A, b, maxiter=10)
+    except krypy.utils.ConvergenceError as e:
+        out["gmres_m10_resnorms"] = np.array(e.solver.resnorms)
+        out["gmres_m10_iter"] = e.solver.iter
+        out["gmres_m10_xk"] = e.solver.xk
+        out["gmres_m10_msg"] = np.array(str(e))
+    save("toy", **out)
+
+
+def gen_lap2d_restart(krypy, nx, rhs):
+    A, b = lap2d_system(nx, rhs=rhs)
+    ls = krypy.linsys.LinearSystem(A, b)
+    tol, m, R = 1e-8, 100, 50
+    # reference driver
+    sol = krypy.linsys.RestartedGmres(ls, maxiter=m, max_restarts=R, tol=tol)
+    # same loop, cycle by cycle, to capture closed-loop data
+    xk = None
+    cyc = {}
+    c = 0
+    resn = [np.inf]
+    while c == 0 or resn[-1] > tol:
+        try:
+            s = krypy.linsys.Gmres(ls, x0=xk, maxiter=m, tol=tol, store_arnoldi=True)
+        except krypy.utils.ConvergenceError as e:
+            s = e.solver
+        cyc["c%d_x0" % c] = np.zeros(A.shape[0]) if xk is None else xk[:, 0]
+        cyc["c%d_xk" % c] = s.xk[:, 0]
+        cyc["c%d_H" % c] = s.H
+        cyc["c%d_resnorms" % c] = np.array(s.resnorms)
+        xk = s.xk
+        del resn[-1]
+        resn += s.resnorms
+        c += 1
+    assert np.array_equal(np.array(resn), np.array(sol.resnorms))
+    save("lap2d_restart_nx%d_%s" % (nx, rhs), ncycles=c, total_iters=len(sol.resnorms) - 1,
+         resnorms=np.array(sol.resnorms), xk=sol.xk[:, 0], nx=nx, tol=tol, maxiter=m, **cyc)
+
+
+def gen_lap2d_cycle(krypy, nx=200):
+    A, b = lap2d_system(nx, rhs="rng1")
+    ls = krypy.linsys.LinearSystem(A, b)
+    out = {}
+    for ortho in ("mgs", "dmgs"):
+        try:
+            s = krypy.linsys.Gmres(ls, maxiter=100, tol=1e-8, ortho=ortho, store_arnoldi=True)
+        except krypy.utils.ConvergenceError as e:
+            s = e.solver
+        sums, asums, samp = col_checks(s.V)
+        out.update({ortho + "_resnorms": np.array(s.resnorms), ortho + "_H": s.H,
+                    ortho + "_xk": s.xk[:, 0], ortho + "_Vsum": sums, ortho + "_Vabssum": asums,
+                    ortho + "_Vsample": samp, ortho + "_iter": s.iter})
+    save("lap2d_cycle_nx%d" % nx, nx=nx, **out)
+
+
+def gen_minres(krypy, nx=100):
+    A, b, Mj, Minv = minres_jacobi_system(nx)
+    ls = krypy.linsys.LinearSystem(A, b, M=Mj, Minv=Minv, self_adjoint=True)
+    s = krypy.linsys.Minres(ls, ortho="lanczos", tol=1e-8, maxiter=2000, store_arnoldi=True)
+    sums, asums, samp = col_checks(s.V, stride=499)
+    psums, pasums, psamp = col_checks(s.P, stride=499)
+    save("minres_jacobi_nx%d" % nx, nx=nx, resnorms=np.array(s.resnorms), H=s.H, xk=s.xk[:, 0],
+         iter=s.iter, Vshape=np.array(s.V.shape), Vsum=sums, Vabssum=asums, Vsample=samp,
+         Psum=psums, Pabssum=pasums, Psample=psamp)
+    # unpreconditioned MINRES and CG on the same Laplacian (sparse CG path)
+    ls = krypy.linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
+    s = krypy.linsys.Minres(ls, tol=1e-8, maxiter=2000)
+    s2 = krypy.linsys.Cg(ls, tol=1e-8, maxiter=2000)
+    save("lap2d_minres_cg_nx%d" % nx, nx=nx, minres_resnorms=np.array(s.resnorms),
+         minres_xk=s.xk[:, 0], minres_iter=s.iter, cg_resnorms=np.array(s2.resnorms),
+         cg_xk=s2.xk[:, 0], cg_iter=s2.iter)
+
+
+def gen_cg_dense(krypy, n=512):
+    A, b = dense_spd_system(n)
+    x, s = krypy.cg(A, b, tol=1e-8, store_arnoldi=True)
+    save("cg_dense_n%d" % n, n=n, resnorms=np.array(s.resnorms), xk=s.xk[:, 0], iter=s.iter,
+         H=s.H)
+    # Jacobi-preconditioned CG on the same matrix
+    d = 1.0 / np.diag(A)
+    M = sp.diags(d).tocsr()
+    x, s = krypy.cg(A, b, M=M, tol=1e-8)
+    save("cg_dense_jacobi_n%d" % n, n=n, resnorms=np.array(s.resnorms), xk=s.xk[:, 0],
+         iter=s.iter)
+
+
+def gen_deflation(krypy, nx=24):
+    A, b = lap3d_system(nx, rhs="ones")
+    ls = krypy.linsys.LinearSystem(A, b, self_adjoint=True)
+    fac = krypy.recycling.factories.RitzFactorySimple(n_vectors=16, which="sm")
+    rec = krypy.recycling.RecyclingGmres()
+    out = {}
+    sols = []
+    for i in range(3):
+        s = rec.solve(ls, vector_factory=fac, tol=1e-8, maxiter=300)
+        sols.append(s)
+        out["s%d_iters" % i] = len(s.resnorms) - 1
+        out["s%d_resnorms" % i] = np.array(s.resnorms)
+        out["s%d_xk" % i] = s.xk[:, 0]
+        out["s%d_E" % i] = s.E
+        out["s%d_C" % i] = s.C
+        out["s%d_B_" % i] = s.B_
+        out["s%d_H" % i] = s.H
+        out["s%d_UMlr" % i] = s.UMlr
+        # the vectors the factory hands to the next solve
+        if i < 2:
+            out["s%d_U_next" % i] = fac.get(s)
+        r = krypy.deflation.Ritz(s)
+        out["s%d_ritz_values" % i] = r.values
+    save("deflation_lap3d_nx%d" % nx, nx=nx, **out)
+
+
+def gen_kernels(krypy):
+    """Kernel-level vectors (fixture F7): inner, norm, one Arnoldi step, projection, qr."""
+    ku = krypy.utils
+    out = {}
+    for N in (1, 63, 64, 65, 4097, 100000):
+        for k in (1, 2, 16, 101):
+            if N * k > 2_000_000 and k == 101:
+                continue
+            X, w = kernel_panel(N, k, seed=N + k)
+            key = "N%d_k%d_" % (N, k)
+            out[key + "inner"] = ku.inner(X, w)
+            out[key + "norm"] = ku.norm(w)
+    # one Arnoldi advance on a Laplacian with a random start, mgs / dmgs / lanczos (+ Jacobi M)
+    A, b = lap2d_system(40, rhs="rng1")
+    v = b.reshape(-1, 1)
+    for ortho in ("mgs", "dmgs", "lanczos"):
+        ar = ku.Arnoldi(A, v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        out["arn_%s_H" % ortho] = ar.H
+        out["arn_%s_V" % ortho] = ar.V
+    d = np.linspace(0.5, 1.5, A.shape[0])
+    M = sp.diags(d).tocsr()
+    ar = ku.Arnoldi(A, v, maxiter=12, ortho="lanczos", M=M)
+    for _ in range(12):
+        ar.advance()
+    out["arn_lanczosM_H"], out["arn_lanczosM_V"], out["arn_lanczosM_P"] = ar.H, ar.V, ar.P
+    ar = ku.Arnoldi(A, v, maxiter=12, ortho="mgs", M=M)
+    for _ in range(12):
+        ar.advance()
+    out["arn_mgsM_H"], out["arn_mgsM_V"], out["arn_mgsM_P"] = ar.H, ar.V, ar.P
+    # projection + MGS-qr (Identity *instance* as ip_B, as the deflated solvers pass it)
+    X, a = kernel_panel(2000, 16, seed=7)
+    Y, _ = kernel_panel(2000, 16, seed=8)
+    ipI = ku.IdentityLinearOperator((2000, 2000))
+    Q, R = ku.qr(X, ip_B=ipI, reorthos=1)
+    out["qr_Q"], out["qr_R"] = Q, R
+    Q0, R0 = ku.qr(X, ip_B=ipI, reorthos=0)
+    out["qr0_Q"], out["qr0_R"] = Q0, R0
+    P = ku.Projection(X, Y, ip_B=ipI)
+    z, Ya = P.apply_complement(a, return_Ya=True)
+    out["proj_z"], out["proj_Ya"] = z, Ya
+    out["proj_apply"] = P.apply(a)
+    # Givens on the real part of the reference's factor grid (test/test_utils.py:102)
+    fac = [0.0, 1.0, 1e8, 1e-8, -3.0, 4.0]
+    g = []
+    for a_ in fac:
+        for b_ in fac:
+            G = ku.Givens(np.array([[a_], [b_]]))
+            g.append([a_, b_, G.c, G.s, G.r])
+    out["givens"] = np.array(g)
+    save("kernels", **out)
+
+
+def main():
+    warnings.simplefilter("ignore")
+    os.makedirs(OUT, exist_ok=True)
+    krypy = refshim.load()
+    gen_toy(krypy)
+    gen_kernels(krypy)
+    for nx in (64, 128):
+        for rhs in ("ones", "rng1"):
+            gen_lap2d_restart(krypy, nx, rhs)
+    gen_lap2d_cycle(krypy)
+    gen_minres(krypy)
+    gen_cg_dense(krypy)
+    gen_deflation(krypy)
+
+
+if __name__ == "__main__":
+    main()
