@@ -1,0 +1,170 @@
+/*
+ * krylov_hip.h - C ABI of libkrylov_hip.so, the MI355X (gfx950) Krylov solver core.
+ *
+ * The reference (andrenarchy/krypy, pure Python) has no FFI: every flop of its
+ * Arnoldi/Lanczos hot path is a NumPy/SciPy/OpenBLAS call.  This header is the
+ * boundary the device core exposes in place of those calls; each entry point
+ * names the reference call site it replaces (file:line under /root/reference).
+ * The only caller is krypy_amd/_hip.py (ctypes); see INTEGRATION.md for the
+ * binding a KryPy maintainer would add.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *  - every function returns 0 on success, a negative kh_status on failure and
+ *    stores a message retrievable with kh_last_error() (thread-local).
+ *  - handles are opaque; host pointers are caller-owned; device buffers are
+ *    library-owned and released by kh_*_free / kh_ctx_destroy.
+ *  - one HIP stream per context; a context is single-threaded by contract (like
+ *    the reference).  Calls that return host scalars synchronise the stream
+ *    before returning; all others are asynchronous on the context's stream.
+ *  - all vectors are real fp64.  A kh_vec is a block of `ncols` column vectors of
+ *    length n, each column contiguous and 256-byte aligned (leading dimension
+ *    rounded up to 32 doubles): the reference's (N, k) ndarrays, stored
+ *    column-major so that basis vectors stream at full HBM width.
+ *  - reductions are deterministic: fixed grid, fixed-order tree, no float atomics.
+ */
+#ifndef KRYLOV_HIP_H
+#define KRYLOV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kh_ctx_s* kh_ctx;
+typedef struct kh_mat_s* kh_mat;
+typedef struct kh_vec_s* kh_vec;
+
+typedef enum {
+    KH_OK = 0,
+    KH_ERR_HIP = -1,      /* a HIP runtime call failed (message has hipGetErrorString) */
+    KH_ERR_ARG = -2,      /* invalid argument (shape mismatch, bad index, NULL handle) */
+    KH_ERR_NOMEM = -3,    /* device or pinned-host allocation failed */
+    KH_ERR_COMM = -4,     /* RCCL call failed */
+    KH_ERR_UNSUPPORTED = -5
+} kh_status;
+
+/* Gram-Schmidt variants of kh_arnoldi_step */
+typedef enum {
+    KH_GS_MGS = 0,   /* reference order: for j: alpha=<v_j,w>; w-=alpha*b_j  (utils.py:1012-1029) */
+    KH_GS_CGS = 1    /* panel form: h=V^T w; w-=B h  (one reduction per sweep)                     */
+} kh_gs_mode;
+
+/* ---- library / context ------------------------------------------------------------ */
+const char* kh_last_error(void);
+int kh_version(void);
+int kh_device_count(int* count);
+/* create a context on HIP device `device` (one stream, scratch for reductions) */
+int kh_ctx_create(int device, kh_ctx* out);
+int kh_ctx_destroy(kh_ctx ctx);
+int kh_ctx_sync(kh_ctx ctx);
+/* info[0]=compute units, info[1]=total device memory (bytes), info[2]=free bytes, info[3]=reduction grid */
+int kh_ctx_info(kh_ctx ctx, int64_t info[4]);
+/* tuning knobs (0 keeps the default): reduction grid size, SpMV LDS tile (nnz) */
+int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
+/* event timing on the context's stream (for bench.py's per-kernel roofline numbers) */
+int kh_timer_start(kh_ctx ctx);
+int kh_timer_stop(kh_ctx ctx, double* elapsed_ms);
+
+/* ---- multi-GPU (one process per GPU; RCCL over xGMI) ------------------------------- */
+/* 128-byte ncclUniqueId; rank 0 creates it, the launcher broadcasts it to all ranks */
+int kh_comm_unique_id(unsigned char id[128]);
+int kh_comm_init(kh_ctx ctx, int rank, int nranks, const unsigned char id[128]);
+int kh_comm_destroy(kh_ctx ctx);
+/* in-place sum all-reduce of `count` host doubles through a device staging buffer (setup paths) */
+int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count);
+/* describe the halo of a block-row-sharded matrix: this rank sends `nsend_*` of its first/last
+ * local rows to the previous/next rank and receives as many ghost entries from them.  After
+ * this call kh_apply() on `A` exchanges halos (ncclSend/ncclRecv) before the local SpMV; the
+ * matrix' column indices must address [local rows | ghosts from prev | ghosts from next]. */
+int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next,
+                    int64_t nrecv_prev, int64_t nrecv_next);
+
+/* ---- vectors ---------------------------------------------------------------------- */
+int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out);   /* zero-filled */
+int kh_vec_free(kh_vec v);
+int kh_vec_shape(kh_vec v, int64_t* n, int64_t* ncols, int64_t* ld);
+/* host <-> device; `host` is column-major with leading dimension host_ld (>= n) */
+int kh_vec_upload(kh_vec v, int64_t col0, int64_t ncols, const double* host, int64_t host_ld);
+int kh_vec_download(kh_vec v, int64_t col0, int64_t ncols, double* host, int64_t host_ld);
+int kh_vec_zero(kh_vec v, int64_t col0, int64_t ncols);
+int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncols);
+
+/* ---- operators (replace MatrixLinearOperator._dot -> A.dot(X), utils.py:1593-1594) --- */
+/* CSR as SciPy holds it: int32 indptr[n_rows+1], int32 indices[nnz] (sorted or not), fp64 data.
+ * n_cols may exceed n_rows for a sharded matrix with ghost columns. */
+int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
+                  const int32_t* indices, const double* data, kh_mat* out);
+/* dense row-major (C-ordered ndarray), leading dimension lda */
+int kh_dense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a, int64_t lda,
+                    kh_mat* out);
+/* diagonal operator (Jacobi M / Minv given as scipy.sparse.diags) */
+int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out);
+int kh_mat_free(kh_mat A);
+/* Y[:, ycol:ycol+nc] = A * X[:, xcol:xcol+nc].  CSR rows are summed left to right in storage
+ * order with separate multiply and add, i.e. bit-identical to scipy's csr_matvec(s). */
+int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols);
+
+/* ---- inner products, norms, updates (utils.inner/norm utils.py:160-238) ------------- */
+/* out[j] = <V[:, j0+j], W[:, wcol]>, j < ncols   (numpy.dot(X.T.conj(), Y), utils.py:183) */
+int kh_dot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol,
+                 double* out);
+/* out (row-major nx*ny) = X[:, x0:x0+nx]^T Y[:, y0:y0+ny] */
+int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y0, int64_t ny,
+               double* out);
+/* W[:, wcol] -= sum_j h[j] * V[:, j0+j], applied left to right, multiply then subtract
+ * (the `Av -= alpha * V[:, [j]]` of utils.py:1027-1029) */
+int kh_axpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W,
+                  int64_t wcol);
+/* Y[:, y0:y0+nc] = beta*Y[:, ...] + alpha * X[:, x0:x0+k] @ C  with C (k x nc) row-major.
+ * (V[:, :k].dot(yy) linsys.py:947;  V.dot(c) utils.py:549;  Ritz.get_vectors deflation.py:845) */
+int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc,
+               double alpha, double beta, kh_vec Y, int64_t y0);
+/* out = ||W[:, wcol]||_2   (numpy.linalg.norm(x, 2), utils.py:226) */
+int kh_nrm2(kh_ctx ctx, kh_vec W, int64_t wcol, double* out);
+/* Z[:, zcol] = alpha*X[:, xcol] + beta*Y[:, ycol]   (Z may alias X or Y) */
+int kh_waxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, double alpha, kh_vec X, int64_t xcol,
+              double beta, kh_vec Y, int64_t ycol);
+/* Z[:, zcol] = X[:, xcol] / s   (true division, as `V[:, [k+1]] = Av / H[k+1, k]` utils.py:1045) */
+int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s);
+
+/* ---- fused hot path ------------------------------------------------------------------ */
+/* One Arnoldi.advance() (utils.py:954-1048, mgs/dmgs/lanczos branches) entirely on the device:
+ *   w = A V[:,k]           (skipped when A == NULL: W[:, wcol] already holds the operator result)
+ *   lanczos (start==k>0):  w -= h_km1 * B[:,k-1]                      (utils.py:1000-1009)
+ *   `sweeps` times, j=start..k:  alpha=<V_j,w>; hcol[j]+=alpha; w -= alpha*B_j   (1012-1029)
+ *   hcol[k+1] = ||w||  or sqrt(<w, Md w>) when Md != NULL             (1030-1034)
+ *   V[:,k+1] = (Md w | w)/hcol[k+1],  P[:,k+1] = w/hcol[k+1]          (1041-1045)
+ * with B = P when P != NULL (preconditioned: V = M P) else V.  Md is a diagonal kh_mat or NULL.
+ * hcol_out receives k+2 doubles (entries below `start` are zero).  The invariance test and the
+ * Hessenberg/Givens algebra stay on the host (O(k)).  MW is an optional work column for Md*w.
+ */
+int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                    int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
+                    double* hcol_out);
+
+/* r = b - A x fused with its squared norm: R[:, rcol] = B[:, bcol] - A X[:, xcol]; *nrm = ||r||_2
+ * (LinearSystem.get_residual linsys.py:156-160 for M = Ml = identity) */
+int kh_residual(kh_ctx ctx, kh_mat A, kh_vec B, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,
+                int64_t rcol, double* nrm);
+
+/* One MINRES vector update (linsys.py:844-846):
+ *   z = (V[:,k] - r0*W0 - r1*W1)/r2;   W0 <- W1;  W1 <- z;   yk += y0*z
+ * Wk holds the two columns W0|W1 addressed through `slot` (the column that is W0 now and
+ * receives z): no copies. */
+int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
+                     double r2, double y0, kh_vec YK, int64_t ycol);
+
+/* One CG step after Ap is known (linsys.py:655-665), fused:
+ *   yk += alpha*p;  r -= alpha*Ap;  z = Md r (or r);  *rho_new = <r, z>
+ *   and, when beta_valid, nothing else; the direction update p = z + (rho_new/rho_old) p is
+ *   kh_waxpby. */
+int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol,
+                 kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
+                 double* rho_new);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRYLOV_HIP_H */

@@ -1,0 +1,402 @@
+"""ctypes binding of ``libkrylov_hip.so`` (C ABI: ``include/krylov_hip.h``).
+
+This is the only place that talks to the device library.  There is no CPU
+fallback: if the library is missing, cannot be loaded, or no MI355X is
+visible, :class:`BackendError` is raised as soon as a context is needed.
+
+The Python classes here are thin: :class:`Context` owns a ``kh_ctx`` (one HIP
+stream, reduction scratch), :class:`DeviceVectors` a column-major block of
+fp64 column vectors resident in HBM, :class:`DeviceMatrix` an operator (CSR /
+dense / diagonal).  Every numeric method maps 1:1 onto a C entry point.
+"""
+import ctypes
+import os
+
+import numpy
+
+__all__ = ["BackendError", "Context", "DeviceVectors", "DeviceMatrix", "get_context",
+           "library_path", "load_library", "GS_MGS", "GS_CGS"]
+
+GS_MGS = 0
+GS_CGS = 1
+
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+_c_int32_p = ctypes.POINTER(ctypes.c_int32)
+_c_int64_p = ctypes.POINTER(ctypes.c_int64)
+_H = ctypes.c_void_p   # opaque handles
+_I64 = ctypes.c_int64
+_D = ctypes.c_double
+_INT = ctypes.c_int
+
+
+class BackendError(RuntimeError):
+    """HIP / RCCL failure, or the device library is unavailable.
+
+    The reference has no counterpart (it never leaves NumPy); error codes of the
+    C ABI are mapped onto this exception, carrying ``kh_last_error()``.
+    """
+
+
+# name -> (argtypes); every function returns int status except kh_last_error/kh_version
+_SIGNATURES = {
+    "kh_device_count": [ctypes.POINTER(_INT)],
+    "kh_ctx_create": [_INT, ctypes.POINTER(_H)],
+    "kh_ctx_destroy": [_H],
+    "kh_ctx_sync": [_H],
+    "kh_ctx_info": [_H, _c_int64_p],
+    "kh_ctx_tune": [_H, _INT, _INT],
+    "kh_timer_start": [_H],
+    "kh_timer_stop": [_H, _c_double_p],
+    "kh_comm_unique_id": [ctypes.c_char_p],
+    "kh_comm_init": [_H, _INT, _INT, ctypes.c_char_p],
+    "kh_comm_destroy": [_H],
+    "kh_comm_allreduce_host": [_H, _c_double_p, _I64],
+    "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
+    "kh_vec_alloc": [_H, _I64, _I64, ctypes.POINTER(_H)],
+    "kh_vec_free": [_H],
+    "kh_vec_shape": [_H, _c_int64_p, _c_int64_p, _c_int64_p],
+    "kh_vec_upload": [_H, _I64, _I64, _c_double_p, _I64],
+    "kh_vec_download": [_H, _I64, _I64, _c_double_p, _I64],
+    "kh_vec_zero": [_H, _I64, _I64],
+    "kh_vec_copy": [_H, _I64, _H, _I64, _I64],
+    "kh_csr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
+                      ctypes.POINTER(_H)],
+    "kh_dense_upload": [_H, _I64, _I64, _c_double_p, _I64, ctypes.POINTER(_H)],
+    "kh_diag_upload": [_H, _I64, _c_double_p, ctypes.POINTER(_H)],
+    "kh_mat_free": [_H],
+    "kh_apply": [_H, _H, _H, _I64, _H, _I64, _I64],
+    "kh_dot_panel": [_H, _H, _I64, _I64, _H, _I64, _c_double_p],
+    "kh_gemm_tn": [_H, _H, _I64, _I64, _H, _I64, _I64, _c_double_p],
+    "kh_axpy_panel": [_H, _H, _I64, _I64, _c_double_p, _H, _I64],
+    "kh_gemm_nn": [_H, _H, _I64, _I64, _c_double_p, _I64, _D, _D, _H, _I64],
+    "kh_nrm2": [_H, _H, _I64, _c_double_p],
+    "kh_waxpby": [_H, _H, _I64, _D, _H, _I64, _D, _H, _I64],
+    "kh_vdiv": [_H, _H, _I64, _H, _I64, _D],
+    "kh_arnoldi_step": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _c_double_p],
+    "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
+    "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
+    "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
+}
+
+_lib = None
+
+
+def library_path():
+    """Location of the in-tree shared library (``KRYPY_AMD_LIB`` overrides the path of the
+    *same* HIP library, e.g. an experimental build; there is no alternative backend)."""
+    env = os.environ.get("KRYPY_AMD_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libkrylov_hip.so")
+
+
+def load_library():
+    """dlopen ``libkrylov_hip.so`` and declare the C ABI; raises BackendError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise BackendError(
+            "libkrylov_hip.so not found at %s - build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C krypy_amd/csrc`. "
+            "krypy_amd has no CPU fallback." % path)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:
+        raise BackendError("cannot load %s: %s" % (path, exc))
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here == ABI/header mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.kh_last_error.restype = ctypes.c_char_p
+    lib.kh_last_error.argtypes = []
+    lib.kh_version.restype = ctypes.c_int
+    lib.kh_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names the header declares (used by the CPU-side ABI test)."""
+    return sorted(list(_SIGNATURES) + ["kh_last_error", "kh_version"])
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        msg = lib.kh_last_error()
+        raise BackendError("%s failed (status %d): %s" % (
+            what, rc, msg.decode("utf-8", "replace") if msg else "?"))
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_c_double_p)
+
+
+class DeviceMatrix(object):
+    """An operator resident on the device (``kh_mat``)."""
+
+    def __init__(self, ctx, handle, kind, shape, nnz=0):
+        self.ctx, self.handle, self.kind, self.shape, self.nnz = ctx, handle, kind, shape, nnz
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx._alive:
+                self.ctx._lib.kh_mat_free(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class DeviceVectors(object):
+    """A block of ``ncols`` fp64 column vectors of length ``n`` in HBM (``kh_vec``).
+
+    Column-contiguous, 256-byte aligned columns: the device image of the
+    reference's ``(N, k)`` ndarrays.
+    """
+
+    def __init__(self, ctx, n, ncols):
+        self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
+        h = _H()
+        _check(ctx._lib, ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h)),
+               "kh_vec_alloc(%d x %d)" % (self.n, self.ncols))
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx._alive:
+                self.ctx._lib.kh_vec_free(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+    def upload(self, col0, arr):
+        """Copy a host ``(n, k)`` (or ``(n,)``) array into columns ``col0 ..``."""
+        a = numpy.asarray(arr, dtype=numpy.float64)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        if a.shape[0] != self.n:
+            raise BackendError("upload: %d rows into a block of length %d" % (a.shape[0], self.n))
+        a = numpy.asfortranarray(a)
+        k = a.shape[1]
+        ld = max(a.strides[1] // 8, self.n) if k > 1 else max(self.n, 1)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_upload(self.handle, col0, k, _dptr(a), ld),
+               "kh_vec_upload")
+        return self
+
+    def download(self, col0=0, ncols=None):
+        """Return columns ``[col0, col0+ncols)`` as a fresh Fortran-ordered ``(n, ncols)`` array."""
+        ncols = self.ncols - col0 if ncols is None else ncols
+        out = numpy.empty((self.n, ncols), dtype=numpy.float64, order="F")
+        if self.n and ncols:
+            _check(self.ctx._lib, self.ctx._lib.kh_vec_download(self.handle, col0, ncols, _dptr(out),
+                                                                max(self.n, 1)), "kh_vec_download")
+        return out
+
+    def zero(self, col0=0, ncols=None):
+        ncols = self.ncols - col0 if ncols is None else ncols
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_zero(self.handle, col0, ncols), "kh_vec_zero")
+
+    def copy_from(self, dcol, src, scol, ncols=1):
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_copy(self.handle, dcol, src.handle, scol, ncols),
+               "kh_vec_copy")
+
+
+class Context(object):
+    """One GPU, one HIP stream (``kh_ctx``).  Not thread-safe, like the reference."""
+
+    def __init__(self, device=0, lib=None):
+        self._lib = load_library() if lib is None else lib
+        self._alive = False
+        n = _INT(0)
+        rc = self._lib.kh_device_count(ctypes.byref(n))
+        if rc != 0 or n.value == 0:
+            msg = self._lib.kh_last_error()
+            raise BackendError("no HIP device visible (%s); krypy_amd needs an MI355X and has no "
+                               "CPU fallback" % (msg.decode() if msg else "count=0"))
+        h = _H()
+        _check(self._lib, self._lib.kh_ctx_create(device, ctypes.byref(h)), "kh_ctx_create")
+        self._h = h
+        self._alive = True
+        self.device = device
+        self.rank, self.nranks = 0, 1
+
+    def close(self):
+        if self._alive:
+            self._alive = False
+            self._lib.kh_ctx_destroy(self._h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- bookkeeping ----
+    def sync(self):
+        _check(self._lib, self._lib.kh_ctx_sync(self._h), "kh_ctx_sync")
+
+    def info(self):
+        buf = (ctypes.c_int64 * 4)()
+        _check(self._lib, self._lib.kh_ctx_info(self._h, buf), "kh_ctx_info")
+        return dict(compute_units=buf[0], mem_total=buf[1], mem_free=buf[2], reduce_blocks=buf[3])
+
+    def tune(self, reduce_blocks=0, spmv_tile=0):
+        _check(self._lib, self._lib.kh_ctx_tune(self._h, reduce_blocks, spmv_tile), "kh_ctx_tune")
+
+    def timer_start(self):
+        _check(self._lib, self._lib.kh_timer_start(self._h), "kh_timer_start")
+
+    def timer_stop(self):
+        ms = _D(0.0)
+        _check(self._lib, self._lib.kh_timer_stop(self._h, ctypes.byref(ms)), "kh_timer_stop")
+        return ms.value
+
+    # ---- multi-GPU ----
+    def comm_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        _check(self._lib, self._lib.kh_comm_unique_id(buf), "kh_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, nranks, unique_id):
+        _check(self._lib, self._lib.kh_comm_init(self._h, rank, nranks, unique_id), "kh_comm_init")
+        self.rank, self.nranks = rank, nranks
+
+    def allreduce_host(self, vals):
+        a = numpy.ascontiguousarray(vals, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_comm_allreduce_host(self._h, _dptr(a), a.size),
+               "kh_comm_allreduce_host")
+        return a
+
+    def set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
+        _check(self._lib, self._lib.kh_mat_set_halo(self._h, A.handle, nsend_prev, nsend_next,
+                                                    nrecv_prev, nrecv_next), "kh_mat_set_halo")
+
+    # ---- allocation / transfer ----
+    def alloc(self, n, ncols=1):
+        return DeviceVectors(self, n, ncols)
+
+    def upload(self, arr):
+        a = numpy.asarray(arr, dtype=numpy.float64)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        return DeviceVectors(self, a.shape[0], a.shape[1]).upload(0, a)
+
+    def csr(self, A, n_cols=None):
+        """Upload a SciPy CSR matrix (int32 indices, fp64 data) without reordering its rows."""
+        indptr = numpy.ascontiguousarray(A.indptr, dtype=numpy.int32)
+        indices = numpy.ascontiguousarray(A.indices, dtype=numpy.int32)
+        data = numpy.ascontiguousarray(A.data, dtype=numpy.float64)
+        n_rows = A.shape[0]
+        n_cols = A.shape[1] if n_cols is None else n_cols
+        h = _H()
+        _check(self._lib, self._lib.kh_csr_upload(
+            self._h, n_rows, n_cols, data.size, indptr.ctypes.data_as(_c_int32_p),
+            indices.ctypes.data_as(_c_int32_p), _dptr(data), ctypes.byref(h)), "kh_csr_upload")
+        return DeviceMatrix(self, h, "csr", (n_rows, n_cols), data.size)
+
+    def dense(self, A):
+        a = numpy.ascontiguousarray(A, dtype=numpy.float64)
+        h = _H()
+        _check(self._lib, self._lib.kh_dense_upload(self._h, a.shape[0], a.shape[1], _dptr(a),
+                                                    a.shape[1], ctypes.byref(h)), "kh_dense_upload")
+        return DeviceMatrix(self, h, "dense", a.shape, a.size)
+
+    def diag(self, d):
+        d = numpy.ascontiguousarray(d, dtype=numpy.float64)
+        h = _H()
+        _check(self._lib, self._lib.kh_diag_upload(self._h, d.size, _dptr(d), ctypes.byref(h)),
+               "kh_diag_upload")
+        return DeviceMatrix(self, h, "diag", (d.size, d.size), d.size)
+
+    # ---- numerics (each is one C entry point) ----
+    def apply(self, A, X, xcol, Y, ycol, ncols=1):
+        _check(self._lib, self._lib.kh_apply(self._h, A.handle, X.handle, xcol, Y.handle, ycol,
+                                             ncols), "kh_apply")
+
+    def dot_panel(self, V, j0, ncols, W, wcol):
+        out = numpy.empty(max(ncols, 1), dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_dot_panel(self._h, V.handle, j0, ncols, W.handle, wcol,
+                                                 _dptr(out)), "kh_dot_panel")
+        return out[:ncols]
+
+    def gemm_tn(self, X, x0, nx, Y, y0, ny):
+        out = numpy.empty((nx, ny), dtype=numpy.float64)
+        if nx and ny:
+            _check(self._lib, self._lib.kh_gemm_tn(self._h, X.handle, x0, nx, Y.handle, y0, ny,
+                                                   _dptr(out)), "kh_gemm_tn")
+        return out
+
+    def axpy_panel(self, V, j0, ncols, h, W, wcol):
+        h = numpy.ascontiguousarray(h, dtype=numpy.float64).reshape(-1)
+        _check(self._lib, self._lib.kh_axpy_panel(self._h, V.handle, j0, ncols, _dptr(h), W.handle,
+                                                  wcol), "kh_axpy_panel")
+
+    def gemm_nn(self, X, x0, k, C, alpha, beta, Y, y0):
+        C = numpy.ascontiguousarray(C, dtype=numpy.float64)
+        if C.ndim == 1:
+            C = C.reshape(-1, 1)
+        _check(self._lib, self._lib.kh_gemm_nn(self._h, X.handle, x0, k, _dptr(C), C.shape[1],
+                                               alpha, beta, Y.handle, y0), "kh_gemm_nn")
+
+    def nrm2(self, W, wcol):
+        out = _D(0.0)
+        _check(self._lib, self._lib.kh_nrm2(self._h, W.handle, wcol, ctypes.byref(out)), "kh_nrm2")
+        return out.value
+
+    def waxpby(self, Z, zcol, alpha, X, xcol, beta, Y, ycol):
+        _check(self._lib, self._lib.kh_waxpby(self._h, Z.handle, zcol, alpha, X.handle, xcol, beta,
+                                              Y.handle, ycol), "kh_waxpby")
+
+    def vdiv(self, Z, zcol, X, xcol, s):
+        _check(self._lib, self._lib.kh_vdiv(self._h, Z.handle, zcol, X.handle, xcol, s), "kh_vdiv")
+
+    def arnoldi_step(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
+        out = numpy.empty(k + 2, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_arnoldi_step(
+            self._h, A.handle if A is not None else None, Md.handle if Md is not None else None,
+            V.handle, P.handle if P is not None else None, W.handle, wcol, k, start, sweeps,
+            gs_mode, h_km1, _dptr(out)), "kh_arnoldi_step")
+        return out
+
+    def residual(self, A, B, bcol, X, xcol, R, rcol):
+        out = _D(0.0)
+        _check(self._lib, self._lib.kh_residual(self._h, A.handle, B.handle, bcol, X.handle, xcol,
+                                                R.handle, rcol, ctypes.byref(out)), "kh_residual")
+        return out.value
+
+    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
+        _check(self._lib, self._lib.kh_minres_update(self._h, V.handle, k, Wk.handle, slot, r0, r1,
+                                                     r2, y0, YK.handle, ycol), "kh_minres_update")
+
+    def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
+        out = _D(0.0)
+        _check(self._lib, self._lib.kh_cg_update(
+            self._h, alpha, Pd.handle, pcol, AP.handle, apcol, YK.handle, ycol, R.handle, rcol,
+            Md.handle if Md is not None else None, Z.handle if Z is not None else None, zcol,
+            ctypes.byref(out)), "kh_cg_update")
+        return out.value
+
+
+_default_ctx = None
+
+
+def get_context():
+    """The process-wide device context (device = ``LOCAL_RANK`` or ``KRYPY_AMD_DEVICE`` or 0).
+
+    Raises :class:`BackendError` when the HIP library or the GPU is missing.
+    """
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("KRYPY_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+def _install_context_for_testing(ctx):
+    """Swap the process-wide context.  Used ONLY by the CPU test-suite to drive the host
+    layer with the NumPy test double in ``tests/support`` (there is no GPU in the build
+    container); the product never calls this and ships no alternative context."""
+    global _default_ctx
+    old, _default_ctx = _default_ctx, ctx
+    return old

@@ -1,0 +1,502 @@
+// Device kernels of libkrylov_hip: CDNA4 (gfx950, wave64) only.
+//
+// Every kernel on this path is HBM-bandwidth bound: the design rules are
+//  * 16-byte (double2) coalesced loads/stores of column-contiguous vectors,
+//  * a fixed streaming grid (ctx->nb workgroups of 256 threads = 4 wave64) with grid-stride
+//    loops, so every reduction has a fixed, timing-independent summation order,
+//  * reductions = per-thread serial sum -> wave64 shuffle tree -> 4 wave sums through LDS ->
+//    one partial per workgroup; the consumer kernel re-sums the partials in a fixed order in its
+//    prologue (no float atomics, no extra launch on the dependent MGS chain),
+//  * compiled with -ffp-contract=off: `w - alpha*p` rounds twice exactly like NumPy's
+//    `Av -= alpha * V[:, [j]]`; fused multiply-adds are used only where written as fma().
+#pragma once
+#include "kh_internal.h"
+
+namespace kh {
+
+// ------------------------------------------------------------------------------------------
+// deterministic workgroup reductions (256 threads = 4 wave64)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;  // valid in lane 0
+}
+
+// result valid in thread 0 only; sm must hold >= 4 doubles; ends with no barrier pending
+__device__ __forceinline__ double block_sum(double v, double* sm) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) sm[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+    return r;
+}
+
+// every thread of the workgroup gets the fixed-order sum of part[0..nb)
+__device__ __forceinline__ double bcast_sum_partials(const double* __restrict__ part, int nb,
+                                                     double* sm) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += BS) v += part[i];
+    double r = block_sum(v, sm);
+    if (threadIdx.x == 0) sm[4] = r;
+    __syncthreads();
+    r = sm[4];
+    __syncthreads();
+    return r;
+}
+
+// where a kernel takes the coefficient of its axpy from
+enum { A_NONE = 0, A_PART = 1, A_SCAL = 2, A_ARG = 3 };
+// what a kernel reduces after the axpy
+enum { T_NONE = 0, T_DOT = 1, T_NRM = 2, T_NRM_DIAG = 3 };
+
+// ------------------------------------------------------------------------------------------
+// The Gram-Schmidt link kernel.  One launch = `w -= alpha * p` fused with the NEXT reduction:
+//   T_DOT      partial <vnext, w>            (the next MGS coefficient)
+//   T_NRM      partial <w, w>                (H[k+1,k] after the last coefficient)
+//   T_NRM_DIAG mw = d.*w stored, partial <w, mw>   (Jacobi-preconditioned Arnoldi/Lanczos)
+// alpha is the fixed-order sum of the previous launch's partials (A_PART), a device scalar
+// (A_SCAL, multi-GPU after the all-reduce / after the SpMV-fused dot) or an argument (A_ARG,
+// the Lanczos `H[k,k-1]` term).  Workgroup 0 accumulates alpha into *hslot (H[j,k] += alpha).
+// Reference: utils.py:1012-1034.
+// ------------------------------------------------------------------------------------------
+template <int ASRC, int TAIL>
+__global__ __launch_bounds__(BS) void k_gs_link(int64_t n, const double* __restrict__ p,
+                                                const double* __restrict__ vnext,
+                                                double* __restrict__ w,
+                                                const double* __restrict__ dg,
+                                                double* __restrict__ mw,
+                                                const double* __restrict__ part_in, int nb_in,
+                                                const double* __restrict__ scal_in,
+                                                double alpha_arg, double* __restrict__ part_out,
+                                                double* __restrict__ hslot) {
+    __shared__ double sm[8];
+    double alpha = 0.0;
+    if (ASRC == A_PART) alpha = bcast_sum_partials(part_in, nb_in, sm);
+    if (ASRC == A_SCAL) alpha = scal_in[0];
+    if (ASRC == A_ARG) alpha = alpha_arg;
+    if (ASRC != A_NONE && hslot != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+        *hslot += alpha;
+
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2* __restrict__ p2 = reinterpret_cast<const double2*>(p);
+    const double2* __restrict__ v2 = reinterpret_cast<const double2*>(vnext);
+    const double2* __restrict__ d2 = reinterpret_cast<const double2*>(dg);
+    double2* __restrict__ w2 = reinterpret_cast<double2*>(w);
+    double2* __restrict__ mw2 = reinterpret_cast<double2*>(mw);
+    double acc = 0.0;
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += stride) {
+        double2 wv = w2[i];
+        if (ASRC != A_NONE) {
+            const double2 pv = p2[i];
+            wv.x = wv.x - alpha * pv.x;
+            wv.y = wv.y - alpha * pv.y;
+            w2[i] = wv;
+        }
+        if (TAIL == T_DOT) {
+            const double2 vv = v2[i];
+            acc = fma(vv.x, wv.x, acc);
+            acc = fma(vv.y, wv.y, acc);
+        } else if (TAIL == T_NRM) {
+            acc = fma(wv.x, wv.x, acc);
+            acc = fma(wv.y, wv.y, acc);
+        } else if (TAIL == T_NRM_DIAG) {
+            const double2 dv = d2[i];
+            double2 m;
+            m.x = dv.x * wv.x;
+            m.y = dv.y * wv.y;
+            mw2[i] = m;
+            acc = fma(wv.x, m.x, acc);
+            acc = fma(wv.y, m.y, acc);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {  // odd tail element
+        const int64_t i = n - 1;
+        double wv = w[i];
+        if (ASRC != A_NONE) {
+            wv = wv - alpha * p[i];
+            w[i] = wv;
+        }
+        if (TAIL == T_DOT) acc = fma(vnext[i], wv, acc);
+        if (TAIL == T_NRM) acc = fma(wv, wv, acc);
+        if (TAIL == T_NRM_DIAG) {
+            const double m = dg[i] * wv;
+            mw[i] = m;
+            acc = fma(wv, m, acc);
+        }
+    }
+    if (TAIL != T_NONE) {
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Normalise-and-store: h = sqrt(|sum of partials|) (or a device scalar), then
+//   vnext = (mw | w) / h,  pnext = w / h      (true division, utils.py:1041-1045)
+// ------------------------------------------------------------------------------------------
+template <int HSRC>
+__global__ __launch_bounds__(BS) void k_scale_store(int64_t n, const double* __restrict__ w,
+                                                    const double* __restrict__ mw,
+                                                    double* __restrict__ vnext,
+                                                    double* __restrict__ pnext,
+                                                    const double* __restrict__ part_in, int nb_in,
+                                                    const double* __restrict__ scal_in,
+                                                    double* __restrict__ hslot) {
+    __shared__ double sm[8];
+    double h2 = (HSRC == A_PART) ? bcast_sum_partials(part_in, nb_in, sm) : scal_in[0];
+    const double h = sqrt(fabs(h2));
+    if (hslot != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *hslot = h;
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    const double2* __restrict__ m2 = reinterpret_cast<const double2*>(mw);
+    double2* __restrict__ v2 = reinterpret_cast<double2*>(vnext);
+    double2* __restrict__ p2 = reinterpret_cast<double2*>(pnext);
+#pragma unroll 2
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += stride) {
+        const double2 wv = w2[i];
+        double2 o;
+        o.x = wv.x / h;
+        o.y = wv.y / h;
+        if (mw != nullptr) {
+            p2[i] = o;
+            const double2 mv = m2[i];
+            o.x = mv.x / h;
+            o.y = mv.y / h;
+        }
+        v2[i] = o;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        if (mw != nullptr) {
+            pnext[i] = w[i] / h;
+            vnext[i] = mw[i] / h;
+        } else {
+            vnext[i] = w[i] / h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Panel kernels (tall-skinny V^T w and w -= V h), C columns per launch.
+// ------------------------------------------------------------------------------------------
+struct ColPtrs {
+    const double* c[MAXC];
+};
+
+// part_out[c * pstride + workgroup] = partial <V_c, w>
+template <int C>
+__global__ __launch_bounds__(BS) void k_multidot(int64_t n, ColPtrs cols,
+                                                 const double* __restrict__ w,
+                                                 double* __restrict__ part_out, int pstride) {
+    __shared__ double sm[8];
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+    double acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += stride) {
+        const double2 wv = w2[i];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double2 vv = reinterpret_cast<const double2*>(cols.c[c])[i];
+            acc[c] = fma(vv.x, wv.x, acc[c]);
+            acc[c] = fma(vv.y, wv.y, acc[c]);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double wv = w[n - 1];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = fma(cols.c[c][n - 1], wv, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const double r = block_sum(acc[c], sm);
+        if (threadIdx.x == 0) part_out[(int64_t)c * pstride + blockIdx.x] = r;
+        __syncthreads();
+    }
+}
+
+// out[c] (op)= fixed-order sum of part[c*pstride + 0..nb); one workgroup per column.
+// mode 0: out = s, 1: out += s, 2: out = sqrt(|s|)
+__global__ __launch_bounds__(BS) void k_reduce_partials(const double* __restrict__ part, int nb,
+                                                        int pstride, double* __restrict__ out,
+                                                        int mode) {
+    __shared__ double sm[8];
+    const double* p = part + (int64_t)blockIdx.x * pstride;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < nb; i += BS) v += p[i];
+    const double r = block_sum(v, sm);
+    if (threadIdx.x == 0) {
+        if (mode == 0) out[blockIdx.x] = r;
+        if (mode == 1) out[blockIdx.x] += r;
+        if (mode == 2) out[blockIdx.x] = sqrt(fabs(r));
+    }
+}
+
+// w = beta*w - sum_c coef[c] * V_c  applied left to right (multiply, then subtract), optionally
+// followed by the partial <w,w> (TAIL == T_NRM) or the Jacobi variant (T_NRM_DIAG).
+// BETA: 1 -> keep w, 0 -> start from zero (w is not read), 2 -> runtime beta.
+template <int C, int TAIL, int BETA>
+__global__ __launch_bounds__(BS) void k_multiaxpy(int64_t n, ColPtrs cols,
+                                                  const double* __restrict__ coef, double sign,
+                                                  double beta, double* __restrict__ w,
+                                                  const double* __restrict__ dg,
+                                                  double* __restrict__ mw,
+                                                  double* __restrict__ part_out) {
+    __shared__ double sm[8];
+    double h[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) h[c] = sign * coef[c];
+    const int64_t n2 = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    double2* __restrict__ w2 = reinterpret_cast<double2*>(w);
+    const double2* __restrict__ d2 = reinterpret_cast<const double2*>(dg);
+    double2* __restrict__ mw2 = reinterpret_cast<double2*>(mw);
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n2; i += stride) {
+        double2 wv;
+        if (BETA == 0) {
+            wv.x = 0.0;
+            wv.y = 0.0;
+        } else {
+            wv = w2[i];
+            if (BETA == 2) {
+                wv.x = beta * wv.x;
+                wv.y = beta * wv.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double2 vv = reinterpret_cast<const double2*>(cols.c[c])[i];
+            wv.x = wv.x - h[c] * vv.x;
+            wv.y = wv.y - h[c] * vv.y;
+        }
+        w2[i] = wv;
+        if (TAIL == T_NRM) {
+            acc = fma(wv.x, wv.x, acc);
+            acc = fma(wv.y, wv.y, acc);
+        } else if (TAIL == T_NRM_DIAG) {
+            const double2 dv = d2[i];
+            double2 m;
+            m.x = dv.x * wv.x;
+            m.y = dv.y * wv.y;
+            mw2[i] = m;
+            acc = fma(wv.x, m.x, acc);
+            acc = fma(wv.y, m.y, acc);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        double wv = (BETA == 0) ? 0.0 : (BETA == 2 ? beta * w[i] : w[i]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) wv = wv - h[c] * cols.c[c][i];
+        w[i] = wv;
+        if (TAIL == T_NRM) acc = fma(wv, wv, acc);
+        if (TAIL == T_NRM_DIAG) {
+            const double m = dg[i] * wv;
+            mw[i] = m;
+            acc = fma(wv, m, acc);
+        }
+    }
+    if (TAIL != T_NONE) {
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+// z = alpha*x + beta*y  (numpy order: (alpha*x) + (beta*y); alpha==1 / beta==1 skip the multiply)
+__global__ __launch_bounds__(BS) void k_waxpby(int64_t n, double* z, double alpha,
+                                               const double* x, double beta,
+                                               const double* y) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double a = (alpha == 1.0) ? x[i] : alpha * x[i];
+        if (beta == 0.0) {
+            z[i] = a;
+        } else {
+            const double b = (beta == 1.0) ? y[i] : beta * y[i];
+            z[i] = a + b;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BS) void k_vdiv(int64_t n, double* __restrict__ z,
+                                             const double* __restrict__ x, double s) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) z[i] = x[i] / s;
+}
+
+__global__ __launch_bounds__(BS) void k_diag_apply(int64_t n, const double* __restrict__ d,
+                                                   const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) y[i] = d[i] * x[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// MINRES vector recurrences (linsys.py:844-846), one pass:
+//   z = (v - r0*w0 - r1*w1)/r2 ;  w0 <- z (the slot that held W0 becomes the new W1) ; yk += y0*z
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_minres_update(int64_t n, const double* __restrict__ v,
+                                                      double* __restrict__ w0,
+                                                      const double* __restrict__ w1, double r0,
+                                                      double r1, double r2, double y0,
+                                                      double* __restrict__ yk) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double z = ((v[i] - r0 * w0[i]) - r1 * w1[i]) / r2;
+        w0[i] = z;
+        yk[i] = yk[i] + y0 * z;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CG vector recurrences (linsys.py:655-665), one pass:
+//   yk += alpha*p ; r -= alpha*Ap ; z = d.*r (or r) ; partial <r, z>
+// ------------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(BS) void k_cg_update(int64_t n, double alpha,
+                                                  const double* __restrict__ p,
+                                                  const double* __restrict__ ap,
+                                                  double* __restrict__ yk, double* __restrict__ r,
+                                                  const double* __restrict__ dg,
+                                                  double* __restrict__ z,
+                                                  double* __restrict__ part_out) {
+    __shared__ double sm[8];
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        yk[i] = yk[i] + alpha * p[i];
+        const double rv = r[i] - alpha * ap[i];
+        r[i] = rv;
+        double zv = rv;
+        if (DIAG) {
+            zv = dg[i] * rv;
+            z[i] = zv;
+        }
+        acc = fma(rv, zv, acc);
+    }
+    const double s = block_sum(acc, sm);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR SpMV, "CSR-stream": a workgroup owns a run of consecutive rows whose nnz fit the LDS
+// tile.  It streams `data`/`indices` fully coalesced, gathers x (stencil locality -> L2), parks
+// the products a_ij*x_j in LDS, then one lane per row adds that row's products left to right.
+// Separate multiply and add in storage order == scipy's csr_matvec bit for bit.
+// A row longer than the tile gets a workgroup of its own (tree reduction, not bit-ordered).
+// Epilogues: EPI_DOT  partial <v0, y>  (first MGS coefficient, saves one pass over w)
+//            EPI_RES  y = b - A x and partial <y, y>  (explicit residual)
+// blockIdx -> row-block mapping is XCD-aware: XCD x (workgroups b with b%8==x, each with a
+// private 4 MiB L2) walks a contiguous range of row blocks, so the x[i +- nx] neighbours of a
+// stencil row are L2 hits instead of cross-XCD refetches.
+// ------------------------------------------------------------------------------------------
+enum { EPI_NONE = 0, EPI_DOT = 1, EPI_RES = 2 };
+
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int EPI>
+__global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const double* __restrict__ data,
+                                                    const int32_t* __restrict__ rowblk, int nblk,
+                                                    int tile, int64_t nloc,
+                                                    const double* __restrict__ x,
+                                                    const double* __restrict__ ghost,
+                                                    double* __restrict__ y,
+                                                    const double* __restrict__ aux,
+                                                    double* __restrict__ part_out) {
+    extern __shared__ __attribute__((aligned(16))) double prod[];
+    __shared__ double sm[8];
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    const int nz0 = indptr[r0], nz1 = indptr[r1];
+    const int cnt = nz1 - nz0;
+    double acc = 0.0;
+    if (cnt <= tile) {
+        for (int t = threadIdx.x; t < cnt; t += BS) {
+            const int c = indices[nz0 + t];
+            const double xv = (c < nloc) ? x[c] : ghost[c - nloc];
+            prod[t] = data[nz0 + t] * xv;
+        }
+        __syncthreads();
+        for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+            const int p0 = indptr[r] - nz0, p1 = indptr[r + 1] - nz0;
+            double s = 0.0;
+            for (int p = p0; p < p1; ++p) s += prod[p];
+            if (EPI == EPI_RES) {
+                s = aux[r] - s;
+                acc = fma(s, s, acc);
+            }
+            y[r] = s;
+            if (EPI == EPI_DOT) acc = fma(aux[r], s, acc);
+        }
+    } else {  // one long row
+        double s = 0.0;
+        for (int t = threadIdx.x; t < cnt; t += BS) {
+            const int c = indices[nz0 + t];
+            const double xv = (c < nloc) ? x[c] : ghost[c - nloc];
+            s += data[nz0 + t] * xv;
+        }
+        s = block_sum(s, sm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (EPI == EPI_RES) {
+                s = aux[r0] - s;
+                acc = s * s;
+            }
+            y[r0] = s;
+            if (EPI == EPI_DOT) acc = aux[r0] * s;
+        }
+    }
+    if (EPI != EPI_NONE) {
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Dense row-major GEMV (config 4: A 32768^2 fp64 = 8.6 GB streamed once per CG step).
+// One wave64 per row: lanes stride the row with double2 loads, x stays in L2 (256 KB).
+// HBM-bound (0.25 flop/B); MFMA cannot help a single right-hand side.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_cols,
+                                                   const double* __restrict__ a, int64_t lda,
+                                                   const double* __restrict__ x,
+                                                   double* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const double* __restrict__ ar = a + row * lda;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0)) {
+        const double2* __restrict__ a2 = reinterpret_cast<const double2*>(ar);
+        const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
+        const int64_t n2 = n_cols >> 1;
+        for (int64_t i = lane; i < n2; i += 64) {
+            const double2 av = a2[i];
+            const double2 xv = x2[i];
+            acc0 = fma(av.x, xv.x, acc0);
+            acc1 = fma(av.y, xv.y, acc1);
+        }
+        if ((n_cols & 1) && lane == 0) acc0 = fma(ar[n_cols - 1], x[n_cols - 1], acc0);
+    } else {
+        for (int64_t i = lane; i < n_cols; i += 64) acc0 = fma(ar[i], x[i], acc0);
+    }
+    const double s = wave_sum(acc0 + acc1);
+    if (lane == 0) y[row] = s;
+}
+
+}  // namespace kh

@@ -1,0 +1,95 @@
+// Internal definitions of libkrylov_hip (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "krylov_hip.h"
+
+namespace kh {
+
+constexpr int BS = 256;          // threads per workgroup of every vector kernel (4 wave64)
+constexpr int MAXC = 16;         // widest column panel one multidot / multiaxpy launch handles
+constexpr int NB_MAX = 4096;     // upper bound of the reduction grid
+constexpr int SCAL_CAP = 8192;   // device scalar slots (H column, panel coefficients, norms)
+
+extern thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...);
+
+#define KH_HIP(call)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return kh::fail(e_ == hipErrorOutOfMemory ? KH_ERR_NOMEM : KH_ERR_HIP,        \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),        \
+                            __FILE__, __LINE__);                                          \
+    } while (0)
+
+#define KH_ARG(cond, ...)                                     \
+    do {                                                      \
+        if (!(cond)) return kh::fail(KH_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define KH_TRY(call)            \
+    do {                        \
+        int rc_ = (call);       \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+}  // namespace kh
+
+struct kh_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int ncu = 0;
+    int nb = 1024;          // reduction grid (workgroups of the streaming vector kernels)
+    int spmv_tile = 2048;   // nnz staged in LDS per SpMV workgroup
+    double* part = nullptr; // [MAXC + 4][NB_MAX] partial sums
+    double* scal = nullptr; // SCAL_CAP device scalars
+    double* hpin = nullptr; // pinned host staging, SCAL_CAP doubles
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
+    void* rccl_lib = nullptr;
+    void* comm = nullptr;
+    int rank = 0, nranks = 1;
+    double* commbuf = nullptr;  // device staging for host all-reduces
+};
+
+struct kh_vec_s {
+    kh_ctx ctx;
+    int64_t n, ncols, ld;
+    double* d;
+    double* col(int64_t j) const { return d + j * ld; }
+};
+
+enum { KH_MAT_CSR = 0, KH_MAT_DENSE = 1, KH_MAT_DIAG = 2 };
+
+struct kh_mat_s {
+    kh_ctx ctx;
+    int kind;
+    int64_t n_rows, n_cols, nnz;
+    // CSR
+    int32_t* indptr = nullptr;
+    int32_t* indices = nullptr;
+    double* data = nullptr;
+    int32_t* rowblk = nullptr;  // row-block boundaries of the CSR-stream kernel
+    int nblk = 0;
+    int tile = 0;
+    double* part = nullptr;     // nblk partial sums for the fused dot / norm epilogues
+    // dense
+    double* a = nullptr;
+    int64_t lda = 0;
+    // diag
+    double* diag = nullptr;
+    // halo of a block-row shard
+    int64_t nsend_prev = 0, nsend_next = 0, nrecv_prev = 0, nrecv_next = 0;
+    double* ghost = nullptr;    // nrecv_prev + nrecv_next doubles
+};
+
+namespace kh {
+// comm.hip
+int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
+int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x);
+}  // namespace kh

@@ -1,0 +1,849 @@
+// libkrylov_hip: host side of the C ABI declared in include/krylov_hip.h.
+// Launch logic only; the kernels live in kernels.h.  gfx950 only, no compatibility paths.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "kernels.h"
+
+namespace kh {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+static inline int grid_for(kh_ctx ctx, int64_t n) {
+    // enough workgroups to cover n/2 double2 elements, capped at the fixed reduction grid
+    int64_t need = ((n >> 1) + BS - 1) / BS;
+    if (need < 1) need = 1;
+    return (int)std::min<int64_t>(need, ctx->nb);
+}
+
+// partial-sum slots inside ctx->part
+static inline double* part_slot(kh_ctx ctx, int slot) { return ctx->part + (int64_t)slot * NB_MAX; }
+constexpr int SLOT_PING = MAXC, SLOT_PONG = MAXC + 1, SLOT_NRM = MAXC + 2;
+
+// device scalar layout inside ctx->scal
+constexpr int SC_HCOL = 0;       // H column of the running Arnoldi step (k+2 entries)
+constexpr int SC_TMP = 6144;     // scratch scalars (dot0 of the fused SpMV, norms, ...)
+constexpr int SC_COEF = 6400;    // panel coefficients for axpy_panel / gemm_nn (<= 1024)
+constexpr int HCOL_CAP = 6000;
+
+static int check_vec(kh_vec v, int64_t col, int64_t ncols, const char* what) {
+    KH_ARG(v != nullptr, "%s: NULL vector handle", what);
+    KH_ARG(col >= 0 && ncols >= 0 && col + ncols <= v->ncols,
+           "%s: columns [%lld, %lld) out of range (ncols=%lld)", what, (long long)col,
+           (long long)(col + ncols), (long long)v->ncols);
+    return 0;
+}
+
+static int fetch_scalars(kh_ctx ctx, const double* dev, int64_t count, double* out) {
+    KH_ARG(count <= SCAL_CAP, "fetch_scalars: %lld > capacity", (long long)count);
+    KH_HIP(hipMemcpyAsync(ctx->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->hpin, count * sizeof(double));
+    return 0;
+}
+
+static int push_scalars(kh_ctx ctx, const double* host, int64_t count, double* dev) {
+    // pinned staging is reused: wait for earlier consumers of hpin first
+    KH_ARG(count <= SCAL_CAP, "push_scalars: %lld > capacity", (long long)count);
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->hpin, host, count * sizeof(double));
+    KH_HIP(hipMemcpyAsync(dev, ctx->hpin, count * sizeof(double), hipMemcpyHostToDevice,
+                          ctx->stream));
+    return 0;
+}
+
+// ---- panel helpers ------------------------------------------------------------------------
+template <int C>
+static void launch_multidot(kh_ctx ctx, int64_t n, const ColPtrs& cp, const double* w,
+                            double* part) {
+    hipLaunchKernelGGL((k_multidot<C>), dim3(grid_for(ctx, n)), dim3(BS), 0, ctx->stream, n, cp, w,
+                       part, NB_MAX);
+}
+
+// partial sums of <V[:, j0+c], w>, c < nc <= MAXC, into part slots 0..nc-1
+static int multidot_chunk(kh_ctx ctx, kh_vec V, int64_t j0, int nc, const double* w) {
+    ColPtrs cp;
+    int done = 0;
+    const int64_t n = V->n;
+    while (done < nc) {
+        int c = nc - done;
+        c = c >= 16 ? 16 : c >= 8 ? 8 : c >= 4 ? 4 : c >= 2 ? 2 : 1;
+        for (int i = 0; i < c; ++i) cp.c[i] = V->col(j0 + done + i);
+        double* part = part_slot(ctx, done);
+        switch (c) {
+            case 16: launch_multidot<16>(ctx, n, cp, w, part); break;
+            case 8: launch_multidot<8>(ctx, n, cp, w, part); break;
+            case 4: launch_multidot<4>(ctx, n, cp, w, part); break;
+            case 2: launch_multidot<2>(ctx, n, cp, w, part); break;
+            default: launch_multidot<1>(ctx, n, cp, w, part); break;
+        }
+        done += c;
+    }
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int C, int TAIL, int BETA>
+static void launch_multiaxpy(kh_ctx ctx, int64_t n, const ColPtrs& cp, const double* coef,
+                             double sign, double beta, double* w, const double* dg, double* mw,
+                             double* part) {
+    hipLaunchKernelGGL((k_multiaxpy<C, TAIL, BETA>), dim3(grid_for(ctx, n)), dim3(BS), 0,
+                       ctx->stream, n, cp, coef, sign, beta, w, dg, mw, part);
+}
+
+template <int TAIL, int BETA>
+static void dispatch_multiaxpy(kh_ctx ctx, int c, int64_t n, const ColPtrs& cp, const double* coef,
+                               double sign, double beta, double* w, const double* dg, double* mw,
+                               double* part) {
+    switch (c) {
+        case 16: launch_multiaxpy<16, TAIL, BETA>(ctx, n, cp, coef, sign, beta, w, dg, mw, part); break;
+        case 8: launch_multiaxpy<8, TAIL, BETA>(ctx, n, cp, coef, sign, beta, w, dg, mw, part); break;
+        case 4: launch_multiaxpy<4, TAIL, BETA>(ctx, n, cp, coef, sign, beta, w, dg, mw, part); break;
+        case 2: launch_multiaxpy<2, TAIL, BETA>(ctx, n, cp, coef, sign, beta, w, dg, mw, part); break;
+        default: launch_multiaxpy<1, TAIL, BETA>(ctx, n, cp, coef, sign, beta, w, dg, mw, part); break;
+    }
+}
+
+// w = beta*w - sign * sum_c coef_dev[c] * X[:, j0+c]   over nc columns (any nc >= 1), in order.
+// tail (T_NONE/T_NRM/T_NRM_DIAG) is fused into the last chunk and lands in SLOT_NRM.
+static int multiaxpy_cols(kh_ctx ctx, kh_vec X, int64_t j0, int64_t nc, const double* coef_dev,
+                          double sign, double beta, double* w, int tail, const double* dg,
+                          double* mw) {
+    const int64_t n = X->n;
+    int64_t done = 0;
+    ColPtrs cp;
+    while (done < nc) {
+        int64_t left = nc - done;
+        int c = left >= 16 ? 16 : left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        for (int i = 0; i < c; ++i) cp.c[i] = X->col(j0 + done + i);
+        const bool last = (done + c == nc);
+        const int t = last ? tail : T_NONE;
+        const int b = (done > 0) ? 1 : (beta == 1.0 ? 1 : (beta == 0.0 ? 0 : 2));
+        double* part = part_slot(ctx, SLOT_NRM);
+        const double* cf = coef_dev + done;
+#define KH_MA(T, B) dispatch_multiaxpy<T, B>(ctx, c, n, cp, cf, sign, beta, w, dg, mw, part)
+        if (t == T_NONE) {
+            if (b == 1) KH_MA(T_NONE, 1); else if (b == 0) KH_MA(T_NONE, 0); else KH_MA(T_NONE, 2);
+        } else if (t == T_NRM) {
+            if (b == 1) KH_MA(T_NRM, 1); else if (b == 0) KH_MA(T_NRM, 0); else KH_MA(T_NRM, 2);
+        } else {
+            if (b == 1) KH_MA(T_NRM_DIAG, 1); else if (b == 0) KH_MA(T_NRM_DIAG, 0); else KH_MA(T_NRM_DIAG, 2);
+        }
+#undef KH_MA
+        done += c;
+    }
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- operator application -------------------------------------------------------------------
+template <int EPI>
+static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+    const size_t lds = (size_t)A->tile * sizeof(double);
+    hipLaunchKernelGGL((k_spmv_stream<EPI>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr,
+                       A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_rows, x, A->ghost, y,
+                       aux, A->part);
+}
+
+// y = A x for one column; epi/aux select the fused epilogue of the CSR kernel (its partial sums
+// land in A->part and are reduced into scal_out with `rmode` of k_reduce_partials).
+static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
+                     double* scal_out, int rmode) {
+    if (A->kind == KH_MAT_CSR) {
+        if (ctx->nranks > 1 && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0)
+            KH_TRY(comm_halo_exchange(ctx, A, x));
+        if (A->nblk == 0) return 0;
+        if (epi == EPI_NONE) launch_spmv<EPI_NONE>(ctx, A, x, y, nullptr);
+        if (epi == EPI_DOT) launch_spmv<EPI_DOT>(ctx, A, x, y, aux);
+        if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux);
+        KH_HIP(hipGetLastError());
+        if (epi != EPI_NONE) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, A->part,
+                               A->nblk, 0, scal_out, rmode);
+            KH_HIP(hipGetLastError());
+        }
+        return 0;
+    }
+    KH_ARG(epi == EPI_NONE, "fused epilogues exist for CSR operators only");
+    if (A->kind == KH_MAT_DENSE) {
+        const int rows_per_wg = BS / 64;
+        const int grid = (int)((A->n_rows + rows_per_wg - 1) / rows_per_wg);
+        hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols,
+                           A->a, A->lda, x, y);
+    } else {
+        const int grid = (int)std::min<int64_t>((A->n_rows + BS - 1) / BS, ctx->nb * 2);
+        hipLaunchKernelGGL(k_diag_apply, dim3(std::max(grid, 1)), dim3(BS), 0, ctx->stream,
+                           A->n_rows, A->diag, x, y);
+    }
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+static inline int grid_lin(kh_ctx ctx, int64_t n) {
+    int64_t need = (n + BS - 1) / BS;
+    if (need < 1) need = 1;
+    return (int)std::min<int64_t>(need, (int64_t)ctx->nb * 2);
+}
+
+}  // namespace kh
+
+using namespace kh;
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* kh_last_error(void) { return g_err.c_str(); }
+
+int kh_version(void) { return 100; }
+
+int kh_device_count(int* count) {
+    KH_ARG(count != nullptr, "kh_device_count: NULL");
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(KH_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+
+int kh_ctx_create(int device, kh_ctx* out) {
+    KH_ARG(out != nullptr, "kh_ctx_create: NULL out");
+    int ndev = 0;
+    KH_HIP(hipGetDeviceCount(&ndev));
+    KH_ARG(device >= 0 && device < ndev, "kh_ctx_create: device %d not in [0,%d)", device, ndev);
+    KH_HIP(hipSetDevice(device));
+    kh_ctx ctx = new kh_ctx_s();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    KH_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->ncu = prop.multiProcessorCount;
+    ctx->nb = std::min(NB_MAX, std::max(64, ctx->ncu * 4));
+    KH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    KH_HIP(hipMalloc(&ctx->part, sizeof(double) * (size_t)(MAXC + 4) * NB_MAX));
+    KH_HIP(hipMalloc(&ctx->scal, sizeof(double) * SCAL_CAP));
+    KH_HIP(hipMemset(ctx->scal, 0, sizeof(double) * SCAL_CAP));
+    KH_HIP(hipHostMalloc(&ctx->hpin, sizeof(double) * SCAL_CAP, hipHostMallocDefault));
+    KH_HIP(hipEventCreate(&ctx->ev0));
+    KH_HIP(hipEventCreate(&ctx->ev1));
+    *out = ctx;
+    return 0;
+}
+
+int kh_ctx_destroy(kh_ctx ctx) {
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    kh_comm_destroy(ctx);
+    (void)hipFree(ctx->part);
+    (void)hipFree(ctx->scal);
+    (void)hipHostFree(ctx->hpin);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+int kh_ctx_sync(kh_ctx ctx) {
+    KH_ARG(ctx != nullptr, "kh_ctx_sync: NULL ctx");
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int kh_ctx_info(kh_ctx ctx, int64_t info[4]) {
+    KH_ARG(ctx != nullptr && info != nullptr, "kh_ctx_info: NULL");
+    size_t fr = 0, tot = 0;
+    KH_HIP(hipSetDevice(ctx->device));
+    KH_HIP(hipMemGetInfo(&fr, &tot));
+    info[0] = ctx->ncu;
+    info[1] = (int64_t)tot;
+    info[2] = (int64_t)fr;
+    info[3] = ctx->nb;
+    return 0;
+}
+
+int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile) {
+    KH_ARG(ctx != nullptr, "kh_ctx_tune: NULL ctx");
+    if (reduce_blocks > 0) {
+        KH_ARG(reduce_blocks <= NB_MAX, "reduce_blocks %d > %d", reduce_blocks, NB_MAX);
+        ctx->nb = reduce_blocks;
+    }
+    if (spmv_tile > 0) {
+        KH_ARG(spmv_tile >= 256 && spmv_tile <= 8192, "spmv_tile %d not in [256, 8192]", spmv_tile);
+        ctx->spmv_tile = spmv_tile;
+    }
+    return 0;
+}
+
+int kh_timer_start(kh_ctx ctx) {
+    KH_ARG(ctx != nullptr, "kh_timer_start: NULL ctx");
+    KH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return 0;
+}
+
+int kh_timer_stop(kh_ctx ctx, double* elapsed_ms) {
+    KH_ARG(ctx != nullptr && elapsed_ms != nullptr, "kh_timer_stop: NULL");
+    KH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    KH_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *elapsed_ms = (double)ms;
+    return 0;
+}
+
+// ---- vectors ----------------------------------------------------------------------------------
+int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out) {
+    KH_ARG(ctx != nullptr && out != nullptr, "kh_vec_alloc: NULL");
+    KH_ARG(n >= 0 && ncols >= 0, "kh_vec_alloc: negative shape");
+    kh_vec v = new kh_vec_s();
+    v->ctx = ctx;
+    v->n = n;
+    v->ncols = ncols;
+    v->ld = ((n + 31) / 32) * 32;
+    if (v->ld == 0) v->ld = 32;
+    v->d = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)v->ld * (size_t)std::max<int64_t>(ncols, 1);
+    hipError_t e = hipMalloc(&v->d, bytes);
+    if (e != hipSuccess) {
+        delete v;
+        return fail(KH_ERR_NOMEM, "kh_vec_alloc: hipMalloc(%zu bytes) for a (%lld x %lld) block: %s",
+                    bytes, (long long)n, (long long)ncols, hipGetErrorString(e));
+    }
+    KH_HIP(hipMemsetAsync(v->d, 0, bytes, ctx->stream));
+    *out = v;
+    return 0;
+}
+
+int kh_vec_free(kh_vec v) {
+    if (!v) return 0;
+    (void)hipStreamSynchronize(v->ctx->stream);
+    (void)hipFree(v->d);
+    delete v;
+    return 0;
+}
+
+int kh_vec_shape(kh_vec v, int64_t* n, int64_t* ncols, int64_t* ld) {
+    KH_ARG(v != nullptr, "kh_vec_shape: NULL");
+    if (n) *n = v->n;
+    if (ncols) *ncols = v->ncols;
+    if (ld) *ld = v->ld;
+    return 0;
+}
+
+int kh_vec_upload(kh_vec v, int64_t col0, int64_t ncols, const double* host, int64_t host_ld) {
+    KH_TRY(check_vec(v, col0, ncols, "kh_vec_upload"));
+    if (ncols == 0 || v->n == 0) return 0;
+    KH_ARG(host != nullptr && host_ld >= v->n, "kh_vec_upload: bad host buffer");
+    KH_HIP(hipMemcpy2DAsync(v->col(col0), v->ld * sizeof(double), host, host_ld * sizeof(double),
+                            v->n * sizeof(double), ncols, hipMemcpyHostToDevice, v->ctx->stream));
+    KH_HIP(hipStreamSynchronize(v->ctx->stream));
+    return 0;
+}
+
+int kh_vec_download(kh_vec v, int64_t col0, int64_t ncols, double* host, int64_t host_ld) {
+    KH_TRY(check_vec(v, col0, ncols, "kh_vec_download"));
+    if (ncols == 0 || v->n == 0) return 0;
+    KH_ARG(host != nullptr && host_ld >= v->n, "kh_vec_download: bad host buffer");
+    KH_HIP(hipMemcpy2DAsync(host, host_ld * sizeof(double), v->col(col0), v->ld * sizeof(double),
+                            v->n * sizeof(double), ncols, hipMemcpyDeviceToHost, v->ctx->stream));
+    KH_HIP(hipStreamSynchronize(v->ctx->stream));
+    return 0;
+}
+
+int kh_vec_zero(kh_vec v, int64_t col0, int64_t ncols) {
+    KH_TRY(check_vec(v, col0, ncols, "kh_vec_zero"));
+    if (ncols == 0) return 0;
+    KH_HIP(hipMemsetAsync(v->col(col0), 0, sizeof(double) * v->ld * ncols, v->ctx->stream));
+    return 0;
+}
+
+int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncols) {
+    KH_TRY(check_vec(dst, dcol, ncols, "kh_vec_copy(dst)"));
+    KH_TRY(check_vec(src, scol, ncols, "kh_vec_copy(src)"));
+    KH_ARG(dst->n == src->n, "kh_vec_copy: length mismatch %lld vs %lld", (long long)dst->n,
+           (long long)src->n);
+    if (ncols == 0) return 0;
+    KH_HIP(hipMemcpyAsync(dst->col(dcol), src->col(scol), sizeof(double) * src->ld * ncols,
+                          hipMemcpyDeviceToDevice, dst->ctx->stream));
+    return 0;
+}
+
+// ---- operators --------------------------------------------------------------------------------
+static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
+                           std::vector<int32_t>& blk) {
+    // greedy: consecutive rows while their nnz fit the LDS tile (and <= 4 rows per lane);
+    // a row longer than the tile becomes a block of its own
+    blk.clear();
+    blk.push_back(0);
+    const int max_rows = BS * 4;
+    int64_t r = 0;
+    while (r < n_rows) {
+        int64_t r_end = r;
+        int64_t acc = 0;
+        while (r_end < n_rows && (r_end - r) < max_rows) {
+            const int64_t nz = (int64_t)indptr[r_end + 1] - indptr[r_end];
+            if (acc + nz > tile) break;
+            acc += nz;
+            ++r_end;
+        }
+        if (r_end == r) r_end = r + 1;  // long row
+        blk.push_back((int32_t)r_end);
+        r = r_end;
+    }
+    return 0;
+}
+
+int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
+                  const int32_t* indices, const double* data, kh_mat* out) {
+    KH_ARG(ctx && out && indptr, "kh_csr_upload: NULL argument");
+    KH_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "kh_csr_upload: negative size");
+    KH_ARG(n_rows < 2147483647LL && nnz < 2147483647LL, "kh_csr_upload: int32 CSR limits exceeded");
+    KH_ARG(indptr[0] == 0 && indptr[n_rows] == nnz, "kh_csr_upload: indptr[0]=%d indptr[n]=%d nnz=%lld",
+           indptr[0], indptr[n_rows], (long long)nnz);
+    for (int64_t i = 0; i < nnz; ++i)
+        KH_ARG(indices[i] >= 0 && indices[i] < n_cols, "kh_csr_upload: column index %d out of range at %lld",
+               indices[i], (long long)i);
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_CSR;
+    A->n_rows = n_rows;
+    A->n_cols = n_cols;
+    A->nnz = nnz;
+    A->tile = ctx->spmv_tile;
+    std::vector<int32_t> blk;
+    build_rowblocks(indptr, n_rows, A->tile, blk);
+    A->nblk = (int)blk.size() - 1;
+    KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
+    KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
+    KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
+    KH_HIP(hipMalloc(&A->part, sizeof(double) * std::max(A->nblk, 1)));
+    KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        KH_HIP(hipMemcpy(A->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+        KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    }
+    KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_dense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a, int64_t lda,
+                    kh_mat* out) {
+    KH_ARG(ctx && out && a, "kh_dense_upload: NULL argument");
+    KH_ARG(n_rows >= 0 && n_cols >= 0 && lda >= n_cols, "kh_dense_upload: bad shape");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_DENSE;
+    A->n_rows = n_rows;
+    A->n_cols = n_cols;
+    A->lda = ((n_cols + 1) / 2) * 2;  // even leading dimension: rows stay 16-byte aligned
+    const size_t bytes = sizeof(double) * (size_t)A->lda * (size_t)std::max<int64_t>(n_rows, 1);
+    hipError_t e = hipMalloc(&A->a, bytes);
+    if (e != hipSuccess) {
+        delete A;
+        return fail(KH_ERR_NOMEM, "kh_dense_upload: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    KH_HIP(hipMemcpy2D(A->a, A->lda * sizeof(double), a, lda * sizeof(double),
+                       n_cols * sizeof(double), n_rows, hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
+    KH_ARG(ctx && out && (d || n == 0), "kh_diag_upload: NULL argument");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_DIAG;
+    A->n_rows = A->n_cols = n;
+    KH_HIP(hipMalloc(&A->diag, sizeof(double) * (((n + 31) / 32) * 32 + 32)));
+    if (n > 0) KH_HIP(hipMemcpy(A->diag, d, sizeof(double) * n, hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_mat_free(kh_mat A) {
+    if (!A) return 0;
+    (void)hipStreamSynchronize(A->ctx->stream);
+    (void)hipFree(A->indptr);
+    (void)hipFree(A->indices);
+    (void)hipFree(A->data);
+    (void)hipFree(A->rowblk);
+    (void)hipFree(A->part);
+    (void)hipFree(A->a);
+    (void)hipFree(A->diag);
+    (void)hipFree(A->ghost);
+    delete A;
+    return 0;
+}
+
+int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols) {
+    KH_ARG(ctx && A, "kh_apply: NULL handle");
+    KH_TRY(check_vec(X, xcol, ncols, "kh_apply(X)"));
+    KH_TRY(check_vec(Y, ycol, ncols, "kh_apply(Y)"));
+    const int64_t xneed = (A->kind == KH_MAT_CSR) ? A->n_cols - A->nrecv_prev - A->nrecv_next : A->n_cols;
+    KH_ARG(X->n == xneed && Y->n == A->n_rows, "kh_apply: dimension mismatch (A %lldx%lld, x %lld, y %lld)",
+           (long long)A->n_rows, (long long)A->n_cols, (long long)X->n, (long long)Y->n);
+    KH_ARG(!(X == Y && xcol == ycol), "kh_apply: in-place application is not supported");
+    for (int64_t c = 0; c < ncols; ++c)
+        KH_TRY(apply_one(ctx, A, X->col(xcol + c), Y->col(ycol + c), EPI_NONE, nullptr, nullptr, 0));
+    return 0;
+}
+
+// ---- inner products, norms, updates -----------------------------------------------------------
+static int dot_panel_dev(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* w,
+                         double* out_dev, int rmode) {
+    // out_dev[j] (rmode) = <V[:, j0+j], w>, all-reduced over ranks
+    int64_t done = 0;
+    while (done < ncols) {
+        const int nc = (int)std::min<int64_t>(MAXC, ncols - done);
+        KH_TRY(multidot_chunk(ctx, V, j0 + done, nc, w));
+        hipLaunchKernelGGL(k_reduce_partials, dim3(nc), dim3(BS), 0, ctx->stream, ctx->part,
+                           grid_for(ctx, V->n), NB_MAX, out_dev + done, rmode);
+        KH_HIP(hipGetLastError());
+        done += nc;
+    }
+    return 0;
+}
+
+int kh_dot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol,
+                 double* out) {
+    KH_ARG(ctx && out, "kh_dot_panel: NULL");
+    KH_TRY(check_vec(V, j0, ncols, "kh_dot_panel(V)"));
+    KH_TRY(check_vec(W, wcol, 1, "kh_dot_panel(W)"));
+    KH_ARG(V->n == W->n, "kh_dot_panel: length mismatch");
+    KH_ARG(ncols <= 1024, "kh_dot_panel: at most 1024 columns per call");
+    if (ncols == 0) return 0;
+    double* dev = ctx->scal + SC_COEF;
+    KH_TRY(dot_panel_dev(ctx, V, j0, ncols, W->col(wcol), dev, 0));
+    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, dev, ncols));
+    return fetch_scalars(ctx, dev, ncols, out);
+}
+
+int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y0, int64_t ny,
+               double* out) {
+    KH_ARG(ctx && out, "kh_gemm_tn: NULL");
+    KH_TRY(check_vec(X, x0, nx, "kh_gemm_tn(X)"));
+    KH_TRY(check_vec(Y, y0, ny, "kh_gemm_tn(Y)"));
+    KH_ARG(X->n == Y->n, "kh_gemm_tn: length mismatch");
+    KH_ARG(nx <= 1024, "kh_gemm_tn: at most 1024 rows");
+    std::vector<double> colbuf((size_t)std::max<int64_t>(nx, 1));
+    for (int64_t j = 0; j < ny; ++j) {
+        KH_TRY(kh_dot_panel(ctx, X, x0, nx, Y, y0 + j, colbuf.data()));
+        for (int64_t i = 0; i < nx; ++i) out[i * ny + j] = colbuf[i];
+    }
+    return 0;
+}
+
+int kh_axpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W,
+                  int64_t wcol) {
+    KH_ARG(ctx && (h || ncols == 0), "kh_axpy_panel: NULL");
+    KH_TRY(check_vec(V, j0, ncols, "kh_axpy_panel(V)"));
+    KH_TRY(check_vec(W, wcol, 1, "kh_axpy_panel(W)"));
+    KH_ARG(V->n == W->n, "kh_axpy_panel: length mismatch");
+    KH_ARG(ncols <= 1024, "kh_axpy_panel: at most 1024 columns per call");
+    if (ncols == 0) return 0;
+    double* dev = ctx->scal + SC_COEF;
+    KH_TRY(push_scalars(ctx, h, ncols, dev));
+    return multiaxpy_cols(ctx, V, j0, ncols, dev, 1.0, 1.0, W->col(wcol), T_NONE, nullptr, nullptr);
+}
+
+int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc,
+               double alpha, double beta, kh_vec Y, int64_t y0) {
+    KH_ARG(ctx && (C || k == 0 || nc == 0), "kh_gemm_nn: NULL");
+    KH_TRY(check_vec(X, x0, k, "kh_gemm_nn(X)"));
+    KH_TRY(check_vec(Y, y0, nc, "kh_gemm_nn(Y)"));
+    KH_ARG(X->n == Y->n, "kh_gemm_nn: length mismatch");
+    KH_ARG(k <= 1024, "kh_gemm_nn: inner dimension at most 1024");
+    KH_ARG(X != Y, "kh_gemm_nn: X and Y must be different blocks");
+    std::vector<double> coef((size_t)std::max<int64_t>(k, 1));
+    double* dev = ctx->scal + SC_COEF;
+    for (int64_t c = 0; c < nc; ++c) {
+        if (k == 0) {
+            if (beta == 0.0) KH_TRY(kh_vec_zero(Y, y0 + c, 1));
+            else if (beta != 1.0) KH_TRY(kh_waxpby(ctx, Y, y0 + c, beta, Y, y0 + c, 0.0, Y, y0 + c));
+            continue;
+        }
+        for (int64_t i = 0; i < k; ++i) coef[i] = alpha * C[i * nc + c];
+        KH_TRY(push_scalars(ctx, coef.data(), k, dev));
+        // y = beta*y - (-1) * sum coef_i x_i  : exact sign flip, additions left to right
+        KH_TRY(multiaxpy_cols(ctx, X, x0, k, dev, -1.0, beta, Y->col(y0 + c), T_NONE, nullptr, nullptr));
+    }
+    return 0;
+}
+
+int kh_nrm2(kh_ctx ctx, kh_vec W, int64_t wcol, double* out) {
+    KH_ARG(ctx && out, "kh_nrm2: NULL");
+    KH_TRY(check_vec(W, wcol, 1, "kh_nrm2"));
+    const int64_t n = W->n;
+    double* part = part_slot(ctx, SLOT_NRM);
+    hipLaunchKernelGGL((k_gs_link<A_NONE, T_NRM>), dim3(grid_for(ctx, n)), dim3(BS), 0, ctx->stream,
+                       n, nullptr, nullptr, W->col(wcol), nullptr, nullptr, nullptr, 0, nullptr, 0.0,
+                       part, nullptr);
+    KH_HIP(hipGetLastError());
+    double* dev = ctx->scal + SC_TMP;
+    const int mode = ctx->nranks > 1 ? 0 : 2;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid_for(ctx, n),
+                       NB_MAX, dev, mode);
+    KH_HIP(hipGetLastError());
+    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, dev, 1));
+    KH_TRY(fetch_scalars(ctx, dev, 1, out));
+    if (ctx->nranks > 1) *out = sqrt(fabs(*out));
+    return 0;
+}
+
+int kh_waxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, double alpha, kh_vec X, int64_t xcol, double beta,
+              kh_vec Y, int64_t ycol) {
+    KH_ARG(ctx, "kh_waxpby: NULL ctx");
+    KH_TRY(check_vec(Z, zcol, 1, "kh_waxpby(Z)"));
+    KH_TRY(check_vec(X, xcol, 1, "kh_waxpby(X)"));
+    KH_TRY(check_vec(Y, ycol, 1, "kh_waxpby(Y)"));
+    KH_ARG(Z->n == X->n && Z->n == Y->n, "kh_waxpby: length mismatch");
+    const int64_t n = Z->n;
+    hipLaunchKernelGGL(k_waxpby, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, Z->col(zcol),
+                       alpha, X->col(xcol), beta, Y->col(ycol));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s) {
+    KH_ARG(ctx, "kh_vdiv: NULL ctx");
+    KH_TRY(check_vec(Z, zcol, 1, "kh_vdiv(Z)"));
+    KH_TRY(check_vec(X, xcol, 1, "kh_vdiv(X)"));
+    KH_ARG(Z->n == X->n, "kh_vdiv: length mismatch");
+    hipLaunchKernelGGL(k_vdiv, dim3(grid_lin(ctx, Z->n)), dim3(BS), 0, ctx->stream, Z->n,
+                       Z->col(zcol), X->col(xcol), s);
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---- fused hot path -----------------------------------------------------------------------------
+#define KH_LINK(ASRC, TAIL, P, VN, DG, MW, PIN, SIN, AARG, POUT, HS)                                  \
+    hipLaunchKernelGGL((k_gs_link<ASRC, TAIL>), dim3(grid), dim3(BS), 0, ctx->stream, n, P, VN, w, DG, \
+                       MW, PIN, grid, SIN, AARG, POUT, HS)
+
+int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                    int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
+                    double* hcol_out) {
+    KH_ARG(ctx && V && W && hcol_out, "kh_arnoldi_step: NULL argument");
+    KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_arnoldi_step: k=%lld needs %lld basis columns, have %lld",
+           (long long)k, (long long)(k + 2), (long long)V->ncols);
+    KH_ARG(start >= 0 && start <= k, "kh_arnoldi_step: start=%lld not in [0,k]", (long long)start);
+    KH_ARG(sweeps >= 1 && sweeps <= 4, "kh_arnoldi_step: sweeps=%d", sweeps);
+    KH_ARG(k + 2 <= HCOL_CAP, "kh_arnoldi_step: k+2 exceeds the H-column capacity %d", HCOL_CAP);
+    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_arnoldi_step: Md must be a diagonal operator");
+    KH_ARG((Md == nullptr) == (P == nullptr), "kh_arnoldi_step: P and Md go together");
+    KH_ARG(P == nullptr || (P->n == V->n && P->ncols >= V->ncols), "kh_arnoldi_step: P shape");
+    KH_TRY(check_vec(W, wcol, Md ? 2 : 1, "kh_arnoldi_step(W)"));
+    KH_ARG(W->n == V->n, "kh_arnoldi_step: W length");
+    const int64_t n = V->n;
+    kh_vec B = P ? P : V;
+    double* w = W->col(wcol);
+    double* mw = Md ? W->col(wcol + 1) : nullptr;
+    const double* dg = Md ? Md->diag : nullptr;
+    const int grid = grid_for(ctx, n);
+    const bool multi = ctx->nranks > 1;
+    double* hdev = ctx->scal + SC_HCOL;
+    double* tmp = ctx->scal + SC_TMP;
+    KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
+
+    const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
+    const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
+                            A->nblk > 0);
+    // 1. operator
+    if (A != nullptr) {
+        KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
+               (long long)n);
+        if (fuse_dot0)
+            KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_DOT, V->col(start), tmp, 0));
+        else
+            KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_NONE, nullptr, nullptr, 0));
+    }
+
+    double* nrm_part = part_slot(ctx, SLOT_NRM);
+    if (gs_mode == KH_GS_MGS) {
+        // column visiting order of all sweeps
+        const int64_t ncol = k - start + 1;
+        const int64_t len = ncol * sweeps;
+        auto colof = [&](int64_t t) { return start + (t % ncol); };
+        // state: where the coefficient of the pending axpy comes from
+        int src = A_NONE;            // A_PART (slot), A_SCAL (tmp)
+        double* pin = nullptr;
+        // first dot
+        if (fuse_dot0) {
+            if (multi) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+            src = A_SCAL;
+        } else if (presub) {
+            double* pout = part_slot(ctx, SLOT_PING);
+            KH_LINK(A_ARG, T_DOT, B->col(k - 1), V->col(colof(0)), nullptr, nullptr, nullptr, nullptr,
+                    h_km1, pout, nullptr);
+            src = A_PART;
+            pin = pout;
+        } else {
+            double* pout = part_slot(ctx, SLOT_PING);
+            KH_LINK(A_NONE, T_DOT, nullptr, V->col(colof(0)), nullptr, nullptr, nullptr, nullptr, 0.0,
+                    pout, nullptr);
+            src = A_PART;
+            pin = pout;
+        }
+        if (multi && src == A_PART) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, pin, grid, 0, tmp, 0);
+            KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+            src = A_SCAL;
+        }
+        for (int64_t t = 1; t <= len; ++t) {
+            const int64_t jprev = colof(t - 1);
+            const bool last = (t == len);
+            double* pout = last ? nrm_part : part_slot(ctx, (t & 1) ? SLOT_PONG : SLOT_PING);
+            const double* pcol = B->col(jprev);
+            double* hs = hdev + jprev;
+            if (!last) {
+                const double* vn = V->col(colof(t));
+                if (src == A_PART) KH_LINK(A_PART, T_DOT, pcol, vn, nullptr, nullptr, pin, nullptr, 0.0, pout, hs);
+                else KH_LINK(A_SCAL, T_DOT, pcol, vn, nullptr, nullptr, nullptr, tmp, 0.0, pout, hs);
+            } else if (Md) {
+                if (src == A_PART) KH_LINK(A_PART, T_NRM_DIAG, pcol, nullptr, dg, mw, pin, nullptr, 0.0, pout, hs);
+                else KH_LINK(A_SCAL, T_NRM_DIAG, pcol, nullptr, dg, mw, nullptr, tmp, 0.0, pout, hs);
+            } else {
+                if (src == A_PART) KH_LINK(A_PART, T_NRM, pcol, nullptr, nullptr, nullptr, pin, nullptr, 0.0, pout, hs);
+                else KH_LINK(A_SCAL, T_NRM, pcol, nullptr, nullptr, nullptr, nullptr, tmp, 0.0, pout, hs);
+            }
+            KH_HIP(hipGetLastError());
+            src = A_PART;
+            pin = pout;
+            if (multi && !last) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, pin, grid, 0, tmp, 0);
+                KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+                src = A_SCAL;
+            }
+        }
+    } else {
+        // panel (classical) Gram-Schmidt: one reduction round per sweep
+        KH_ARG(gs_mode == KH_GS_CGS, "kh_arnoldi_step: unknown gs_mode %d", gs_mode);
+        const int64_t ncol = k - start + 1;
+        KH_ARG(ncol <= 1024, "kh_arnoldi_step: panel mode handles at most 1024 columns");
+        double* coef = ctx->scal + SC_COEF;
+        if (presub) {
+            // w -= h_km1 * B[:, k-1]
+            KH_LINK(A_ARG, T_NONE, B->col(k - 1), nullptr, nullptr, nullptr, nullptr, nullptr, h_km1,
+                    nullptr, nullptr);
+        }
+        for (int s = 0; s < sweeps; ++s) {
+            KH_TRY(dot_panel_dev(ctx, V, start, ncol, w, coef, 0));
+            if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
+            // H[j,k] += coef  (device-side accumulate through the same reduce kernel is not
+            // needed: one tiny axpy on scalars)
+            hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0,
+                               hdev + start, 1.0, coef);
+            const int tail = (s == sweeps - 1) ? (Md ? T_NRM_DIAG : T_NRM) : T_NONE;
+            KH_TRY(multiaxpy_cols(ctx, B, start, ncol, coef, 1.0, 1.0, w, tail, dg, mw));
+        }
+    }
+    // 3. norm and normalise
+    {
+        double* hs = hdev + (k + 1);
+        double* vn = V->col(k + 1);
+        double* pn = P ? P->col(k + 1) : nullptr;
+        if (multi) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, grid, 0,
+                               tmp + 1, 0);
+            KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
+            hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
+                               pn, nullptr, 0, tmp + 1, hs);
+        } else {
+            hipLaunchKernelGGL((k_scale_store<A_PART>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
+                               pn, nrm_part, grid, nullptr, hs);
+        }
+        KH_HIP(hipGetLastError());
+    }
+    return fetch_scalars(ctx, hdev, k + 2, hcol_out);
+}
+
+int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,
+                int64_t rcol, double* nrm) {
+    KH_ARG(ctx && A && nrm, "kh_residual: NULL");
+    KH_TRY(check_vec(Bv, bcol, 1, "kh_residual(B)"));
+    KH_TRY(check_vec(X, xcol, 1, "kh_residual(X)"));
+    KH_TRY(check_vec(R, rcol, 1, "kh_residual(R)"));
+    KH_ARG(Bv->n == A->n_rows && R->n == A->n_rows, "kh_residual: dimension mismatch");
+    KH_ARG(!(R == X && rcol == xcol), "kh_residual: r must not alias x");
+    double* tmp = ctx->scal + SC_TMP;
+    if (A->kind == KH_MAT_CSR && A->nblk > 0) {
+        KH_TRY(apply_one(ctx, A, X->col(xcol), R->col(rcol), EPI_RES, Bv->col(bcol), tmp,
+                         ctx->nranks > 1 ? 0 : 2));
+        if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+        KH_TRY(fetch_scalars(ctx, tmp, 1, nrm));
+        if (ctx->nranks > 1) *nrm = sqrt(fabs(*nrm));
+        return 0;
+    }
+    KH_ARG(!(R == Bv && rcol == bcol), "kh_residual: r must not alias b for non-CSR operators");
+    KH_TRY(apply_one(ctx, A, X->col(xcol), R->col(rcol), EPI_NONE, nullptr, nullptr, 0));
+    KH_TRY(kh_waxpby(ctx, R, rcol, 1.0, Bv, bcol, -1.0, R, rcol));
+    return kh_nrm2(ctx, R, rcol, nrm);
+}
+
+int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
+                     double r2, double y0, kh_vec YK, int64_t ycol) {
+    KH_ARG(ctx, "kh_minres_update: NULL ctx");
+    KH_TRY(check_vec(V, k, 1, "kh_minres_update(V)"));
+    KH_TRY(check_vec(Wk, 0, 2, "kh_minres_update(W)"));
+    KH_TRY(check_vec(YK, ycol, 1, "kh_minres_update(yk)"));
+    KH_ARG(slot == 0 || slot == 1, "kh_minres_update: slot");
+    KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_minres_update: length mismatch");
+    const int64_t n = V->n;
+    hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, V->col(k),
+                       Wk->col(slot), Wk->col(1 - slot), r0, r1, r2, y0, YK->col(ycol));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
+                 int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
+                 double* rho_new) {
+    KH_ARG(ctx && rho_new, "kh_cg_update: NULL");
+    KH_TRY(check_vec(Pd, pcol, 1, "kh_cg_update(p)"));
+    KH_TRY(check_vec(AP, apcol, 1, "kh_cg_update(Ap)"));
+    KH_TRY(check_vec(YK, ycol, 1, "kh_cg_update(yk)"));
+    KH_TRY(check_vec(R, rcol, 1, "kh_cg_update(r)"));
+    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_update: Md must be diagonal");
+    if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_update(z)"));
+    const int64_t n = R->n;
+    KH_ARG(Pd->n == n && AP->n == n && YK->n == n, "kh_cg_update: length mismatch");
+    double* part = part_slot(ctx, SLOT_NRM);
+    const int grid = grid_lin(ctx, n);
+    if (Md)
+        hipLaunchKernelGGL((k_cg_update<true>), dim3(grid), dim3(BS), 0, ctx->stream, n, alpha,
+                           Pd->col(pcol), AP->col(apcol), YK->col(ycol), R->col(rcol), Md->diag,
+                           Z->col(zcol), part);
+    else
+        hipLaunchKernelGGL((k_cg_update<false>), dim3(grid), dim3(BS), 0, ctx->stream, n, alpha,
+                           Pd->col(pcol), AP->col(apcol), YK->col(ycol), R->col(rcol), nullptr, nullptr,
+                           part);
+    KH_HIP(hipGetLastError());
+    double* tmp = ctx->scal + SC_TMP;
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp, 0);
+    KH_HIP(hipGetLastError());
+    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+    return fetch_scalars(ctx, tmp, 1, rho_new);
+}
+
+}  // extern "C"

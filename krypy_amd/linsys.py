@@ -1,0 +1,704 @@
+"""Linear systems and Krylov solvers (CG, MINRES, GMRES, restarted GMRES) on the MI355X.
+
+Host-side mirror of ``krypy/linsys.py``: identical class names, constructor signatures,
+attributes and error behaviour; the solve still happens inside the constructor and a
+solver object *is* the result.  All N-vectors stay in HBM between iterations; attributes
+that the reference exposes as ndarrays (``xk``, ``x0``, ``MMlr0``, ``Mlr0``, ``V``, ``P``,
+``LinearSystem.Mlb`` ...) are downloaded lazily on first access.  The Hessenberg matrix,
+Givens rotations and the small triangular solves stay on the host like in the reference.
+
+Reference lines are cited as ``linsys.py:<line>`` (= ``/root/reference/krypy/linsys.py``).
+"""
+import warnings
+
+import numpy
+import scipy.linalg
+
+from . import _hip, utils
+from .utils import DVec
+
+__all__ = ["LinearSystem", "Cg", "Minres", "Gmres", "RestartedGmres"]
+
+
+class _LazyHost(object):
+    """Descriptor: attribute stored as a device vector, presented as an ``(N,1)`` ndarray."""
+
+    def __init__(self, name):
+        self.dev = "_" + name + "_dev"
+        self.host = "_" + name + "_host"
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        h = obj.__dict__.get(self.host)
+        if h is None:
+            d = obj.__dict__.get(self.dev)
+            if d is None:
+                return None
+            h = obj.__dict__[self.host] = d.download()
+        return h
+
+    def __set__(self, obj, value):
+        if isinstance(value, DVec):
+            obj.__dict__[self.dev] = value
+            obj.__dict__[self.host] = None
+        else:
+            obj.__dict__[self.host] = value
+            obj.__dict__[self.dev] = None
+
+
+def _dev_of(obj, name, ctx):
+    """Device view of a _LazyHost attribute (uploads a host-assigned value once)."""
+    d = obj.__dict__.get("_" + name + "_dev")
+    if d is None:
+        h = obj.__dict__.get("_" + name + "_host")
+        if h is None:
+            return None
+        d = obj.__dict__["_" + name + "_dev"] = DVec.from_host(h, ctx)
+    return d
+
+
+class LinearSystem(object):
+    Mlb = _LazyHost("Mlb")
+    MMlb = _LazyHost("MMlb")
+
+    def __init__(self, A, b, M=None, Minv=None, Ml=None, Mr=None, ip_B=None, normal=None,
+                 self_adjoint=False, positive_definite=False, exact_solution=None):
+        r"""Representation of a (preconditioned) linear system (linsys.py:12-128).
+
+        .. math:: M M_l A M_r y = M M_l b \quad\text{with}\quad x = M_r y
+
+        Same parameters as the reference.  ``A``, ``M``, ``Minv``, ``Ml``, ``Mr`` given as
+        ndarray / SciPy sparse are uploaded once and applied by HIP kernels (CSR SpMV, dense
+        GEMV, diagonal scaling); ``LinearOperator`` callables work through a host round trip.
+        ``b`` is uploaded once and stays resident.
+        """
+        self.N = N = len(b)
+        shape = (N, N)
+        self.A = utils.get_linearoperator(shape, A)
+        self.M = utils.get_linearoperator(shape, M)
+        self.Minv = utils.get_linearoperator(shape, Minv)
+        self.Ml = utils.get_linearoperator(shape, Ml)
+        self.Mr = utils.get_linearoperator(shape, Mr)
+        self.MlAMr = self.Ml * self.A * self.Mr
+        try:
+            self.ip_B = utils.get_linearoperator(shape, ip_B)
+        except TypeError:
+            self.ip_B = ip_B
+
+        self.flat_vecs, (self.b, self.exact_solution) = utils.shape_vecs(b, exact_solution)
+
+        self.self_adjoint = self_adjoint
+        if self_adjoint:
+            if normal is not None and not normal:
+                warnings.warn("Setting normal=True because self_adjoint=True is provided.")
+            normal = True
+        if normal is None:
+            normal = False
+        self.normal = normal
+        self.positive_definite = positive_definite
+        if self_adjoint and not normal:
+            raise utils.ArgumentError("self-adjointness implies normality")
+
+        self.dtype = utils.find_common_dtype(self.A, self.b, self.M, self.Ml, self.Mr, self.ip_B)
+        utils._require_real(self.dtype, "LinearSystem")
+
+        # device-resident right hand side and its preconditioned forms (linsys.py:119-122)
+        self._ctx = _hip.get_context()
+        self._b_dev = DVec.from_host(self.b, self._ctx)
+        self._plain = all(isinstance(op, utils.IdentityLinearOperator) for op in (self.M, self.Ml))
+        self.Mlb = self.Ml * self._b_dev
+        self.MMlb = self.M * _dev_of(self, "Mlb", self._ctx)
+        self.MMlb_norm = utils.norm(_dev_of(self, "Mlb", self._ctx),
+                                    _dev_of(self, "MMlb", self._ctx), ip_B=self.ip_B)
+
+    # ---- device side ----------------------------------------------------------------
+    def _residual_dev(self, z, compute_norm=False):
+        """``(MMlr, Mlr[, norm])`` as device vectors for a device ``z`` (None = zero vector)."""
+        ctx = self._ctx
+        if z is None:
+            out = (_dev_of(self, "MMlb", ctx), _dev_of(self, "Mlb", ctx))
+            return out + (self.MMlb_norm,) if compute_norm else out
+        Amat = self.A._device_matrix()
+        euclid = self.ip_B is None or isinstance(self.ip_B, utils.IdentityLinearOperator)
+        if self._plain and euclid and Amat is not None and compute_norm:
+            # fused r = b - A z and ||r|| (one pass over the matrix, no extra vector pass)
+            r = DVec(ctx.alloc(self.N, 1))
+            nrm = ctx.residual(Amat, self._b_dev.block, self._b_dev.col, z.block, z.col, r.block, 0)
+            return r, r, nrm
+        Az = self.A * z
+        r = DVec(ctx.alloc(self.N, 1))
+        ctx.waxpby(r.block, 0, 1.0, self._b_dev.block, self._b_dev.col, -1.0, Az.block, Az.col)
+        Mlr = self.Ml * r
+        MMlr = self.M * Mlr
+        if compute_norm:
+            return MMlr, Mlr, utils.norm(Mlr, MMlr, ip_B=self.ip_B)
+        return MMlr, Mlr
+
+    # ---- reference API ----------------------------------------------------------------
+    def get_residual(self, z, compute_norm=False):
+        r"""Residual :math:`r = M M_l (b - A z)` and optionally
+        :math:`\|M M_l (b-Az)\|_{M^{-1}}` (linsys.py:130-161); ``z`` is an ``(N,1)`` array
+        (or ``None`` for the cached right-hand-side quantities); returns ndarrays."""
+        if z is None:
+            if compute_norm:
+                return self.MMlb, self.Mlb, self.MMlb_norm
+            return self.MMlb, self.Mlb
+        zd = z if isinstance(z, DVec) else DVec.from_host(z, self._ctx)
+        res = self._residual_dev(zd, compute_norm)
+        out = (res[0].download(), res[1].download())
+        return out + (res[2],) if compute_norm else out
+
+    def get_ip_Minv_B(self):
+        """Inner product implicitly used with the preconditioner ``M`` (linsys.py:163-176)."""
+        if not isinstance(self.M, utils.IdentityLinearOperator):
+            if isinstance(self.Minv, utils.IdentityLinearOperator):
+                raise utils.ArgumentError(
+                    "Minv has to be provided for the evaluation of the inner "
+                    "product that is implicitly defined by M.")
+            if isinstance(self.ip_B, utils.LinearOperator):
+                return self.Minv * self.ip_B
+            else:
+                return lambda x, y: self.ip_B(x, self.Minv * y)
+        return self.ip_B
+
+    def __repr__(self):
+        ret = "LinearSystem {\n"
+        for k in ["A", "b", "M", "Minv", "Ml", "Mr", "ip_B", "normal", "self_adjoint",
+                  "positive_definite", "exact_solution"]:
+            op = self.__dict__.get(k)
+            if op is not None and not isinstance(op, utils.IdentityLinearOperator):
+                ret += "  " + k + ": " + op.__repr__() + "\n"
+        return ret + "}"
+
+
+class _KrylovSolver(object):
+    """Prototype of a Krylov subspace method for linear systems (linsys.py:277-517)."""
+
+    x0 = _LazyHost("x0")
+    xk = _LazyHost("xk")
+    MMlr0 = _LazyHost("MMlr0")
+    Mlr0 = _LazyHost("Mlr0")
+
+    def __init__(self, linear_system, x0=None, tol=1e-5, maxiter=None, explicit_residual=False,
+                 store_arnoldi=False, dtype=None):
+        r"""Init standard attributes and perform checks (linsys.py:280-405).
+
+        :param linear_system: a :class:`LinearSystem`.
+        :param x0: initial guess, ``(N,1)``/``(N,)`` array (a device :class:`~utils.DVec` is
+          accepted too, which is how restarts avoid a PCIe round trip).  Defaults to zero.
+        :param tol: tolerance for the relative residual norm
+          :math:`\|M M_l (b-A x_k)\|_{M^{-1}} / \|M M_l b\|_{M^{-1}}`.
+        :param maxiter: maximum number of iterations (default ``N``).
+        :param explicit_residual: compute the residual explicitly in each iteration.
+        :param store_arnoldi: expose ``V``, ``H`` (and ``P``) trimmed to the computed part.
+        :param dtype: optional dtype for the Arnoldi/Lanczos basis (real fp64 on the device).
+
+        Attributes after the solve: ``xk``, ``resnorms``, ``errnorms`` (if an exact solution was
+        given), ``iter``, and ``V``/``H``/``P`` with ``store_arnoldi``.  Non-convergence raises
+        :class:`~utils.ConvergenceError` carrying the solver.
+        """
+        if not isinstance(linear_system, LinearSystem):
+            raise utils.ArgumentError("linear_system is not an instance of LinearSystem")
+        self.linear_system = linear_system
+        self._ctx = linear_system._ctx
+        N = linear_system.N
+        self.maxiter = N if maxiter is None else maxiter
+        if isinstance(x0, DVec):
+            self.flat_vecs = False
+            self.x0 = x0
+        else:
+            self.flat_vecs, (x0,) = utils.shape_vecs(x0)
+            self.x0 = x0
+        self.explicit_residual = explicit_residual
+        self.store_arnoldi = store_arnoldi
+
+        self.x0 = self._get_initial_guess(self.x0)
+        x0d = _dev_of(self, "x0", self._ctx)
+        self.MMlr0, self.Mlr0, self.MMlr0_norm = self._get_initial_residual(x0d)
+
+        if x0d is None:
+            self.x0 = DVec.zeros(N, self._ctx)
+        self.tol = tol
+        self.xk = None
+
+        x0dtype = numpy.dtype(float)
+        self.dtype = utils._common_type([linear_system.dtype, x0dtype, dtype])
+        utils._require_real(self.dtype, "solver dtype")
+        self.MlAMr = linear_system.MlAMr
+        self.iter = 0
+        self.resnorms = []
+
+        if self.linear_system.MMlb_norm == 0:
+            z = DVec.zeros(N, self._ctx)
+            self.xk = z
+            self.x0 = z
+            self.resnorms.append(0.0)
+        else:
+            self.resnorms.append(self.MMlr0_norm / self.linear_system.MMlb_norm)
+
+        if self.linear_system.exact_solution is not None:
+            self.errnorms = []
+            self.errnorms.append(self._errnorm(self._get_xk(None)))
+
+        self._solve()
+        self._finalize()
+
+    def _errnorm(self, xk):
+        ctx = self._ctx
+        ex = self.linear_system.__dict__.get("_exact_dev")
+        if ex is None:
+            ex = self.linear_system.__dict__["_exact_dev"] = DVec.from_host(
+                self.linear_system.exact_solution, ctx)
+        d = DVec(ctx.alloc(self.linear_system.N, 1))
+        ctx.waxpby(d.block, 0, 1.0, ex.block, ex.col, -1.0, xk.block, xk.col)
+        return utils.norm(d, ip_B=self.linear_system.ip_B)
+
+    def _get_initial_guess(self, x0):
+        """Hook to preprocess the initial guess (linsys.py:407-413)."""
+        return x0
+
+    def _get_initial_residual(self, x0):
+        """Residual and its norm for the (device) initial guess (linsys.py:415-421)."""
+        return self.linear_system._residual_dev(x0, compute_norm=True)
+
+    def _get_xk(self, yk):
+        """``x0 + Mr*yk`` as a device vector (linsys.py:423-428)."""
+        x0 = _dev_of(self, "x0", self._ctx)
+        if yk is not None:
+            Mryk = self.linear_system.Mr * yk
+            xk = DVec(self._ctx.alloc(self.linear_system.N, 1))
+            self._ctx.waxpby(xk.block, 0, 1.0, x0.block, x0.col, 1.0, Mryk.block, Mryk.col)
+            return xk
+        return x0
+
+    def _finalize_iteration(self, yk, resnorm):
+        """Compute solution, error norm and residual norm if required (linsys.py:430-493).
+
+        :return: the explicit residual norm or ``None``."""
+        self.xk = None
+        xk = None
+        if self.linear_system.exact_solution is not None:
+            xk = self._get_xk(yk)
+            self.xk = xk
+            self.errnorms.append(self._errnorm(xk))
+        rkn = None
+        bnorm = self.linear_system.MMlb_norm
+        if self.explicit_residual or resnorm / bnorm <= self.tol or self.iter + 1 == self.maxiter:
+            if xk is None:
+                xk = self._get_xk(yk)
+                self.xk = xk
+            _, _, rkn = self.linear_system._residual_dev(xk, compute_norm=True)
+            self.resnorms.append(rkn / bnorm)
+            if self.resnorms[-1] > self.tol:
+                if self.iter + 1 == self.maxiter:
+                    self._finalize()
+                    raise utils.ConvergenceError(
+                        ("No convergence in last iteration "
+                         f"(maxiter: {self.maxiter}, "
+                         f"residual: {self.resnorms[-1]})."),
+                        self)
+                elif not self.explicit_residual and resnorm / bnorm <= self.tol:
+                    warnings.warn(
+                        "updated residual is below tolerance, explicit residual is NOT! "
+                        f"(upd={resnorm} <= tol={self.tol} < exp={self.resnorms[-1]})")
+        else:
+            self.resnorms.append(resnorm / bnorm)
+        return rkn
+
+    def _finalize(self):
+        pass
+
+    @staticmethod
+    def operations(nsteps):
+        """Number of operations needed for nsteps of the solver (linsys.py:498-510)."""
+        raise NotImplementedError("operations() has to be overridden by the derived solver class.")
+
+    def _solve(self):
+        raise NotImplementedError("_solve has to be overridden by the derived solver class.")
+
+    def _repr(self, title, extra=()):
+        def ends(v):
+            return "[{}, ..., {}]".format(v[0], v[-1])
+        lines = [title,
+                 "    MMlr0 = " + ends(self.MMlr0),
+                 "    MMlr0_norm = {}".format(self.MMlr0_norm),
+                 "    MlAMr: {} x {} matrix".format(*self.MlAMr.shape),
+                 "    Mlr0: " + ends(self.Mlr0)]
+        lines += list(extra)
+        lines += ["    flat_vecs: {}".format(self.flat_vecs),
+                  "    store_arnoldi: {}".format(self.store_arnoldi)]
+        if hasattr(self, "ortho"):
+            lines.append("    ortho: {}".format(self.ortho))
+        lines += ["    tol: {}".format(self.tol),
+                  "    maxiter: {}".format(self.maxiter),
+                  "    iter: {}".format(self.iter),
+                  "    explicit residual: {}".format(self.explicit_residual),
+                  "    resnorms: [{}, ..., {}]".format(self.resnorms[0], self.resnorms[-1]),
+                  "    x0: " + ends(self.x0),
+                  "    xk: " + ends(self.xk)]
+        return "\n".join(lines)
+
+
+class Cg(_KrylovSolver):
+    r"""Preconditioned CG method (linsys.py:520-708).
+
+    One device pass per recurrence: the operator application, ``<p, Ap>``, then a fused
+    kernel for ``yk += alpha p; r -= alpha Ap; z = M r; <r, z>`` when ``M`` is the identity or
+    a diagonal (Jacobi) operator, and the direction update ``p = z + beta p``.
+    """
+
+    def __init__(self, linear_system, **kwargs):
+        if not linear_system.self_adjoint or not linear_system.positive_definite:
+            warnings.warn("Cg applied to a non-self-adjoint or non-definite "
+                          "linear system. Consider using Minres or Gmres.")
+        super(Cg, self).__init__(linear_system, **kwargs)
+
+    def __repr__(self):
+        return self._repr("krypy CG object")
+
+    def _solve(self):
+        ls = self.linear_system
+        ctx = self._ctx
+        N = ls.N
+        euclid = ls.ip_B is None or isinstance(ls.ip_B, utils.IdentityLinearOperator)
+        M_id = isinstance(ls.M, utils.IdentityLinearOperator)
+        Md = None if M_id else ls.M._device_matrix()
+        fused = euclid and (M_id or (Md is not None and Md.kind == "diag"))
+
+        yk = DVec(ctx.alloc(N, 1))
+        self.rhos = rhos = [self.MMlr0_norm ** 2]
+        # working copies (linsys.py:603-607)
+        self._Mlrk = _dev_of(self, "Mlr0", ctx).copy()
+        self._MMlrk = self._Mlrk if M_id else _dev_of(self, "MMlr0", ctx).copy()
+        p = _dev_of(self, "MMlr0", ctx).copy()
+        Ap = DVec(ctx.alloc(N, 1))
+        self.iter = 0
+
+        if self.store_arnoldi:
+            self._Vb = ctx.alloc(N, self.maxiter + 1)
+            if self.MMlr0_norm > 0:
+                ctx.vdiv(self._Vb, 0, self._MMlrk.block, self._MMlrk.col, float(self.MMlr0_norm))
+            self._Pb = None
+            if not M_id:
+                self._Pb = ctx.alloc(N, self.maxiter + 1)
+                if self.MMlr0_norm > 0:
+                    ctx.vdiv(self._Pb, 0, self._Mlrk.block, self._Mlrk.col, float(self.MMlr0_norm))
+            self.H = numpy.zeros((self.maxiter + 1, self.maxiter))
+            alpha_old = 0
+
+        while self.resnorms[-1] > self.tol and self.iter < self.maxiter:
+            k = self.iter
+            if k > 0:
+                # p = MMlrk + rhos[-1]/rhos[-2] * p   (linsys.py:627)
+                omega = rhos[-1] / rhos[-2]
+                ctx.waxpby(p.block, p.col, 1.0, self._MMlrk.block, self._MMlrk.col, float(omega),
+                           p.block, p.col)
+            self.MlAMr._apply_dev(p.block, p.col, Ap.block, Ap.col, 1)
+            pAp = utils._inner_dev(p.block, p.col, 1, Ap.block, Ap.col, 1, ls.ip_B)[0, 0]
+            alpha = rhos[-1] / pAp
+            if abs(numpy.imag(alpha)) > 1e-12:
+                warnings.warn(
+                    f"Iter {k}: abs(alpha.imag) = {abs(alpha.imag)} > 1e-12. "
+                    "Is your operator self-adjoint in the provided inner product?")
+            alpha = float(numpy.real(alpha))
+
+            if self.store_arnoldi:
+                if k > 0:
+                    self.H[k - 1, k] = self.H[k, k - 1]
+                    self.H[k, k] = (1.0 + alpha * omega / alpha_old) / alpha
+                else:
+                    self.H[k, k] = 1.0 / alpha
+
+            if fused:
+                rho_new = ctx.cg_update(alpha, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
+                                        self._Mlrk.block, self._Mlrk.col, None if M_id else Md,
+                                        None if M_id else self._MMlrk.block,
+                                        0 if M_id else self._MMlrk.col)
+                MMlrk_norm = numpy.sqrt(abs(rho_new))
+            else:
+                ctx.waxpby(yk.block, yk.col, 1.0, yk.block, yk.col, alpha, p.block, p.col)
+                ctx.waxpby(self._Mlrk.block, self._Mlrk.col, 1.0, self._Mlrk.block,
+                           self._Mlrk.col, -alpha, Ap.block, Ap.col)
+                self._MMlrk = ls.M * self._Mlrk
+                MMlrk_norm = utils.norm(self._Mlrk, self._MMlrk, ip_B=ls.ip_B)
+            rhos.append(MMlrk_norm ** 2)
+
+            if self.store_arnoldi:
+                sgn = float((-1) ** (k + 1))
+                ctx.vdiv(self._Vb, k + 1, self._MMlrk.block, self._MMlrk.col, sgn * MMlrk_norm)
+                if self._Pb is not None:
+                    ctx.vdiv(self._Pb, k + 1, self._Mlrk.block, self._Mlrk.col, sgn * MMlrk_norm)
+                self.H[k + 1, k] = numpy.sqrt(rhos[-1] / rhos[-2]) / alpha
+                alpha_old = alpha
+
+            rkn = self._finalize_iteration(yk, MMlrk_norm)
+            if rkn is not None:
+                rhos[-1] = rkn ** 2
+            self.iter += 1
+
+        if self.xk is None:
+            self.xk = self._get_xk(yk)
+
+    # the reference keeps Mlrk / MMlrk as ndarray attributes
+    @property
+    def Mlrk(self):
+        return self._Mlrk.download()
+
+    @property
+    def MMlrk(self):
+        return self._MMlrk.download()
+
+    def _finalize(self):
+        super(Cg, self)._finalize()
+        if self.store_arnoldi and "V" not in self.__dict__ and hasattr(self, "_Vb"):
+            self.V = self._Vb.download(0, self.iter + 1)
+            if self._Pb is not None:
+                self.P = self._Pb.download()
+            self.H = self.H[: self.iter + 1, : self.iter]
+
+    @staticmethod
+    def operations(nsteps):
+        """Number of operations needed for nsteps of CG (linsys.py:698-708)."""
+        return {"A": 1 + nsteps, "M": 2 + nsteps, "Ml": 2 + nsteps, "Mr": 1 + nsteps,
+                "ip_B": 2 + 2 * nsteps, "axpy": 2 + 2 * nsteps}
+
+
+class _ArnoldiBasisMixin(object):
+    """``V`` / ``P`` of Arnoldi-based solvers: device blocks, downloaded on access."""
+
+    @property
+    def V(self):
+        v = self.__dict__.get("_V_trim")
+        if v is not None:
+            return v
+        return self._basis_source()._V.download()
+
+    @property
+    def P(self):
+        p = self.__dict__.get("_P_trim")
+        if p is not None:
+            return p
+        src = self._basis_source()
+        if src._P is None:
+            raise AttributeError("P")
+        return src._P.download()
+
+
+class Minres(_ArnoldiBasisMixin, _KrylovSolver):
+    r"""Preconditioned MINRES method (linsys.py:711-875).
+
+    Lanczos three-term recurrence on the device (:class:`~utils.Arnoldi` with
+    ``ortho='lanczos'``: SpMV, two fused axpy/dot kernels, Jacobi scaling fused into the norm),
+    the 4x1 ``R`` QR update with two remembered Givens rotations on the host, and one fused
+    kernel for ``z = (v_k - R0 W0 - R1 W1)/R2; W <- [W1, z]; yk += y0 z``.
+
+    ``lanczos``: the Lanczos relation (an :class:`~utils.Arnoldi`).
+    """
+
+    def __init__(self, linear_system, ortho="lanczos", **kwargs):
+        if not linear_system.self_adjoint:
+            warnings.warn("Minres applied to a non-self-adjoint "
+                          "linear system. Consider using Gmres.")
+        self.ortho = ortho
+        super(Minres, self).__init__(linear_system, **kwargs)
+
+    def __repr__(self):
+        return self._repr("krypy MINRES object")
+
+    def _basis_source(self):
+        return self.lanczos
+
+    def _solve(self):
+        ls = self.linear_system
+        ctx = self._ctx
+        N = ls.N
+        self.lanczos = utils.Arnoldi(
+            self.MlAMr, _dev_of(self, "Mlr0", ctx), maxiter=self.maxiter, ortho=self.ortho,
+            M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B)
+
+        W = ctx.alloc(N, 2)     # the two remembered direction vectors (linsys.py:807)
+        slot = 0                # column of W that currently holds W0
+        y = [self.MMlr0_norm, 0.0]
+        G2 = None
+        G1 = None
+        yk = DVec(ctx.alloc(N, 1))
+
+        def rot(G, u, v):
+            return G[0] * u + G[1] * v, -G[1] * u + G[0] * v
+
+        while (self.resnorms[-1] > self.tol and self.lanczos.iter < self.lanczos.maxiter
+               and not self.lanczos.invariant):
+            k = self.iter = self.lanczos.iter
+            self.lanczos.advance()
+            H = self.lanczos.H
+            # QR update of the Lanczos matrix (linsys.py:826-841), scalars only
+            R0 = 0.0
+            R1 = float(H[k - 1, k])   # k == 0 reads H[-1, 0] like the reference: zero
+            if G1 is not None:
+                R0, R1 = rot(G1, R0, R1)
+            R2, R3 = float(H[k, k]), float(H[k + 1, k])
+            if G2 is not None:
+                R1, R2 = rot(G2, R1, R2)
+            G1 = G2
+            g = utils.Givens(numpy.array([[R2], [R3]]))
+            G2 = (float(g.c), float(g.s))
+            R2 = float(g.r)
+            y = list(rot(G2, y[0], y[1]))
+            # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
+            ctx.minres_update(self.lanczos._V, k, W, slot, R0, R1, R2, float(y[0]), yk.block, yk.col)
+            slot = 1 - slot
+            y = [y[1], 0.0]
+            self._finalize_iteration(yk, numpy.abs(y[0]))
+
+        if self.xk is None:
+            self.xk = self._get_xk(yk)
+
+    def _finalize(self):
+        super(Minres, self)._finalize()
+        if self.store_arnoldi and hasattr(self, "lanczos"):
+            got = self.lanczos.get()
+            self._V_trim, self.H = got[0], got[1]
+            if not isinstance(self.linear_system.M, utils.IdentityLinearOperator):
+                self._P_trim = got[2]
+
+    @staticmethod
+    def operations(nsteps):
+        """Number of operations needed for nsteps of MINRES (linsys.py:864-874)."""
+        return {"A": 1 + nsteps, "M": 2 + nsteps, "Ml": 2 + nsteps, "Mr": 1 + nsteps,
+                "ip_B": 2 + 2 * nsteps, "axpy": 4 + 8 * nsteps}
+
+
+class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
+    r"""Preconditioned GMRES method (linsys.py:877-1018).
+
+    Per iteration one device call (:meth:`utils.Arnoldi.advance`: SpMV, the Gram-Schmidt
+    chain against the growing basis, norm, normalise) and an O(k) host update of the Givens QR
+    of the Hessenberg matrix.  ``x_k = x_0 + M_r V_k R_k^{-1} y`` is formed on the device
+    only when needed (convergence test with the explicit residual, last iteration).
+    """
+
+    def __init__(self, linear_system, ortho="mgs", **kwargs):
+        self.ortho = ortho
+        super(Gmres, self).__init__(linear_system, **kwargs)
+
+    def __repr__(self):
+        return self._repr("krypy GMRES object", extra=(
+            "    R: {} x {} matrix".format(*self.R.shape),
+            "    V: {} x {} matrix".format(self.linear_system.N, self.maxiter + 1)))
+
+    def _basis_source(self):
+        return self.arnoldi
+
+    def _get_xk(self, y):
+        if y is None:
+            return _dev_of(self, "x0", self._ctx)
+        k = self.arnoldi.iter
+        if k > 0:
+            yy = scipy.linalg.solve_triangular(self.R[:k, :k], y)
+            ctx = self._ctx
+            yk = DVec(ctx.alloc(self.linear_system.N, 1))
+            ctx.gemm_nn(self.arnoldi._V, 0, k, yy, 1.0, 0.0, yk.block, 0)
+            return super(Gmres, self)._get_xk(yk)
+        return _dev_of(self, "x0", self._ctx)
+
+    def _solve(self):
+        ls = self.linear_system
+        ctx = self._ctx
+        self.arnoldi = utils.Arnoldi(
+            self.MlAMr, _dev_of(self, "Mlr0", ctx), maxiter=self.maxiter, ortho=self.ortho,
+            M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B)
+        cs = []  # Givens rotations as (c, s) floats
+        self.R = numpy.zeros([self.maxiter + 1, self.maxiter], dtype=self.dtype)
+        y = numpy.zeros((self.maxiter + 1, 1), dtype=self.dtype)
+        y[0] = self.MMlr0_norm
+        R = self.R
+
+        while (self.resnorms[-1] > self.tol and self.arnoldi.iter < self.arnoldi.maxiter
+               and not self.arnoldi.invariant):
+            k = self.iter = self.arnoldi.iter
+            self.arnoldi.advance()
+            # new Hessenberg column through the previous rotations (linsys.py:980-991); plain
+            # floats: k tiny numpy calls per step would cost more than the device step itself
+            col = self.arnoldi.H[: k + 2, k].tolist()
+            for i in range(k):
+                c, s = cs[i]
+                t0, t1 = col[i], col[i + 1]
+                col[i] = c * t0 + s * t1
+                col[i + 1] = -s * t0 + c * t1
+            g = utils.Givens(numpy.array([[col[k]], [col[k + 1]]]))
+            c, s = float(g.c), float(g.s)
+            cs.append((c, s))
+            t0, t1 = col[k], col[k + 1]
+            col[k] = c * t0 + s * t1
+            col[k + 1] = -s * t0 + c * t1
+            R[: k + 2, k] = col
+            t0, t1 = float(y[k, 0]), float(y[k + 1, 0])
+            y[k, 0] = c * t0 + s * t1
+            y[k + 1, 0] = -s * t0 + c * t1
+            self._finalize_iteration(y[: k + 1], abs(y[k + 1, 0]))
+
+        if self.xk is None:
+            self.xk = self._get_xk(y[: self.arnoldi.iter])
+
+    def _finalize(self):
+        super(Gmres, self)._finalize()
+        if self.store_arnoldi and hasattr(self, "arnoldi"):
+            got = self.arnoldi.get()
+            self._V_trim, self.H = got[0], got[1]
+            if not isinstance(self.linear_system.M, utils.IdentityLinearOperator):
+                self._P_trim = got[2]
+
+    @staticmethod
+    def operations(nsteps):
+        """Number of operations needed for nsteps of GMRES (linsys.py:1008-1018)."""
+        return {"A": 1 + nsteps, "M": 2 + nsteps, "Ml": 2 + nsteps, "Mr": 1 + nsteps,
+                "ip_B": 2 + nsteps + nsteps * (nsteps + 1) / 2,
+                "axpy": 4 + 2 * nsteps + nsteps * (nsteps + 1) / 2}
+
+
+class _RestartedSolver(object):
+    """Base class for restarted solvers (linsys.py:1021-1072).
+
+    The last approximation is handed to the next cycle as a device vector (no host round
+    trip); ``xk`` downloads on access like for the plain solvers.
+    """
+
+    xk = _LazyHost("xk")
+
+    def __init__(self, Solver, linear_system, max_restarts=0, **kwargs):
+        """:param max_restarts: maximum number of restarts; the maximum number of iterations
+        is ``(max_restarts+1)*maxiter``."""
+        self.xk = None
+        kwargs = dict(kwargs)
+        self.resnorms = [numpy.inf]
+        if linear_system.exact_solution is not None:
+            self.errnorms = [numpy.inf]
+        tol = None
+        restart = 0
+        while restart == 0 or (self.resnorms[-1] > tol and restart <= max_restarts):
+            try:
+                xk_dev = self.__dict__.get("_xk_dev")
+                if xk_dev is not None:
+                    kwargs.update({"x0": xk_dev})
+                sol = Solver(linear_system, **kwargs)
+            except utils.ConvergenceError as e:
+                sol = e.solver
+            self.xk = _dev_of(sol, "xk", sol._ctx)
+            tol = sol.tol
+            del self.resnorms[-1]
+            self.resnorms += sol.resnorms
+            if linear_system.exact_solution is not None:
+                del self.errnorms[-1]
+                self.errnorms += sol.errnorms
+            restart += 1
+        if self.resnorms[-1] > tol:
+            raise utils.ConvergenceError(f"No convergence after {max_restarts} restarts.", self)
+
+
+class RestartedGmres(_RestartedSolver):
+    """Restarted GMRES method (linsys.py:1075-1081): ``GMRES(m)`` is
+    ``RestartedGmres(ls, maxiter=m, max_restarts=R)``."""
+
+    def __init__(self, *args, **kwargs):
+        super(RestartedGmres, self).__init__(Gmres, *args, **kwargs)

@@ -1,0 +1,1110 @@
+"""Krylov kernel utilities: operator algebra, inner products, Givens, Arnoldi, projections.
+
+Host-side mirror of ``krypy/utils.py`` for the hot path named in SURVEY.md section 8
+(same names, argument meaning and error behaviour), with every N-vector operation
+executed on the MI355X through :mod:`krypy_amd._hip`.  Small dense algebra
+(Hessenberg, Givens, d x d factors) stays on the host exactly as in the reference.
+
+Vectors that never need to leave the GPU are handled as :class:`DVec` (a column
+of a :class:`~krypy_amd._hip.DeviceVectors` block); the public functions accept and
+return NumPy arrays with the reference's shapes.
+
+Reference lines are cited as ``utils.py:<line>`` (= ``/root/reference/krypy/utils.py``).
+"""
+import warnings
+
+import numpy
+import scipy.linalg
+import scipy.sparse
+from scipy.linalg import blas
+
+from . import _hip
+from ._hip import BackendError  # noqa: F401  (re-exported)
+
+__all__ = [
+    "ArgumentError", "AssumptionError", "ConvergenceError", "LinearOperatorError",
+    "InnerProductError", "RuntimeError", "BackendError",
+    "Arnoldi", "Givens", "IdentityLinearOperator", "LinearOperator", "MatrixLinearOperator",
+    "ZeroLinearOperator", "Projection", "arnoldi", "arnoldi_res", "find_common_dtype",
+    "get_linearoperator", "inner", "ip_euclid", "norm", "norm_squared", "orthonormality", "qr",
+    "shape_vec", "shape_vecs", "DVec",
+]
+
+
+# ----------------------------------------------------------------------------------------
+# exceptions (utils.py:62-103)
+# ----------------------------------------------------------------------------------------
+class ArgumentError(Exception):
+    """Raised when an argument is invalid (krypy's analogue of ValueError)."""
+
+
+class AssumptionError(Exception):
+    """Raised when valid arguments turn out to violate an assumption of the method."""
+
+
+class ConvergenceError(Exception):
+    """Raised when a method did not converge; ``solver`` holds the last approximation."""
+
+    def __init__(self, msg, solver):
+        super(ConvergenceError, self).__init__(msg)
+        self.solver = solver
+
+
+class LinearOperatorError(Exception):
+    """Raised when a :class:`LinearOperator` cannot be applied."""
+
+
+class InnerProductError(Exception):
+    """Raised when the inner product is indefinite."""
+
+
+class RuntimeError(Exception):  # noqa: A001  (same name as in the reference, utils.py:102)
+    """Raised for errors that do not fit in any other exception."""
+
+
+# ----------------------------------------------------------------------------------------
+# dtype / shape helpers (utils.py:106-143)
+# ----------------------------------------------------------------------------------------
+def _common_type(dtypes):
+    ts = [numpy.dtype(t) for t in dtypes if t is not None]
+    return numpy.result_type(*ts) if ts else numpy.dtype(float)
+
+
+def _is_sparse(A):
+    # scipy.sparse.isspmatrix is False for the newer sparse *arrays*; accept both
+    return scipy.sparse.issparse(A)
+
+
+def find_common_dtype(*args):
+    """Common dtype of ndarrays, sparse matrices and LinearOperators (others are ignored)."""
+    dtypes = []
+    for arg in args:
+        if type(arg) is numpy.ndarray or _is_sparse(arg) or isinstance(arg, (LinearOperator, DVec)):
+            if hasattr(arg, "dtype"):
+                dtypes.append(arg.dtype)
+            else:
+                warnings.warn("object %s does not have a dtype." % arg.__repr__)
+    return _common_type(dtypes)
+
+
+def shape_vec(x):
+    """Take a (n,) ndarray and return it as (n,1) ndarray."""
+    return numpy.reshape(x, (x.shape[0], 1))
+
+
+def shape_vecs(*args):
+    """Reshape all ndarrays with ``shape==(n,)`` to ``shape==(n,1)``; others pass through."""
+    ret_args = []
+    flat_vecs = True
+    for arg in args:
+        if type(arg) is numpy.ndarray:
+            if len(arg.shape) == 1:
+                arg = shape_vec(arg)
+            else:
+                flat_vecs = False
+        ret_args.append(arg)
+    return flat_vecs, ret_args
+
+
+def _require_real(dtype, what):
+    if numpy.dtype(dtype).kind == "c":
+        raise NotImplementedError(
+            "%s is complex: the MI355X kernels of this round are real fp64 only "
+            "(complex c128 kernels are a SURVEY.md 8(f) 'next' row); there is no CPU fallback."
+            % what)
+
+
+# ----------------------------------------------------------------------------------------
+# device vector view
+# ----------------------------------------------------------------------------------------
+class DVec(object):
+    """One N-vector resident in HBM: column ``col`` of a DeviceVectors ``block``."""
+
+    __slots__ = ("block", "col")
+    dtype = numpy.dtype(numpy.float64)
+
+    def __init__(self, block, col=0):
+        self.block, self.col = block, col
+
+    @property
+    def n(self):
+        return self.block.n
+
+    @property
+    def shape(self):
+        return (self.block.n, 1)
+
+    @property
+    def ctx(self):
+        return self.block.ctx
+
+    def download(self):
+        """Host copy with the reference's ``(N, 1)`` shape."""
+        return numpy.ascontiguousarray(self.block.download(self.col, 1))
+
+    def copy(self):
+        out = self.ctx.alloc(self.n, 1)
+        out.copy_from(0, self.block, self.col, 1)
+        return DVec(out, 0)
+
+    @staticmethod
+    def from_host(x, ctx=None):
+        ctx = _hip.get_context() if ctx is None else ctx
+        x = numpy.asarray(x)
+        _require_real(x.dtype, "vector")
+        if x.ndim == 2 and x.shape[1] != 1:
+            raise ArgumentError("expected a single column, got shape %s" % (x.shape,))
+        return DVec(ctx.upload(x.reshape(-1, 1)), 0)
+
+    @staticmethod
+    def zeros(n, ctx=None):
+        ctx = _hip.get_context() if ctx is None else ctx
+        return DVec(ctx.alloc(n, 1), 0)
+
+
+def _as_dvec(x, ctx=None):
+    return x if isinstance(x, DVec) else DVec.from_host(x, ctx)
+
+
+def _upload_block(X, ctx=None):
+    """(N,k) host array or DeviceVectors -> DeviceVectors."""
+    if isinstance(X, _hip.DeviceVectors) or hasattr(X, "download") and hasattr(X, "ncols"):
+        return X
+    ctx = _hip.get_context() if ctx is None else ctx
+    X = numpy.asarray(X)
+    _require_real(X.dtype, "array")
+    return ctx.upload(X)
+
+
+# ----------------------------------------------------------------------------------------
+# inner products and norms (utils.py:146-238)
+# ----------------------------------------------------------------------------------------
+def ip_euclid(X, Y):
+    """Euclidean inner product ``X^* Y`` with ``shape==(m,n)`` (utils.py:146-157), on device."""
+    return inner(X, Y)
+
+
+def _inner_dev(Xb, x0, nx, Yb, y0, ny, ip_B=None):
+    """<X[:, x0:x0+nx], Y[:, y0:y0+ny]> for device blocks -> (nx, ny) host array."""
+    ctx = Xb.ctx
+    if ip_B is None or isinstance(ip_B, IdentityLinearOperator):
+        return ctx.gemm_tn(Xb, x0, nx, Yb, y0, ny)
+    N = Xb.n
+    try:
+        B = get_linearoperator((N, N), ip_B)
+    except TypeError:
+        # user callable (X, Y) -> (m, n): it gets host arrays, like in the reference (utils.py:189)
+        return numpy.asarray(ip_B(Xb.download(x0, nx), Yb.download(y0, ny)))
+    # operator B is applied to the thinner side (utils.py:190-193)
+    if nx > ny:
+        T = ctx.alloc(N, nx)
+        B._apply_dev(Xb, x0, T, 0, nx)
+        return ctx.gemm_tn(T, 0, nx, Yb, y0, ny)
+    T = ctx.alloc(N, ny)
+    B._apply_dev(Yb, y0, T, 0, ny)
+    return ctx.gemm_tn(Xb, x0, nx, T, 0, ny)
+
+
+def inner(X, Y, ip_B=None):
+    """Euclidean and non-Euclidean inner product (utils.py:160-193).
+
+    :param X: array with ``shape==(N,m)`` (or a device block / :class:`DVec`).
+    :param Y: array with ``shape==(N,n)``.
+    :param ip_B: ``None`` (Euclidean), a self-adjoint positive definite operator ``B``
+        (array / sparse / LinearOperator: ``X^* B Y``) or a callable ``(X, Y) -> <X,Y>``.
+    :return: ``(m,n)`` ndarray, always 2-dimensional.
+    """
+    Xb, x0, nx = _block_of(X)
+    Yb, y0, ny = _block_of(Y, Xb.ctx)
+    if Xb.n != Yb.n:
+        raise ArgumentError("inner: X and Y have different lengths")
+    if nx == 0 or ny == 0:
+        return numpy.zeros((nx, ny))
+    return _inner_dev(Xb, x0, nx, Yb, y0, ny, ip_B)
+
+
+def _block_of(X, ctx=None):
+    if isinstance(X, DVec):
+        return X.block, X.col, 1
+    if hasattr(X, "download") and hasattr(X, "ncols"):
+        return X, 0, X.ncols
+    X = numpy.asarray(X)
+    if X.ndim != 2:
+        raise ArgumentError("expected a 2-dimensional array")
+    b = _upload_block(X, ctx)
+    return b, 0, X.shape[1]
+
+
+def norm_squared(x, Mx=None, inner_product=ip_euclid):
+    """Squared norm w.r.t. a given scalar product (utils.py:196-211)."""
+    assert len(x.shape) == 2
+    rho = inner_product(x, x) if Mx is None else inner_product(x, Mx)
+    if rho.shape == (1, 1):
+        if abs(rho[0, 0].imag) > abs(rho[0, 0]) * 1e-10 or rho[0, 0].real < 0.0:
+            raise InnerProductError("<x,Mx> = %g. Is the inner product indefinite?" % rho[0, 0])
+    return numpy.linalg.norm(rho, 2)
+
+
+def norm(x, y=None, ip_B=None):
+    r"""Norm :math:`\sqrt{\langle x,y\rangle}` (utils.py:214-238); ``y=None`` means ``y=x``."""
+    euclid = ip_B is None or isinstance(ip_B, IdentityLinearOperator)
+    if y is None and euclid:
+        xb, x0, nx = _block_of(x)
+        if nx == 1:
+            return xb.ctx.nrm2(xb, x0)
+        return numpy.linalg.norm(xb.download(x0, nx), 2)  # matrix 2-norm of a small panel
+    if y is None:
+        y = x
+    ip = inner(x, y, ip_B=ip_B)
+    nrm_diag = numpy.linalg.norm(numpy.diag(ip), 2)
+    nrm_diag_imag = numpy.linalg.norm(numpy.imag(numpy.diag(ip)), 2)
+    if nrm_diag_imag > nrm_diag * 1e-10:
+        raise InnerProductError(
+            "inner product defined by ip_B not positive definite? "
+            "||diag(ip).imag||/||diag(ip)||=%g" % (nrm_diag_imag / nrm_diag))
+    return numpy.sqrt(numpy.linalg.norm(ip, 2))
+
+
+def orthonormality(V, ip_B=None):
+    """:math:`\\| I_n - \\langle V,V \\rangle \\|_2` (utils.py:297-305)."""
+    G = inner(V, V, ip_B=ip_B)
+    return numpy.linalg.norm(numpy.eye(G.shape[0]) - G, 2)
+
+
+def arnoldi_res(A, V, H, ip_B=None):
+    """Arnoldi residual ``||A V_{n-1} - V_n H||`` or ``||A V_n - V_n H_n||`` (utils.py:308-329)."""
+    N = V.shape[0]
+    invariant = H.shape[0] == H.shape[1]
+    A = get_linearoperator((N, N), A)
+    res = A * (V if invariant else V[:, :-1]) - numpy.dot(V, H)
+    return norm(res, ip_B=ip_B)
+
+
+# ----------------------------------------------------------------------------------------
+# Givens rotation (utils.py:405-436) - host, O(1)
+# ----------------------------------------------------------------------------------------
+class Givens(object):
+    def __init__(self, x):
+        """Givens rotation ``G=[[c,s],[-conj(s),c]]`` with ``G x = [r, 0]^T`` (BLAS ``drotg``
+        sign convention, exactly as the reference obtains it)."""
+        if x.shape != (2, 1):
+            raise ArgumentError("x is not a vector of shape (2,1)")
+        a = x[0].item()
+        b = x[1].item()
+        if numpy.isreal(x).all():
+            a = numpy.real(a)
+            b = numpy.real(b)
+            c, s = blas.drotg(a, b)
+        else:
+            c, s = blas.zrotg(a, b)
+        self.c = c
+        self.s = s
+        self.r = c * a + s * b
+        self.G = numpy.array([[c, s], [-numpy.conj(s), c]])
+
+    def apply(self, x):
+        """Apply the rotation to a ``(2, m)`` array."""
+        return numpy.dot(self.G, x)
+
+
+# ----------------------------------------------------------------------------------------
+# linear operators (utils.py:1365-1602)
+# ----------------------------------------------------------------------------------------
+def _isintlike(x):
+    try:
+        return bool(int(x) == x)
+    except (TypeError, ValueError):
+        return False
+
+
+class LinearOperator(object):
+    """Linear operator ``C^n -> C^m`` defined by callables acting on ``(n, k)`` arrays.
+
+    Same constructor and algebra as the reference (utils.py:1365-1456).  In addition every
+    operator can act on device-resident vectors (:meth:`_apply_dev`); operators built from
+    user callables do so through a download -> callback -> upload round trip, which is
+    correct but slow - matrices (ndarray / CSR / diagonal) run as HIP kernels.
+    """
+
+    def __init__(self, shape, dtype, dot=None, dot_adj=None):
+        if len(shape) != 2 or not _isintlike(shape[0]) or not _isintlike(shape[1]):
+            raise LinearOperatorError("shape must be (m,n) with m and n integer")
+        self.shape = shape
+        self.dtype = numpy.dtype(dtype)  # defaults to float64
+        if dot is None and dot_adj is None:
+            raise LinearOperatorError("dot or dot_adj have to be defined")
+        self._dot = dot
+        self._dot_adj = dot_adj
+        self._tmp = {}
+
+    # -- host API ---------------------------------------------------------------------
+    def dot(self, X):
+        X = numpy.asanyarray(X)
+        m, n = self.shape
+        if X.shape[0] != n:
+            raise LinearOperatorError("dimension mismatch")
+        if self._dot is None:
+            raise LinearOperatorError("dot undefined")
+        if X.shape[1] == 0:
+            return numpy.zeros(X.shape)
+        return self._dot(X)
+
+    def dot_adj(self, X):
+        X = numpy.asanyarray(X)
+        m, n = self.shape
+        if X.shape[0] != m:
+            raise LinearOperatorError("dimension mismatch")
+        if self._dot_adj is None:
+            raise LinearOperatorError("dot_adj undefined")
+        if X.shape[1] == 0:
+            return numpy.zeros(X.shape)
+        return self._dot_adj(X)
+
+    @property
+    def adj(self):
+        return _AdjointLinearOperator(self)
+
+    # -- device API -------------------------------------------------------------------
+    def _device_matrix(self):
+        """The DeviceMatrix this operator *is* (plain matrices only), else None."""
+        return None
+
+    def _scratch(self, ctx, n, ncols, key=0):
+        k = (id(ctx), n, ncols, key)
+        buf = self._tmp.get(k)
+        if buf is None:
+            buf = self._tmp[k] = ctx.alloc(n, ncols)
+        return buf
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        """``Y[:, ycol:ycol+ncols] = self * X[:, xcol:xcol+ncols]`` for device blocks.
+
+        Default: the operator is a user callable on host arrays (utils.py:1371-1390 contract),
+        so the columns make a host round trip."""
+        if self._dot is None:
+            raise LinearOperatorError("dot undefined")
+        Y.upload(ycol, self._dot(X.download(xcol, ncols)))
+
+    def _mul_dvec(self, x):
+        if x.n != self.shape[1]:
+            raise LinearOperatorError("dimension mismatch")
+        y = x.ctx.alloc(self.shape[0], 1)
+        self._apply_dev(x.block, x.col, y, 0, 1)
+        return DVec(y, 0)
+
+    # -- algebra (utils.py:1407-1447) ---------------------------------------------------
+    def __mul__(self, X):
+        try:
+            if isinstance(X, IdentityLinearOperator):
+                return self
+            elif isinstance(self, IdentityLinearOperator):
+                return X
+            elif isinstance(X, LinearOperator):
+                return _ProductLinearOperator(self, X)
+            elif isinstance(X, DVec):
+                return self._mul_dvec(X)
+            elif numpy.isscalar(X):
+                return _ScaledLinearOperator(self, X)
+            else:
+                return self.dot(X)
+        except LinearOperatorError:
+            return NotImplemented
+
+    def __rmul__(self, X):
+        try:
+            return _ScaledLinearOperator(self, X)
+        except LinearOperatorError:
+            return NotImplemented
+
+    def __pow__(self, X):
+        try:
+            return _PowerLinearOperator(self, X)
+        except LinearOperatorError:
+            return NotImplemented
+
+    def __add__(self, X):
+        try:
+            return _SumLinearOperator(self, X)
+        except LinearOperatorError:
+            return NotImplemented
+
+    def __neg__(self):
+        try:
+            return _ScaledLinearOperator(self, -1)
+        except LinearOperatorError:
+            return NotImplemented
+
+    def __sub__(self, X):
+        return self + (-X)
+
+    def __repr__(self):
+        m, n = self.shape
+        return "<%dx%d %s with dtype=%s>" % (m, n, self.__class__.__name__, str(self.dtype))
+
+
+def _get_dtype(operators, dtypes=None):
+    dtypes = [] if dtypes is None else dtypes
+    for obj in operators:
+        if obj is not None and hasattr(obj, "dtype"):
+            dtypes.append(obj.dtype)
+    return _common_type(dtypes)
+
+
+class _SumLinearOperator(LinearOperator):
+    def __init__(self, A, B):
+        if not isinstance(A, LinearOperator) or not isinstance(B, LinearOperator):
+            raise LinearOperatorError("both operands have to be a LinearOperator")
+        if A.shape != B.shape:
+            raise LinearOperatorError("shape mismatch")
+        self.args = (A, B)
+        super(_SumLinearOperator, self).__init__(A.shape, _get_dtype([A, B]), self._dot,
+                                                 self._dot_adj)
+
+    def _dot(self, X):
+        return self.args[0].dot(X) + self.args[1].dot(X)
+
+    def _dot_adj(self, X):
+        return self.args[0].dot_adj(X) + self.args[1].dot_adj(X)
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        ctx = X.ctx
+        T = self._scratch(ctx, self.shape[0], 1)
+        for c in range(ncols):
+            self.args[0]._apply_dev(X, xcol + c, Y, ycol + c, 1)
+            self.args[1]._apply_dev(X, xcol + c, T, 0, 1)
+            ctx.waxpby(Y, ycol + c, 1.0, Y, ycol + c, 1.0, T, 0)
+
+
+class _ProductLinearOperator(LinearOperator):
+    def __init__(self, A, B):
+        if not isinstance(A, LinearOperator) or not isinstance(B, LinearOperator):
+            raise LinearOperatorError("both operands have to be a LinearOperator")
+        if A.shape[1] != B.shape[0]:
+            raise LinearOperatorError("shape mismatch")
+        self.args = (A, B)
+        super(_ProductLinearOperator, self).__init__(
+            (A.shape[0], B.shape[1]), _get_dtype([A, B]), self._dot, self._dot_adj)
+
+    def _dot(self, X):
+        return self.args[0].dot(self.args[1].dot(X))
+
+    def _dot_adj(self, X):
+        return self.args[1].dot_adj(self.args[0].dot_adj(X))
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        T = self._scratch(X.ctx, self.args[1].shape[0], ncols)
+        self.args[1]._apply_dev(X, xcol, T, 0, ncols)
+        self.args[0]._apply_dev(T, 0, Y, ycol, ncols)
+
+
+class _ScaledLinearOperator(LinearOperator):
+    def __init__(self, A, alpha):
+        if not isinstance(A, LinearOperator):
+            raise LinearOperatorError("LinearOperator expected as A")
+        if not numpy.isscalar(alpha):
+            raise LinearOperatorError("scalar expected as alpha")
+        self.args = (A, alpha)
+        super(_ScaledLinearOperator, self).__init__(
+            A.shape, _get_dtype([A], [numpy.asarray(alpha).dtype]), self._dot, self._dot_adj)
+
+    def _dot(self, X):
+        return self.args[1] * self.args[0].dot(X)
+
+    def _dot_adj(self, X):
+        return numpy.conj(self.args[1]) * self.args[0].dot_adj(X)
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        _require_real(numpy.asarray(self.args[1]).dtype, "scale factor")
+        self.args[0]._apply_dev(X, xcol, Y, ycol, ncols)
+        for c in range(ncols):
+            X.ctx.waxpby(Y, ycol + c, float(self.args[1]), Y, ycol + c, 0.0, Y, ycol + c)
+
+
+class _PowerLinearOperator(LinearOperator):
+    def __init__(self, A, p):
+        if not isinstance(A, LinearOperator):
+            raise LinearOperatorError("LinearOperator expected as A")
+        if A.shape[0] != A.shape[1]:
+            raise LinearOperatorError("square LinearOperator expected as A")
+        if not _isintlike(p):
+            raise LinearOperatorError("integer expected as p")
+        self.args = (A, p)
+        super(_PowerLinearOperator, self).__init__(A.shape, A.dtype, self._dot, self._dot_adj)
+
+    def _power(self, fun, X):
+        res = X.copy()
+        for _ in range(self.args[1]):
+            res = fun(res)
+        return res
+
+    def _dot(self, X):
+        return self._power(self.args[0].dot, X)
+
+    def _dot_adj(self, X):
+        return self._power(self.args[0]._dot_adj, X)
+
+
+class _AdjointLinearOperator(LinearOperator):
+    def __init__(self, A):
+        if not isinstance(A, LinearOperator):
+            raise LinearOperatorError("LinearOperator expected as A")
+        self.args = (A,)
+        m, n = A.shape
+        super(_AdjointLinearOperator, self).__init__((n, m), A.dtype, A._dot_adj, A._dot)
+
+
+class IdentityLinearOperator(LinearOperator):
+    def __init__(self, shape):
+        super(IdentityLinearOperator, self).__init__(shape, numpy.dtype(None), self._dot,
+                                                     self._dot_adj)
+
+    def _dot(self, X):
+        return X
+
+    def _dot_adj(self, X):
+        return X
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        Y.copy_from(ycol, X, xcol, ncols)
+
+    def _mul_dvec(self, x):
+        return x
+
+
+class ZeroLinearOperator(LinearOperator):
+    def __init__(self, shape):
+        super(ZeroLinearOperator, self).__init__(shape, numpy.dtype(None), self._dot,
+                                                 self._dot_adj)
+
+    def _dot(self, X):
+        return numpy.zeros(X.shape)
+
+    def _dot_adj(self, X):
+        return numpy.zeros(X.shape)
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        Y.zero(ycol, ncols)
+
+
+def _diagonal_of(A):
+    """The diagonal if the sparse matrix ``A`` is square and purely diagonal, else None."""
+    if A.shape[0] != A.shape[1]:
+        return None
+    if A.format == "dia":
+        if len(A.offsets) == 1 and A.offsets[0] == 0:
+            return numpy.asarray(A.diagonal(), dtype=float)
+        return None
+    C = A.tocoo()
+    if C.nnz <= A.shape[0] and numpy.array_equal(C.row, C.col):
+        return numpy.asarray(A.diagonal(), dtype=float)
+    return None
+
+
+class MatrixLinearOperator(LinearOperator):
+    """Operator given by an ndarray or a SciPy sparse matrix (utils.py:1585-1602).
+
+    The matrix is uploaded once (CSR as SciPy stores it / dense row-major / a plain
+    diagonal) and applied by the HIP kernels; ``dot`` on host arrays uploads the
+    operand, applies the kernel and downloads the result.
+    """
+
+    def __init__(self, A):
+        super(MatrixLinearOperator, self).__init__(A.shape, A.dtype, self._dot, self._dot_adj)
+        self._A = A
+        self._A_adj = None
+        self._dmat = None
+        self._adj_op = None
+
+    def _device_matrix(self, ctx=None):
+        if self._dmat is None:
+            ctx = _hip.get_context() if ctx is None else ctx
+            _require_real(self.dtype, "matrix")
+            A = self._A
+            if _is_sparse(A):
+                d = _diagonal_of(A)
+                if d is not None:
+                    self._dmat = ctx.diag(d)
+                else:
+                    self._dmat = ctx.csr(scipy.sparse.csr_matrix(A))
+            else:
+                self._dmat = ctx.dense(numpy.asarray(A))
+        return self._dmat
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        X.ctx.apply(self._device_matrix(X.ctx), X, xcol, Y, ycol, ncols)
+
+    def _dot(self, X):
+        X = numpy.asarray(X)
+        _require_real(X.dtype, "operand")
+        ctx = _hip.get_context()
+        Xd = ctx.upload(X)
+        Yd = ctx.alloc(self.shape[0], X.shape[1])
+        self._apply_dev(Xd, 0, Yd, 0, X.shape[1])
+        return numpy.ascontiguousarray(Yd.download())
+
+    def _dot_adj(self, X):
+        if self._adj_op is None:
+            self._A_adj = self._A.T.conj()
+            self._adj_op = MatrixLinearOperator(
+                scipy.sparse.csr_matrix(self._A_adj) if _is_sparse(self._A_adj)
+                else numpy.ascontiguousarray(self._A_adj))
+        return self._adj_op._dot(X)
+
+    def __repr__(self):
+        return self._A.__repr__()
+
+
+def get_linearoperator(shape, A, timer=None):
+    """Enhances aslinearoperator if A is None (utils.py:241-273).
+
+    Accepts a :class:`LinearOperator`, ``None`` (identity), ndarray, SciPy sparse matrix or
+    array (superset of the reference, which rejects ``csr_array``), ``numpy.matrix`` and
+    SciPy ``LinearOperator`` with a ``dtype``.
+    """
+    import scipy.sparse.linalg as scipylinalg
+
+    if isinstance(A, LinearOperator):
+        ret = A
+    elif A is None:
+        ret = IdentityLinearOperator(shape)
+    elif isinstance(A, numpy.matrix):
+        ret = MatrixLinearOperator(numpy.atleast_2d(numpy.asarray(A)))
+    elif isinstance(A, numpy.ndarray) or _is_sparse(A):
+        ret = MatrixLinearOperator(A)
+    elif isinstance(A, scipylinalg.LinearOperator):
+        if not hasattr(A, "dtype"):
+            raise ArgumentError("scipy LinearOperator has no dtype.")
+        ret = LinearOperator(A.shape, dot=A.matmat, dot_adj=A.rmatmat, dtype=A.dtype)
+    else:
+        raise TypeError("type not understood")
+    if timer is not None:
+        raise NotImplementedError("timed operators belong to the recycling layer (SURVEY 8f)")
+    if shape != ret.shape:
+        raise LinearOperatorError("shape mismatch")
+    return ret
+
+
+# ----------------------------------------------------------------------------------------
+# Arnoldi / Lanczos (utils.py:854-1081)
+# ----------------------------------------------------------------------------------------
+_GS_OF_ORTHO = {  # ortho -> (gs_mode, sweeps)
+    "mgs": (_hip.GS_MGS, 1),
+    "dmgs": (_hip.GS_MGS, 2),
+    "lanczos": (_hip.GS_MGS, 1),
+    # extensions (not in the reference): panel classical Gram-Schmidt, one reduction per sweep
+    "cgs": (_hip.GS_CGS, 1),
+    "cgs2": (_hip.GS_CGS, 2),
+}
+
+
+class Arnoldi(object):
+    def __init__(self, A, v, maxiter=None, ortho="mgs", M=None, Mv=None, Mv_norm=None, ip_B=None):
+        """Arnoldi algorithm: ``A V_n = V_{n+1} H_n`` (utils.py:855-952), basis in HBM.
+
+        :param A: linear operator (anything :func:`get_linearoperator` accepts).
+        :param v: initial vector, ``(N,1)`` ndarray (or a :class:`DVec`).
+        :param maxiter: maximal number of iterations (default ``N``).
+        :param ortho: ``'mgs'`` (default), ``'dmgs'``, ``'lanczos'`` as in the reference
+            (``'house'`` is a sequential reflector chain, out of scope of the device path), plus
+            the extensions ``'cgs'`` / ``'cgs2'`` (panel Gram-Schmidt, one / two passes).
+        :param M: self-adjoint positive definite preconditioner; then ``P`` with ``V = M P``
+            is built too.
+        :param ip_B: inner product, see :func:`inner`.
+
+        ``V`` and ``P`` are ``(N, maxiter+1)`` column-major blocks on the device; the
+        attributes ``V`` / ``P`` download them on access.  ``H`` lives on the host.
+        """
+        N = v.shape[0]
+        self.A = get_linearoperator((N, N), A)
+        self.maxiter = N if maxiter is None else maxiter
+        self.ortho = ortho
+        self.M = get_linearoperator((N, N), M)
+        if isinstance(self.M, IdentityLinearOperator):
+            self.M = None
+        self.ip_B = ip_B
+        self.dtype = find_common_dtype(A, v, M)
+        _require_real(self.dtype, "Arnoldi input")
+        self.dtype = numpy.dtype(numpy.float64)
+        self.iter = 0
+        self.invariant = False
+        if ortho == "house":
+            raise NotImplementedError(
+                "ortho='house' (Householder Arnoldi) is a sequential host algorithm outside the "
+                "device hot path (SURVEY.md section 2, row 3)")
+        if ortho not in _GS_OF_ORTHO:
+            raise ArgumentError(
+                f"Invalid value '{ortho}' for argument 'ortho'. "
+                + "Valid are house, mgs, dmgs and lanczos.")
+        self._gs_mode, self._sweeps = _GS_OF_ORTHO[ortho]
+        self.reorthos = self._sweeps - 1
+
+        ctx = self._ctx = v.ctx if isinstance(v, DVec) else _hip.get_context()
+        self._V = ctx.alloc(N, self.maxiter + 1)
+        self._P = ctx.alloc(N, self.maxiter + 1) if self.M is not None else None
+        self._W = ctx.alloc(N, 2)
+        self.H = numpy.zeros((self.maxiter + 1, self.maxiter), dtype=self.dtype)
+        self._h2 = 0.0   # running sum of squares of H (Frobenius), for the invariance pre-test
+        # fused device path: Euclidean inner product, M a plain diagonal (or absent)
+        self._euclid = ip_B is None or isinstance(ip_B, IdentityLinearOperator)
+        self._Md = None
+        if self.M is not None:
+            md = self.M._device_matrix()
+            if md is not None and md.kind == "diag":
+                self._Md = md
+        self._fused = self._euclid and (self.M is None or self._Md is not None)
+        self._Amat = self.A._device_matrix() if self._fused else None
+
+        v = _as_dvec(v, ctx)
+        if self.M is not None:
+            p = v
+            v = (self.M * p) if Mv is None else _as_dvec(Mv, ctx)
+            self.vnorm = norm(p, v, ip_B=ip_B) if Mv_norm is None else Mv_norm
+            if self.vnorm > 0:
+                ctx.vdiv(self._P, 0, p.block, p.col, float(self.vnorm))
+        else:
+            self.vnorm = norm(v, ip_B=ip_B) if Mv_norm is None else Mv_norm
+        if self.vnorm > 0:
+            ctx.vdiv(self._V, 0, v.block, v.col, float(self.vnorm))
+        else:
+            self.invariant = True
+
+    # the reference exposes ndarrays; here they are downloaded on demand
+    @property
+    def V(self):
+        return self._V.download()
+
+    @property
+    def P(self):
+        if self._P is None:
+            raise AttributeError("P")
+        return self._P.download()
+
+    def advance(self):
+        """Carry out one iteration of Arnoldi (utils.py:954-1048)."""
+        if self.iter >= self.maxiter:
+            raise ArgumentError("Maximum number of iterations reached.")
+        if self.invariant:
+            raise ArgumentError("Krylov subspace was found to be invariant in the previous iteration.")
+        k = self.iter
+        ctx = self._ctx
+        H = self.H
+        start = 0
+        h_km1 = 0.0
+        if self.ortho == "lanczos":
+            start = k
+            if k > 0:
+                H[k - 1, k] = H[k, k - 1]
+                h_km1 = float(H[k, k - 1])
+        if self._fused:
+            if self._Amat is not None:
+                hcol = ctx.arnoldi_step(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
+                                        self._sweeps, self._gs_mode, h_km1)
+            else:
+                self.A._apply_dev(self._V, k, self._W, 0, 1)
+                hcol = ctx.arnoldi_step(None, self._Md, self._V, self._P, self._W, 0, k, start,
+                                        self._sweeps, self._gs_mode, h_km1)
+            H[start: k + 1, k] += hcol[start: k + 1]
+            hn = hcol[k + 1]
+        else:
+            hn = self._advance_general(k, start, h_km1)
+        H[k + 1, k] = hn
+        # invariance test  H[k+1,k] / ||H[:k+2,:k+1]||_2 <= 1e-14  (utils.py:1035-1039).
+        # ||.||_2 <= ||.||_F, so the quotient by the Frobenius norm is a lower bound: only when
+        # THAT is tiny is the exact 2-norm (an O(k^3) SVD) needed.  Same decisions, O(k) cost.
+        col = H[: k + 2, k]
+        self._h2 += float(numpy.dot(col, col))
+        fro = numpy.sqrt(self._h2)
+        is_inv = False
+        if not (fro > 0) or not (hn / fro > 1e-14):
+            nrm2 = numpy.linalg.norm(H[: k + 2, : k + 1], 2)
+            is_inv = not (hn / nrm2 > 1e-14) if nrm2 > 0 else True
+        if is_inv:
+            self.invariant = True
+            # the reference leaves column k+1 untouched (zeros); undo the speculative store
+            self._V.zero(k + 1, 1)
+            if self._P is not None:
+                self._P.zero(k + 1, 1)
+        self.iter += 1
+
+    def _advance_general(self, k, start, h_km1):
+        """Arnoldi step for a non-Euclidean inner product or a general preconditioner ``M``:
+        same loop as the reference (utils.py:1011-1045) with each vector operation on the device."""
+        ctx = self._ctx
+        V, P, W, H = self._V, self._P, self._W, self.H
+        B = P if self.M is not None else V
+        self.A._apply_dev(V, k, W, 0, 1)
+        if start > 0:
+            ctx.axpy_panel(B, k - 1, 1, [h_km1], W, 0)
+        for _ in range(self._sweeps):
+            for j in range(start, k + 1):
+                alpha = _inner_dev(V, j, 1, W, 0, 1, self.ip_B)[0, 0]
+                if self.ortho == "lanczos":
+                    if abs(numpy.imag(alpha)) > 1e-10:
+                        warnings.warn(
+                            f"Iter {self.iter}: abs(alpha.imag) = {abs(alpha.imag)} > 1e-10. "
+                            "Is your operator self-adjoint in the provided inner product?")
+                    alpha = numpy.real(alpha)
+                H[j, k] += alpha
+                ctx.axpy_panel(B, j, 1, [float(alpha)], W, 0)
+        if self.M is not None:
+            self.M._apply_dev(W, 0, W, 1, 1)
+            ip = _inner_dev(W, 0, 1, W, 1, 1, self.ip_B)
+        else:
+            ip = _inner_dev(W, 0, 1, W, 0, 1, self.ip_B)
+        hn = float(numpy.sqrt(numpy.linalg.norm(ip, 2)))
+        if hn > 0:
+            if self.M is not None:
+                ctx.vdiv(P, k + 1, W, 0, hn)
+                ctx.vdiv(V, k + 1, W, 1, hn)
+            else:
+                ctx.vdiv(V, k + 1, W, 0, hn)
+        return hn
+
+    def get(self):
+        """``(V, H[, P])`` trimmed to the computed part (utils.py:1050-1061)."""
+        k = self.iter
+        nv, hr = (k, k) if self.invariant else (k + 1, k + 1)
+        V, H = self._V.download(0, nv), self.H[:hr, :k]
+        if self.M is not None:
+            return V, H, self._P.download(0, nv)
+        return V, H
+
+    def get_last(self):
+        """Last Arnoldi vector and Hessenberg column (utils.py:1063-1074)."""
+        k = self.iter
+        if self.invariant:
+            V, H = None, self.H[:k, [k - 1]]
+            return (V, H, None) if self.M is not None else (V, H)
+        V, H = self._V.download(k, 1), self.H[: k + 1, [k - 1]]
+        if self.M is not None:
+            return V, H, self._P.download(k, 1)
+        return V, H
+
+
+def arnoldi(*args, **kwargs):
+    """Run Arnoldi to ``maxiter`` or invariance and return ``get()`` (utils.py:1077-1081)."""
+    _arnoldi = Arnoldi(*args, **kwargs)
+    while _arnoldi.iter < _arnoldi.maxiter and not _arnoldi.invariant:
+        _arnoldi.advance()
+    return _arnoldi.get()
+
+
+# ----------------------------------------------------------------------------------------
+# QR and projections (utils.py:439-707)
+# ----------------------------------------------------------------------------------------
+def _qr_mgs_dev(Q, ip_B, reorthos):
+    """In-place modified Gram-Schmidt of the device block ``Q`` (utils.py:694-707)."""
+    ctx = Q.ctx
+    k = Q.ncols
+    R = numpy.zeros((k, k))
+    for i in range(k):
+        for _ in range(reorthos + 1):
+            for j in range(i):
+                alpha = _inner_dev(Q, j, 1, Q, i, 1, ip_B)[0, 0]
+                R[j, i] += alpha
+                ctx.axpy_panel(Q, j, 1, [float(alpha)], Q, i)
+        R[i, i] = numpy.sqrt(numpy.linalg.norm(_inner_dev(Q, i, 1, Q, i, 1, ip_B), 2))
+        if R[i, i] >= 1e-15:
+            ctx.vdiv(Q, i, Q, i, float(R[i, i]))
+    return R
+
+
+def qr(X, ip_B=None, reorthos=1):
+    """QR factorization with customizable inner product (utils.py:680-707).
+
+    ``ip_B is None`` -> ``scipy.linalg.qr(X, mode='economic')`` on the host array, exactly the
+    reference's call (a LAPACK call there as well, and not on the Krylov hot path).  Any other
+    ``ip_B`` - including an ``IdentityLinearOperator`` *instance*, which is what the deflated
+    solvers pass - runs ``reorthos+1`` sweeps of modified Gram-Schmidt on the device.
+
+    ``X`` may be a host ``(N,k)`` array (returns host ``Q``) or a device block (returns a
+    device block).
+    """
+    on_device = hasattr(X, "download") and hasattr(X, "ncols")
+    if ip_B is None and not on_device and X.shape[1] > 0:
+        return scipy.linalg.qr(X, mode="economic")
+    if on_device:
+        Q = X.ctx.alloc(X.n, X.ncols)
+        Q.copy_from(0, X, 0, X.ncols)
+    else:
+        _require_real(numpy.asarray(X).dtype, "X")
+        Q = _hip.get_context().upload(numpy.asarray(X, dtype=float))
+    R = _qr_mgs_dev(Q, ip_B, reorthos)
+    if on_device:
+        return Q, R
+    return numpy.ascontiguousarray(Q.download()), R
+
+
+class Projection(object):
+    def __init__(self, X, Y=None, ip_B=None, orthogonalize=True, iterations=2):
+        """Generic (oblique) projection :math:`P_{\\mathcal{X},\\mathcal{Y}^\\perp}`
+        (utils.py:440-520) with device-resident bases.
+
+        ``X`` / ``Y``: ``(N,k)`` host arrays or device blocks.  The XQRY representation of the
+        reference is kept: ``V,VR = qr(X)``, ``W,WR = qr(Y)``, ``Q,R = qr(<W,V>)`` (the last
+        one a k x k host factorisation).  Attributes ``V``/``W`` download on access.
+        """
+        self.ip_B = ip_B
+        if iterations < 1:
+            raise ArgumentError("iterations < 1 not allowed")
+        self.orthogonalize = orthogonalize
+        self.iterations = iterations
+        Y = X if Y is None else Y
+        xs = (X.n, X.ncols) if hasattr(X, "ncols") else X.shape
+        ys = (Y.n, Y.ncols) if hasattr(Y, "ncols") else Y.shape
+        if len(xs) != 2:
+            raise ArgumentError("X does not have shape==(N,k)")
+        if xs != ys:
+            raise ArgumentError("X and Y have different shapes")
+        self._N, self._k = xs
+        self.VR = self.WR = self.Q = self.R = None
+        self._Vd = self._Wd = None
+        if self._k == 0:
+            return
+        same = Y is X
+        Xd = _upload_block(X)
+        if orthogonalize:
+            if ip_B is None:
+                # reference: Householder QR of the host array (utils.py:692-693)
+                Qh, self.VR = scipy.linalg.qr(Xd.download(), mode="economic")
+                self._Vd = Xd.ctx.upload(Qh)
+            else:
+                self._Vd, self.VR = qr(Xd, ip_B=ip_B)
+        else:
+            self._Vd = Xd
+        if same and orthogonalize:
+            self._Wd, self.WR = self._Vd, self.VR
+        else:
+            Yd = _upload_block(Y, Xd.ctx)
+            if orthogonalize:
+                if ip_B is None:
+                    Qh, self.WR = scipy.linalg.qr(Yd.download(), mode="economic")
+                    self._Wd = Yd.ctx.upload(Qh)
+                else:
+                    self._Wd, self.WR = qr(Yd, ip_B=ip_B)
+            else:
+                self._Wd = Yd
+            M = _inner_dev(self._Wd, 0, self._k, self._Vd, 0, self._k, ip_B)
+            self.Q, self.R = scipy.linalg.qr(M)
+
+    @property
+    def V(self):
+        return numpy.zeros((self._N, 0)) if self._k == 0 else self._Vd.download()
+
+    @property
+    def W(self):
+        return numpy.zeros((self._N, 0)) if self._k == 0 else self._Wd.download()
+
+    # -- device primitives ------------------------------------------------------------
+    def _coeffs(self, a, want_Ya):
+        """c = R^{-1} Q^H <W, a>  and  Ya = WR^H <W, a>  (utils.py:540-548)."""
+        c = _inner_dev(self._Wd, 0, self._k, a.block, a.col, 1, self.ip_B)
+        Ya = None
+        if want_Ya:
+            Ya = c.copy()
+            if self.WR is not None:
+                Ya = self.WR.T.conj().dot(Ya)
+        if self.Q is not None and self.R is not None:
+            c = scipy.linalg.solve_triangular(self.R, self.Q.T.conj().dot(c))
+        return c, Ya
+
+    def _apply_dvec(self, a, return_Ya=False):
+        """Single application ``V c`` for a :class:`DVec` (utils.py:522-552)."""
+        c, Ya = self._coeffs(a, return_Ya)
+        out = a.ctx.alloc(self._N, 1)
+        a.ctx.gemm_nn(self._Vd, 0, self._k, c, 1.0, 0.0, out, 0)
+        return (DVec(out), Ya) if return_Ya else DVec(out)
+
+    def _apply_complement_dvec(self, a, return_Ya=False):
+        """``z = a - P a`` with ``iterations-1`` refinement sweeps (utils.py:604-627).
+
+        Each sweep is one tall-skinny ``W^T z`` panel product and one ``z -= V c`` panel
+        update on the device; ``z`` is a fresh vector."""
+        ctx = a.ctx
+        z = a.copy()
+        if self._k == 0:
+            return (z, numpy.zeros((0, 1))) if return_Ya else z
+        c, Ya = self._coeffs(a, return_Ya)
+        ctx.axpy_panel(self._Vd, 0, self._k, c, z.block, z.col)
+        for _ in range(self.iterations - 1):
+            c, _unused = self._coeffs(z, False)
+            ctx.axpy_panel(self._Vd, 0, self._k, c, z.block, z.col)
+        return (z, Ya) if return_Ya else z
+
+    # -- host API (arrays in, arrays out) ---------------------------------------------
+    def _columns(self, a, fn):
+        a = numpy.asarray(a)
+        _require_real(a.dtype, "a")
+        blk = _hip.get_context().upload(a)
+        outs = [fn(DVec(blk, j)) for j in range(a.shape[1])]
+        return outs
+
+    def _apply(self, a, return_Ya=False):
+        if self._k == 0:
+            Pa = numpy.zeros(a.shape)
+            return (Pa, numpy.zeros((0, a.shape[1]))) if return_Ya else Pa
+        res = self._columns(a, lambda v: self._apply_dvec(v, return_Ya))
+        if return_Ya:
+            return (numpy.column_stack([r[0].download() for r in res]),
+                    numpy.column_stack([r[1] for r in res]))
+        return numpy.column_stack([r.download() for r in res])
+
+    def apply(self, a, return_Ya=False):
+        """Apply the projection, ``iterations`` sweeps (utils.py:566-591)."""
+        if self._k == 0:
+            Pa = numpy.zeros(a.shape)
+            return (Pa, numpy.zeros((0, a.shape[1]))) if return_Ya else Pa
+        ctx = _hip.get_context()
+
+        def one(v):
+            if return_Ya:
+                x, Ya = self._apply_dvec(v, True)
+            else:
+                x, Ya = self._apply_dvec(v), None
+            for _ in range(self.iterations - 1):
+                z = v.copy()
+                ctx.waxpby(z.block, z.col, 1.0, v.block, v.col, -1.0, x.block, x.col)
+                w = self._apply_dvec(z)
+                ctx.waxpby(x.block, x.col, 1.0, x.block, x.col, 1.0, w.block, w.col)
+            return x, Ya
+        res = self._columns(a, one)
+        X = numpy.column_stack([r[0].download() for r in res])
+        if return_Ya:
+            return X, numpy.column_stack([r[1] for r in res])
+        return X
+
+    def apply_complement(self, a, return_Ya=False):
+        """Apply the complementary projection ``a - P a`` (utils.py:604-627)."""
+        if self._k == 0:
+            return (a.copy(), numpy.zeros((0, a.shape[1]))) if return_Ya else a.copy()
+        res = self._columns(a, lambda v: self._apply_complement_dvec(v, return_Ya))
+        if return_Ya:
+            return (numpy.column_stack([r[0].download() for r in res]),
+                    numpy.column_stack([r[1] for r in res]))
+        return numpy.column_stack([r.download() for r in res])
+
+    def _get_operator(self, fun, fun_adj):
+        return LinearOperator((self._N, self._N), numpy.dtype(float), fun, fun_adj)
+
+    def operator(self):
+        """``LinearOperator`` corresponding to :meth:`apply` (utils.py:645-654)."""
+        if self._k == 0:
+            return ZeroLinearOperator((self._N, self._N))
+        return self._get_operator(self.apply, None)
+
+    def operator_complement(self):
+        """``LinearOperator`` corresponding to :meth:`apply_complement` (utils.py:656-665)."""
+        if self._k == 0:
+            return IdentityLinearOperator((self._N, self._N))
+        op = self._get_operator(self.apply_complement, None)
+        op._apply_dev = self._complement_apply_dev
+        return op
+
+    def _complement_apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        for c in range(ncols):
+            z = self._apply_complement_dvec(DVec(X, xcol + c))
+            Y.copy_from(ycol + c, z.block, z.col, 1)
+
+    def matrix(self):
+        """Dense matrix of the projection - testing only (utils.py:667-677)."""
+        return self.apply(numpy.eye(self._N))

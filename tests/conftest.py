@@ -22,3 +22,30 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+@pytest.fixture
+def cpu_double():
+    """Install the NumPy test double as the process-wide context (CPU tests of the host layer)."""
+    from krypy_amd import _hip
+    from tests.support.numpy_context import NumpyContext
+
+    ctx = NumpyContext()
+    old = _hip._install_context_for_testing(ctx)
+    yield ctx
+    _hip._install_context_for_testing(old)
+
+
+_real_ctx = []
+
+
+@pytest.fixture
+def hip():
+    """The real HIP context (GPU tests).  Fails - never skips - when the library or GPU is absent."""
+    from krypy_amd import _hip
+
+    if not _real_ctx:
+        _hip._install_context_for_testing(None)
+        _real_ctx.append(_hip.get_context())
+    _hip._install_context_for_testing(_real_ctx[0])
+    return _real_ctx[0]

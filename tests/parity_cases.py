@@ -1,0 +1,456 @@
+"""Parity cases shared by the CPU host-logic tests (NumPy test double) and the GPU tests
+(real HIP library, through the C ABI).  Each case drives the *public* krypy_amd API the way
+the reference's own tests drive krypy, and compares with
+
+* the golden vectors emitted by the real reference (tests/golden, oracle/gen_golden.py),
+* the CPU oracle (oracle/krylov_ref.py) on the same seeded inputs,
+* the reference's known-answer scalars (test/test_convenience_wrappers.py:10-12,37-39).
+
+Tolerance: 1e-10 relative (BASELINE.json north_star, fp64), per restart cycle, with the cycle
+re-seeded from the reference's x0 (open-loop drift across restarts is a
+property of the algorithm, not of the implementation); total iteration counts are compared
+open-loop.
+"""
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+import krypy_amd
+from krypy_amd import deflation, linsys, utils
+from oracle import krylov_ref as ref
+from oracle.inputs import (dense_spd_system, kernel_panel, lap2d_system, lap3d_system,
+                           minres_jacobi_system, toy_system)
+from tests.conftest import load_golden as golden
+
+RTOL = 1e-10
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b) / np.abs(b))
+
+
+def check_resnorms(got, want, tol=RTOL, explicit_last=True, explicit_tol=1e-7):
+    """Recurrence residual norms to ``tol``; a trailing explicit residual (pure cancellation,
+    see tests/test_oracle_golden.py) to 1e-7."""
+    got, want = np.asarray(got, float), np.asarray(want, float)
+    assert len(got) == len(want), (len(got), len(want))
+    if explicit_last:
+        assert relmax(got[:-1], want[:-1]) < tol, relmax(got[:-1], want[:-1])
+        assert relmax(got[-1:], want[-1:]) < explicit_tol
+    else:
+        assert relmax(got, want) < tol
+
+
+KNOWN = {  # reference test/test_convenience_wrappers.py:10-12 and 37-39
+    "cg": [1004.1873775173957, 1000.0003174916551, 999.9999999997555],
+    "gmres": [1004.1873724888546, 1000.0003124630923, 999.999994971191],
+    "minres": [1004.187372488912, 1000.0003124632159, 999.9999949713145],
+    "cg_defl": [1004.1873775173271, 1000.0003174918709, 1000.0],
+    "minres_defl": [1004.1873774950692, 1000.0003174918709, 1000.0],
+    "gmres_defl": [1004.1873774950692, 1000.0003174918709, 1000.0],
+}
+
+
+def _three(x):
+    return [np.sum(np.abs(x)), np.sqrt(np.dot(x, x)), np.max(np.abs(x))]
+
+
+# ---------------------------------------------------------------------------------------------
+# config 1: README toy through the convenience wrappers (reference: test_convenience_wrappers.py)
+# ---------------------------------------------------------------------------------------------
+def case_toy_known_answers():
+    A, b = toy_system()
+    g = golden("toy")
+    for name in ("cg", "gmres", "minres"):
+        fn = getattr(krypy_amd, name)
+        bb = np.ones((100, 1))
+        sol, _ = fn(A, bb)
+        assert sol.shape == bb.shape
+        sol, out = fn(A, b)
+        assert sol.shape == b.shape
+        for got, want in zip(_three(sol), KNOWN[name]):
+            assert abs(got - want) < 1e-11 * want, (name, got, want)
+        check_resnorms(out.resnorms, g[name + "_resnorms"], tol=1e-9)
+        assert out.iter == int(g[name + "_iter"])
+        assert out.xk.shape == (100, 1)
+
+
+def case_toy_custom_inner_product():
+    """inner_product=numpy.dot: a user callable as ip_B (host round trip per inner product)."""
+    A, b = toy_system()
+    for name in ("cg", "gmres", "minres"):
+        sol, _ = getattr(krypy_amd, name)(A, b, inner_product=np.dot)
+        for got, want in zip(_three(sol), KNOWN[name]):
+            assert abs(got - want) < 1e-11 * want, (name, got, want)
+
+
+def case_toy_deflated():
+    A, b = toy_system()
+    g = golden("toy")
+    U = np.zeros(100)
+    U[0] = 1.0
+    for name in ("cg", "minres", "gmres"):
+        sol, out = getattr(krypy_amd, name)(A, b, U=U)
+        for got, want in zip(_three(sol), KNOWN[name + "_defl"]):
+            assert abs(got - want) < 1e-11 * want, (name, got, want)
+        assert len(out.resnorms) == len(g[name + "_defl_resnorms"])
+        assert rel(out.E, g[name + "_defl_E"]) < RTOL
+        assert out.projection.iterations == 2
+
+
+def case_toy_solver_attributes():
+    """Observable behaviours of SURVEY.md 3.5."""
+    A, b = toy_system()
+    g = golden("toy")
+    x, sol = krypy_amd.gmres(A, b, store_arnoldi=True)
+    band = lambda H: np.triu(np.tril(H, 1), -1)  # noqa: E731
+    assert sol.H.shape == g["gmres_H"].shape and sol.V.shape == g["gmres_V"].shape
+    assert rel(band(sol.H), band(g["gmres_H"])) < 1e-9
+    assert rel(sol.V, g["gmres_V"]) < 1e-6
+    assert sol.R.shape == (101, 100)
+    # no store_arnoldi: untrimmed work arrays stay visible
+    x, sol = krypy_amd.gmres(A, b)
+    assert sol.V.shape == (100, 101) and sol.R.shape == (101, 100)
+    assert isinstance(sol.resnorms, list)
+    # ConvergenceError carries the solver; iter / resnorms conventions
+    try:
+        krypy_amd.gmres(A, b, maxiter=10)
+        raise AssertionError("ConvergenceError expected")
+    except utils.ConvergenceError as e:
+        assert e.solver.iter == 9 == int(g["gmres_m10_iter"])
+        check_resnorms(e.solver.resnorms, g["gmres_m10_resnorms"])
+        assert rel(e.solver.xk, g["gmres_m10_xk"]) < RTOL
+        assert str(e).startswith("No convergence in last iteration (maxiter: 10, residual: 0.1065")
+    # exact x0: zero iterations; zero rhs: zero solution
+    xe = np.linalg.solve(A, b)
+    x, sol = krypy_amd.gmres(A, b, x0=xe)
+    assert sol.iter == 0 and len(sol.resnorms) == 1 and sol.resnorms[0] < 1e-13
+    x, sol = krypy_amd.gmres(A, np.zeros(100))
+    assert sol.resnorms == [0.0] and np.all(sol.xk == 0) and sol.xk.shape == (100, 1)
+    # cg counts iterations differently from minres/gmres
+    _, s = krypy_amd.cg(A, b)
+    assert s.iter == len(s.resnorms) - 1
+    _, s = krypy_amd.minres(A, b)
+    assert s.iter == len(s.resnorms) - 2
+
+
+def case_api_errors():
+    A, b = toy_system()
+    ls = linsys.LinearSystem(A, b)
+    try:
+        linsys.Gmres("not a linear system")
+        raise AssertionError
+    except utils.ArgumentError:
+        pass
+    try:
+        utils.Arnoldi(A, b.reshape(-1, 1), ortho="nope")
+        raise AssertionError
+    except utils.ArgumentError:
+        pass
+    try:
+        linsys.LinearSystem(A, b, self_adjoint=True, normal=False)
+    except utils.ArgumentError:
+        pass
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        linsys.Cg(ls, maxiter=200)
+        assert any("non-self-adjoint" in str(x.message) for x in w)
+    try:
+        utils.get_linearoperator((100, 100), "bogus")
+        raise AssertionError
+    except TypeError:
+        pass
+    try:
+        utils.get_linearoperator((99, 99), A)
+        raise AssertionError
+    except utils.LinearOperatorError:
+        pass
+    ar = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=2)
+    ar.advance()
+    ar.advance()
+    try:
+        ar.advance()
+        raise AssertionError
+    except utils.ArgumentError:
+        pass
+    try:
+        linsys.LinearSystem(A.astype(complex), b)
+        raise AssertionError("complex must fail loudly")
+    except NotImplementedError:
+        pass
+    G = utils.Givens(np.array([[-3.0], [4.0]]))
+    assert abs(G.c + 0.6) < 1e-15 and abs(G.s - 0.8) < 1e-15 and abs(G.r - 5) < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------
+# kernels behind utils.inner / norm / Arnoldi.advance / qr / Projection (fixture F7)
+# ---------------------------------------------------------------------------------------------
+def case_inner_norm_panels():
+    g = golden("kernels")
+    for N in (1, 63, 64, 65, 4097, 100000):
+        for k in (1, 2, 16, 101):
+            key = "N%d_k%d_" % (N, k)
+            if key + "inner" not in g:
+                continue
+            X, w = kernel_panel(N, k, seed=N + k)
+            got = utils.inner(X, w)
+            assert got.shape == (k, 1)
+            scale = np.linalg.norm(X, axis=0) * np.linalg.norm(w)
+            assert np.max(np.abs(got[:, 0] - g[key + "inner"][:, 0]) / scale) < 1e-14
+            assert abs(utils.norm(w) - g[key + "norm"]) < 1e-14 * g[key + "norm"]
+
+
+def case_arnoldi_steps():
+    g = golden("kernels")
+    A, b = lap2d_system(40, rhs="rng1")
+    v = b.reshape(-1, 1)
+    for ortho in ("mgs", "dmgs", "lanczos"):
+        ar = utils.Arnoldi(A, v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        assert rel(ar.H, g["arn_%s_H" % ortho]) < RTOL, ortho
+        assert rel(ar.V, g["arn_%s_V" % ortho]) < RTOL, ortho
+        V, H = ar.get()
+        assert V.shape == (1600, 13) and H.shape == (13, 12)
+    M = sp.diags(np.linspace(0.5, 1.5, A.shape[0])).tocsr()
+    for ortho in ("mgs", "lanczos"):
+        ar = utils.Arnoldi(A, v, maxiter=12, ortho=ortho, M=M)
+        for _ in range(12):
+            ar.advance()
+        assert rel(ar.H, g["arn_%sM_H" % ortho]) < RTOL
+        assert rel(ar.V, g["arn_%sM_V" % ortho]) < RTOL
+        assert rel(ar.P, g["arn_%sM_P" % ortho]) < RTOL
+        assert len(ar.get()) == 3
+    # panel Gram-Schmidt extensions stay within the tolerance of the reference's MGS
+    for ortho in ("cgs", "cgs2"):
+        ar = utils.Arnoldi(A, v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        assert rel(ar.H, g["arn_mgs_H"]) < RTOL, ortho
+        assert rel(ar.V, g["arn_mgs_V"]) < RTOL, ortho
+
+
+def case_arnoldi_invariant():
+    """Invariant subspace detection (utils.py:1035-1039): 3 distinct eigenvalues -> 3 steps."""
+    d = np.array([1.0] * 10 + [2.0] * 10 + [5.0] * 10)
+    A = sp.diags(d).tocsr()
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((30, 1))
+    V, H = utils.arnoldi(A, v, maxiter=10)
+    assert H.shape == (3, 3) and V.shape == (30, 3)
+    st = ref.arnoldi_init(A, v[:, 0], 10)
+    while st.iter < 10 and not st.invariant:
+        ref.arnoldi_step(st)
+    assert st.invariant and st.iter == 3
+    assert rel(H, st.H[:3, :3]) < 1e-8
+    # GMRES stops on the invariant subspace with the exact solution
+    b = v[:, 0]
+    x, sol = krypy_amd.gmres(A, b, tol=1e-12)
+    assert np.linalg.norm(A.dot(x) - b) < 1e-10 * np.linalg.norm(b)
+
+
+def case_qr_projection():
+    g = golden("kernels")
+    X, a = kernel_panel(2000, 16, seed=7)
+    Y, _ = kernel_panel(2000, 16, seed=8)
+    ipI = utils.IdentityLinearOperator((2000, 2000))
+    Q, R = utils.qr(X, ip_B=ipI, reorthos=1)
+    assert rel(Q, g["qr_Q"]) < RTOL and rel(R, g["qr_R"]) < RTOL
+    Q0, R0 = utils.qr(X, ip_B=ipI, reorthos=0)
+    assert rel(Q0, g["qr0_Q"]) < RTOL and rel(R0, g["qr0_R"]) < RTOL
+    P = utils.Projection(X, Y, ip_B=ipI)
+    z, Ya = P.apply_complement(a, return_Ya=True)
+    assert rel(z, g["proj_z"]) < 1e-9 and rel(Ya, g["proj_Ya"]) < RTOL
+    assert rel(P.apply(a), g["proj_apply"]) < 1e-9
+    # projection identities of the reference's test_projection (test_utils.py:170-223)
+    Pa = P.apply(a)
+    assert rel(P.apply(Pa), Pa) < 1e-9                       # P^2 = P
+    assert np.linalg.norm(utils.inner(Y, z)) < 1e-9 * np.linalg.norm(a)   # range(I-P) _|_ Y
+    op = P.operator_complement()
+    assert rel(op * a, z) < 1e-12
+    P0 = utils.Projection(np.zeros((2000, 0)))
+    assert np.array_equal(P0.apply_complement(a), a)
+
+
+def case_operator_algebra():
+    A, b = lap2d_system(20, rhs="rng1")
+    N = A.shape[0]
+    x = np.random.default_rng(5).standard_normal((N, 3))
+    op = utils.get_linearoperator((N, N), A)
+    assert np.array_equal(op * x, A.dot(x))              # CSR SpMV is bit-identical to scipy
+    D = sp.diags(np.linspace(1, 2, N)).tocsr()
+    dop = utils.get_linearoperator((N, N), D)
+    assert np.allclose((dop * op) * x, D.dot(A.dot(x)), rtol=1e-14, atol=0)
+    assert np.allclose((op + dop) * x, A.dot(x) + D.dot(x), rtol=1e-13, atol=1e-13)
+    assert np.allclose((2.5 * op) * x, 2.5 * A.dot(x), rtol=1e-14)
+    assert np.allclose((op - dop) * x, A.dot(x) - D.dot(x), rtol=1e-13, atol=1e-13)
+    assert np.allclose((op ** 2) * x, A.dot(A.dot(x)), rtol=1e-13)
+    I = utils.IdentityLinearOperator((N, N))
+    assert (I * op) is op and (op * I) is op
+    assert np.array_equal(op.adj * x, A.T.dot(x))
+    Ad = A.toarray()
+    dense = utils.get_linearoperator((N, N), Ad)
+    assert np.allclose(dense * x, Ad.dot(x), rtol=1e-13, atol=1e-13)
+    # user callable operator: host round trip
+    cb = utils.LinearOperator((N, N), float, dot=lambda X: 3.0 * X)
+    ls = linsys.LinearSystem(A, b, Ml=cb)
+    assert np.allclose(ls.Mlb, 3.0 * b.reshape(-1, 1))
+    z = np.zeros((N, 0))
+    assert (op * z).shape == (N, 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# config 2 shape: restarted GMRES(100) on the 2-D Laplacian ladder (fixture F2, F3)
+# ---------------------------------------------------------------------------------------------
+def case_restarted_gmres(nx, rhs, ortho="mgs"):
+    g = golden("lap2d_restart_nx%d_%s" % (nx, rhs))
+    A, b = lap2d_system(nx, rhs=rhs)
+    ls = linsys.LinearSystem(A, b)
+    sol = linsys.RestartedGmres(ls, maxiter=100, max_restarts=50, tol=1e-8, ortho=ortho)
+    assert len(sol.resnorms) - 1 == int(g["total_iters"])       # same iteration count
+    assert abs(sol.resnorms[-1] - g["resnorms"][-1]) < 1e-5 * g["resnorms"][-1]
+    assert np.linalg.norm(A.dot(sol.xk[:, 0]) - b) <= 1.0001e-8 * np.linalg.norm(b)
+    for c in range(int(g["ncycles"])):
+        try:
+            s = linsys.Gmres(ls, x0=g["c%d_x0" % c], maxiter=100, tol=1e-8, ortho=ortho,
+                             store_arnoldi=True)
+        except utils.ConvergenceError as e:
+            s = e.solver
+        check_resnorms(s.resnorms, g["c%d_resnorms" % c])
+        assert rel(s.H, g["c%d_H" % c]) < (RTOL if rhs != "ones" else 1e-6)
+        assert rel(s.xk[:, 0], g["c%d_xk" % c]) < RTOL
+
+
+def case_restart_failure():
+    A, b = lap2d_system(64, rhs="rng1")
+    ls = linsys.LinearSystem(A, b)
+    try:
+        linsys.RestartedGmres(ls, maxiter=20, max_restarts=1, tol=1e-8)
+        raise AssertionError
+    except utils.ConvergenceError as e:
+        assert str(e) == "No convergence after 1 restarts."
+        assert len(e.solver.resnorms) == 41 and e.solver.xk.shape == (4096, 1)
+
+
+def case_one_cycle_nx200(ortho):
+    g = golden("lap2d_cycle_nx200")
+    A, b = lap2d_system(200, rhs="rng1")
+    ls = linsys.LinearSystem(A, b)
+    try:
+        s = linsys.Gmres(ls, maxiter=100, tol=1e-8, ortho=ortho, store_arnoldi=True)
+        raise AssertionError("ConvergenceError expected")
+    except utils.ConvergenceError as e:
+        s = e.solver
+    key = ortho if ortho in ("mgs", "dmgs") else "mgs"   # cgs/cgs2 are compared with MGS
+    assert s.iter == int(g[key + "_iter"])
+    check_resnorms(s.resnorms, g[key + "_resnorms"])
+    assert rel(s.H, g[key + "_H"]) < RTOL
+    assert rel(s.xk[:, 0], g[key + "_xk"]) < RTOL
+    V = s.V
+    assert rel(V.sum(axis=0), g[key + "_Vsum"]) < 1e-9
+    assert rel(V[::997, :], g[key + "_Vsample"]) < 1e-9
+    # assert_arnoldi properties of the reference (test_utils.py:440-542)
+    H = s.H
+    assert np.all(np.tril(H, -2) == 0) and np.all(np.diag(H, -1) > 0)
+    n = H.shape[1]
+    assert np.linalg.norm(A.dot(V[:, :n]) - V.dot(H)) < 1e-12 * np.linalg.norm(H)
+    assert np.linalg.norm(V.T.dot(V) - np.eye(n + 1)) < 1e-10
+
+
+# ---------------------------------------------------------------------------------------------
+# config 3 shape: MINRES + Jacobi (fixture F4); sparse CG
+# ---------------------------------------------------------------------------------------------
+def case_minres_jacobi():
+    g = golden("minres_jacobi_nx100")
+    A, b, M, Minv = minres_jacobi_system(100)
+    ls = linsys.LinearSystem(A, b, M=M, Minv=Minv, self_adjoint=True)
+    s = linsys.Minres(ls, ortho="lanczos", tol=1e-8, maxiter=2000, store_arnoldi=True)
+    assert s.iter == int(g["iter"]) and len(s.resnorms) == len(g["resnorms"])
+    assert relmax(s.resnorms[:60], g["resnorms"][:60]) < RTOL
+    assert relmax(s.resnorms, g["resnorms"]) < 1e-6
+    assert rel(s.xk[:, 0], g["xk"]) < 1e-8
+    assert tuple(s.V.shape) == tuple(g["Vshape"]) == tuple(s.P.shape)
+    assert rel(s.H[:60, :59], g["H"][:60, :59]) < RTOL
+    assert rel(s.V[::499, :40], g["Vsample"][:, :40]) < 1e-9
+    assert rel(s.P[::499, :40], g["Psample"][:, :40]) < 1e-9
+    o = ref.minres(A, b, M=M, tol=1e-8, maxiter=2000)
+    assert s.iter == o.iter
+
+
+def case_minres_cg_sparse():
+    g = golden("lap2d_minres_cg_nx100")
+    A, b = lap2d_system(100, rhs="rng1")
+    ls = linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
+    s = linsys.Minres(ls, tol=1e-8, maxiter=2000)
+    assert s.iter == int(g["minres_iter"])
+    assert relmax(s.resnorms[:60], g["minres_resnorms"][:60]) < RTOL
+    assert rel(s.xk[:, 0], g["minres_xk"]) < 1e-8
+    s = linsys.Cg(ls, tol=1e-8, maxiter=2000)
+    assert s.iter == int(g["cg_iter"])
+    assert relmax(s.resnorms[:60], g["cg_resnorms"][:60]) < RTOL
+    assert rel(s.xk[:, 0], g["cg_xk"]) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# config 4 shape: dense CG (fixture F5)
+# ---------------------------------------------------------------------------------------------
+def case_cg_dense():
+    g = golden("cg_dense_n512")
+    A, b = dense_spd_system(512)
+    x, s = krypy_amd.cg(A, b, tol=1e-8, store_arnoldi=True)
+    assert s.iter == int(g["iter"])
+    check_resnorms(s.resnorms, g["resnorms"])
+    assert rel(s.xk[:, 0], g["xk"]) < RTOL
+    assert rel(s.H, g["H"]) < 1e-9
+    g = golden("cg_dense_jacobi_n512")
+    M = sp.diags(1.0 / np.diag(A)).tocsr()
+    x, s = krypy_amd.cg(A, b, M=M, tol=1e-8)
+    assert s.iter == int(g["iter"])
+    check_resnorms(s.resnorms, g["resnorms"])
+    assert rel(s.xk[:, 0], g["xk"]) < RTOL
+
+
+# ---------------------------------------------------------------------------------------------
+# config 5 shape: deflated GMRES with 16 recycled Ritz vectors (fixture F6)
+# ---------------------------------------------------------------------------------------------
+def case_deflated_gmres_recycling():
+    g = golden("deflation_lap3d_nx24")
+    A, b = lap3d_system(24, rhs="ones")
+    ls = linsys.LinearSystem(A, b, self_adjoint=True)
+    s0 = deflation.DeflatedGmres(ls, tol=1e-8, maxiter=300, store_arnoldi=True)
+    assert len(s0.resnorms) - 1 == int(g["s0_iters"])
+    check_resnorms(s0.resnorms, g["s0_resnorms"], tol=1e-9, explicit_tol=1e-5)
+    # Ritz vectors for the next solve: same 16-dimensional space as the reference's
+    ritz = deflation.Ritz(s0)
+    assert rel(np.sort(ritz.values), np.sort(g["s0_ritz_values"])) < 1e-8
+    idx = np.argsort(np.abs(ritz.values))[:16]
+    U1 = ritz.get_vectors(idx)
+    Q, _ = np.linalg.qr(g["s0_U_next"])
+    assert np.linalg.norm(U1 - Q.dot(Q.T.dot(U1))) / np.linalg.norm(U1) < 1e-6
+    # solve 1 with the reference's U
+    s1 = deflation.DeflatedGmres(ls, U=g["s0_U_next"], tol=1e-8, maxiter=300, store_arnoldi=True)
+    assert len(s1.resnorms) - 1 == int(g["s1_iters"])
+    check_resnorms(s1.resnorms, g["s1_resnorms"], tol=1e-8, explicit_tol=1e-5)
+    assert rel(s1.E, g["s1_E"]) < RTOL
+    assert rel(s1.C, g["s1_C"]) < 1e-8
+    assert rel(s1.B_, g["s1_B_"]) < 1e-8
+    assert rel(s1.UMlr, g["s1_UMlr"]) < RTOL
+    assert rel(s1.xk[:, 0], g["s1_xk"]) < 1e-9
+    # identities of the reference's test_deflation_solver (test_deflation.py:53-69)
+    U, AU = s1.projection.U, s1.projection.AU
+    n = s1.H.shape[1]
+    assert np.allclose(s1.E, U.T.dot(AU), atol=1e-6)
+    assert np.allclose(s1.C, U.T.dot(A.dot(s1.V[:, :n])), atol=1e-6)
+    assert np.allclose(s1.B_, s1.V.T.dot(AU), atol=1e-6)
+    # solve 2 from our own Ritz vectors: converges in <= iterations of solve 0
+    U2 = deflation.Ritz(s1)
+    U2 = U2.get_vectors(np.argsort(np.abs(U2.values))[:16])
+    s2 = deflation.DeflatedGmres(ls, U=U2, tol=1e-8, maxiter=300)
+    assert len(s2.resnorms) - 1 == int(g["s2_iters"])

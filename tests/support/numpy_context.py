@@ -1,0 +1,229 @@
+"""NumPy test double of ``krypy_amd._hip.Context`` - TEST INFRASTRUCTURE ONLY.
+
+The build container has no GPU, so the CPU test-suite (``-m "not gpu"``) drives the
+product's *host layer* (operator algebra, Arnoldi bookkeeping, Givens/QR updates, restart
+and deflation logic, error behaviour) with this stand-in for the device library.  It
+implements the same method set as ``Context`` with plain NumPy, one method per C entry
+point, following the documented semantics of ``include/krylov_hip.h``.
+
+It is installed explicitly by ``tests/conftest.py`` through
+``krypy_amd._hip._install_context_for_testing``; the package never imports it, ships no
+alternative backend, and the ``-m gpu`` tests never use it (they run the real HIP library).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+
+class NumpyVectors(object):
+    def __init__(self, ctx, n, ncols):
+        self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
+        self.a = np.zeros((self.n, self.ncols), order="F")
+        self.handle = self
+
+    def upload(self, col0, arr):
+        a = np.asarray(arr, dtype=float)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        assert a.shape[0] == self.n
+        self.a[:, col0: col0 + a.shape[1]] = a
+        return self
+
+    def download(self, col0=0, ncols=None):
+        ncols = self.ncols - col0 if ncols is None else ncols
+        return np.array(self.a[:, col0: col0 + ncols], order="F", copy=True)
+
+    def zero(self, col0=0, ncols=None):
+        ncols = self.ncols - col0 if ncols is None else ncols
+        self.a[:, col0: col0 + ncols] = 0.0
+
+    def copy_from(self, dcol, src, scol, ncols=1):
+        assert src.n == self.n
+        self.a[:, dcol: dcol + ncols] = src.a[:, scol: scol + ncols]
+
+
+class NumpyMatrix(object):
+    def __init__(self, ctx, kind, mat, shape):
+        self.ctx, self.kind, self.mat, self.shape = ctx, kind, mat, shape
+        self.handle = self
+        self.nnz = getattr(mat, "nnz", np.size(mat))
+
+
+class NumpyContext(object):
+    """Same public surface as ``krypy_amd._hip.Context``; counts calls for host-logic tests."""
+
+    def __init__(self, comm=None):
+        self.calls = {}
+        self.rank, self.nranks = 0, 1
+        self._comm = comm           # optional object with allreduce(np.ndarray) (gloo tests)
+        self.device = -1
+        self._alive = True
+        self._t0 = None
+
+    def _count(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def _allreduce(self, x):
+        if self._comm is None:
+            return x
+        return self._comm.allreduce(np.asarray(x, dtype=float))
+
+    # bookkeeping
+    def sync(self):
+        pass
+
+    def close(self):
+        pass
+
+    def info(self):
+        return dict(compute_units=0, mem_total=0, mem_free=0, reduce_blocks=0)
+
+    def tune(self, reduce_blocks=0, spmv_tile=0):
+        pass
+
+    def timer_start(self):
+        import time
+        self._t0 = time.perf_counter()
+
+    def timer_stop(self):
+        import time
+        return (time.perf_counter() - self._t0) * 1e3
+
+    def allreduce_host(self, vals):
+        return self._allreduce(np.asarray(vals, dtype=float))
+
+    # allocation
+    def alloc(self, n, ncols=1):
+        return NumpyVectors(self, n, ncols)
+
+    def upload(self, arr):
+        a = np.asarray(arr, dtype=float)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        return NumpyVectors(self, a.shape[0], a.shape[1]).upload(0, a)
+
+    def csr(self, A, n_cols=None):
+        A = sp.csr_matrix(A)
+        return NumpyMatrix(self, "csr", A, A.shape)
+
+    def dense(self, A):
+        A = np.ascontiguousarray(A, dtype=float)
+        return NumpyMatrix(self, "dense", A, A.shape)
+
+    def diag(self, d):
+        d = np.ascontiguousarray(d, dtype=float)
+        return NumpyMatrix(self, "diag", d, (d.size, d.size))
+
+    # numerics
+    def _matvec(self, A, x):
+        if A.kind == "diag":
+            return A.mat * x
+        if getattr(A, "halo", None) is not None:
+            x = A.halo(x)
+        return A.mat.dot(x)
+
+    def apply(self, A, X, xcol, Y, ycol, ncols=1):
+        self._count("apply")
+        for c in range(ncols):
+            Y.a[:, ycol + c] = self._matvec(A, X.a[:, xcol + c])
+
+    def dot_panel(self, V, j0, ncols, W, wcol):
+        self._count("dot_panel")
+        return self._allreduce(V.a[:, j0: j0 + ncols].T.dot(W.a[:, wcol]))
+
+    def gemm_tn(self, X, x0, nx, Y, y0, ny):
+        self._count("gemm_tn")
+        out = X.a[:, x0: x0 + nx].T.dot(Y.a[:, y0: y0 + ny])
+        return self._allreduce(out.ravel()).reshape(nx, ny)
+
+    def axpy_panel(self, V, j0, ncols, h, W, wcol):
+        self._count("axpy_panel")
+        h = np.asarray(h, dtype=float).reshape(-1)
+        for j in range(ncols):
+            W.a[:, wcol] = W.a[:, wcol] - h[j] * V.a[:, j0 + j]
+
+    def gemm_nn(self, X, x0, k, C, alpha, beta, Y, y0):
+        self._count("gemm_nn")
+        C = np.asarray(C, dtype=float)
+        if C.ndim == 1:
+            C = C.reshape(-1, 1)
+        for c in range(C.shape[1]):
+            y = np.zeros(Y.n) if beta == 0.0 else beta * Y.a[:, y0 + c]
+            for i in range(k):
+                y = y + (alpha * C[i, c]) * X.a[:, x0 + i]
+            Y.a[:, y0 + c] = y
+
+    def nrm2(self, W, wcol):
+        self._count("nrm2")
+        w = W.a[:, wcol]
+        return float(np.sqrt(self._allreduce(np.array([np.dot(w, w)]))[0]))
+
+    def waxpby(self, Z, zcol, alpha, X, xcol, beta, Y, ycol):
+        self._count("waxpby")
+        a = X.a[:, xcol] if alpha == 1.0 else alpha * X.a[:, xcol]
+        if beta == 0.0:
+            Z.a[:, zcol] = a
+        else:
+            Z.a[:, zcol] = a + (Y.a[:, ycol] if beta == 1.0 else beta * Y.a[:, ycol])
+
+    def vdiv(self, Z, zcol, X, xcol, s):
+        self._count("vdiv")
+        Z.a[:, zcol] = X.a[:, xcol] / s
+
+    def arnoldi_step(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
+        """Semantics of kh_arnoldi_step (include/krylov_hip.h)."""
+        self._count("arnoldi_step")
+        B = P if P is not None else V
+        hcol = np.zeros(k + 2)
+        if A is not None:
+            W.a[:, wcol] = self._matvec(A, V.a[:, k])
+        w = W.a[:, wcol]
+        if start > 0 and start == k:
+            w = w - h_km1 * B.a[:, k - 1]
+        for _ in range(sweeps):
+            if gs_mode == 0:
+                for j in range(start, k + 1):
+                    alpha = self._allreduce(np.array([np.dot(V.a[:, j], w)]))[0]
+                    hcol[j] += alpha
+                    w = w - alpha * B.a[:, j]
+            else:
+                h = self._allreduce(V.a[:, start: k + 1].T.dot(w))
+                hcol[start: k + 1] += h
+                for j in range(start, k + 1):
+                    w = w - h[j - start] * B.a[:, j]
+        if Md is not None:
+            mw = Md.mat * w
+            W.a[:, wcol + 1] = mw
+            hn = float(np.sqrt(abs(self._allreduce(np.array([np.dot(w, mw)]))[0])))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                P.a[:, k + 1] = w / hn
+                V.a[:, k + 1] = mw / hn
+        else:
+            hn = float(np.sqrt(self._allreduce(np.array([np.dot(w, w)]))[0]))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                V.a[:, k + 1] = w / hn
+        W.a[:, wcol] = w
+        hcol[k + 1] = hn
+        return hcol
+
+    def residual(self, A, B, bcol, X, xcol, R, rcol):
+        self._count("residual")
+        r = B.a[:, bcol] - self._matvec(A, X.a[:, xcol])
+        R.a[:, rcol] = r
+        return float(np.sqrt(self._allreduce(np.array([np.dot(r, r)]))[0]))
+
+    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
+        self._count("minres_update")
+        z = ((V.a[:, k] - r0 * Wk.a[:, slot]) - r1 * Wk.a[:, 1 - slot]) / r2
+        Wk.a[:, slot] = z
+        YK.a[:, ycol] = YK.a[:, ycol] + y0 * z
+
+    def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
+        self._count("cg_update")
+        YK.a[:, ycol] = YK.a[:, ycol] + alpha * Pd.a[:, pcol]
+        r = R.a[:, rcol] - alpha * AP.a[:, apcol]
+        R.a[:, rcol] = r
+        z = r
+        if Md is not None:
+            z = Md.mat * r
+            Z.a[:, zcol] = z
+        return float(self._allreduce(np.array([np.dot(r, z)]))[0])

@@ -1,0 +1,193 @@
+"""GPU parity tests (-m gpu): the shared parity cases on the REAL HIP library through the
+C ABI, plus kernel-level checks against SciPy/NumPy on the same seeded inputs, and
+size-independent properties at BASELINE.json's full size (N = 10^7).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import krylov_ref as ref
+from oracle.inputs import lap2d_system
+from tests import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+SIMPLE = [
+    pc.case_toy_known_answers, pc.case_toy_custom_inner_product, pc.case_toy_deflated,
+    pc.case_toy_solver_attributes, pc.case_api_errors, pc.case_inner_norm_panels,
+    pc.case_arnoldi_steps, pc.case_arnoldi_invariant, pc.case_qr_projection,
+    pc.case_operator_algebra, pc.case_restart_failure, pc.case_minres_jacobi,
+    pc.case_minres_cg_sparse, pc.case_cg_dense, pc.case_deflated_gmres_recycling,
+]
+
+
+def test_native_library_is_the_one_running(hip):
+    """The context is the ctypes binding of libkrylov_hip.so, not a test double."""
+    from krypy_amd import _hip
+
+    assert isinstance(hip, _hip.Context)
+    info = hip.info()
+    assert info["compute_units"] >= 64 and info["mem_total"] > 2 ** 34
+    with open("/proc/self/maps") as f:
+        assert "libkrylov_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("case", SIMPLE, ids=lambda f: f.__name__)
+def test_case(hip, case):
+    case()
+
+
+@pytest.mark.parametrize("nx,rhs,ortho", [(64, "ones", "mgs"), (64, "rng1", "mgs"),
+                                           (64, "rng1", "cgs2"), (128, "ones", "mgs"),
+                                           (128, "rng1", "mgs"), (128, "rng1", "cgs")])
+def test_restarted_gmres(hip, nx, rhs, ortho):
+    pc.case_restarted_gmres(nx, rhs, ortho)
+
+
+@pytest.mark.parametrize("ortho", ["mgs", "dmgs", "cgs", "cgs2"])
+def test_one_cycle_nx200(hip, ortho):
+    pc.case_one_cycle_nx200(ortho)
+
+
+# ---- kernel level ----------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 256, 257, 4097, 100003])
+def test_vector_kernels_edge_sizes(hip, n):
+    rng = np.random.default_rng(n)
+    V = rng.standard_normal((n, 5))
+    w = rng.standard_normal((n, 1))
+    Vd, Wd = hip.upload(V), hip.upload(w)
+    scale = np.linalg.norm(V, axis=0) * np.linalg.norm(w) + 1e-300
+    got = hip.dot_panel(Vd, 0, 5, Wd, 0)
+    assert np.max(np.abs(got - V.T.dot(w[:, 0])) / scale) < 1e-14
+    assert abs(hip.nrm2(Wd, 0) - np.linalg.norm(w)) <= 1e-14 * np.linalg.norm(w)
+    h = rng.standard_normal(5)
+    hip.axpy_panel(Vd, 0, 5, h, Wd, 0)
+    want = w[:, 0].copy()
+    for j in range(5):
+        want = want - h[j] * V[:, j]
+    assert np.array_equal(Wd.download()[:, 0], want)          # multiply-then-subtract, in order
+    C = rng.standard_normal((5, 2))
+    Y = hip.alloc(n, 2)
+    hip.gemm_nn(Vd, 0, 5, C, 1.0, 0.0, Y, 0)
+    assert np.allclose(Y.download(), V.dot(C), rtol=1e-13, atol=1e-13)
+    Z = hip.alloc(n, 1)
+    hip.waxpby(Z, 0, 2.0, Vd, 1, -0.5, Vd, 2)
+    assert np.array_equal(Z.download()[:, 0], 2.0 * V[:, 1] + (-0.5) * V[:, 2])
+    hip.vdiv(Z, 0, Vd, 3, 3.7)
+    assert np.array_equal(Z.download()[:, 0], V[:, 3] / 3.7)
+
+
+def test_reductions_are_deterministic(hip):
+    rng = np.random.default_rng(0)
+    V = hip.upload(rng.standard_normal((1 << 20, 3)))
+    W = hip.upload(rng.standard_normal((1 << 20, 1)))
+    first = hip.dot_panel(V, 0, 3, W, 0)
+    for _ in range(5):
+        assert np.array_equal(hip.dot_panel(V, 0, 3, W, 0), first)
+
+
+@pytest.mark.parametrize("kind", ["lap2d", "random", "empty_rows", "long_row", "rect"])
+def test_csr_spmv_bit_identical_to_scipy(hip, kind):
+    rng = np.random.default_rng(11)
+    if kind == "lap2d":
+        A = ref.laplace2d(97, 53)
+    elif kind == "random":
+        A = sp.random(20000, 20000, density=2e-3, random_state=3, format="csr")
+    elif kind == "empty_rows":
+        A = sp.random(5000, 5000, density=1e-3, random_state=4, format="csr")
+        A = sp.vstack([A[:100], sp.csr_matrix((300, 5000)), A[400:]]).tocsr()
+    elif kind == "long_row":
+        A = sp.random(300, 50000, density=1e-3, random_state=5, format="lil")
+        A[7, :] = rng.standard_normal(50000)             # 50000 nnz > LDS tile
+        A = A.tocsr()
+    else:
+        A = sp.random(1000, 3000, density=5e-3, random_state=6, format="csr")
+    A.sort_indices()
+    x = rng.standard_normal((A.shape[1], 2))
+    Ad = hip.csr(A)
+    X, Y = hip.upload(x), hip.alloc(A.shape[0], 2)
+    hip.apply(Ad, X, 0, Y, 0, 2)
+    got, want = Y.download(), A.dot(x)
+    if kind == "long_row":
+        mask = np.ones(A.shape[0], bool)
+        mask[7] = False
+        assert np.array_equal(got[mask], want[mask])
+        assert np.allclose(got[7], want[7], rtol=1e-12)    # tree-reduced row: not bit-ordered
+    else:
+        assert np.array_equal(got, want)
+
+
+def test_dense_gemv_and_diag(hip):
+    rng = np.random.default_rng(2)
+    for n, m in ((1, 1), (37, 41), (512, 512), (1000, 999)):
+        A = rng.standard_normal((n, m))
+        x = rng.standard_normal((m, 1))
+        Y = hip.alloc(n, 1)
+        hip.apply(hip.dense(A), hip.upload(x), 0, Y, 0, 1)
+        assert np.allclose(Y.download(), A.dot(x), rtol=1e-13, atol=1e-12)
+    d = rng.standard_normal(777)
+    x = rng.standard_normal((777, 1))
+    Y = hip.alloc(777, 1)
+    hip.apply(hip.diag(d), hip.upload(x), 0, Y, 0, 1)
+    assert np.array_equal(Y.download()[:, 0], d * x[:, 0])
+
+
+def test_fused_residual(hip):
+    A, b = lap2d_system(150, rhs="rng1")
+    x = np.random.default_rng(9).standard_normal((A.shape[0], 1))
+    R = hip.alloc(A.shape[0], 1)
+    nrm = hip.residual(hip.csr(A), hip.upload(b), 0, hip.upload(x), 0, R, 0)
+    want = b - A.dot(x[:, 0])
+    assert np.array_equal(R.download()[:, 0], want)
+    assert abs(nrm - np.linalg.norm(want)) < 1e-14 * nrm
+
+
+def test_arnoldi_step_matches_oracle_step_by_step(hip):
+    """kh_arnoldi_step against the oracle's arnoldi_step on the same inputs, every step."""
+    A, b = lap2d_system(120, rhs="rng1")
+    m = 40
+    for ortho, gs, sweeps in (("mgs", 0, 1), ("dmgs", 0, 2), ("mgs", 1, 2)):
+        st = ref.arnoldi_init(A, b, m, ortho=ortho)
+        V = hip.alloc(A.shape[0], m + 1)
+        W = hip.alloc(A.shape[0], 2)
+        V.upload(0, st.V[:, :1])
+        Ad = hip.csr(A)
+        for k in range(m):
+            ref.arnoldi_step(st)
+            hcol = hip.arnoldi_step(Ad, None, V, None, W, 0, k, 0, sweeps, gs)
+            assert np.linalg.norm(hcol - st.H[: k + 2, k]) < 1e-12 * np.linalg.norm(hcol)
+        assert np.linalg.norm(V.download() - st.V) < 1e-10 * np.sqrt(m)
+
+
+# ---- full size (config 2: N = 10^7): size-independent properties -------------------------------
+def test_full_size_properties(hip):
+    """nx=4000, ny=2500 5-point Laplacian, N = 10^7, nnz = 49,987,000 (BASELINE.json config 2).
+
+    SpMV is checked bit-for-bit against SciPy; one 30-step Arnoldi relation A V_k = V_{k+1} H
+    is verified on the device (residual and orthogonality), for both Gram-Schmidt variants."""
+    from krypy_amd import linsys, utils
+
+    A = ref.laplace2d(4000, 2500)
+    N = A.shape[0]
+    assert N == 10_000_000 and A.nnz == 49_987_000 and A.indices.dtype == np.int32
+    b = np.random.default_rng(0).standard_normal(N)
+    ls = linsys.LinearSystem(A, b)
+    x = np.random.default_rng(1).standard_normal((N, 1))
+    assert np.array_equal(ls.A * x, A.dot(x))
+    for ortho in ("mgs", "cgs2"):
+        ar = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=30, ortho=ortho)
+        for _ in range(30):
+            ar.advance()
+        H = ar.H
+        assert np.all(np.diag(H, -1) > 0)
+        G = hip.gemm_tn(ar._V, 0, 31, ar._V, 0, 31)
+        assert np.linalg.norm(G - np.eye(31)) < 1e-12
+        # || A V_30 - V_31 H ||_F through the device: column by column
+        T = hip.alloc(N, 2)
+        Ad = ls.A._device_matrix()
+        worst = 0.0
+        for j in (0, 7, 29):
+            hip.apply(Ad, ar._V, j, T, 0, 1)
+            hip.gemm_nn(ar._V, 0, 31, H[:, j], -1.0, 1.0, T, 0)
+            worst = max(worst, hip.nrm2(T, 0))
+        assert worst < 1e-12 * np.linalg.norm(H, 2)
