@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py - GMRES(100) iterations/sec on the 2-D 5-point Laplacian, N = 10^7, fp64.
+
+Contract (see the task statement): ``python bench.py --gpus N --steps K --warmup W`` prints ONE
+JSON line on rank 0.  A *step* is one GMRES(100) restart cycle (100 Arnoldi iterations + the
+cycle end: triangular solve, x update, explicit residual) of
+``RestartedGmres(ls, maxiter=100, max_restarts=K-1, tol=1e-8)`` on
+
+    A = kron(I_2500, T_4000) + kron(T_2500, I_4000)   (N = 10,000,000, nnz = 49,987,000, CSR)
+    b = numpy.random.default_rng(0).standard_normal(N),  x0 = 0
+
+(BASELINE.json configs[1]; tolerance is not reached at this N - SURVEY.md section 0 - so the
+timed region is a fixed number of cycles and the expected ConvergenceError is caught).
+Inputs (CSR matrix, b) are resident in HBM before the timed region starts.
+
+value = K*100 iterations / wall time (max over ranks, barrier + device sync on both sides).
+For N > 1 the matrix rows and all vectors are sharded in contiguous slabs (one process per
+GPU, launched with torch.distributed.run); halo exchange + dot-product all-reduces go through
+RCCL inside libkrylov_hip.so; torch.distributed (gloo) is used only to hand the ncclUniqueId
+to the ranks and for the timing barrier.  Total work is fixed -> "scaling": "strong".
+
+Extra objects on the JSON line:
+  roofline     the dominant kernel (Gram-Schmidt link / panel kernels), timed live with HIP
+               events on the library's stream; algorithmic bytes per SURVEY.md 8(d).
+  cpu_baseline the CPU oracle (NumPy/SciPy restatement of the reference) timed on a bounded
+               sample of the same workload on the host cores (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def laplace2d(nx, ny, row0=None, row1=None):
+    """5-point Laplacian kron(I_ny,T_nx)+kron(T_ny,I_nx) as sorted int32 CSR, built with array
+    arithmetic (no Python loops); optionally only grid rows [row0, row1) of the ny dimension."""
+    import scipy.sparse as sp
+
+    r0 = 0 if row0 is None else row0
+    r1 = ny if row1 is None else row1
+    jj, ii = np.meshgrid(np.arange(r0, r1, dtype=np.int64), np.arange(nx, dtype=np.int64),
+                         indexing="ij")
+    row = (jj * nx + ii).ravel()
+    cols = [row - nx, row - 1, row, row + 1, row + nx]
+    ok = [(jj > 0).ravel(), (ii > 0).ravel(), np.ones(row.size, bool), (ii < nx - 1).ravel(),
+          (jj < ny - 1).ravel()]
+    vals = [-1.0, -1.0, 4.0, -1.0, -1.0]
+    C = np.stack(cols, axis=1)
+    K = np.stack(ok, axis=1)
+    Vv = np.broadcast_to(np.array(vals), C.shape)
+    counts = K.sum(axis=1)
+    indptr = np.zeros(row.size + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    indices = C[K]
+    data = Vv[K].astype(np.float64)
+    A = sp.csr_matrix((data, indices.astype(np.int64), indptr), shape=(row.size, nx * ny))
+    return A
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5, help="timed GMRES(100) restart cycles")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up cycles")
+    ap.add_argument("--nx", type=int, default=4000)
+    ap.add_argument("--ny", type=int, default=2500)
+    ap.add_argument("--restart", type=int, default=100)
+    ap.add_argument("--ortho", default=os.environ.get("KRYPY_AMD_BENCH_ORTHO", "mgs"),
+                    help="mgs (reference order, default) | dmgs | cgs | cgs2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-steps", type=int, default=12)
+    return ap.parse_args()
+
+
+def cpu_baseline(A, b, m, sample_steps):
+    """Time the CPU oracle on a bounded sample: the first `sample_steps` Arnoldi steps of the
+    GMRES(m) cycle at full N (single BLAS thread).  An MGS step costs a + c*k, so the per-step
+    times are fitted linearly in k and summed over k = 0..m-1 to give iterations/sec."""
+    from oracle import krylov_ref as ref
+
+    try:
+        from threadpoolctl import threadpool_limits
+        limiter = threadpool_limits(limits=1)
+    except Exception:
+        limiter = None
+    t0 = time.perf_counter()
+    st = ref.arnoldi_init(A, b, m)
+    ts = []
+    for _ in range(sample_steps):
+        t1 = time.perf_counter()
+        ref.arnoldi_step(st)
+        ts.append(time.perf_counter() - t1)
+    total = time.perf_counter() - t0
+    t2 = time.perf_counter()
+    for _ in range(3):
+        A.dot(b)
+    spmv = (time.perf_counter() - t2) / 3
+    if limiter is not None:
+        limiter.unregister() if hasattr(limiter, "unregister") else None
+    k = np.arange(sample_steps)
+    c, a = np.polyfit(k[1:], np.array(ts)[1:], 1) if sample_steps > 2 else (0.0, np.mean(ts))
+    cycle = float(np.sum(a + c * np.arange(m)))
+    return {
+        "value": m / cycle, "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": ("first %d Arnoldi steps of GMRES(%d) at N=%d with the NumPy/SciPy oracle "
+                   "(oracle/krylov_ref.py), 1 BLAS thread, %.1f s of CPU work; per-step time "
+                   "fitted as a+c*k (a=%.3f s, c=%.3f s) and summed over k=0..%d"
+                   % (sample_steps, m, A.shape[0], total, a, c, m - 1)),
+        "spmv_ms": spmv * 1e3,
+        "spmv_gbs": (12.0 * A.nnz + 4.0 * (A.shape[0] + 1) + 16.0 * A.shape[0]) / spmv / 1e9,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # plumbing only: unique-id broadcast + barrier
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import krypy_amd
+    from krypy_amd import _hip, linsys, utils
+
+    ctx = _hip.get_context()
+    nx, ny, m = args.nx, args.ny, args.restart
+    N = nx * ny
+    ortho = args.ortho
+    if world > 1:
+        from krypy_amd import dist as kdist
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
+        # contiguous slabs of grid rows (y index): every shard holds whole x-lines
+        cuts = [(ny * p) // world for p in range(world + 1)]
+        Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
+        op = kdist.ShardedCSROperator(Aloc, cuts[rank] * nx, N, ctx)
+        b_full = np.random.default_rng(0).standard_normal(N)
+        b = b_full[cuts[rank] * nx: cuts[rank + 1] * nx].copy()
+        A_for_ls = op
+        if ortho == "mgs" and os.environ.get("KRYPY_AMD_BENCH_ORTHO") is None:
+            ortho = "cgs2"   # k+1 dependent all-reduces per step (MGS) are latency bound on xGMI
+        nnz_global = 5 * N - 2 * nx - 2 * ny
+    else:
+        A_for_ls = laplace2d(nx, ny)
+        nnz_global = A_for_ls.nnz
+        b = np.random.default_rng(0).standard_normal(N)
+
+    ls = linsys.LinearSystem(A_for_ls, b)
+
+    def run_cycles(ncyc, x0):
+        try:
+            sol = linsys.RestartedGmres(ls, x0=x0, maxiter=m, max_restarts=ncyc - 1, tol=1e-8,
+                                        ortho=ortho)
+        except utils.ConvergenceError as e:
+            sol = e.solver
+        return sol
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    x0 = None
+    sol = None
+    if args.warmup > 0:
+        sol = run_cycles(args.warmup, None)
+        x0 = sol.__dict__["_xk_dev"]
+    barrier()
+    t0 = time.perf_counter()
+    sol = run_cycles(args.steps, x0)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    n_iters = len(sol.resnorms) - 1
+    assert n_iters == args.steps * m, (n_iters, args.steps, m)
+    its = n_iters / dt
+
+    # ---- roofline of the dominant kernel, timed live with HIP events on the library stream ----
+    nloc = ls.N
+    roof = None
+    extra = {}
+    try:
+        from krypy_amd import _bench
+        roof, extra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS)
+    except Exception as exc:   # never lose the headline number to the instrumentation
+        extra = {"roofline_error": repr(exc)}
+
+    out = {
+        "metric": "GMRES iterations/sec + SpMV HBM GB/s, n=10^7 5-pt Laplacian fp64",
+        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "GMRES(%d) restart cycles, 2-D 5-pt Laplacian %dx%d CSR (N=%d, nnz=%d), "
+                               "b=rng(0) normal, x0=0, tol=1e-8 (BASELINE.json configs[1])"
+                               % (m, nx, ny, N, nnz_global),
+                   "ortho": ortho, "restart": m, "iterations_timed": n_iters,
+                   "parallelism": "1 GPU" if world == 1 else "row-sharded x%d (RCCL)" % world,
+                   "final_relres": float(sol.resnorms[-1])},
+        "roofline": roof,
+    }
+    out.update(extra)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(A_for_ls, b, m, args.cpu_sample_steps)
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -164,6 +164,13 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
                  kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
                  double* rho_new);
 
+/* ---- measurement ----------------------------------------------------------------------- */
+/* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot
+ * kernel, HIP events on the context's stream.  which: 0 Gram-Schmidt link (axpy+dot),
+ * 1 multidot<16>, 2 multiaxpy<16>, 3 link with norm tail, 4 scale-and-store.
+ * V needs >= 17 columns, W 2 columns. */
+int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,68 @@
+"""Live roofline measurements for bench.py: HIP-event timing of the hot kernels on the
+library's own stream (``kh_bench_kernel`` / ``kh_timer_*``), with the algorithmic byte counts of
+SURVEY.md section 8(d).  Not part of the solver path."""
+import numpy
+
+# kernel ids of kh_bench_kernel
+K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE = 0, 1, 2, 3, 4
+
+
+def _gbs(nbytes, ms):
+    return nbytes / (ms * 1e-3) / 1e9
+
+
+def roofline(ctx, ls, ortho, peak_gbs, reps=60):
+    """Returns (roofline dict of the dominant kernel, extra dict with the other kernels)."""
+    n = ls.N
+    ncol = 18
+    V = ctx.alloc(n, ncol)
+    W = ctx.alloc(n, 2)
+    rng = numpy.random.default_rng(1)
+    for j in range(ncol):
+        V.upload(j, rng.standard_normal(n))
+    W.upload(0, rng.standard_normal(n))
+    kernels = {}
+
+    def run(which, nbytes, name, moved):
+        ctx.bench_kernel(which, V, W, 5)             # warm-up
+        ms = ctx.bench_kernel(which, V, W, reps)
+        kernels[name] = {"avg_ms": ms, "algorithmic_bytes": nbytes, "achieved_gbs": _gbs(nbytes, ms),
+                         "moved_bytes_model": moved, "moved_gbs_model": _gbs(moved, ms)}
+        return ms
+
+    # algorithmic bytes per launch ("16 N (k+1)" per step = 16 N per basis column:
+    # the column is read once for the projection and once for the update; w is accounted once per
+    # step, not per column).  moved_bytes_model = what the launch really streams through L2.
+    run(K_GS_LINK, 16.0 * n, "k_gs_link<A_PART,T_DOT>", 32.0 * n)
+    run(K_MULTIDOT16, 8.0 * n * 16 + 8.0 * n, "k_multidot<16>", 8.0 * n * 17)
+    run(K_MULTIAXPY16, 8.0 * n * 16 + 16.0 * n, "k_multiaxpy<16>", 8.0 * n * 18)
+    run(K_AXPY_NRM, 8.0 * n + 16.0 * n, "k_gs_link<A_PART,T_NRM>", 24.0 * n)
+    run(K_SCALE_STORE, 16.0 * n, "k_scale_store", 16.0 * n)
+    extra = {"kernels": kernels}
+    Amat = ls.A._device_matrix()
+    if Amat is not None and Amat.kind == "csr":
+        X, Y = ctx.alloc(n, 1), ctx.alloc(Amat.shape[0], 1)
+        X.upload(0, rng.standard_normal(n))
+        for _ in range(3):
+            ctx.apply(Amat, X, 0, Y, 0, 1)
+        ctx.timer_start()
+        for _ in range(reps):
+            ctx.apply(Amat, X, 0, Y, 0, 1)
+        ms = ctx.timer_stop() / reps
+        nb = 12.0 * Amat.nnz + 4.0 * (Amat.shape[0] + 1) + 16.0 * Amat.shape[0]
+        extra["spmv"] = {"kernel": "k_spmv_stream", "avg_ms": ms, "algorithmic_bytes": nb,
+                         "achieved_gbs": _gbs(nb, ms), "frac_of_peak": _gbs(nb, ms) / peak_gbs}
+    if ortho in ("cgs", "cgs2"):
+        # the two panel kernels alternate; report the pair as one unit of 16 columns
+        d, a = kernels["k_multidot<16>"], kernels["k_multiaxpy<16>"]
+        nb = d["algorithmic_bytes"] + a["algorithmic_bytes"]
+        ms = d["avg_ms"] + a["avg_ms"]
+        name = "k_multidot<16>+k_multiaxpy<16>"
+    else:
+        d = kernels["k_gs_link<A_PART,T_DOT>"]
+        nb, ms, name = d["algorithmic_bytes"], d["avg_ms"], "k_gs_link<A_PART,T_DOT>"
+    ach = _gbs(nb, ms)
+    roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": peak_gbs, "unit": "GB/s",
+            "frac": ach / peak_gbs, "traffic": None, "avg_launch_ms": ms,
+            "algorithmic_bytes_per_launch": nb}
+    return roof, extra

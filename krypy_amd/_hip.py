@@ -76,6 +76,7 @@ _SIGNATURES = {
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
+    "kh_bench_kernel": [_H, _INT, _H, _H, _INT, _c_double_p],
 }
 
 _lib = None
@@ -376,6 +377,13 @@ class Context(object):
             Md.handle if Md is not None else None, Z.handle if Z is not None else None, zcol,
             ctypes.byref(out)), "kh_cg_update")
         return out.value
+
+
+    def bench_kernel(self, which, V, W, reps):
+        ms = _D(0.0)
+        _check(self._lib, self._lib.kh_bench_kernel(self._h, which, V.handle, W.handle, reps,
+                                                    ctypes.byref(ms)), "kh_bench_kernel")
+        return ms.value
 
 
 _default_ctx = None

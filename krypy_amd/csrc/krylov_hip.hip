@@ -155,7 +155,8 @@ template <int EPI>
 static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
     const size_t lds = (size_t)A->tile * sizeof(double);
     hipLaunchKernelGGL((k_spmv_stream<EPI>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr,
-                       A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_rows, x, A->ghost, y,
+                       A->indices, A->data, A->rowblk, A->nblk, A->tile,
+                       A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y,
                        aux, A->part);
 }
 
@@ -844,6 +845,64 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     KH_HIP(hipGetLastError());
     if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
     return fetch_scalars(ctx, tmp, 1, rho_new);
+}
+
+// Timing harness for bench.py: `reps` back-to-back launches of one hot kernel between two HIP
+// events on the context's stream.  The launches rotate through the columns of V exactly like the
+// solver does (p = V[:, j], vnext = V[:, j+1]) so cache behaviour matches the real chain.
+int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double* avg_ms) {
+    KH_ARG(ctx && V && W && avg_ms, "kh_bench_kernel: NULL");
+    KH_ARG(V->ncols >= 17 && W->ncols >= 2 && V->n == W->n, "kh_bench_kernel: need >= 17 basis columns");
+    KH_ARG(reps >= 1, "kh_bench_kernel: reps");
+    const int64_t n = V->n;
+    const int grid = grid_for(ctx, n);
+    double* w = W->col(0);
+    double* mw = W->col(1);
+    double* pa = part_slot(ctx, SLOT_PING);
+    double* pb = part_slot(ctx, SLOT_PONG);
+    KH_HIP(hipMemsetAsync(pa, 0, sizeof(double) * NB_MAX * 2, ctx->stream));  // alpha = 0: w unchanged
+    KH_HIP(hipMemsetAsync(ctx->scal + SC_COEF, 0, sizeof(double) * MAXC, ctx->stream));
+    const double four = 4.0;  // k_scale_store divides by sqrt(4)
+    KH_TRY(push_scalars(ctx, &four, 1, ctx->scal + SC_TMP + 8));
+    ColPtrs cp;
+    for (int i = 0; i < MAXC; ++i) cp.c[i] = V->col(i);
+    KH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        const int j = r % 16;
+        switch (which) {
+            case 0:
+                hipLaunchKernelGGL((k_gs_link<A_PART, T_DOT>), dim3(grid), dim3(BS), 0, ctx->stream, n,
+                                   V->col(j), V->col(j + 1), w, nullptr, nullptr, (r & 1) ? pb : pa, grid,
+                                   nullptr, 0.0, (r & 1) ? pa : pb, nullptr);
+                break;
+            case 1:
+                hipLaunchKernelGGL((k_multidot<16>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part,
+                                   NB_MAX);
+                break;
+            case 2:
+                hipLaunchKernelGGL((k_multiaxpy<16, T_NONE, 1>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp,
+                                   ctx->scal + SC_COEF, 1.0, 1.0, w, nullptr, nullptr, nullptr);
+                break;
+            case 3:
+                hipLaunchKernelGGL((k_gs_link<A_PART, T_NRM>), dim3(grid), dim3(BS), 0, ctx->stream, n,
+                                   V->col(j), nullptr, w, nullptr, nullptr, pa, grid, nullptr, 0.0,
+                                   part_slot(ctx, SLOT_NRM), nullptr);
+                break;
+            case 4:
+                hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, nullptr,
+                                   mw, nullptr, nullptr, 0, ctx->scal + SC_TMP + 8, nullptr);
+                break;
+            default:
+                return fail(KH_ERR_ARG, "kh_bench_kernel: unknown kernel id %d", which);
+        }
+    }
+    KH_HIP(hipGetLastError());
+    KH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    KH_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / reps;
+    return 0;
 }
 
 }  // extern "C"
