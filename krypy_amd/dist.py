@@ -1,0 +1,102 @@
+"""Block-row sharding of the Krylov path over the GPUs of one node (one process per GPU).
+
+The reference is single-process; this module is the new component SURVEY.md 8(e) describes:
+matrix rows and every N-vector are split into contiguous slabs, one per rank; ``H``, the Givens
+rotations and all small factors stay replicated on every rank's host.  Two exchanges exist and
+both run inside ``libkrylov_hip.so`` over RCCL/xGMI:
+
+* all-reduce(sum, fp64) of dot-product panels (inside ``kh_dot_panel``, ``kh_nrm2``,
+  ``kh_arnoldi_step``, ``kh_residual``, ``kh_cg_update``) - the host layer is unchanged, it just
+  sees the local slab length as ``N``;
+* a nearest-neighbour halo exchange before each sharded SpMV (``kh_mat_set_halo``): for a banded
+  matrix (stencils) a rank needs the last ``h`` entries of the previous slab and the first ``h``
+  of the next one.
+
+Usage (every rank)::
+
+    ctx = krypy_amd._hip.get_context(); ctx.comm_init(rank, nranks, unique_id)
+    op = ShardedCSROperator(A_rows, row0, n_global, ctx)   # A_rows: CSR of rows [row0, row1),
+    ls = LinearSystem(op, b_local)                         #         global column indices
+    RestartedGmres(ls, maxiter=100, max_restarts=R, ortho="cgs2")
+"""
+import numpy
+import scipy.sparse
+
+from . import _hip, utils
+
+__all__ = ["slab_cuts", "localize_columns", "ShardedCSROperator"]
+
+
+def slab_cuts(n, nranks, align=1):
+    """Row boundaries ``cuts[p] .. cuts[p+1]`` of ``nranks`` near-equal contiguous slabs whose
+    sizes are multiples of ``align`` (e.g. one grid line), except possibly the last."""
+    units = (n + align - 1) // align
+    cuts = [min(n, ((units * p) // nranks) * align) for p in range(nranks + 1)]
+    cuts[-1] = n
+    return cuts
+
+
+def localize_columns(A_rows, row0, n_global):
+    """Remap the global column indices of the row slab ``[row0, row0+nloc)`` to the local layout
+    ``[local rows | ghosts from the previous slab | ghosts from the next slab]``.
+
+    Returns ``(A_local, nrecv_prev, nrecv_next)`` where ``A_local`` is CSR with
+    ``nloc + nrecv_prev + nrecv_next`` columns and row order / in-row order untouched (the
+    per-row summation order of the SpMV is the same as for the unsharded matrix)."""
+    A = scipy.sparse.csr_matrix(A_rows)
+    nloc = A.shape[0]
+    row1 = row0 + nloc
+    idx = A.indices.astype(numpy.int64)
+    below = idx < row0
+    above = idx >= row1
+    nrecv_prev = int(row0 - idx[below].min()) if below.any() else 0
+    nrecv_next = int(idx[above].max() - row1 + 1) if above.any() else 0
+    new = idx - row0
+    new[below] = nloc + (idx[below] - (row0 - nrecv_prev))
+    new[above] = nloc + nrecv_prev + (idx[above] - row1)
+    A_local = scipy.sparse.csr_matrix(
+        (A.data, new.astype(numpy.int32), A.indptr), shape=(nloc, nloc + nrecv_prev + nrecv_next))
+    return A_local, nrecv_prev, nrecv_next
+
+
+class ShardedCSROperator(utils.LinearOperator):
+    """The local row slab of a block-row-sharded CSR matrix, as a krypy ``LinearOperator``.
+
+    ``shape`` is ``(nloc, nloc)``: from the host layer's point of view the problem is the
+    local slab; halo exchange and all-reduces happen below the C ABI.
+    """
+
+    def __init__(self, A_rows, row0, n_global, ctx=None):
+        ctx = _hip.get_context() if ctx is None else ctx
+        self._ctx = ctx
+        utils._require_real(A_rows.dtype, "sharded matrix")
+        A_local, nrp, nrn = localize_columns(A_rows, row0, n_global)
+        nloc = A_local.shape[0]
+        # every rank learns its neighbours' halo widths: what rank p receives from p-1 is what
+        # p-1 has to send "next", and vice versa
+        table = numpy.zeros(2 * ctx.nranks)
+        table[2 * ctx.rank] = nrp
+        table[2 * ctx.rank + 1] = nrn
+        table = ctx.allreduce_host(table)
+        nsend_prev = int(table[2 * (ctx.rank - 1) + 1]) if ctx.rank > 0 else 0
+        nsend_next = int(table[2 * (ctx.rank + 1)]) if ctx.rank + 1 < ctx.nranks else 0
+        if nsend_prev > nloc or nsend_next > nloc:
+            raise utils.ArgumentError("halo wider than the local slab: use fewer ranks")
+        self._dmat = ctx.csr(A_local, n_cols=A_local.shape[1])
+        ctx.set_halo(self._dmat, nsend_prev, nsend_next, nrp, nrn)
+        self.halo = (nsend_prev, nsend_next, nrp, nrn)
+        self.row0, self.n_global = row0, n_global
+        super(ShardedCSROperator, self).__init__((nloc, nloc), numpy.dtype(float), self._dot_host)
+
+    def _device_matrix(self, ctx=None):
+        return self._dmat
+
+    def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
+        self._ctx.apply(self._dmat, X, xcol, Y, ycol, ncols)
+
+    def _dot_host(self, X):
+        X = numpy.asarray(X, dtype=float)
+        Xd = self._ctx.upload(X)
+        Yd = self._ctx.alloc(self.shape[0], X.shape[1])
+        self._apply_dev(Xd, 0, Yd, 0, X.shape[1])
+        return numpy.ascontiguousarray(Yd.download())

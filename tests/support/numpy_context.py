@@ -227,3 +227,54 @@ class NumpyContext(object):
             z = Md.mat * r
             Z.a[:, zcol] = z
         return float(self._allreduce(np.array([np.dot(r, z)]))[0])
+
+
+class GlooComm(object):
+    """torch.distributed (gloo, CPU) stand-in for the RCCL calls of libkrylov_hip: sum
+    all-reduce of small panels and the nearest-neighbour halo exchange.  world_size-2 tests only."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def allreduce(self, x):
+        import torch
+        import torch.distributed as dist
+
+        t = torch.from_numpy(np.array(x, dtype=np.float64, copy=True).reshape(-1))
+        dist.all_reduce(t)
+        return t.numpy().reshape(np.shape(x))
+
+    def exchange(self, x, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
+        import torch
+        import torch.distributed as dist
+
+        reqs = []
+        gp = torch.zeros(nrecv_prev, dtype=torch.float64)
+        gn = torch.zeros(nrecv_next, dtype=torch.float64)
+        if self.rank > 0:
+            if nsend_prev:
+                reqs.append(dist.isend(torch.from_numpy(np.array(x[:nsend_prev])), self.rank - 1))
+            if nrecv_prev:
+                reqs.append(dist.irecv(gp, self.rank - 1))
+        if self.rank + 1 < self.world:
+            if nsend_next:
+                reqs.append(dist.isend(torch.from_numpy(np.array(x[len(x) - nsend_next:])),
+                                       self.rank + 1))
+            if nrecv_next:
+                reqs.append(dist.irecv(gn, self.rank + 1))
+        for r in reqs:
+            r.wait()
+        return gp.numpy(), gn.numpy()
+
+
+def _set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
+    comm = self._comm
+
+    def halo(x):
+        gp, gn = comm.exchange(x, nsend_prev, nsend_next, nrecv_prev, nrecv_next)
+        return np.concatenate([x, gp, gn])
+
+    A.halo = halo
+
+
+NumpyContext.set_halo = _set_halo

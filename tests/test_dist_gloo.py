@@ -1,0 +1,149 @@
+"""world_size-2 CPU tests (gloo) of the block-row-sharded path: slab partition, column
+localisation, halo exchange plan and all-reduced reductions, driven through the SAME host layer
+(krypy_amd.dist.ShardedCSROperator + LinearSystem + RestartedGmres / DeflatedGmres / Minres).
+
+RCCL itself cannot run here (no GPU); the NumPy test double routes the two exchanges through
+torch.distributed/gloo instead, which proves the sharding logic the RCCL path relies on."""
+import multiprocessing as mp
+import os
+import socket
+import traceback
+
+import numpy as np
+import pytest
+
+from oracle.inputs import lap2d_system, lap3d_system
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, q):
+    try:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from krypy_amd import _hip
+        from tests.support.numpy_context import GlooComm, NumpyContext
+
+        ctx = NumpyContext(comm=GlooComm(rank, world))
+        ctx.rank, ctx.nranks = rank, world
+        _hip._install_context_for_testing(ctx)
+        q.put((rank, "ok", case(rank, world, ctx)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def _run(case, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        rank, status, payload = q.get(timeout=600)
+        assert status == "ok", payload
+        out[rank] = payload
+    for p in procs:
+        p.join(timeout=60)
+    return out
+
+
+def _case_gmres(rank, world, ctx):
+    from krypy_amd import dist as kdist, linsys, utils
+    nx = 48
+    A, b = lap2d_system(nx, rhs="rng1")
+    cuts = kdist.slab_cuts(A.shape[0], world, align=nx)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    op = kdist.ShardedCSROperator(A[r0:r1], r0, A.shape[0], ctx)
+    assert op.halo == ((nx if rank > 0 else 0), (nx if rank + 1 < world else 0),
+                       (nx if rank > 0 else 0), (nx if rank + 1 < world else 0))
+    ls = linsys.LinearSystem(op, b[r0:r1])
+    res = {}
+    for ortho in ("mgs", "cgs2"):
+        sol = linsys.RestartedGmres(ls, maxiter=40, max_restarts=30, tol=1e-8, ortho=ortho)
+        res[ortho] = (np.array(sol.resnorms), sol.xk[:, 0].copy())
+    return r0, r1, res
+
+
+def test_sharded_restarted_gmres_matches_single_process():
+    from oracle import krylov_ref as ref
+    out = _run(_case_gmres)
+    A, b = lap2d_system(48, rhs="rng1")
+    o = ref.restarted_gmres(A, b, tol=1e-8, maxiter=40, max_restarts=30)
+    for ortho in ("mgs", "cgs2"):
+        x = np.zeros(A.shape[0])
+        for rank, (r0, r1, res) in out.items():
+            resn, xk = res[ortho]
+            x[r0:r1] = xk
+            assert len(resn) == len(o.resnorms)                     # same iteration count
+            first = slice(0, 40)                                     # first cycle: 1e-10
+            assert np.max(np.abs(resn[first] - np.array(o.resnorms)[first])
+                          / np.array(o.resnorms)[first]) < 1e-10
+        assert np.array_equal(out[0][2][ortho][0], out[1][2][ortho][0])   # replicated scalars agree
+        assert np.linalg.norm(A.dot(x) - b) <= 1.0001e-8 * np.linalg.norm(b)
+        assert np.linalg.norm(x - o.xk) < 1e-7 * np.linalg.norm(o.xk)
+
+
+def _case_deflated_and_minres(rank, world, ctx):
+    from krypy_amd import deflation, dist as kdist, linsys
+    nx = 12
+    A, b = lap3d_system(nx, rhs="ones")
+    N = A.shape[0]
+    cuts = kdist.slab_cuts(N, world, align=nx * nx)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    op = kdist.ShardedCSROperator(A[r0:r1], r0, N, ctx)
+    ls = linsys.LinearSystem(op, b[r0:r1], self_adjoint=True)
+    U = np.random.default_rng(4).standard_normal((N, 5))
+    s = deflation.DeflatedGmres(ls, U=U[r0:r1], tol=1e-9, maxiter=200, store_arnoldi=True)
+    m = linsys.Minres(ls, tol=1e-9, maxiter=300)
+    c = linsys.Cg(linsys.LinearSystem(op, b[r0:r1], self_adjoint=True, positive_definite=True),
+                  tol=1e-9, maxiter=300)
+    return r0, r1, np.array(s.resnorms), s.xk[:, 0].copy(), s.E, np.array(m.resnorms), \
+        m.xk[:, 0].copy(), np.array(c.resnorms)
+
+
+def test_sharded_deflated_gmres_minres_cg():
+    from oracle import krylov_ref as ref
+    out = _run(_case_deflated_and_minres)
+    A, b = lap3d_system(12, rhs="ones")
+    U = np.random.default_rng(4).standard_normal((A.shape[0], 5))
+    o = ref.deflated_gmres(A, b, U, tol=1e-9, maxiter=200)
+    om = ref.minres(A, b, tol=1e-9, maxiter=300)
+    oc = ref.cg(A, b, tol=1e-9, maxiter=300)
+    x = np.zeros(A.shape[0])
+    xm = np.zeros(A.shape[0])
+    for rank, (r0, r1, resn, xk, E, mres, mx, cres) in out.items():
+        x[r0:r1], xm[r0:r1] = xk, mx
+        assert len(resn) == len(o.resnorms) and len(mres) == len(om.resnorms)
+        assert len(cres) == len(oc.resnorms)
+        assert np.max(np.abs(resn[:-1] - np.array(o.resnorms)[:-1]) / np.array(o.resnorms)[:-1]) < 1e-8
+        assert np.linalg.norm(E - o.E) < 1e-10 * np.linalg.norm(o.E)
+    assert np.linalg.norm(x - o.xk) < 1e-8 * np.linalg.norm(o.xk)
+    assert np.linalg.norm(xm - om.xk) < 1e-7 * np.linalg.norm(om.xk)
+
+
+def test_slab_cuts_and_localize():
+    from krypy_amd import dist as kdist
+    assert kdist.slab_cuts(100, 4) == [0, 25, 50, 75, 100]
+    assert kdist.slab_cuts(2500 * 4000, 8, align=4000)[1] == 312 * 4000
+    cuts = kdist.slab_cuts(10, 3, align=4)
+    assert cuts[0] == 0 and cuts[-1] == 10 and all(a <= b for a, b in zip(cuts, cuts[1:]))
+    A, _ = lap2d_system(6, rhs="ones")
+    Al, nrp, nrn = kdist.localize_columns(A[12:24], 12, 36)
+    assert (nrp, nrn) == (6, 6) and Al.shape == (12, 24)
+    x = np.arange(36.0)
+    xl = np.concatenate([x[12:24], x[6:12], x[24:30]])
+    assert np.array_equal(Al.dot(xl), A[12:24].dot(x))
+    Al, nrp, nrn = kdist.localize_columns(A[0:12], 0, 36)
+    assert (nrp, nrn) == (0, 6)
