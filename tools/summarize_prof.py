@@ -1,0 +1,82 @@
+#!/usr/bin/env python
+"""Summarise the rocprofv3 sqlite outputs of tools/profile.sh into a markdown file for profiles/.
+
+  python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/r01_<tag>.md
+
+Kernel table = `rocprofv3 --kernel-trace --stats` (calls, total, average duration, share, VGPR /
+SGPR / LDS).  HBM traffic = the FETCH_SIZE / WRITE_SIZE PMC passes, per launch, with the gfx950
+correction of /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE reports 1/2 of the bytes of a
+wide coalesced stream -> doubled; WRITE_SIZE is taken as reported, KiB).
+"""
+import json
+import os
+import sqlite3
+import sys
+
+
+def q(db, sql):
+    con = sqlite3.connect(db)
+    try:
+        return con.execute(sql).fetchall()
+    finally:
+        con.close()
+
+
+def short(name):
+    name = name.replace("void kh::", "").replace("kh::", "")
+    return name.split("(")[0]
+
+
+def main(src, dst):
+    lines = ["# rocprofv3 summary: %s" % os.path.basename(src.rstrip("/")), ""]
+    bj = os.path.join(src, "bench_trace.json")
+    if os.path.exists(bj):
+        try:
+            b = json.loads(open(bj).read().strip().splitlines()[-1])
+            lines += ["Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d "
+                      "--no-cpu-baseline --ortho %s` on one MI355X." % (b["steps"], b["warmup"], b["config"]["ortho"]),
+                      "", "bench.py under the profiler: **%.1f iterations/s** (%.1f ms per GMRES(100) cycle); "
+                      "live HIP-event average of the dominant kernel `%s`: **%.3f us**." % (
+                          b["value"], b["ms_per_step"], b["roofline"]["kernel"],
+                          b["roofline"]["avg_launch_ms"] * 1e3), ""]
+        except Exception as exc:  # pragma: no cover
+            lines += ["(bench json unreadable: %r)" % exc, ""]
+    tdb = os.path.join(src, "trace", "trace_results.db")
+    rows = q(tdb, "select name,total_calls,total_duration,average,percentage from top_kernels")
+    res = dict((r[0], r[1:]) for r in q(
+        tdb, "select name, max(vgpr_count), max(sgpr_count), max(lds_size) from kernels group by name"))
+    lines += ["## Kernel trace (`--kernel-trace --stats`)", "",
+              "| kernel | calls | total ms | avg us | % | VGPR | SGPR | LDS B |", "|---|---:|---:|---:|---:|---:|---:|---:|"]
+    for name, calls, tot, avg, pct in rows:
+        v = res.get(name, ("", "", ""))
+        lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
+            short(name), calls, tot / 1e3, avg, pct, v[0], v[1], v[2]))
+    lines.append("")
+    pm = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        db = os.path.join(src, "pmc_" + cname, "pmc_results.db")
+        if not os.path.exists(db):
+            continue
+        for name, n, avg in q(db, "select name, count(*), avg(counter_value) from pmc_events "
+                                  "where counter_name='%s' group by name" % cname):
+            pm.setdefault(name, {})[cname] = (n, avg)
+    if pm:
+        lines += ["## HBM traffic per launch (PMC passes, separate runs)", "",
+                  "FETCH_SIZE / WRITE_SIZE are KiB per dispatch, averaged over all dispatches of the kernel. "
+                  "`HBM read` = 2 x FETCH_SIZE (gfx950 correction for 16 B/lane coalesced streams), "
+                  "`HBM write` = WRITE_SIZE.", "",
+                  "| kernel | launches | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM read MB | HBM write MB | total MB |",
+                  "|---|---:|---:|---:|---:|---:|---:|"]
+        for name, d in sorted(pm.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", (0, 0))[0]):
+            f = d.get("FETCH_SIZE", (0, 0.0))
+            w = d.get("WRITE_SIZE", (0, 0.0))
+            rd, wr = 2 * f[1] * 1024 / 1e6, w[1] * 1024 / 1e6
+            lines.append("| `%s` | %d | %.0f | %.0f | %.1f | %.1f | %.1f |" % (
+                short(name), f[0], f[1], w[1], rd, wr, rd + wr))
+        lines.append("")
+    open(dst, "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
