@@ -143,6 +143,16 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
 int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
                     int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
                     double* hcol_out);
+/* The same step split in two so that the host can process step k's Hessenberg column while the
+ * device already runs step k+1 (whose kernels depend on device data only): _begin enqueues the
+ * whole step plus an asynchronous copy of the H column into pinned slot `slot` (0..3) and records
+ * an event; _end waits for that event only and returns `count` (= k+2) doubles.  Steps begun in
+ * order on one context execute in order.  A speculative step past convergence/invariance only
+ * writes V[:,k+1] (P[:,k+1]) and the work vector; the caller discards it. */
+int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W,
+                          int64_t wcol, int64_t k, int64_t start, int sweeps, int gs_mode,
+                          double h_km1, int slot);
+int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out);
 
 /* r = b - A x fused with its squared norm: R[:, rcol] = B[:, bcol] - A X[:, xcol]; *nrm = ||r||_2
  * (LinearSystem.get_residual linsys.py:156-160 for M = Ml = identity) */

@@ -73,6 +73,8 @@ _SIGNATURES = {
     "kh_waxpby": [_H, _H, _I64, _D, _H, _I64, _D, _H, _I64],
     "kh_vdiv": [_H, _H, _I64, _H, _I64, _D],
     "kh_arnoldi_step": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _c_double_p],
+    "kh_arnoldi_step_begin": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _INT],
+    "kh_arnoldi_step_end": [_H, _INT, _I64, _c_double_p],
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
@@ -358,6 +360,18 @@ class Context(object):
             self._h, A.handle if A is not None else None, Md.handle if Md is not None else None,
             V.handle, P.handle if P is not None else None, W.handle, wcol, k, start, sweeps,
             gs_mode, h_km1, _dptr(out)), "kh_arnoldi_step")
+        return out
+
+    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot):
+        _check(self._lib, self._lib.kh_arnoldi_step_begin(
+            self._h, A.handle if A is not None else None, Md.handle if Md is not None else None,
+            V.handle, P.handle if P is not None else None, W.handle, wcol, k, start, sweeps,
+            gs_mode, h_km1, slot), "kh_arnoldi_step_begin")
+
+    def arnoldi_step_end(self, slot, count):
+        out = numpy.empty(count, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_arnoldi_step_end(self._h, slot, count, _dptr(out)),
+               "kh_arnoldi_step_end")
         return out
 
     def residual(self, A, B, bcol, X, xcol, R, rcol):

@@ -68,7 +68,7 @@ int load_rccl() {
 namespace kh {
 
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
-    if (ctx->nranks <= 1 || count == 0) return 0;
+    if (ctx->comm == nullptr || count == 0) return 0;   // a 1-rank communicator still goes through RCCL
     KH_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                              ctx->stream));
     return 0;
@@ -138,7 +138,7 @@ int kh_comm_destroy(kh_ctx ctx) {
 
 int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count) {
     KH_ARG(ctx && (vals || count == 0), "kh_comm_allreduce_host: NULL");
-    if (ctx->nranks <= 1 || count == 0) return 0;
+    if (ctx->comm == nullptr || count == 0) return 0;
     KH_ARG(count <= kh::SCAL_CAP, "kh_comm_allreduce_host: at most %d values", kh::SCAL_CAP);
     KH_HIP(hipMemcpyAsync(ctx->commbuf, vals, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
     KH_TRY(kh::comm_allreduce_dev(ctx, ctx->commbuf, count));

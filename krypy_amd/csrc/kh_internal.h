@@ -12,7 +12,8 @@ namespace kh {
 constexpr int BS = 256;          // threads per workgroup of every vector kernel (4 wave64)
 constexpr int MAXC = 16;         // widest column panel one multidot / multiaxpy launch handles
 constexpr int NB_MAX = 4096;     // upper bound of the reduction grid
-constexpr int SCAL_CAP = 8192;   // device scalar slots (H column, panel coefficients, norms)
+constexpr int SCAL_CAP = 8192;   // device scalar slots (panel coefficients, norms)
+#define KH_NSLOT 4               // Arnoldi steps that may be in flight (H-column slots)
 
 extern thread_local std::string g_err;
 
@@ -50,6 +51,10 @@ struct kh_ctx_s {
     double* scal = nullptr; // SCAL_CAP device scalars
     double* hpin = nullptr; // pinned host staging, SCAL_CAP doubles
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double* hslot_dev[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    double* hslot_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t hev[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t hcap = 0;
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -34,10 +34,28 @@ static inline double* part_slot(kh_ctx ctx, int slot) { return ctx->part + (int6
 constexpr int SLOT_PING = MAXC, SLOT_PONG = MAXC + 1, SLOT_NRM = MAXC + 2;
 
 // device scalar layout inside ctx->scal
-constexpr int SC_HCOL = 0;       // H column of the running Arnoldi step (k+2 entries)
 constexpr int SC_TMP = 6144;     // scratch scalars (dot0 of the fused SpMV, norms, ...)
 constexpr int SC_COEF = 6400;    // panel coefficients for axpy_panel / gemm_nn (<= 1024)
-constexpr int HCOL_CAP = 6000;
+
+// H-column slots: up to NSLOT Arnoldi steps can be in flight on the stream (the host processes
+// step k's column while steps k+1.. already run), each with its own device column, pinned copy
+// and completion event.
+static int ensure_hcap(kh_ctx ctx, int64_t need) {
+    if (need <= ctx->hcap) return 0;
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t cap = std::max<int64_t>(need * 2, 1024);
+    for (int s = 0; s < KH_NSLOT; ++s) {
+        if (ctx->hslot_dev[s]) (void)hipFree(ctx->hslot_dev[s]);
+        if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);
+        ctx->hslot_dev[s] = nullptr;
+        ctx->hslot_pin[s] = nullptr;
+        KH_HIP(hipMalloc(&ctx->hslot_dev[s], sizeof(double) * cap));
+        KH_HIP(hipHostMalloc(&ctx->hslot_pin[s], sizeof(double) * cap, hipHostMallocDefault));
+        if (!ctx->hev[s]) KH_HIP(hipEventCreateWithFlags(&ctx->hev[s], hipEventDisableTiming));
+    }
+    ctx->hcap = cap;
+    return 0;
+}
 
 static int check_vec(kh_vec v, int64_t col, int64_t ncols, const char* what) {
     KH_ARG(v != nullptr, "%s: NULL vector handle", what);
@@ -251,6 +269,11 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     kh_comm_destroy(ctx);
+    for (int s = 0; s < KH_NSLOT; ++s) {
+        if (ctx->hslot_dev[s]) (void)hipFree(ctx->hslot_dev[s]);
+        if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);
+        if (ctx->hev[s]) (void)hipEventDestroy(ctx->hev[s]);
+    }
     (void)hipFree(ctx->part);
     (void)hipFree(ctx->scal);
     (void)hipHostFree(ctx->hpin);
@@ -642,15 +665,16 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
     hipLaunchKernelGGL((k_gs_link<ASRC, TAIL>), dim3(grid), dim3(BS), 0, ctx->stream, n, P, VN, w, DG, \
                        MW, PIN, grid, SIN, AARG, POUT, HS)
 
-int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
-                    int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
-                    double* hcol_out) {
-    KH_ARG(ctx && V && W && hcol_out, "kh_arnoldi_step: NULL argument");
+int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                          int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1, int slot) {
+    KH_ARG(ctx && V && W, "kh_arnoldi_step: NULL argument");
+    KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_arnoldi_step: slot %d not in [0,%d)", slot, KH_NSLOT);
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_arnoldi_step: k=%lld needs %lld basis columns, have %lld",
            (long long)k, (long long)(k + 2), (long long)V->ncols);
     KH_ARG(start >= 0 && start <= k, "kh_arnoldi_step: start=%lld not in [0,k]", (long long)start);
     KH_ARG(sweeps >= 1 && sweeps <= 4, "kh_arnoldi_step: sweeps=%d", sweeps);
-    KH_ARG(k + 2 <= HCOL_CAP, "kh_arnoldi_step: k+2 exceeds the H-column capacity %d", HCOL_CAP);
+    // sized for the whole basis up front: never reallocated while steps of this basis are in flight
+    KH_TRY(ensure_hcap(ctx, std::max<int64_t>(k + 2, V->ncols + 1)));
     KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_arnoldi_step: Md must be a diagonal operator");
     KH_ARG((Md == nullptr) == (P == nullptr), "kh_arnoldi_step: P and Md go together");
     KH_ARG(P == nullptr || (P->n == V->n && P->ncols >= V->ncols), "kh_arnoldi_step: P shape");
@@ -663,7 +687,7 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
     const double* dg = Md ? Md->diag : nullptr;
     const int grid = grid_for(ctx, n);
     const bool multi = ctx->nranks > 1;
-    double* hdev = ctx->scal + SC_HCOL;
+    double* hdev = ctx->hslot_dev[slot];
     double* tmp = ctx->scal + SC_TMP;
     KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
 
@@ -776,7 +800,28 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
         }
         KH_HIP(hipGetLastError());
     }
-    return fetch_scalars(ctx, hdev, k + 2, hcol_out);
+    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * (k + 2), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+    return 0;
+}
+
+int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
+    KH_ARG(ctx && hcol_out, "kh_arnoldi_step_end: NULL");
+    KH_ARG(slot >= 0 && slot < KH_NSLOT && count >= 0 && count <= ctx->hcap,
+           "kh_arnoldi_step_end: slot %d / count %lld", slot, (long long)count);
+    KH_ARG(ctx->hev[slot] != nullptr, "kh_arnoldi_step_end: no step was begun");
+    KH_HIP(hipEventSynchronize(ctx->hev[slot]));
+    memcpy(hcol_out, ctx->hslot_pin[slot], sizeof(double) * count);
+    return 0;
+}
+
+int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                    int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
+                    double* hcol_out) {
+    KH_ARG(hcol_out != nullptr, "kh_arnoldi_step: NULL argument");
+    KH_TRY(kh_arnoldi_step_begin(ctx, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, 0));
+    return kh_arnoldi_step_end(ctx, 0, k + 2, hcol_out);
 }
 
 int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,

@@ -643,6 +643,8 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
 
     def _finalize(self):
         super(Gmres, self)._finalize()
+        if hasattr(self, "arnoldi"):
+            self.arnoldi._settle()      # drop a speculative look-ahead step, if any
         if self.store_arnoldi and hasattr(self, "arnoldi"):
             got = self.arnoldi.get()
             self._V_trim, self.H = got[0], got[1]

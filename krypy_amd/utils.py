@@ -753,6 +753,12 @@ class Arnoldi(object):
                 self._Md = md
         self._fused = self._euclid and (self.M is None or self._Md is not None)
         self._Amat = self.A._device_matrix() if self._fused else None
+        # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
+        # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU
+        # never idles while the host does its O(k) work.  A speculative step past the end of the
+        # iteration is discarded by _settle().  (Lanczos needs H[k,k-1] from the host: no look-ahead.)
+        self._lookahead = 1 if (self._Amat is not None and ortho != "lanczos") else 0
+        self._enq = 0          # number of steps enqueued on the device so far
 
         v = _as_dvec(v, ctx)
         if self.M is not None:
@@ -771,13 +777,33 @@ class Arnoldi(object):
     # the reference exposes ndarrays; here they are downloaded on demand
     @property
     def V(self):
+        self._settle()
         return self._V.download()
 
     @property
     def P(self):
         if self._P is None:
             raise AttributeError("P")
+        self._settle()
         return self._P.download()
+
+    def _begin(self):
+        """Enqueue Arnoldi step ``self._enq`` on the device (no host synchronisation)."""
+        k = self._enq
+        self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k, 0,
+                                     self._sweeps, self._gs_mode, 0.0, k % 4)
+        self._enq = k + 1
+
+    def _settle(self):
+        """Discard speculative steps: wait for them and clear the basis columns they wrote, so
+        that the arrays look exactly like the reference's (untouched columns are zero)."""
+        while self._enq > self.iter:
+            k = self._enq - 1
+            self._ctx.arnoldi_step_end(k % 4, k + 2)
+            self._V.zero(k + 1, 1)
+            if self._P is not None:
+                self._P.zero(k + 1, 1)
+            self._enq = k
 
     def advance(self):
         """Carry out one iteration of Arnoldi (utils.py:954-1048)."""
@@ -796,7 +822,12 @@ class Arnoldi(object):
                 H[k - 1, k] = H[k, k - 1]
                 h_km1 = float(H[k, k - 1])
         if self._fused:
-            if self._Amat is not None:
+            if self._lookahead:
+                last = min(k + self._lookahead, self.maxiter - 1)
+                while self._enq <= last:
+                    self._begin()
+                hcol = ctx.arnoldi_step_end(k % 4, k + 2)
+            elif self._Amat is not None:
                 hcol = ctx.arnoldi_step(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
             else:
@@ -818,13 +849,15 @@ class Arnoldi(object):
         if not (fro > 0) or not (hn / fro > 1e-14):
             nrm2 = numpy.linalg.norm(H[: k + 2, : k + 1], 2)
             is_inv = not (hn / nrm2 > 1e-14) if nrm2 > 0 else True
+        self.iter += 1
         if is_inv:
             self.invariant = True
-            # the reference leaves column k+1 untouched (zeros); undo the speculative store
+            # the reference leaves column k+1 untouched (zeros); undo the stores of this step and
+            # of any step enqueued ahead of it
+            self._settle()
             self._V.zero(k + 1, 1)
             if self._P is not None:
                 self._P.zero(k + 1, 1)
-        self.iter += 1
 
     def _advance_general(self, k, start, h_km1):
         """Arnoldi step for a non-Euclidean inner product or a general preconditioner ``M``:
@@ -863,6 +896,7 @@ class Arnoldi(object):
     def get(self):
         """``(V, H[, P])`` trimmed to the computed part (utils.py:1050-1061)."""
         k = self.iter
+        self._settle()
         nv, hr = (k, k) if self.invariant else (k + 1, k + 1)
         V, H = self._V.download(0, nv), self.H[:hr, :k]
         if self.M is not None:

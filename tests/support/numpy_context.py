@@ -205,6 +205,14 @@ class NumpyContext(object):
         hcol[k + 1] = hn
         return hcol
 
+    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot):
+        if not hasattr(self, "_slots"):
+            self._slots = {}
+        self._slots[slot] = self.arnoldi_step(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+
+    def arnoldi_step_end(self, slot, count):
+        return self._slots[slot][:count].copy()
+
     def residual(self, A, B, bcol, X, xcol, R, rcol):
         self._count("residual")
         r = B.a[:, bcol] - self._matvec(A, X.a[:, xcol])

@@ -191,3 +191,20 @@ def test_full_size_properties(hip):
             hip.gemm_nn(ar._V, 0, 31, H[:, j], -1.0, 1.0, T, 0)
             worst = max(worst, hip.nrm2(T, 0))
         assert worst < 1e-12 * np.linalg.norm(H, 2)
+
+
+def test_rccl_single_rank_communicator(hip):
+    """The RCCL plumbing (dlopen, unique id, ncclCommInitRank, ncclAllReduce on the library's
+    stream) on the one GPU this box has; the 2-rank logic is covered by tests/test_dist_gloo.py."""
+    from krypy_amd import _hip
+
+    ctx = _hip.Context(0)
+    uid = ctx.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(0, 1, uid)
+    vals = np.array([1.5, -2.0, 3.25])
+    assert np.array_equal(ctx.allreduce_host(vals.copy()), vals)
+    V = ctx.upload(np.arange(12.0).reshape(6, 2, order="F"))
+    W = ctx.upload(np.ones(6))
+    assert np.allclose(ctx.dot_panel(V, 0, 2, W, 0), [15.0, 51.0])
+    ctx.close()
