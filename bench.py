@@ -200,7 +200,7 @@ def main():
     # ---- the other Gram-Schmidt variants on the same inputs (outside the timed region) ----
     others = {}
     if world == 1 and args.other_modes:
-        for mode in [t for t in args.other_modes.split(",") if t and t != ortho]:
+        for mode in [t for t in args.other_modes.split(",") if t and t != ortho and t != "none"]:
             barrier()
             t1 = time.perf_counter()
             s2 = run_cycles(args.steps, x0, ortho=mode)
