@@ -1,0 +1,242 @@
+// Register-resident modified Gram-Schmidt chain: ONE launch per Arnoldi step.
+//
+// The reference's MGS (utils.py:1012-1034) is a chain of k+1 *dependent* dot/axpy pairs on the
+// same vector w.  Run as k+1 launches (k_gs_link) every link re-streams w through HBM: 32 N
+// bytes per basis column, and the kernel saturates the memory system at 0.41 of the algorithmic
+// roofline.  On MI355X the aggregate register file (256 CUs x 512 KB = 128 MB) is larger than w
+// (80 MB at N = 10^7), so this kernel keeps w in VGPRs for the whole chain:
+//
+//   load w (the SpMV result) into registers                                   8 N bytes
+//   for every basis column j (reference order, `sweeps` passes):
+//       partial <v_j, w>           stream v_j once                            8 N
+//       grid-wide fixed-order sum  one 8-byte granule pair per workgroup      (latency)
+//       w -= alpha * b_j           re-read of the same column (MALL/L2 warm)  8 N
+//   ||w||^2 (or <w, D w>) grid-wide,  v_{k+1} = w / h written straight from registers   8 N
+//
+// i.e. 16 N per column - the SURVEY 8(d) figure - instead of 32 N, no w traffic at all, and the
+// summation order is still the reference's.  Workgroups exchange their partial sums inside the
+// launch with the data-tagged 8-byte granule protocol of the CDNA4 guide (Guideline 16, R2):
+// one relaxed agent-scope atomic store per granule {epoch tag | 32 value bits}, consumers re-read
+// the granules with relaxed agent-scope atomic loads until every tag matches - no flag, no fence,
+// placement independent.  Granule buffers alternate by epoch parity; a workgroup can only be one
+// epoch ahead of the slowest one, so two buffers suffice.  Every spin is bounded: on timeout an
+// error word is set, all workgroups fall through, and the host disables this path.
+//
+// Residency: one 512-thread workgroup per CU (<= 256 VGPRs per lane); the launch is cooperative
+// so that a grid that cannot be co-resident is rejected instead of deadlocking.
+#pragma once
+#include "kernels.h"
+
+namespace kh {
+
+constexpr int CH_BS = 512;       // threads per workgroup (8 wave64, 2 per SIMD)
+constexpr int CH_GMAX = 512;     // max workgroups (granule sweep = 2*G words, one per thread pass)
+
+struct ChainArgs {
+    int64_t n2;        // vector length in double2 (n even)
+    int64_t chunk2;    // double2 per workgroup
+    const double* V;   // dot columns:    V + j*ld
+    const double* B;   // update columns: B + j*ld  (P when preconditioned, else V)
+    int64_t ld;
+    int64_t col0;      // first column
+    int ncol;          // columns per sweep
+    int sweeps;
+    const double* w_in;
+    const double* dg;  // Jacobi diagonal or nullptr
+    double* mw_out;    // unused scratch (kept for symmetry), may be nullptr
+    double* vnext;     // V[:, k+1]
+    double* pnext;     // P[:, k+1] or nullptr
+    double* hdev;      // H column on the device (zeroed by the caller); hdev[j] += alpha
+    int64_t hnext;     // index of H[k+1,k] in hdev
+    unsigned long long* gran;  // [2][2*G] granules
+    unsigned epoch0;
+    int* err;
+    int presub;        // Lanczos: w -= h_km1 * bprev first
+    double h_km1;
+    const double* bprev;
+};
+
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Fixed-order sum of one double per workgroup over the whole grid; every thread gets the result.
+__device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned long long* gran,
+                                           int G, int* err, double* smd, unsigned* smu) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // 1. workgroup partial (8 waves, fixed order)
+    part = wave_sum(part);
+    if (lane == 0) smd[wid] = part;
+    __syncthreads();
+    unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
+    if (tid == 0) {
+        double s = smd[0];
+#pragma unroll
+        for (int i = 1; i < CH_BS / 64; ++i) s += smd[i];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        st_agent(slot + 2 * blockIdx.x, tag | (bits & 0xffffffffull));
+        st_agent(slot + 2 * blockIdx.x + 1, tag | (bits >> 32));
+    }
+    // 2. sweep all granules of this epoch (bounded spin)
+    for (int g = tid; g < 2 * G; g += CH_BS) {
+        unsigned long long x = ld_agent(slot + g);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            x = ld_agent(slot + g);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1u << 22)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        smu[g] = (unsigned)x;
+    }
+    __syncthreads();
+    // 3. fixed-order sum of the G workgroup partials
+    double v = 0.0;
+    for (int b = tid; b < G; b += CH_BS) {
+        const unsigned long long bits = ((unsigned long long)smu[2 * b + 1] << 32) | smu[2 * b];
+        v += __longlong_as_double((long long)bits);
+    }
+    v = wave_sum(v);
+    __syncthreads();          // smd reuse
+    if (lane == 0) smd[wid] = v;
+    __syncthreads();
+    double s = smd[0];
+#pragma unroll
+    for (int i = 1; i < CH_BS / 64; ++i) s += smd[i];
+    __syncthreads();
+    return s;
+}
+
+// Every vector this kernel reads is a kh_vec / diag buffer allocated with CH_SLACK zeroed doubles
+// behind its last column, so loads need no clamping: an out-of-range lane reads finite data of a
+// neighbouring chunk/column (or zeros) and its w stays exactly 0 (select on registers).
+constexpr int64_t CH_SLACK = 2 * (int64_t)CH_GMAX * CH_BS + 64 * CH_BS;  // doubles
+
+// loads are issued in batches of CH_BATCH rows; the empty asm is a compiler memory barrier that
+// keeps the next batch's loads from being hoisted (w already pins 4*R2 VGPRs)
+constexpr int CH_BATCH = 8;
+#define CH_FENCE(r) if (((r) + 1) % CH_BATCH == 0) asm volatile("" ::: "memory")
+
+// Two instantiations per R2.  MASKED=false is the fast kernel for large vectors: the blocks were
+// allocated with a leading dimension padded to whole workgroup chunks (kh_vec_alloc), the padding
+// is zero and stays zero, so the hot loops carry no predicate at all (out-of-range lanes hold
+// w = 0 and read p = 0); only the final store is masked.  MASKED=true is the general kernel for
+// small or unpadded vectors.  `rem` = number of valid double2 starting at this thread's first.
+template <int R2, bool MASKED>
+__global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
+    __shared__ double smd[CH_BS / 64];
+    __shared__ unsigned smu[2 * CH_GMAX];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    // chunk2 == R2 * CH_BS: thread `tid` owns elements first + r*CH_BS, r < R2
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    double2 w[R2];
+    {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = win2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+            CH_FENCE(r);
+        }
+    }
+    if (a.presub) {
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 p = p2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? w[r].x - a.h_km1 * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - a.h_km1 * p.y : 0.0;
+            CH_FENCE(r);
+        }
+    }
+    unsigned epoch = a.epoch0;
+    const int total = a.ncol * a.sweeps;
+    for (int t = 0; t < total; ++t) {
+        const int64_t j = a.col0 + (t % a.ncol);
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + j * a.ld) + first;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = v2[(int64_t)r * CH_BS];
+            acc0 = fma(v.x, w[r].x, acc0);
+            acc1 = fma(v.y, w[r].y, acc1);
+            CH_FENCE(r);
+        }
+        const double alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+        if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+        const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + j * a.ld) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 p = b2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+            CH_FENCE(r);
+        }
+    }
+    // norm: <w,w> or <w, D w>
+    double acc = 0.0;
+    if (a.dg != nullptr) {
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 d = d2[(int64_t)r * CH_BS];
+            acc = fma(w[r].x, d.x * w[r].x, acc);
+            acc = fma(w[r].y, d.y * w[r].y, acc);
+            CH_FENCE(r);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            acc = fma(w[r].x, w[r].x, acc);
+            acc = fma(w[r].y, w[r].y, acc);
+        }
+    }
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu);
+    const double h = sqrt(fabs(h2));
+    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+    if (a.dg != nullptr) {
+        double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                const double2 d = d2[(int64_t)r * CH_BS];
+                double2 o, m;
+                o.x = w[r].x / h;
+                o.y = w[r].y / h;
+                m.x = (d.x * w[r].x) / h;
+                m.y = (d.y * w[r].y) / h;
+                pn2[(int64_t)r * CH_BS] = o;
+                vn2[(int64_t)r * CH_BS] = m;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                double2 o;
+                o.x = w[r].x / h;
+                o.y = w[r].y / h;
+                vn2[(int64_t)r * CH_BS] = o;
+            }
+        }
+    }
+#undef CH_OK
+}
+
+}  // namespace kh

@@ -55,6 +55,12 @@ struct kh_ctx_s {
     double* hslot_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t hev[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     int64_t hcap = 0;
+    // register-resident MGS chain (chain.h)
+    int chain_enabled = 1;
+    unsigned long long* chain_gran = nullptr;
+    int* chain_err = nullptr;        // device error word
+    int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned chain_epoch = 1;
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

@@ -7,6 +7,8 @@
 #include <vector>
 
 #include "kernels.h"
+#include "chain.h"
+#include <stdlib.h>
 
 namespace kh {
 
@@ -212,6 +214,102 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
     return 0;
 }
 
+// ---- register-resident MGS chain (chain.h) -------------------------------------------------
+template <int R2, bool MASKED>
+static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
+    void* kargs[] = {(void*)&a};
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_mgs_chain<R2, MASKED>), dim3(G),
+                                      dim3(CH_BS), kargs, 0, ctx->stream);
+}
+
+// rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
+static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
+    if (n < 2 || (n & 1)) return false;
+    const int64_t n2 = n >> 1;
+    static const int kR2[] = {4, 8, 16, 24, 32, 40};
+    for (int c : kR2) {
+        const int64_t g = (n2 + (int64_t)c * CH_BS - 1) / ((int64_t)c * CH_BS);
+        if (g <= ctx->ncu && g <= CH_GMAX) {
+            *r2_out = c;
+            *g_out = (int)g;
+            return true;
+        }
+    }
+    return false;   // w does not fit the register file: stream it (k_gs_link)
+}
+
+// leading dimension of a block of n-vectors: large vectors are padded to whole chain chunks so
+// that the predicate-free kernel applies (<= 0.4 % extra memory at N = 10^7)
+static int64_t padded_ld(kh_ctx ctx, int64_t n) {
+    int64_t ld = ((n + 31) / 32) * 32;
+    int r2 = 0, g = 0;
+    if (n >= (1 << 16) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
+    return ld == 0 ? 32 : ld;
+}
+
+// returns 1 if the chain was launched, 0 if this step is not eligible (caller uses the link
+// kernels), negative on error
+static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
+                     kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
+                     double* hdev, int slot) {
+    if (!ctx->chain_enabled || ctx->nranks > 1) return 0;
+    const int64_t n = V->n;
+    const int64_t n2 = n >> 1;
+    int r2 = 0, G = 0;
+    if (!chain_geometry(ctx, n, &r2, &G)) return 0;
+    const int64_t chunk2 = (int64_t)r2 * CH_BS;
+    // predicate-free kernel iff every block involved is padded to G whole chunks
+    const int64_t need_ld = (int64_t)G * chunk2 * 2;
+    const bool padded = V->ld >= need_ld && B->ld >= need_ld && (P == nullptr || P->ld >= need_ld) &&
+                        wld >= need_ld;
+    if (ctx->chain_epoch > 0xfff00000u) {
+        KH_HIP(hipStreamSynchronize(ctx->stream));
+        KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
+        ctx->chain_epoch = 1;
+    }
+    ChainArgs a;
+    a.n2 = n2;
+    a.chunk2 = chunk2;
+    a.V = V->d;
+    a.B = B->d;
+    a.ld = V->ld;
+    a.col0 = start;
+    a.ncol = (int)(k - start + 1);
+    a.sweeps = sweeps;
+    a.w_in = w;
+    a.dg = dg;
+    a.mw_out = nullptr;
+    a.vnext = V->col(k + 1);
+    a.pnext = P ? P->col(k + 1) : nullptr;
+    a.hdev = hdev;
+    a.hnext = k + 1;
+    a.gran = ctx->chain_gran;
+    a.epoch0 = ctx->chain_epoch;
+    a.err = ctx->chain_err;
+    a.presub = presub ? 1 : 0;
+    a.h_km1 = h_km1;
+    a.bprev = presub ? B->col(k - 1) : nullptr;
+    hipError_t e;
+#define KH_CHAIN(R) (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a))
+    if (r2 == 4) e = KH_CHAIN(4);
+    else if (r2 == 8) e = KH_CHAIN(8);
+    else if (r2 == 16) e = KH_CHAIN(16);
+    else if (r2 == 24) e = KH_CHAIN(24);
+    else if (r2 == 32) e = KH_CHAIN(32);
+    else e = KH_CHAIN(40);
+#undef KH_CHAIN
+    if (e != hipSuccess) {
+        // e.g. hipErrorCooperativeLaunchTooLarge: not all workgroups can be co-resident
+        (void)hipGetLastError();
+        ctx->chain_enabled = 0;
+        return 0;
+    }
+    ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);
+    KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    return 1;
+}
+
 static inline int grid_lin(kh_ctx ctx, int64_t n) {
     int64_t need = (n + BS - 1) / BS;
     if (need < 1) need = 1;
@@ -260,6 +358,19 @@ int kh_ctx_create(int device, kh_ctx* out) {
     KH_HIP(hipHostMalloc(&ctx->hpin, sizeof(double) * SCAL_CAP, hipHostMallocDefault));
     KH_HIP(hipEventCreate(&ctx->ev0));
     KH_HIP(hipEventCreate(&ctx->ev1));
+    KH_HIP(hipMalloc(&ctx->chain_gran, sizeof(unsigned long long) * 4 * CH_GMAX));
+    KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
+    KH_HIP(hipMalloc(&ctx->chain_err, sizeof(int)));
+    KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
+    for (int s = 0; s < KH_NSLOT; ++s) {
+        KH_HIP(hipHostMalloc(&ctx->chain_err_pin[s], sizeof(int), hipHostMallocDefault));
+        *ctx->chain_err_pin[s] = 0;
+    }
+    {
+        const char* e = getenv("KRYPY_AMD_MGS_CHAIN");
+        ctx->chain_enabled = (e == nullptr) ? 1 : atoi(e);
+        if (ctx->ncu > CH_GMAX) ctx->chain_enabled = 0;
+    }
     *out = ctx;
     return 0;
 }
@@ -274,6 +385,10 @@ int kh_ctx_destroy(kh_ctx ctx) {
         if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);
         if (ctx->hev[s]) (void)hipEventDestroy(ctx->hev[s]);
     }
+    (void)hipFree(ctx->chain_gran);
+    (void)hipFree(ctx->chain_err);
+    for (int s = 0; s < KH_NSLOT; ++s)
+        if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
     (void)hipFree(ctx->part);
     (void)hipFree(ctx->scal);
     (void)hipHostFree(ctx->hpin);
@@ -339,10 +454,11 @@ int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out) {
     v->ctx = ctx;
     v->n = n;
     v->ncols = ncols;
-    v->ld = ((n + 31) / 32) * 32;
-    if (v->ld == 0) v->ld = 32;
+    v->ld = padded_ld(ctx, n);
     v->d = nullptr;
-    const size_t bytes = sizeof(double) * (size_t)v->ld * (size_t)std::max<int64_t>(ncols, 1);
+    // CH_SLACK zeroed doubles behind the last column: the register-resident chain kernel reads
+    // whole CH_BS-strided rows without clamping (chain.h)
+    const size_t bytes = sizeof(double) * ((size_t)v->ld * (size_t)std::max<int64_t>(ncols, 1) + CH_SLACK);
     hipError_t e = hipMalloc(&v->d, bytes);
     if (e != hipSuccess) {
         delete v;
@@ -499,7 +615,9 @@ int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
     A->ctx = ctx;
     A->kind = KH_MAT_DIAG;
     A->n_rows = A->n_cols = n;
-    KH_HIP(hipMalloc(&A->diag, sizeof(double) * (((n + 31) / 32) * 32 + 32)));
+    const size_t dbytes = sizeof(double) * (((n + 31) / 32) * 32 + CH_SLACK);
+    KH_HIP(hipMalloc(&A->diag, dbytes));
+    KH_HIP(hipMemset(A->diag, 0, dbytes));
     if (n > 0) KH_HIP(hipMemcpy(A->diag, d, sizeof(double) * n, hipMemcpyHostToDevice));
     *out = A;
     return 0;
@@ -692,8 +810,12 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
 
     const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
+    // reference-order MGS: keep w in registers for the whole chain when it fits (chain.h)
+    int cr2 = 0, cg = 0;
+    const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && ctx->nranks == 1 &&
+                             chain_geometry(ctx, n, &cr2, &cg));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
-                            A->nblk > 0);
+                            A->nblk > 0 && !want_chain);
     // 1. operator
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
@@ -705,7 +827,15 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     }
 
     double* nrm_part = part_slot(ctx, SLOT_NRM);
-    if (gs_mode == KH_GS_MGS) {
+    bool chained = false;
+    if (want_chain) {
+        const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hdev, slot);
+        if (rc < 0) return rc;
+        chained = (rc == 1);
+    }
+    if (chained) {
+        // the whole Gram-Schmidt chain, the norm and the normalised store ran in one launch
+    } else if (gs_mode == KH_GS_MGS) {
         // column visiting order of all sweeps
         const int64_t ncol = k - start + 1;
         const int64_t len = ncol * sweeps;
@@ -784,7 +914,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
         }
     }
     // 3. norm and normalise
-    {
+    if (!chained) {
         double* hs = hdev + (k + 1);
         double* vn = V->col(k + 1);
         double* pn = P ? P->col(k + 1) : nullptr;
@@ -813,6 +943,13 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
     KH_ARG(ctx->hev[slot] != nullptr, "kh_arnoldi_step_end: no step was begun");
     KH_HIP(hipEventSynchronize(ctx->hev[slot]));
     memcpy(hcol_out, ctx->hslot_pin[slot], sizeof(double) * count);
+    if (*ctx->chain_err_pin[slot] != 0) {
+        *ctx->chain_err_pin[slot] = 0;
+        ctx->chain_enabled = 0;
+        (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
+        return fail(KH_ERR_HIP, "grid-wide reduction of the MGS chain kernel timed out (workgroups not "
+                                "co-resident?); the chain path is now disabled for this context");
+    }
     return 0;
 }
 
