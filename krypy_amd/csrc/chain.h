@@ -121,10 +121,20 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
 // neighbouring chunk/column (or zeros) and its w stays exactly 0 (select on registers).
 constexpr int64_t CH_SLACK = 2 * (int64_t)CH_GMAX * CH_BS + 64 * CH_BS;  // doubles
 
-// loads are issued in batches of CH_BATCH rows; the empty asm is a compiler memory barrier that
-// keeps the next batch's loads from being hoisted (w already pins 4*R2 VGPRs)
-constexpr int CH_BATCH = 8;
-#define CH_FENCE(r) if (((r) + 1) % CH_BATCH == 0) asm volatile("" ::: "memory")
+// Software pipeline: the rows a thread owns are streamed in batches of PB rows through a two-deep
+// register ring.  The loads of batch b+1 are issued before batch b is consumed, and the ring runs
+// ACROSS phase boundaries: the first batch of the update phase (b_j) is in flight while the grid
+// reduction of <v_j, w> completes, the first batch of the next column's dot phase while the update
+// finishes.  The empty asm is a compiler memory barrier that pins the issue order (w already holds
+// 4*R2 VGPRs; the ring adds 8*PB).
+#define CH_ISSUE_FENCE() asm volatile("" ::: "memory")
+
+template <int R2>
+struct ChainShape {
+    static constexpr int PB = (R2 == 40) ? 5 : (R2 == 4 ? 2 : 4);   // rows per batch
+    static constexpr int NB = R2 / PB;                              // batches per phase (even)
+    static_assert(NB * PB == R2 && (NB % 2) == 0, "ring parity must reset every phase");
+};
 
 // Two instantiations per R2.  MASKED=false is the fast kernel for large vectors: the blocks were
 // allocated with a leading dimension padded to whole workgroup chunks (kh_vec_alloc), the padding
@@ -133,6 +143,8 @@ constexpr int CH_BATCH = 8;
 // small or unpadded vectors.  `rem` = number of valid double2 starting at this thread's first.
 template <int R2, bool MASKED>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
+    constexpr int PB = ChainShape<R2>::PB;
+    constexpr int NB = ChainShape<R2>::NB;
     __shared__ double smd[CH_BS / 64];
     __shared__ unsigned smu[2 * CH_GMAX];
     const int tid = threadIdx.x;
@@ -143,6 +155,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
     double2 w[R2];
+    double2 ring[2][PB];
     {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
@@ -150,7 +163,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             const double2 v = win2[(int64_t)r * CH_BS];
             w[r].x = CH_OK(r) ? v.x : 0.0;
             w[r].y = CH_OK(r) ? v.y : 0.0;
-            CH_FENCE(r);
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
     if (a.presub) {
@@ -160,31 +173,58 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             const double2 p = p2[(int64_t)r * CH_BS];
             w[r].x = CH_OK(r) ? w[r].x - a.h_km1 * p.x : 0.0;
             w[r].y = CH_OK(r) ? w[r].y - a.h_km1 * p.y : 0.0;
-            CH_FENCE(r);
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
     unsigned epoch = a.epoch0;
     const int total = a.ncol * a.sweeps;
+    // prologue: first batch of the first column
+    {
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld) + first;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        CH_ISSUE_FENCE();
+    }
     for (int t = 0; t < total; ++t) {
         const int64_t j = a.col0 + (t % a.ncol);
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + j * a.ld) + first;
+        const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + j * a.ld) + first;
+        // ---- dot phase: <v_j, w> ----
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            const double2 v = v2[(int64_t)r * CH_BS];
-            acc0 = fma(v.x, w[r].x, acc0);
-            acc1 = fma(v.y, w[r].y, acc1);
-            CH_FENCE(r);
+        for (int b = 0; b < NB; ++b) {
+            // issue the next batch: v_j rows of batch b+1, or the first rows of b_j
+            const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : b2;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 v = ring[b & 1][i];
+                acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                acc1 = fma(v.y, w[b * PB + i].y, acc1);
+            }
         }
         const double alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
         if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
-        const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + j * a.ld) + first;
+        // ---- update phase: w -= alpha * b_j ----
+        const int64_t jn = a.col0 + ((t + 1) % a.ncol);
+        const double2* __restrict__ vn = (t + 1 < total)
+            ? reinterpret_cast<const double2*>(a.V + jn * a.ld) + first
+            : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
 #pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            const double2 p = b2[(int64_t)r * CH_BS];
-            w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-            w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
-            CH_FENCE(r);
+        for (int b = 0; b < NB; ++b) {
+            const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = ring[b & 1][i];
+                const int r = b * PB + i;
+                w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
+                w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+            }
         }
     }
     // norm: <w,w> or <w, D w>
@@ -196,7 +236,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             const double2 d = d2[(int64_t)r * CH_BS];
             acc = fma(w[r].x, d.x * w[r].x, acc);
             acc = fma(w[r].y, d.y * w[r].y, acc);
-            CH_FENCE(r);
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     } else {
 #pragma unroll
