@@ -51,6 +51,7 @@ struct ChainArgs {
     unsigned long long* gran;  // [2][2*G] granules
     unsigned epoch0;
     int* err;
+    int debug;         // measurement only: 1 = skip the grid reduction, 2 = skip the streaming phases
     int presub;        // Lanczos: w -= h_km1 * bprev first
     double h_km1;
     const double* bprev;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + j * a.ld) + first;
         // ---- dot phase: <v_j, w> ----
         double acc0 = 0.0, acc1 = 0.0;
+        if (a.debug != 2)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             // issue the next batch: v_j rows of batch b+1, or the first rows of b_j
@@ -205,13 +207,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
                 acc1 = fma(v.y, w[b * PB + i].y, acc1);
             }
         }
-        const double alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+        const double alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                            : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
         if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
         // ---- update phase: w -= alpha * b_j ----
         const int64_t jn = a.col0 + ((t + 1) % a.ncol);
         const double2* __restrict__ vn = (t + 1 < total)
             ? reinterpret_cast<const double2*>(a.V + jn * a.ld) + first
             : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
+        if (a.debug != 2)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : vn;

@@ -215,11 +215,23 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
 }
 
 // ---- register-resident MGS chain (chain.h) -------------------------------------------------
+// Plain launch (a cooperative launch goes through a separate hardware queue and costs ~1 ms of
+// cross-queue synchronisation per Arnoldi step when interleaved with ordinary kernels).  Residency
+// is what matters for the in-kernel grid reduction, and it is identical for plain and cooperative
+// launches: it is checked here against the occupancy of this instantiation, and every spin in the
+// kernel is bounded.
 template <int R2, bool MASKED>
 static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
-    void* kargs[] = {(void*)&a};
-    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&k_mgs_chain<R2, MASKED>), dim3(G),
-                                      dim3(CH_BS), kargs, 0, ctx->stream);
+    static int blocks_per_cu = -1;
+    if (blocks_per_cu < 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED>, CH_BS, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    return hipGetLastError();
 }
 
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
@@ -286,6 +298,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.gran = ctx->chain_gran;
     a.epoch0 = ctx->chain_epoch;
     a.err = ctx->chain_err;
+    a.debug = ctx->chain_debug;
     a.presub = presub ? 1 : 0;
     a.h_km1 = h_km1;
     a.bprev = presub ? B->col(k - 1) : nullptr;
@@ -1042,6 +1055,7 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
     double* mw = W->col(1);
     double* pa = part_slot(ctx, SLOT_PING);
     double* pb = part_slot(ctx, SLOT_PONG);
+    KH_TRY(ensure_hcap(ctx, 1024));
     KH_HIP(hipMemsetAsync(pa, 0, sizeof(double) * NB_MAX * 2, ctx->stream));  // alpha = 0: w unchanged
     KH_HIP(hipMemsetAsync(ctx->scal + SC_COEF, 0, sizeof(double) * MAXC, ctx->stream));
     const double four = 4.0;  // k_scale_store divides by sqrt(4)
@@ -1074,6 +1088,18 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
                 hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, nullptr,
                                    mw, nullptr, nullptr, 0, ctx->scal + SC_TMP + 8, nullptr);
                 break;
+            case 5:
+            case 6:
+            case 7: {
+                // the register-resident chain over 16 columns x 4 sweeps = 64 links per launch
+                ctx->chain_debug = which - 5;
+                KH_HIP(hipMemsetAsync(ctx->hslot_dev[0], 0, sizeof(double) * 64, ctx->stream));
+                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 15, 0, 4, false, 0.0,
+                                         ctx->hslot_dev[0], 0);
+                ctx->chain_debug = 0;
+                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
+                break;
+            }
             default:
                 return fail(KH_ERR_ARG, "kh_bench_kernel: unknown kernel id %d", which);
         }
