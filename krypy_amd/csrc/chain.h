@@ -132,14 +132,9 @@ constexpr int64_t CH_SLACK = 2 * (int64_t)CH_GMAX * CH_BS + 64 * CH_BS;  // doub
 
 template <int R2>
 struct ChainShape {
-    static constexpr int PB = (R2 == 4) ? 2 : 4;            // rows per batch
-    static constexpr int NB = R2 / PB;                      // batches per phase (even)
-    // batches of v_j kept in LDS between the dot and the update phase when the update reads the
-    // same column (B == V): 8 KB per row, <= 16 rows = 128 KB of the CU's 160 KB
-    static constexpr int LB = (NB >= 4) ? 4 : NB;
-    static constexpr int LROWS = LB * PB;
-    static_assert(NB * PB == R2 && (NB % 2) == 0 && ((NB - LB) % 2) == 0,
-                  "ring parity must reset every phase");
+    static constexpr int PB = (R2 == 40) ? 5 : (R2 == 4 ? 2 : 4);   // rows per batch
+    static constexpr int NB = R2 / PB;                              // batches per phase (even)
+    static_assert(NB * PB == R2 && (NB % 2) == 0, "ring parity must reset every phase");
 };
 
 // Two instantiations per R2.  MASKED=false is the fast kernel for large vectors: the blocks were
@@ -147,19 +142,12 @@ struct ChainShape {
 // is zero and stays zero, so the hot loops carry no predicate at all (out-of-range lanes hold
 // w = 0 and read p = 0); only the final store is masked.  MASKED=true is the general kernel for
 // small or unpadded vectors.  `rem` = number of valid double2 starting at this thread's first.
-//
-// CACHE=true (update column == dot column, i.e. no preconditioner): the first LROWS rows of v_j are
-// parked in LDS during the dot phase and the update phase reads them back from there instead of
-// from memory - the per-column traffic drops from 16 N to (2 - LROWS/R2) * 8 N bytes.
-template <int R2, bool MASKED, bool CACHE>
+template <int R2, bool MASKED>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
-    constexpr int LB = CACHE ? ChainShape<R2>::LB : 0;     // cached batches
-    constexpr int NU = NB - LB;                            // update batches streamed from memory
     __shared__ double smd[CH_BS / 64];
     __shared__ unsigned smu[2 * CH_GMAX];
-    extern __shared__ __attribute__((aligned(16))) double2 vcache[];   // [LROWS][CH_BS]
     const int tid = threadIdx.x;
     const int G = gridDim.x;
     // chunk2 == R2 * CH_BS: thread `tid` owns elements first + r*CH_BS, r < R2
@@ -207,18 +195,14 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         if (a.debug != 2)
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            // issue the next batch: v_j rows of batch b+1, or the first streamed rows of b_j
-            const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS
-                                                          : b2 + (int64_t)LB * PB * CH_BS;
-            if (b + 1 < NB || NU > 0) {
+            // issue the next batch: v_j rows of batch b+1, or the first rows of b_j
+            const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : b2;
 #pragma unroll
-                for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
-            }
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const double2 v = ring[b & 1][i];
-                if (b < LB) vcache[(b * PB + i) * CH_BS + tid] = v;
                 acc0 = fma(v.x, w[b * PB + i].x, acc0);
                 acc1 = fma(v.y, w[b * PB + i].y, acc1);
             }
@@ -231,35 +215,19 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         const double2* __restrict__ vn = (t + 1 < total)
             ? reinterpret_cast<const double2*>(a.V + jn * a.ld) + first
             : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
-        if (a.debug != 2) {
-            // streamed batches first (their first loads were issued before the grid reduction) ...
+        if (a.debug != 2)
 #pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int b = LB + u;
-                const double2* __restrict__ nx = (u + 1 < NU) ? b2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+        for (int b = 0; b < NB; ++b) {
+            const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : vn;
 #pragma unroll
-                for (int i = 0; i < PB; ++i) ring[(u + 1) & 1][i] = nx[(int64_t)i * CH_BS];
-                CH_ISSUE_FENCE();
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
 #pragma unroll
-                for (int i = 0; i < PB; ++i) {
-                    const double2 p = ring[u & 1][i];
-                    const int r = b * PB + i;
-                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
-                }
-            }
-            if (NU == 0) {   // everything is cached: only the next column's first batch to issue
-#pragma unroll
-                for (int i = 0; i < PB; ++i) ring[0][i] = vn[(int64_t)i * CH_BS];
-                CH_ISSUE_FENCE();
-            }
-            // ... then the rows parked in LDS, while the next column's first batch is in flight
-#pragma unroll
-            for (int r = 0; r < LB * PB; ++r) {
-                const double2 p = vcache[r * CH_BS + tid];
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = ring[b & 1][i];
+                const int r = b * PB + i;
                 w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
                 w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
-                if ((r + 1) % 2 == 0) CH_ISSUE_FENCE();   // bound the LDS reads in flight (VGPRs)
             }
         }
     }

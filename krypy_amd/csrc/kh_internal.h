@@ -62,7 +62,6 @@ struct kh_ctx_s {
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     unsigned chain_epoch = 1;
     int chain_debug = 0;
-    int chain_cache = 1;            // park part of v_j in LDS between dot and update
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

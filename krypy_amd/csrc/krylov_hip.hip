@@ -220,24 +220,17 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
 // is what matters for the in-kernel grid reduction, and it is identical for plain and cooperative
 // launches: it is checked here against the occupancy of this instantiation, and every spin in the
 // kernel is bounded.
-template <int R2, bool MASKED, bool CACHE>
+template <int R2, bool MASKED>
 static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
-    constexpr size_t lds = CACHE ? (size_t)ChainShape<R2>::LROWS * CH_BS * sizeof(double2) : 0;
     if (blocks_per_cu < 0) {
-        if (lds > 48 * 1024) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain<R2, MASKED, CACHE>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e0 != hipSuccess) return e0;
-        }
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CACHE>,
-                                                                    CH_BS, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED>, CH_BS, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CACHE>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -310,10 +303,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.h_km1 = h_km1;
     a.bprev = presub ? B->col(k - 1) : nullptr;
     hipError_t e;
-    const bool cache = (B == V) && ctx->chain_cache;
-#define KH_CHAIN(R)                                                                                 \
-    (padded ? (cache ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, false, false>(ctx, G, a)) \
-            : (cache ? launch_chain<R, true, true>(ctx, G, a) : launch_chain<R, true, false>(ctx, G, a)))
+#define KH_CHAIN(R) (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a))
     if (r2 == 4) e = KH_CHAIN(4);
     else if (r2 == 8) e = KH_CHAIN(8);
     else if (r2 == 16) e = KH_CHAIN(16);
@@ -392,8 +382,6 @@ int kh_ctx_create(int device, kh_ctx* out) {
     {
         const char* e = getenv("KRYPY_AMD_MGS_CHAIN");
         ctx->chain_enabled = (e == nullptr) ? 1 : atoi(e);
-        const char* c = getenv("KRYPY_AMD_CHAIN_LDS");
-        ctx->chain_cache = (c == nullptr) ? 1 : atoi(c);
         if (ctx->ncu > CH_GMAX) ctx->chain_enabled = 0;
     }
     *out = ctx;
