@@ -74,11 +74,12 @@ def parse_args():
     ap.add_argument("--nx", type=int, default=4000)
     ap.add_argument("--ny", type=int, default=2500)
     ap.add_argument("--restart", type=int, default=100)
-    ap.add_argument("--ortho", default=os.environ.get("KRYPY_AMD_BENCH_ORTHO", "cgs"),
-                    help="Gram-Schmidt variant of the timed region: cgs (panel classical GS, default: "
-                         "one reduction per step, the only form that scales over xGMI) | mgs (the "
-                         "reference's sequential order) | cgs2 | dmgs.  All pass the 1e-10 parity tests.")
-    ap.add_argument("--other-modes", default="mgs,cgs2",
+    ap.add_argument("--ortho", default=os.environ.get("KRYPY_AMD_BENCH_ORTHO", "auto"),
+                    help="Gram-Schmidt variant of the timed region.  auto = mgs on one GPU (the "
+                         "reference's sequential order, register-resident chain kernel) and cgs on "
+                         "several GPUs (panel classical GS: one all-reduce per step instead of k+1). "
+                         "Also: mgs | dmgs | cgs | cgs2.  All pass the 1e-10 parity tests.")
+    ap.add_argument("--other-modes", default="cgs,cgs2",
                     help="comma list of further variants measured AFTER the timed region (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=24)
@@ -145,6 +146,8 @@ def main():
     nx, ny, m = args.nx, args.ny, args.restart
     N = nx * ny
     ortho = args.ortho
+    if ortho == "auto":
+        ortho = "mgs" if world == 1 else "cgs"
     if world > 1:
         from krypy_amd import dist as kdist
         uid = [ctx.comm_unique_id() if rank == 0 else None]

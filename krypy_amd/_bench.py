@@ -4,7 +4,8 @@ SURVEY.md section 8(d).  Not part of the solver path."""
 import numpy
 
 # kernel ids of kh_bench_kernel
-K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE = 0, 1, 2, 3, 4
+K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN = 0, 1, 2, 3, 4, 5
+CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 
 def _gbs(nbytes, ms):
@@ -38,6 +39,16 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
     run(K_MULTIAXPY16, 8.0 * n * 16 + 16.0 * n, "k_multiaxpy<16>", 8.0 * n * 18)
     run(K_AXPY_NRM, 8.0 * n + 16.0 * n, "k_gs_link<A_PART,T_NRM>", 24.0 * n)
     run(K_SCALE_STORE, 16.0 * n, "k_scale_store", 16.0 * n)
+    chain = None
+    try:
+        # register-resident MGS chain: one launch = load w (8N) + 64 links x (v_j read for the dot +
+        # b_j read for the update = 16N, the SURVEY 8d per-column figure) + store v_{k+1} (8N)
+        nb = 16.0 * n * CHAIN_LINKS + 16.0 * n
+        run(K_CHAIN, nb, "k_mgs_chain (64 links/launch)", nb)
+        chain = kernels["k_mgs_chain (64 links/launch)"]
+        chain["us_per_link"] = chain["avg_ms"] * 1e3 / CHAIN_LINKS
+    except Exception as exc:   # not eligible (odd n, w larger than the register file, multi-GPU)
+        kernels["k_mgs_chain"] = {"unavailable": repr(exc)}
     extra = {"kernels": kernels}
     Amat = ls.A._device_matrix()
     if Amat is not None and Amat.kind == "csr":
@@ -58,6 +69,8 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         nb = d["algorithmic_bytes"] + a["algorithmic_bytes"]
         ms = d["avg_ms"] + a["avg_ms"]
         name = "k_multidot<16>+k_multiaxpy<16>"
+    elif chain is not None:
+        nb, ms, name = chain["algorithmic_bytes"], chain["avg_ms"], "k_mgs_chain<40,false> (64 links per launch)"
     else:
         d = kernels["k_gs_link<A_PART,T_DOT>"]
         nb, ms, name = d["algorithmic_bytes"], d["avg_ms"], "k_gs_link<A_PART,T_DOT>"
