@@ -168,10 +168,21 @@ def main():
 
     ls = linsys.LinearSystem(A_for_ls, b)
 
+    cycle_marks = []
+
+    class StampedGmres(linsys.Gmres):
+        """linsys.Gmres that notes the host time when its cycle ends (diagnostics only: one
+        perf_counter call per 100 iterations)."""
+
+        def _finalize(self):
+            super(StampedGmres, self)._finalize()
+            cycle_marks.append(time.perf_counter())
+
     def run_cycles(ncyc, x0, ortho=ortho):
         try:
-            sol = linsys.RestartedGmres(ls, x0=x0, maxiter=m, max_restarts=ncyc - 1, tol=1e-8,
-                                        ortho=ortho)
+            # RestartedGmres == _RestartedSolver(Gmres, ...) (linsys.py:1075-1081)
+            sol = linsys._RestartedSolver(StampedGmres, ls, x0=x0, maxiter=m,
+                                          max_restarts=ncyc - 1, tol=1e-8, ortho=ortho)
         except utils.ConvergenceError as e:
             sol = e.solver
         return sol
@@ -187,10 +198,12 @@ def main():
         sol = run_cycles(args.warmup, None)
         x0 = sol.__dict__["_xk_dev"]
     barrier()
+    del cycle_marks[:]
     t0 = time.perf_counter()
     sol = run_cycles(args.steps, x0)
     ctx.sync()
     dt = time.perf_counter() - t0
+    cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
     if dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64)
@@ -233,7 +246,7 @@ def main():
                                % (m, nx, ny, N, nnz_global),
                    "ortho": ortho, "restart": m, "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if world == 1 else "row-sharded x%d (RCCL)" % world,
-                   "final_relres": float(sol.resnorms[-1])},
+                   "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms},
         "roofline": roof,
     }
     out.update(extra)
