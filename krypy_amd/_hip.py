@@ -160,15 +160,19 @@ class DeviceVectors(object):
 
     def __init__(self, ctx, n, ncols):
         self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
-        h = _H()
-        _check(ctx._lib, ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h)),
-               "kh_vec_alloc(%d x %d)" % (self.n, self.ncols))
+        h = ctx._pool_take(self.n, self.ncols)
+        if h is None:
+            h = _H()
+            rc = ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h))
+            if rc != 0 and ctx._pool_flush():
+                rc = ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h))
+            _check(ctx._lib, rc, "kh_vec_alloc(%d x %d)" % (self.n, self.ncols))
         self.handle = h
 
     def __del__(self):
         try:
             if self.handle is not None and self.ctx._alive:
-                self.ctx._lib.kh_vec_free(self.handle)
+                self.ctx._pool_give(self.n, self.ncols, self.handle)
         except Exception:
             pass
         self.handle = None
@@ -223,11 +227,55 @@ class Context(object):
         self._alive = True
         self.device = device
         self.rank, self.nranks = 0, 1
+        self._pool, self._pool_bytes = {}, 0
 
     def close(self):
         if self._alive:
+            self._pool_flush()
             self._alive = False
             self._lib.kh_ctx_destroy(self._h)
+
+    # ---- block pool: a restarted solver allocates and drops an (N, m+1) basis every cycle
+    # (8 GB at N = 10^7, m = 100); hipMalloc/hipFree of that size costs tens of ms, so released
+    # blocks are parked (at most _POOL_PER_SHAPE per shape, _POOL_FRACTION of device memory in
+    # total) and handed out again zero-filled, which is what kh_vec_alloc guarantees. ----
+    _POOL_PER_SHAPE = 2
+    _POOL_FRACTION = 0.35
+
+    def _pool_take(self, n, ncols):
+        lst = self.__dict__.setdefault("_pool", {}).get((n, ncols))
+        if not lst:
+            return None
+        h = lst.pop()
+        self._pool_bytes -= 8 * n * max(ncols, 1)
+        _check(self._lib, self._lib.kh_vec_zero(h, 0, ncols), "kh_vec_zero(pool)")
+        return h
+
+    def _pool_give(self, n, ncols, h):
+        pool = self.__dict__.setdefault("_pool", {})
+        self.__dict__.setdefault("_pool_bytes", 0)
+        if "_pool_cap" not in self.__dict__:
+            try:
+                self._pool_cap = int(self.info()["mem_total"] * self._POOL_FRACTION)
+            except Exception:
+                self._pool_cap = 0
+        nbytes = 8 * n * max(ncols, 1)
+        lst = pool.setdefault((n, ncols), [])
+        if len(lst) < self._POOL_PER_SHAPE and self._pool_bytes + nbytes <= self._pool_cap:
+            lst.append(h)
+            self._pool_bytes += nbytes
+        else:
+            self._lib.kh_vec_free(h)
+
+    def _pool_flush(self):
+        pool = self.__dict__.get("_pool") or {}
+        n = 0
+        for lst in pool.values():
+            while lst:
+                self._lib.kh_vec_free(lst.pop())
+                n += 1
+        self._pool_bytes = 0
+        return n
 
     def __del__(self):
         try:
