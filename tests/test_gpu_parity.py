@@ -208,3 +208,69 @@ def test_rccl_single_rank_communicator(hip):
     W = ctx.upload(np.ones(6))
     assert np.allclose(ctx.dot_panel(V, 0, 2, W, 0), [15.0, 51.0])
     ctx.close()
+
+
+def _second_context(chain):
+    """A private context with the register-resident MGS chain switched on/off (read at creation)."""
+    import os
+    from krypy_amd import _hip
+
+    old = os.environ.get("KRYPY_AMD_MGS_CHAIN")
+    os.environ["KRYPY_AMD_MGS_CHAIN"] = "1" if chain else "0"
+    try:
+        return _hip.Context(0)
+    finally:
+        if old is None:
+            del os.environ["KRYPY_AMD_MGS_CHAIN"]
+        else:
+            os.environ["KRYPY_AMD_MGS_CHAIN"] = old
+
+
+@pytest.mark.parametrize("shape", [(120, 120), (39, 41), (700, 300)])
+def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
+    """The one-launch register-resident chain (chain.h) and the per-column link kernels are two
+    implementations of the same reference-order MGS: identical up to the order of the partial sums
+    (1e-13), for even n (chain) and odd n (chain not eligible -> link kernels on both sides),
+    plain, double (dmgs), Jacobi-preconditioned and Lanczos steps."""
+    nx, ny = shape
+    A = ref.laplace2d(nx, ny)
+    n = A.shape[0]
+    b = np.random.default_rng(5).standard_normal(n)
+    d = np.linspace(0.5, 1.5, n)
+    m = 24
+    results = []
+    for chain in (True, False):
+        ctx = _second_context(chain)
+        Ad, Md = ctx.csr(A), ctx.diag(d)
+        out = {}
+        for name, sweeps, use_m, lanczos in (("mgs", 1, False, False), ("dmgs", 2, False, False),
+                                              ("mgsM", 1, True, False), ("lanczos", 1, False, True)):
+            V = ctx.alloc(n, m + 1)
+            P = ctx.alloc(n, m + 1) if use_m else None
+            W = ctx.alloc(n, 2)
+            v0 = b / np.linalg.norm(b)
+            if use_m:
+                nrm = np.sqrt(np.dot(b, d * b))
+                P.upload(0, b / nrm)
+                V.upload(0, d * b / nrm)
+            else:
+                V.upload(0, v0)
+            H = np.zeros((m + 1, m))
+            for k in range(m):
+                start = k if lanczos else 0
+                hk = float(H[k, k - 1]) if (lanczos and k > 0) else 0.0
+                hcol = ctx.arnoldi_step(Ad, Md if use_m else None, V, P, W, 0, k, start, sweeps, 0, hk)
+                H[start: k + 2, k] = hcol[start: k + 2]
+            out[name] = (H, V.download())
+        results.append(out)
+        ctx.close()
+    for name in results[0]:
+        Hc, Vc = results[0][name]
+        Hl, Vl = results[1][name]
+        assert np.linalg.norm(Hc - Hl) < 1e-12 * np.linalg.norm(Hl), name
+        assert np.linalg.norm(Vc - Vl) < 1e-10, name
+    # and both agree with the oracle
+    st = ref.arnoldi_init(A, b, m)
+    for _ in range(m):
+        ref.arnoldi_step(st)
+    assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
