@@ -33,7 +33,7 @@ def test_config3_minres_jacobi_full_size(hip):
     dt = time.perf_counter() - t0
     res = np.array(sol.resnorms)
     assert len(res) == 201 and np.all(np.diff(res[:-1]) <= 1e-14)
-    H = sol.lanczos.H[:200, :199]
+    H = sol.lanczos.H[:199, :199]
     assert np.allclose(H, H.T, atol=1e-10) and np.all(np.triu(H, 2) == 0)
     x = sol.xk[:, 0]
     r = b - A.dot(x)
