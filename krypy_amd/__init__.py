@@ -9,8 +9,8 @@ HIP kernels for gfx950 through a ctypes C-ABI (``include/krylov_hip.h``).
 There is no CPU fallback: without ``libkrylov_hip.so`` and an MI355X every solve raises
 ``krypy_amd.utils.BackendError``.
 """
-from . import deflation, linsys, utils
+from . import deflation, linsys, recycling, utils
 from .__about__ import __version__
 from ._convenience import cg, gmres, minres
 
-__all__ = ["linsys", "deflation", "utils", "cg", "minres", "gmres", "__version__"]
+__all__ = ["linsys", "deflation", "recycling", "utils", "cg", "minres", "gmres", "__version__"]

@@ -17,7 +17,8 @@ import scipy.linalg
 from . import _hip, utils
 from .utils import DVec
 
-__all__ = ["LinearSystem", "Cg", "Minres", "Gmres", "RestartedGmres"]
+__all__ = ["LinearSystem", "TimedLinearSystem", "ConvertedTimedLinearSystem", "Cg", "Minres", "Gmres",
+           "RestartedGmres"]
 
 
 class _LazyHost(object):
@@ -170,6 +171,47 @@ class LinearSystem(object):
             if op is not None and not isinstance(op, utils.IdentityLinearOperator):
                 ret += "  " + k + ": " + op.__repr__() + "\n"
         return ret + "}"
+
+
+class TimedLinearSystem(LinearSystem):
+    def __init__(self, A, b, M=None, Minv=None, Ml=None, Mr=None, ip_B=None, normal=None,
+                 self_adjoint=False, positive_definite=False, exact_solution=None):
+        """LinearSystem whose operators (and a callable inner product) are timed
+        (linsys.py:204-252); ``timings`` is a :class:`~krypy_amd.utils.Timings`."""
+        self.timings = utils.Timings()
+        N = len(b)
+        shape = (N, N)
+        try:
+            _ip_B = utils.get_linearoperator(shape, ip_B, timer=self.timings["ip_B"])
+        except TypeError:
+
+            def _ip_B(X, Y):
+                (_, m) = X.shape
+                (_, n) = Y.shape
+                if m == 0 or n == 0:
+                    return ip_B(X, Y)
+                with self.timings["ip_B"]:
+                    ret = ip_B(X, Y)
+                self.timings["ip_B"][-1] /= m * n
+                return ret
+
+        super(TimedLinearSystem, self).__init__(
+            A=utils.get_linearoperator(shape, A, self.timings["A"]), b=b,
+            M=utils.get_linearoperator(shape, M, self.timings["M"]),
+            Minv=utils.get_linearoperator(shape, Minv, self.timings["Minv"]),
+            Ml=utils.get_linearoperator(shape, Ml, self.timings["Ml"]),
+            Mr=utils.get_linearoperator(shape, Mr, self.timings["Mr"]),
+            ip_B=_ip_B, normal=normal, self_adjoint=self_adjoint,
+            positive_definite=positive_definite, exact_solution=exact_solution)
+
+
+class ConvertedTimedLinearSystem(TimedLinearSystem):
+    def __init__(self, linear_system):
+        """Timed copy of an existing LinearSystem (linsys.py:255-274)."""
+        kwargs = {k: linear_system.__dict__[k]
+                  for k in ["A", "b", "M", "Minv", "Ml", "Mr", "ip_B", "normal", "self_adjoint",
+                            "positive_definite", "exact_solution"]}
+        super(ConvertedTimedLinearSystem, self).__init__(**kwargs)
 
 
 class _KrylovSolver(object):

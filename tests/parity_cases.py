@@ -454,3 +454,43 @@ def case_deflated_gmres_recycling():
     U2 = U2.get_vectors(np.argsort(np.abs(U2.values))[:16])
     s2 = deflation.DeflatedGmres(ls, U=U2, tol=1e-8, maxiter=300)
     assert len(s2.resnorms) - 1 == int(g["s2_iters"])
+
+
+# ---------------------------------------------------------------------------------------------
+# recycling driver (reference: test/test_recycling.py:8-39 and fixture F6)
+# ---------------------------------------------------------------------------------------------
+def case_recycling_gmres_lap3d():
+    from krypy_amd import recycling
+
+    g = golden("deflation_lap3d_nx24")
+    A, b = lap3d_system(24, rhs="ones")
+    ls = linsys.LinearSystem(A, b, self_adjoint=True)
+    fac = recycling.factories.RitzFactorySimple(n_vectors=16, which="sm")
+    rec = recycling.RecyclingGmres()
+    its = []
+    for i in range(3):
+        s = rec.solve(ls, vector_factory=fac, tol=1e-8, maxiter=300)
+        its.append(len(s.resnorms) - 1)
+        assert s.resnorms[-1] <= 1e-8
+    assert its == [int(g["s0_iters"]), int(g["s1_iters"]), int(g["s2_iters"])]   # 59 / 25 / 23
+    assert rec.timings.get("solve") > 0 and rec.last_solver is s
+
+
+def case_recycling_factories_toy():
+    """test_recycling.py: 3 solvers x 7 selection modes on a 100x100 diagonal."""
+    from krypy_amd import recycling
+
+    N = 100
+    d = np.linspace(1, 2, N)
+    d[:5] = [1e-8, 1e-4, 1e-2, 2e-2, 3e-2]
+    ls = linsys.LinearSystem(np.diag(d), np.ones((N, 1)), normal=True, self_adjoint=True,
+                             positive_definite=True)
+    for Solver in (recycling.RecyclingCg, recycling.RecyclingMinres, recycling.RecyclingGmres):
+        for which in ("lm", "sm", "lr", "sr", "li", "si", "smallest_res"):
+            fac = recycling.factories.RitzFactorySimple(n_vectors=3, which=which)
+            rs = Solver()
+            sols = [rs.solve(ls, vector_factory=fac, maxiter=50, tol=1e-5, x0=None) for _ in range(3)]
+            for s in sols:
+                assert s.resnorms[-1] <= 1e-5 and s.projection.U.shape[0] == N
+            for s in sols[1:]:
+                assert len(s.resnorms) <= len(sols[0].resnorms)
