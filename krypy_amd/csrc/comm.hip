@@ -9,6 +9,7 @@
 // librccl is resolved with dlopen at kh_comm_init so that single-GPU processes never load it.
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kh_internal.h"
@@ -75,7 +76,7 @@ int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
 }
 
 int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x) {
-    if (ctx->nranks <= 1) return 0;
+    if (ctx->comm == nullptr) return 0;
     const int64_t nloc = A->n_rows;
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     KH_NCCL(g_rccl.GroupStart());
@@ -120,6 +121,10 @@ int kh_comm_init(kh_ctx ctx, int rank, int nranks, const unsigned char id[128]) 
     ctx->comm = comm;
     ctx->rank = rank;
     ctx->nranks = nranks;
+    {
+        const char* e = getenv("KRYPY_AMD_FORCE_MULTI");
+        ctx->force_multi = (e != nullptr && atoi(e) != 0) ? 1 : 0;
+    }
     KH_HIP(hipMalloc(&ctx->commbuf, sizeof(double) * kh::SCAL_CAP));
     return 0;
 }
@@ -129,6 +134,7 @@ int kh_comm_destroy(kh_ctx ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
+    ctx->force_multi = 0;
     ctx->nranks = 1;
     ctx->rank = 0;
     (void)hipFree(ctx->commbuf);

@@ -66,6 +66,7 @@ struct kh_ctx_s {
     void* rccl_lib = nullptr;
     void* comm = nullptr;
     int rank = 0, nranks = 1;
+    int force_multi = 0;   // tests: run the multi-rank code path on a 1-rank communicator
     double* commbuf = nullptr;  // device staging for host all-reduces
 };
 
@@ -99,6 +100,10 @@ struct kh_mat_s {
     int64_t nsend_prev = 0, nsend_next = 0, nrecv_prev = 0, nrecv_next = 0;
     double* ghost = nullptr;    // nrecv_prev + nrecv_next doubles
 };
+
+// true when reductions must be all-reduced / halos exchanged (several ranks, or a 1-rank
+// communicator in forced mode: the multi-rank code path is then testable on a single GPU)
+static inline bool kh_multi(const kh_ctx_s* ctx) { return ctx->nranks > 1 || ctx->force_multi; }
 
 namespace kh {
 // comm.hip

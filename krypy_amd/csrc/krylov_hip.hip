@@ -185,7 +185,7 @@ static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const 
 static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
                      double* scal_out, int rmode) {
     if (A->kind == KH_MAT_CSR) {
-        if (ctx->nranks > 1 && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0)
+        if (kh_multi(ctx) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0)
             KH_TRY(comm_halo_exchange(ctx, A, x));
         if (A->nblk == 0) return 0;
         if (epi == EPI_NONE) launch_spmv<EPI_NONE>(ctx, A, x, y, nullptr);
@@ -264,7 +264,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
                      double* hdev, int slot) {
-    if (!ctx->chain_enabled || ctx->nranks > 1) return 0;
+    if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     const int64_t n = V->n;
     const int64_t n2 = n >> 1;
     int r2 = 0, G = 0;
@@ -690,7 +690,7 @@ int kh_dot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int6
     if (ncols == 0) return 0;
     double* dev = ctx->scal + SC_COEF;
     KH_TRY(dot_panel_dev(ctx, V, j0, ncols, W->col(wcol), dev, 0));
-    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, dev, ncols));
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, dev, ncols));
     return fetch_scalars(ctx, dev, ncols, out);
 }
 
@@ -756,13 +756,13 @@ int kh_nrm2(kh_ctx ctx, kh_vec W, int64_t wcol, double* out) {
                        part, nullptr);
     KH_HIP(hipGetLastError());
     double* dev = ctx->scal + SC_TMP;
-    const int mode = ctx->nranks > 1 ? 0 : 2;
+    const int mode = kh_multi(ctx) ? 0 : 2;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid_for(ctx, n),
                        NB_MAX, dev, mode);
     KH_HIP(hipGetLastError());
-    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, dev, 1));
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, dev, 1));
     KH_TRY(fetch_scalars(ctx, dev, 1, out));
-    if (ctx->nranks > 1) *out = sqrt(fabs(*out));
+    if (kh_multi(ctx)) *out = sqrt(fabs(*out));
     return 0;
 }
 
@@ -817,7 +817,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     double* mw = Md ? W->col(wcol + 1) : nullptr;
     const double* dg = Md ? Md->diag : nullptr;
     const int grid = grid_for(ctx, n);
-    const bool multi = ctx->nranks > 1;
+    const bool multi = kh_multi(ctx);
     double* hdev = ctx->hslot_dev[slot];
     double* tmp = ctx->scal + SC_TMP;
     KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
@@ -825,7 +825,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
     // reference-order MGS: keep w in registers for the whole chain when it fits (chain.h)
     int cr2 = 0, cg = 0;
-    const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && ctx->nranks == 1 &&
+    const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) &&
                              chain_geometry(ctx, n, &cr2, &cg));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
                             A->nblk > 0 && !want_chain);
@@ -985,10 +985,10 @@ int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t
     double* tmp = ctx->scal + SC_TMP;
     if (A->kind == KH_MAT_CSR && A->nblk > 0) {
         KH_TRY(apply_one(ctx, A, X->col(xcol), R->col(rcol), EPI_RES, Bv->col(bcol), tmp,
-                         ctx->nranks > 1 ? 0 : 2));
-        if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+                         kh_multi(ctx) ? 0 : 2));
+        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
         KH_TRY(fetch_scalars(ctx, tmp, 1, nrm));
-        if (ctx->nranks > 1) *nrm = sqrt(fabs(*nrm));
+        if (kh_multi(ctx)) *nrm = sqrt(fabs(*nrm));
         return 0;
     }
     KH_ARG(!(R == Bv && rcol == bcol), "kh_residual: r must not alias b for non-CSR operators");
@@ -1038,7 +1038,7 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     double* tmp = ctx->scal + SC_TMP;
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp, 0);
     KH_HIP(hipGetLastError());
-    if (ctx->nranks > 1) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
     return fetch_scalars(ctx, tmp, 1, rho_new);
 }
 

@@ -275,3 +275,45 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     for _ in range(m):
         ref.arnoldi_step(st)
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
+
+
+def test_multi_rank_code_path_on_one_gpu(hip):
+    """The code path libkrylov_hip takes on N > 1 GPUs (partial sums -> k_reduce_partials -> device
+    scalar -> ncclAllReduce -> consumer kernels reading the scalar; halo exchange hook; panel
+    all-reduces) exercised with a 1-rank RCCL communicator in forced mode: results must equal the
+    single-GPU path.  The 2-rank sharding logic itself is covered by tests/test_dist_gloo.py."""
+    import os
+    from krypy_amd import _hip, dist as kdist
+
+    os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
+    try:
+        ctx = _hip.Context(0)
+        ctx.comm_init(0, 1, ctx.comm_unique_id())
+    finally:
+        del os.environ["KRYPY_AMD_FORCE_MULTI"]
+    A, b = lap2d_system(90, rhs="rng1")
+    n = A.shape[0]
+    op = kdist.ShardedCSROperator(A, 0, n, ctx)       # one slab = the whole matrix, empty halos
+    assert op.halo == (0, 0, 0, 0)
+    Ad = op._device_matrix()
+    m = 20
+    for ortho, gs, sweeps in (("mgs", 0, 1), ("dmgs", 0, 2), ("mgs", 1, 1), ("mgs", 1, 2)):
+        st = ref.arnoldi_init(A, b, m, ortho=ortho)
+        V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+        V.upload(0, st.V[:, :1])
+        for k in range(m):
+            ref.arnoldi_step(st)
+            hcol = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, sweeps, gs)
+            assert np.linalg.norm(hcol - st.H[: k + 2, k]) < 1e-12 * np.linalg.norm(hcol), (ortho, gs, k)
+        assert np.linalg.norm(V.download() - st.V) < 1e-10
+    x = np.random.default_rng(3).standard_normal((n, 1))
+    X, R, B = ctx.upload(x), ctx.alloc(n, 1), ctx.upload(b)
+    nrm = ctx.residual(Ad, B, 0, X, 0, R, 0)
+    want = b - A.dot(x[:, 0])
+    assert np.array_equal(R.download()[:, 0], want) and abs(nrm - np.linalg.norm(want)) < 1e-13 * nrm
+    assert abs(ctx.nrm2(X, 0) - np.linalg.norm(x)) < 1e-14 * np.linalg.norm(x)
+    Z, YK = ctx.alloc(n, 1), ctx.alloc(n, 1)
+    rho = ctx.cg_update(0.5, X, 0, B, 0, YK, 0, R, 0, None, None, 0)
+    r2 = want - 0.5 * b
+    assert abs(rho - np.dot(r2, r2)) < 1e-12 * rho
+    ctx.close()
