@@ -81,6 +81,9 @@ def parse_args():
                          "Also: mgs | dmgs | cgs | cgs2.  All pass the 1e-10 parity tests.")
     ap.add_argument("--other-modes", default="cgs,cgs2",
                     help="comma list of further variants measured AFTER the timed region (N=1 only)")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="testing: take the multi-GPU code path (gloo init, RCCL communicator, "
+                         "ShardedCSROperator, all-reduced reductions) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-steps", type=int, default=24)
     return ap.parse_args()
@@ -134,9 +137,14 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
 
+    sharded = world > 1 or args.force_sharded
+    if args.force_sharded:
+        os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
     dist = None
-    if world > 1:
+    if sharded:
         import torch.distributed as dist  # plumbing only: unique-id broadcast + barrier
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import krypy_amd
@@ -147,8 +155,8 @@ def main():
     N = nx * ny
     ortho = args.ortho
     if ortho == "auto":
-        ortho = "mgs" if world == 1 else "cgs"
-    if world > 1:
+        ortho = "cgs" if sharded else "mgs"
+    if sharded:
         from krypy_amd import dist as kdist
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -215,7 +223,7 @@ def main():
 
     # ---- the other Gram-Schmidt variants on the same inputs (outside the timed region) ----
     others = {}
-    if world == 1 and args.other_modes:
+    if not sharded and args.other_modes:
         for mode in [t for t in args.other_modes.split(",") if t and t != ortho and t != "none"]:
             barrier()
             t1 = time.perf_counter()
@@ -245,14 +253,14 @@ def main():
                                "b=rng(0) normal, x0=0, tol=1e-8 (BASELINE.json configs[1])"
                                % (m, nx, ny, N, nnz_global),
                    "ortho": ortho, "restart": m, "iterations_timed": n_iters,
-                   "parallelism": "1 GPU" if world == 1 else "row-sharded x%d (RCCL)" % world,
+                   "parallelism": "1 GPU" if not sharded else "row-sharded x%d (RCCL)" % world,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms},
         "roofline": roof,
     }
     out.update(extra)
     if others:
         out["other_modes"] = others
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(A_for_ls, b, m, args.cpu_sample_steps)
         except Exception as exc:
