@@ -128,7 +128,34 @@ def cpu_baseline(A, b, m, sample_steps):
     }
 
 
+class _StdoutToStderr(object):
+    """Everything written to fd 1 while this is active goes to stderr (RCCL and gloo print banners
+    on stdout); the contract is ONE JSON line on stdout."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
+    with _StdoutToStderr():
+        out, rank, dist = _run()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        with _StdoutToStderr():
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def _run():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,11 +292,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(A_for_ls, b, m, args.cpu_sample_steps)
         except Exception as exc:
             out["cpu_baseline"] = {"error": repr(exc)}
-    if rank == 0:
-        print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    return out, rank, dist
 
 
 if __name__ == "__main__":
