@@ -236,8 +236,9 @@ static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
 
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
 static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
-    if (n < 2 || (n & 1)) return false;
-    const int64_t n2 = n >> 1;
+    if (n < 2) return false;
+    // an odd n is handled as n+1: the extra element is the (always zero) padding behind the column
+    const int64_t n2 = (n + 1) >> 1;
     static const int kR2[] = {4, 8, 16, 24, 32, 40};
     for (int c : kR2) {
         const int64_t g = (n2 + (int64_t)c * CH_BS - 1) / ((int64_t)c * CH_BS);
@@ -266,9 +267,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                      double* hdev, int slot) {
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     const int64_t n = V->n;
-    const int64_t n2 = n >> 1;
+    const int64_t n2 = (n + 1) >> 1;
     int r2 = 0, G = 0;
     if (!chain_geometry(ctx, n, &r2, &G)) return 0;
+    if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n || (P && P->ld <= n))) return 0;
     const int64_t chunk2 = (int64_t)r2 * CH_BS;
     // predicate-free kernel iff every block involved is padded to G whole chunks
     const int64_t need_ld = (int64_t)G * chunk2 * 2;
