@@ -230,6 +230,22 @@ def gen_kernels(krypy):
     save("kernels", **out)
 
 
+def gen_ipB(krypy, nx=24):
+    """Non-Euclidean inner product <x,y>_B = x^T B y with a diagonal SPD B:
+    GMRES and one Arnoldi run of the reference with ip_B given as a sparse matrix."""
+    A, b = lap2d_system(nx, rhs="rng1")
+    N = A.shape[0]
+    Bd = np.linspace(0.5, 2.0, N)
+    B = sp.diags(Bd).tocsr()
+    ls = krypy.linsys.LinearSystem(A, b, ip_B=B)
+    s = krypy.linsys.Gmres(ls, tol=1e-10, maxiter=200, store_arnoldi=True)
+    ar = krypy.utils.Arnoldi(A, b.reshape(-1, 1), maxiter=15, ortho="mgs", ip_B=B)
+    for _ in range(15):
+        ar.advance()
+    save("ipB_lap2d_nx%d" % nx, nx=nx, resnorms=np.array(s.resnorms), xk=s.xk[:, 0], H=s.H,
+         iter=s.iter, arn_H=ar.H, arn_V=ar.V)
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -243,6 +259,7 @@ def main():
     gen_minres(krypy)
     gen_cg_dense(krypy)
     gen_deflation(krypy)
+    gen_ipB(krypy)
 
 
 if __name__ == "__main__":

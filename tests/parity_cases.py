@@ -494,3 +494,32 @@ def case_recycling_factories_toy():
                 assert s.resnorms[-1] <= 1e-5 and s.projection.U.shape[0] == N
             for s in sols[1:]:
                 assert len(s.resnorms) <= len(sols[0].resnorms)
+
+
+# ---------------------------------------------------------------------------------------------
+# non-Euclidean inner product given as an SPD matrix B (general device path:
+# B applied by the diagonal/CSR kernel to the thinner side, then the Euclidean panel product)
+# ---------------------------------------------------------------------------------------------
+def case_inner_product_matrix_B():
+    g = golden("ipB_lap2d_nx24")
+    A, b = lap2d_system(24, rhs="rng1")
+    N = A.shape[0]
+    B = sp.diags(np.linspace(0.5, 2.0, N)).tocsr()
+    ls = linsys.LinearSystem(A, b, ip_B=B)
+    s = linsys.Gmres(ls, tol=1e-10, maxiter=200, store_arnoldi=True)
+    assert s.iter == int(g["iter"])
+    # the final explicit residual sits at 1e-10: cancellation eps*|A||x|/|r| ~ 1e-5
+    check_resnorms(s.resnorms, g["resnorms"], tol=1e-8, explicit_tol=1e-4)
+    assert rel(s.xk[:, 0], g["xk"]) < 1e-9
+    ar = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=15, ortho="mgs", ip_B=B)
+    for _ in range(15):
+        ar.advance()
+    assert rel(ar.H, g["arn_H"]) < RTOL and rel(ar.V, g["arn_V"]) < RTOL
+    # B-orthonormal basis; a callable with the same meaning gives the same numbers
+    Bd = np.linspace(0.5, 2.0, N)
+    assert np.linalg.norm(ar.V.T.dot(Bd[:, None] * ar.V) - np.eye(16)) < 1e-11
+    ar2 = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=15, ip_B=lambda X, Y: X.T.dot(Bd[:, None] * Y))
+    for _ in range(15):
+        ar2.advance()
+    assert rel(ar2.H, g["arn_H"]) < RTOL
+    assert abs(utils.norm(b.reshape(-1, 1), ip_B=B) - np.sqrt(np.dot(b, Bd * b))) < 1e-12
