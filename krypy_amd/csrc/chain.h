@@ -54,6 +54,7 @@ struct ChainArgs {
     int debug;         // measurement only: 1 = skip the grid reduction, 2 = skip the streaming phases
     int presub;        // Lanczos: w -= h_km1 * bprev first
     double h_km1;
+    const double* h_km1_dev;   // when non-null the coefficient is read from the device (look-ahead)
     const double* bprev;
 };
 
@@ -168,12 +169,13 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         }
     }
     if (a.presub) {
+        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
         const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 p = p2[(int64_t)r * CH_BS];
-            w[r].x = CH_OK(r) ? w[r].x - a.h_km1 * p.x : 0.0;
-            w[r].y = CH_OK(r) ? w[r].y - a.h_km1 * p.y : 0.0;
+            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }

@@ -264,7 +264,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 // kernels), negative on error
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
-                     double* hdev, int slot) {
+                     const double* h_km1_dev, double* hdev, int slot) {
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     const int64_t n = V->n;
     const int64_t n2 = (n + 1) >> 1;
@@ -303,6 +303,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.debug = ctx->chain_debug;
     a.presub = presub ? 1 : 0;
     a.h_km1 = h_km1;
+    a.h_km1_dev = h_km1_dev;
     a.bprev = presub ? B->col(k - 1) : nullptr;
     hipError_t e;
 #define KH_CHAIN(R) (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a))
@@ -825,6 +826,10 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
 
     const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
+    // look-ahead Lanczos: h_km1 = NaN means "H[k,k-1] of the step begun just before this one",
+    // still on the device in the previous H-column slot
+    const double* hk_dev = nullptr;
+    if (presub && h_km1 != h_km1) hk_dev = ctx->hslot_dev[(slot + KH_NSLOT - 1) % KH_NSLOT] + k;
     // reference-order MGS: keep w in registers for the whole chain when it fits (chain.h)
     int cr2 = 0, cg = 0;
     const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) &&
@@ -844,7 +849,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     double* nrm_part = part_slot(ctx, SLOT_NRM);
     bool chained = false;
     if (want_chain) {
-        const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hdev, slot);
+        const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot);
         if (rc < 0) return rc;
         chained = (rc == 1);
     }
@@ -864,8 +869,12 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
             src = A_SCAL;
         } else if (presub) {
             double* pout = part_slot(ctx, SLOT_PING);
-            KH_LINK(A_ARG, T_DOT, B->col(k - 1), V->col(colof(0)), nullptr, nullptr, nullptr, nullptr,
-                    h_km1, pout, nullptr);
+            if (hk_dev)
+                KH_LINK(A_SCAL, T_DOT, B->col(k - 1), V->col(colof(0)), nullptr, nullptr, nullptr, hk_dev,
+                        0.0, pout, nullptr);
+            else
+                KH_LINK(A_ARG, T_DOT, B->col(k - 1), V->col(colof(0)), nullptr, nullptr, nullptr, nullptr,
+                        h_km1, pout, nullptr);
             src = A_PART;
             pin = pout;
         } else {
@@ -914,8 +923,12 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
         double* coef = ctx->scal + SC_COEF;
         if (presub) {
             // w -= h_km1 * B[:, k-1]
-            KH_LINK(A_ARG, T_NONE, B->col(k - 1), nullptr, nullptr, nullptr, nullptr, nullptr, h_km1,
-                    nullptr, nullptr);
+            if (hk_dev)
+                KH_LINK(A_SCAL, T_NONE, B->col(k - 1), nullptr, nullptr, nullptr, nullptr, hk_dev, 0.0,
+                        nullptr, nullptr);
+            else
+                KH_LINK(A_ARG, T_NONE, B->col(k - 1), nullptr, nullptr, nullptr, nullptr, nullptr, h_km1,
+                        nullptr, nullptr);
         }
         for (int s = 0; s < sweeps; ++s) {
             KH_TRY(dot_panel_dev(ctx, V, start, ncol, w, coef, 0));
@@ -1097,7 +1110,7 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
                 ctx->chain_debug = which - 5;
                 KH_HIP(hipMemsetAsync(ctx->hslot_dev[0], 0, sizeof(double) * 64, ctx->stream));
                 const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 15, 0, 4, false, 0.0,
-                                         ctx->hslot_dev[0], 0);
+                                         nullptr, ctx->hslot_dev[0], 0);
                 ctx->chain_debug = 0;
                 if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
                 break;

@@ -841,8 +841,9 @@ class Arnoldi(object):
         # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
         # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU
         # never idles while the host does its O(k) work.  A speculative step past the end of the
-        # iteration is discarded by _settle().  (Lanczos needs H[k,k-1] from the host: no look-ahead.)
-        self._lookahead = 1 if (self._Amat is not None and ortho != "lanczos") else 0
+        # iteration is discarded by _settle().  (A Lanczos step takes H[k,k-1] from the previous step's
+        # device-side H column, so it can run ahead as well.)
+        self._lookahead = 1 if self._Amat is not None else 0
         self._enq = 0          # number of steps enqueued on the device so far
 
         v = _as_dvec(v, ctx)
@@ -875,8 +876,15 @@ class Arnoldi(object):
     def _begin(self):
         """Enqueue Arnoldi step ``self._enq`` on the device (no host synchronisation)."""
         k = self._enq
-        self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k, 0,
-                                     self._sweeps, self._gs_mode, 0.0, k % 4)
+        start, h_km1 = 0, 0.0
+        if self.ortho == "lanczos":
+            start = k
+            if k > 0:
+                # the previous step has been begun but maybe not fetched yet: NaN tells the library
+                # to read H[k,k-1] from that step's device-side H column
+                h_km1 = float(self.H[k, k - 1]) if self.iter >= k else float("nan")
+        self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
+                                     self._sweeps, self._gs_mode, h_km1, k % 4)
         self._enq = k + 1
 
     def _settle(self):

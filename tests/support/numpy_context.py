@@ -208,6 +208,8 @@ class NumpyContext(object):
     def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot):
         if not hasattr(self, "_slots"):
             self._slots = {}
+        if h_km1 != h_km1:      # NaN: H[k,k-1] of the step begun just before (device-side value)
+            h_km1 = float(self._slots[(slot - 1) % 4][k])
         self._slots[slot] = self.arnoldi_step(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
 
     def arnoldi_step_end(self, slot, count):
