@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Secondary measurements (not the bench.py contract): BASELINE.json configs 3, 4 and the
+single-GPU shape of config 5 at full size, iterations/s with inputs resident in HBM.
+  python tools/bench_configs.py [3] [4] [5]      -> one JSON line per config
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+from krypy_amd import _hip, deflation, linsys, utils  # noqa: E402
+
+
+def config3(ctx, steps=400):
+    A = bench.laplace2d(4000, 2500)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+    d = A.diagonal()
+    ls = linsys.LinearSystem(A, b, M=sp.diags(1.0 / d).tocsr(), Minv=sp.diags(d).tocsr(),
+                             self_adjoint=True)
+    out = {}
+    for it in range(2):          # first pass = warm-up
+        ctx.sync()
+        t0 = time.perf_counter()
+        try:
+            s = linsys.Minres(ls, ortho="lanczos", tol=1e-12, maxiter=steps)
+        except utils.ConvergenceError as e:
+            s = e.solver
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        n_it = len(s.resnorms) - 1
+        del s
+    # algorithmic bytes per iteration (SURVEY 8d fused lower bound): SpMV + ~12 vector passes
+    nb = 12.0 * A.nnz + 4.0 * (N + 1) + 16.0 * N + 12 * 8.0 * N
+    out.update(config="3: MINRES + Jacobi, 2-D Laplacian N=1e7, ortho=lanczos, %d steps" % steps,
+               iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+               algorithmic_gbs=nb * n_it / dt / 1e9, frac_of_8TBs=nb * n_it / dt / 8e12)
+    return out
+
+
+def config4(ctx, n=32768):
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((n, n))
+    A = (A + A.T) * (0.5 / np.sqrt(n))
+    A[np.diag_indices(n)] += 3.0
+    b = rng.standard_normal(n)
+    ls = linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
+    for it in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        s = linsys.Cg(ls, tol=1e-8, maxiter=200)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    n_it = s.iter
+    nb = 8.0 * n * n + 10 * 8.0 * n
+    return dict(config="4: dense SPD n=%d CG tol 1e-8" % n, iterations=n_it,
+                iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+                algorithmic_gbs=nb * n_it / dt / 1e9, frac_of_8TBs=nb * n_it / dt / 8e12,
+                final_relres=float(s.resnorms[-1]))
+
+
+def config5(ctx, nx=200, m=100, d=16):
+    import oracle.krylov_ref as ref
+    A = ref.laplace3d(nx)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+    ls = linsys.LinearSystem(A, b, self_adjoint=True)
+    try:
+        s0 = deflation.DeflatedGmres(ls, tol=1e-12, maxiter=m, store_arnoldi=True)
+    except utils.ConvergenceError as e:
+        s0 = e.solver
+    ritz = deflation.Ritz(s0)
+    U = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:d])
+    for it in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        try:
+            s1 = deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m)
+        except utils.ConvergenceError as e:
+            s1 = e.solver
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    n_it = len(s1.resnorms) - 1
+    return dict(config="5 (one-GPU shape): 3-D 7-pt %d^3 (N=%d), DeflatedGmres(%d) with %d Ritz vectors"
+                       % (nx, N, m, d), iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+                plain_relres=float(s0.resnorms[-1]), deflated_relres=float(s1.resnorms[-1]))
+
+
+if __name__ == "__main__":
+    ctx = _hip.get_context()
+    which = sys.argv[1:] or ["3", "4", "5"]
+    for w in which:
+        print(json.dumps({"3": config3, "4": config4, "5": config5}[w](ctx)), flush=True)
