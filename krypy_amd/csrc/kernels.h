@@ -407,7 +407,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-template <int EPI>
+template <int EPI, int ITEMS>
 __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
                                                     const double* __restrict__ data,
@@ -418,7 +418,7 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                                                     double* __restrict__ y,
                                                     const double* __restrict__ aux,
                                                     double* __restrict__ part_out) {
-    extern __shared__ __attribute__((aligned(16))) double prod[];
+    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products
     __shared__ double sm[8];
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
@@ -426,10 +426,28 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
     const int cnt = nz1 - nz0;
     double acc = 0.0;
     if (cnt <= tile) {
-        for (int t = threadIdx.x; t < cnt; t += BS) {
-            const int c = indices[nz0 + t];
-            const double xv = (c < nloc) ? x[c] : ghost[c - nloc];
-            prod[t] = data[nz0 + t] * xv;
+        if (cnt > 0) {
+            // all index/value loads first, then all gathers: ITEMS independent loads in flight per
+            // lane (clamped addresses instead of predicated loads, which would serialise)
+            int c[ITEMS];
+            double a[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                const int tc = t < cnt ? t : cnt - 1;
+                c[i] = indices[nz0 + tc];
+                a[i] = data[nz0 + tc];
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
+                a[i] = a[i] * xv;
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                if (t < cnt) prod[t] = a[i];
+            }
         }
         __syncthreads();
         for (int r = r0 + threadIdx.x; r < r1; r += BS) {

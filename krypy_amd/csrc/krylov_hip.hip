@@ -171,13 +171,21 @@ static int multiaxpy_cols(kh_ctx ctx, kh_vec X, int64_t j0, int64_t nc, const do
 }
 
 // ---- operator application -------------------------------------------------------------------
+template <int EPI, int ITEMS>
+static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+    const size_t lds = (size_t)A->tile * sizeof(double);
+    hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr,
+                       A->indices, A->data, A->rowblk, A->nblk, A->tile,
+                       A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part);
+}
+
 template <int EPI>
 static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
-    const size_t lds = (size_t)A->tile * sizeof(double);
-    hipLaunchKernelGGL((k_spmv_stream<EPI>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr,
-                       A->indices, A->data, A->rowblk, A->nblk, A->tile,
-                       A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y,
-                       aux, A->part);
+    switch (A->tile / BS) {      // tile is one of 1024 / 2048 / 4096 (kh_ctx_tune)
+        case 4: launch_spmv_items<EPI, 4>(ctx, A, x, y, aux); break;
+        case 16: launch_spmv_items<EPI, 16>(ctx, A, x, y, aux); break;
+        default: launch_spmv_items<EPI, 8>(ctx, A, x, y, aux); break;
+    }
 }
 
 // y = A x for one column; epi/aux select the fused epilogue of the CSR kernel (its partial sums
@@ -440,7 +448,8 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile) {
         ctx->nb = reduce_blocks;
     }
     if (spmv_tile > 0) {
-        KH_ARG(spmv_tile >= 256 && spmv_tile <= 8192, "spmv_tile %d not in [256, 8192]", spmv_tile);
+        KH_ARG(spmv_tile == 1024 || spmv_tile == 2048 || spmv_tile == 4096,
+               "spmv_tile %d must be 1024, 2048 or 4096", spmv_tile);
         ctx->spmv_tile = spmv_tile;
     }
     return 0;
