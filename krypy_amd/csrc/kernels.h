@@ -498,22 +498,36 @@ __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_col
     const int64_t row = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const double* __restrict__ ar = a + row * lda;
-    double acc0 = 0.0, acc1 = 0.0;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     if (((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0)) {
         const double2* __restrict__ a2 = reinterpret_cast<const double2*>(ar);
         const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
         const int64_t n2 = n_cols >> 1;
-        for (int64_t i = lane; i < n2; i += 64) {
+        int64_t i = lane;
+        // four independent 16-byte row loads in flight per lane (1 KB per wave instruction)
+        for (; i + 192 < n2; i += 256) {
+            const double2 a0 = a2[i], a1 = a2[i + 64], a2v = a2[i + 128], a3 = a2[i + 192];
+            const double2 x0 = x2[i], x1 = x2[i + 64], x2v = x2[i + 128], x3 = x2[i + 192];
+            acc0 = fma(a0.x, x0.x, acc0);
+            acc0 = fma(a0.y, x0.y, acc0);
+            acc1 = fma(a1.x, x1.x, acc1);
+            acc1 = fma(a1.y, x1.y, acc1);
+            acc2 = fma(a2v.x, x2v.x, acc2);
+            acc2 = fma(a2v.y, x2v.y, acc2);
+            acc3 = fma(a3.x, x3.x, acc3);
+            acc3 = fma(a3.y, x3.y, acc3);
+        }
+        for (; i < n2; i += 64) {
             const double2 av = a2[i];
             const double2 xv = x2[i];
             acc0 = fma(av.x, xv.x, acc0);
-            acc1 = fma(av.y, xv.y, acc1);
+            acc0 = fma(av.y, xv.y, acc0);
         }
         if ((n_cols & 1) && lane == 0) acc0 = fma(ar[n_cols - 1], x[n_cols - 1], acc0);
     } else {
         for (int64_t i = lane; i < n_cols; i += 64) acc0 = fma(ar[i], x[i], acc0);
     }
-    const double s = wave_sum(acc0 + acc1);
+    const double s = wave_sum((acc0 + acc1) + (acc2 + acc3));
     if (lane == 0) y[row] = s;
 }
 
