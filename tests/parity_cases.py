@@ -523,3 +523,90 @@ def case_inner_product_matrix_B():
         ar2.advance()
     assert rel(ar2.H, g["arn_H"]) < RTOL
     assert abs(utils.norm(b.reshape(-1, 1), ip_B=B) - np.sqrt(np.dot(b, Bd * b))) < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's solver matrix zoo (test/test_linsys.py:50-232, real-valued part) with the
+# preconditioner hooks M / Ml / Mr / Minv really applied, x0 and rhs-shape variants: check_solver
+# properties + agreement with the CPU oracle.
+# ---------------------------------------------------------------------------------------------
+def _zoo():
+    spd = np.linspace(1, 2, 10)
+    spd[-1] = 1e-2
+    ind = np.linspace(1, 2, 10)
+    ind[-1] = -1
+    non = np.diag(np.arange(1, 11, dtype=float))
+    non[-1, -1] = -1e1
+    non[0, -1] = 1e1
+    return [("spd", np.diag(spd), dict(normal=True, self_adjoint=True, positive_definite=True)),
+            ("symm_indef", np.diag(ind), dict(normal=True, self_adjoint=True)),
+            ("nonsymm", non, dict())]
+
+
+def check_solver(sol, Solver, ls, params, A, M, Ml):
+    """test_linsys.py:166-232 restated (host arrays for the independent recomputation)."""
+    b = ls.b[:, 0] if ls.b.ndim == 2 else ls.b
+    xk = sol.xk[:, 0]
+    if "max_restarts" not in params:
+        assert len(sol.resnorms) - 1 <= params["maxiter"]
+    else:
+        assert len(sol.resnorms) - 1 <= params["maxiter"] * (params["max_restarts"] + 1)
+    assert sol.resnorms[-1] <= params["tol"]
+    Mlr = ref.apply_op(Ml, b - A.dot(xk))
+    MMlr = ref.apply_op(M, Mlr)
+    Mlb = ref.apply_op(Ml, b)
+    bn = np.sqrt(np.dot(Mlb, ref.apply_op(M, Mlb)))
+    assert abs(sol.resnorms[-1] - np.sqrt(abs(np.dot(Mlr, MMlr))) / bn) < 1e-13
+    if ls.exact_solution is not None:
+        assert abs(sol.errnorms[-1] - np.linalg.norm(ls.exact_solution[:, 0] - xk)) < 1e-12
+        assert len(sol.errnorms) == len(sol.resnorms)
+    if params.get("x0") is not None:
+        x0 = np.asarray(params["x0"]).reshape(-1)
+        Mlr0 = ref.apply_op(Ml, b - A.dot(x0))
+        if np.sqrt(abs(np.dot(Mlr0, ref.apply_op(M, Mlr0)))) / bn < params["tol"]:
+            assert len(sol.resnorms) == 1
+    if Solver is linsys.Gmres:
+        assert len(sol.resnorms) - 1 <= len(b)
+
+
+def case_solver_zoo():
+    n_checked = 0
+    for name, A, flags in _zoo():
+        Ainv = np.linalg.inv(A)
+        x = np.ones(10)
+        precs = [dict(), dict(Ml=Ainv), dict(Mr=Ainv), dict(Ml=0.5 * np.eye(10), Mr=Ainv)]
+        if flags.get("positive_definite"):
+            Md = np.diag(np.linspace(1, 10, 10))
+            precs += [dict(M=Md, Minv=np.linalg.inv(Md)), dict(M=Ainv, Minv=A)]
+        for prec in precs:
+            for b_shape, exact in (((10, 1), None), ((10,), x.reshape(-1, 1))):
+                b = A.dot(x).reshape(b_shape)
+                ls = linsys.LinearSystem(A, b, exact_solution=exact, **prec, **flags)
+                solvers = [linsys.Gmres, linsys.RestartedGmres]
+                if flags.get("self_adjoint") and "Mr" not in prec and "Ml" not in prec:
+                    solvers.append(linsys.Minres)
+                if flags.get("positive_definite") and "Mr" not in prec and "Ml" not in prec:
+                    solvers.append(linsys.Cg)
+                for Solver in solvers:
+                    for x0 in (None, np.zeros((10, 1)), np.ones((10, 1))):
+                        for tol in (1e-13, 1e-2):
+                            params = dict(x0=x0, tol=tol, maxiter=15)
+                            if Solver is linsys.RestartedGmres:
+                                params.update(maxiter=7, max_restarts=20)
+                            with warnings.catch_warnings():
+                                warnings.simplefilter("ignore")
+                                sol = Solver(ls, **params)
+                            check_solver(sol, Solver, ls, params, A, prec.get("M"), prec.get("Ml"))
+                            # iterate-for-iterate against the oracle (single-cycle solvers, loose
+                            # tolerance only: at 1e-13 the last entries are rounding noise)
+                            if Solver is not linsys.RestartedGmres and tol == 1e-2:
+                                fn = {linsys.Gmres: ref.gmres, linsys.Minres: ref.minres,
+                                      linsys.Cg: ref.cg}[Solver]
+                                o = fn(A, b.reshape(-1), x0=None if x0 is None else x0[:, 0], tol=tol,
+                                       maxiter=15, M=prec.get("M"), Ml=prec.get("Ml"),
+                                       Mr=prec.get("Mr"))
+                                assert len(o.resnorms) == len(sol.resnorms), (name, prec.keys())
+                                assert np.allclose(o.resnorms, sol.resnorms, rtol=1e-9, atol=1e-15)
+                                assert rel(sol.xk[:, 0], o.xk) < 1e-9
+                            n_checked += 1
+    assert n_checked > 200
