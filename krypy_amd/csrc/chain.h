@@ -285,4 +285,165 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #undef CH_OK
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident PANEL (classical) Gram-Schmidt: two launches per sweep, any number of ranks.
+//
+//   k_cgs_dots    w in registers; streams ALL columns once; per column one wave64 partial per
+//                 wave (no workgroup barrier, no grid synchronisation at all) -> part[j][G*8]
+//   (k_reduce_partials over the G*8 wave partials of every column -> h; ncclAllReduce on N GPUs)
+//   k_cgs_update  w in registers; streams all columns again: w -= h_j b_j (multiply-then-subtract,
+//                 left to right, like the reference's update), then writes w back together with
+//                 the wave partials of <w,w> (or <w, D w>, storing D w)
+//
+// Traffic per sweep: 16 N per column + 32 N, against 16 N per column + 24 N per 16-column chunk
+// for the chunked panel kernels, and 2 launches instead of 2*ceil((k+1)/16): this is the form
+// that scales over xGMI (one all-reduce per sweep) and keeps launch count flat when the shards
+// get short.
+// ------------------------------------------------------------------------------------------
+struct CgsArgs {
+    int64_t n2, chunk2;
+    const double* Vb;      // column base: Vb + j*ld  (V for the dots, B for the update)
+    int64_t ld;
+    int64_t col0;
+    int ncol;
+    double* w;             // in (dots) / in+out (update)
+    const double* coef;    // update: h[0..ncol)
+    double* part;          // dots: [ncol][pstride] wave partials; update: [pstride] norm partials
+    int pstride;
+    const double* dg;      // update: Jacobi diagonal or nullptr
+    double* mw;            // update: D w
+};
+
+template <int R2, bool MASKED>
+__global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
+    constexpr int PB = ChainShape<R2>::PB;
+    constexpr int NB = ChainShape<R2>::NB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    double2 w[R2];
+    double2 ring[2][PB];
+    {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = win2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    }
+    {
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + a.col0 * a.ld) + first;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        CH_ISSUE_FENCE();
+    }
+    const int slot = blockIdx.x * (CH_BS / 64) + wid;
+    for (int t = 0; t < a.ncol; ++t) {
+        const double2* __restrict__ v2 =
+            reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
+        const double2* __restrict__ vn =
+            reinterpret_cast<const double2*>(a.Vb + (a.col0 + (t + 1 < a.ncol ? t + 1 : t)) * a.ld) + first;
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 v = ring[b & 1][i];
+                acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                acc1 = fma(v.y, w[b * PB + i].y, acc1);
+            }
+        }
+        const double s = wave_sum(acc0 + acc1);
+        if (lane == 0) a.part[(int64_t)t * a.pstride + slot] = s;
+    }
+#undef CH_OK
+}
+
+template <int R2, bool MASKED>
+__global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
+    constexpr int PB = ChainShape<R2>::PB;
+    constexpr int NB = ChainShape<R2>::NB;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    double2 w[R2];
+    double2 ring[2][PB];
+    double2* __restrict__ w2 = reinterpret_cast<double2*>(a.w) + first;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const double2 v = w2[(int64_t)r * CH_BS];
+        w[r].x = CH_OK(r) ? v.x : 0.0;
+        w[r].y = CH_OK(r) ? v.y : 0.0;
+        if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+    }
+    {
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + a.col0 * a.ld) + first;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        CH_ISSUE_FENCE();
+    }
+    for (int t = 0; t < a.ncol; ++t) {
+        const double h = a.coef[t];
+        const double2* __restrict__ b2 =
+            reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
+        const double2* __restrict__ bn =
+            reinterpret_cast<const double2*>(a.Vb + (a.col0 + (t + 1 < a.ncol ? t + 1 : t)) * a.ld) + first;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : bn;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = ring[b & 1][i];
+                const int r = b * PB + i;
+                w[r].x = CH_OK(r) ? w[r].x - h * p.x : 0.0;
+                w[r].y = CH_OK(r) ? w[r].y - h * p.y : 0.0;
+            }
+        }
+    }
+    // write w back with the wave partials of its (M-)norm
+    double acc = 0.0;
+    if (a.dg != nullptr) {
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+        double2* __restrict__ m2 = reinterpret_cast<double2*>(a.mw) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                const double2 d = d2[(int64_t)r * CH_BS];
+                double2 m;
+                m.x = d.x * w[r].x;
+                m.y = d.y * w[r].y;
+                acc = fma(w[r].x, m.x, acc);
+                acc = fma(w[r].y, m.y, acc);
+                m2[(int64_t)r * CH_BS] = m;
+                w2[(int64_t)r * CH_BS] = w[r];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                acc = fma(w[r].x, w[r].x, acc);
+                acc = fma(w[r].y, w[r].y, acc);
+                w2[(int64_t)r * CH_BS] = w[r];
+            }
+        }
+    }
+    const double s = wave_sum(acc);
+    if (lane == 0) a.part[blockIdx.x * (CH_BS / 64) + wid] = s;
+#undef CH_OK
+}
+
 }  // namespace kh

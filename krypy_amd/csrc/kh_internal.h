@@ -62,6 +62,7 @@ struct kh_ctx_s {
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     unsigned chain_epoch = 1;
     int chain_debug = 0;
+    double* cgs_part = nullptr;     // [CGS_MAXCOL][wave partials] of the register-resident panel GS
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
     void* rccl_lib = nullptr;
     void* comm = nullptr;

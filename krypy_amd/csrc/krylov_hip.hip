@@ -334,6 +334,76 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     return 1;
 }
 
+// ---- register-resident panel Gram-Schmidt (k_cgs_dots / k_cgs_update, chain.h) -----------------
+constexpr int CGS_MAXCOL = 256;
+constexpr int CGS_PSTRIDE = CH_GMAX * (CH_BS / 64);   // wave partials per column
+
+template <int R2, bool MASKED>
+static hipError_t launch_cgs(kh_ctx ctx, int G, CgsArgs& a, bool update) {
+    if (update)
+        hipLaunchKernelGGL((k_cgs_update<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    return hipGetLastError();
+}
+
+// One Arnoldi step's panel sweeps with w register-resident.  Returns 1 when done (the norm's wave
+// partials are in SLOT_NRM.., *nrm_count of them), 0 when not eligible, negative on error.
+static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, const double* dg, double* mw,
+                       int64_t start, int64_t ncol, int sweeps, bool multi, double* hdev, double* coef,
+                       int* nrm_count) {
+    if (!ctx->chain_enabled || ncol > CGS_MAXCOL) return 0;
+    const int64_t n = V->n;
+    int r2 = 0, G = 0;
+    if (!chain_geometry(ctx, n, &r2, &G)) return 0;
+    if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n)) return 0;
+    const int64_t n2 = (n + 1) >> 1;
+    const int64_t chunk2 = (int64_t)r2 * CH_BS;
+    const int64_t need_ld = (int64_t)G * chunk2 * 2;
+    const bool padded = V->ld >= need_ld && B->ld >= need_ld && wld >= need_ld;
+    if (ctx->cgs_part == nullptr)
+        KH_HIP(hipMalloc(&ctx->cgs_part, sizeof(double) * (size_t)CGS_MAXCOL * CGS_PSTRIDE));
+    const int nwave = G * (CH_BS / 64);
+    CgsArgs a;
+    a.n2 = n2;
+    a.chunk2 = chunk2;
+    a.ld = V->ld;
+    a.col0 = start;
+    a.ncol = (int)ncol;
+    a.w = w;
+    a.pstride = CGS_PSTRIDE;
+    a.dg = nullptr;
+    a.mw = nullptr;
+#define KH_CGS(R, UPD) (padded ? launch_cgs<R, false>(ctx, G, a, UPD) : launch_cgs<R, true>(ctx, G, a, UPD))
+#define KH_CGS_ANY(UPD)                                                                        \
+    (r2 == 4 ? KH_CGS(4, UPD) : r2 == 8 ? KH_CGS(8, UPD) : r2 == 16 ? KH_CGS(16, UPD)            \
+     : r2 == 24 ? KH_CGS(24, UPD) : r2 == 32 ? KH_CGS(32, UPD) : KH_CGS(40, UPD))
+    for (int s = 0; s < sweeps; ++s) {
+        a.Vb = V->d;
+        a.coef = nullptr;
+        a.part = ctx->cgs_part;
+        KH_HIP(KH_CGS_ANY(false));
+        hipLaunchKernelGGL(k_reduce_partials, dim3((int)ncol), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
+                           CGS_PSTRIDE, coef, 0);
+        KH_HIP(hipGetLastError());
+        if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
+        hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0, hdev + start,
+                           1.0, coef);
+        a.Vb = B->d;
+        a.ld = B->ld;
+        a.coef = coef;
+        a.part = part_slot(ctx, SLOT_NRM);
+        a.dg = (s == sweeps - 1) ? dg : nullptr;
+        a.mw = mw;
+        KH_HIP(KH_CGS_ANY(true));
+        a.ld = V->ld;
+    }
+#undef KH_CGS_ANY
+#undef KH_CGS
+    *nrm_count = nwave;
+    return 1;
+}
+
 static inline int grid_lin(kh_ctx ctx, int64_t n) {
     int64_t need = (n + BS - 1) / BS;
     if (need < 1) need = 1;
@@ -409,6 +479,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
         if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);
         if (ctx->hev[s]) (void)hipEventDestroy(ctx->hev[s]);
     }
+    (void)hipFree(ctx->cgs_part);
     (void)hipFree(ctx->chain_gran);
     (void)hipFree(ctx->chain_err);
     for (int s = 0; s < KH_NSLOT; ++s)
@@ -856,6 +927,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     }
 
     double* nrm_part = part_slot(ctx, SLOT_NRM);
+    int nrm_count = grid;     // number of partial sums the norm arrives in
     bool chained = false;
     if (want_chain) {
         const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot);
@@ -939,7 +1011,10 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
                 KH_LINK(A_ARG, T_NONE, B->col(k - 1), nullptr, nullptr, nullptr, nullptr, nullptr, h_km1,
                         nullptr, nullptr);
         }
-        for (int s = 0; s < sweeps; ++s) {
+        const int rc = try_cgs_reg(ctx, V, B, w, W->ld, dg, mw, start, ncol, sweeps, multi, hdev, coef,
+                                   &nrm_count);
+        if (rc < 0) return rc;
+        for (int s = 0; rc == 0 && s < sweeps; ++s) {     // chunked panel kernels (w streamed)
             KH_TRY(dot_panel_dev(ctx, V, start, ncol, w, coef, 0));
             if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
             // H[j,k] += coef  (device-side accumulate through the same reduce kernel is not
@@ -956,14 +1031,14 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
         double* vn = V->col(k + 1);
         double* pn = P ? P->col(k + 1) : nullptr;
         if (multi) {
-            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, grid, 0,
+            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, nrm_count, 0,
                                tmp + 1, 0);
             KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
             hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
                                pn, nullptr, 0, tmp + 1, hs);
         } else {
             hipLaunchKernelGGL((k_scale_store<A_PART>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
-                               pn, nrm_part, grid, nullptr, hs);
+                               pn, nrm_part, nrm_count, nullptr, hs);
         }
         KH_HIP(hipGetLastError());
     }
