@@ -177,8 +177,10 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
 /* ---- measurement ----------------------------------------------------------------------- */
 /* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot
  * kernel, HIP events on the context's stream.  which: 0 Gram-Schmidt link (axpy+dot),
- * 1 multidot<16>, 2 multiaxpy<16>, 3 link with norm tail, 4 scale-and-store.
- * V needs >= 17 columns, W 2 columns. */
+ * 1 multidot<16>, 2 multiaxpy<16>, 3 link with norm tail, 4 scale-and-store, 5 register-resident
+ * MGS chain (16 columns x 4 sweeps = 64 links per launch; 6/7: without the grid reduction / the
+ * reduction alone), 8 register-resident panel GS over 16 columns (k_cgs_dots + k_reduce_partials +
+ * k_cgs_update).  V needs >= 17 columns, W 2 columns. */
 int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double* avg_ms);
 
 #ifdef __cplusplus

@@ -4,7 +4,7 @@ SURVEY.md section 8(d).  Not part of the solver path."""
 import numpy
 
 # kernel ids of kh_bench_kernel
-K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN = 0, 1, 2, 3, 4, 5
+K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN, K_CGS = 0, 1, 2, 3, 4, 5, 8
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 
@@ -49,6 +49,15 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         chain["us_per_link"] = chain["avg_ms"] * 1e3 / CHAIN_LINKS
     except Exception as exc:   # not eligible (odd n, w larger than the register file, multi-GPU)
         kernels["k_mgs_chain"] = {"unavailable": repr(exc)}
+    cgs = None
+    try:
+        # register-resident panel GS: 16 columns read once for the dots, once for the update, w read
+        # twice and written once
+        nb = 16.0 * n * 16 + 32.0 * n
+        run(K_CGS, nb, "k_cgs_dots+k_cgs_update (16 columns)", nb)
+        cgs = kernels["k_cgs_dots+k_cgs_update (16 columns)"]
+    except Exception as exc:
+        kernels["k_cgs_dots+k_cgs_update"] = {"unavailable": repr(exc)}
     extra = {"kernels": kernels}
     Amat = ls.A._device_matrix()
     if Amat is not None and Amat.kind == "csr":
@@ -63,7 +72,9 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         nb = 12.0 * Amat.nnz + 4.0 * (Amat.shape[0] + 1) + 16.0 * Amat.shape[0]
         extra["spmv"] = {"kernel": "k_spmv_stream", "avg_ms": ms, "algorithmic_bytes": nb,
                          "achieved_gbs": _gbs(nb, ms), "frac_of_peak": _gbs(nb, ms) / peak_gbs}
-    if ortho in ("cgs", "cgs2"):
+    if ortho in ("cgs", "cgs2") and cgs is not None:
+        nb, ms, name = cgs["algorithmic_bytes"], cgs["avg_ms"], "k_cgs_dots+k_cgs_update (16 columns per launch pair)"
+    elif ortho in ("cgs", "cgs2"):
         # the two panel kernels alternate; report the pair as one unit of 16 columns
         d, a = kernels["k_multidot<16>"], kernels["k_multiaxpy<16>"]
         nb = d["algorithmic_bytes"] + a["algorithmic_bytes"]

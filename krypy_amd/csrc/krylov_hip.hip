@@ -1199,6 +1199,15 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
                 if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
                 break;
             }
+            case 8: {
+                // register-resident panel GS over 16 columns: k_cgs_dots + reduce + k_cgs_update
+                int cnt = 0;
+                KH_HIP(hipMemsetAsync(ctx->hslot_dev[0], 0, sizeof(double) * 64, ctx->stream));
+                const int rc = try_cgs_reg(ctx, V, V, w, W->ld, nullptr, nullptr, 0, 16, 1, false,
+                                           ctx->hslot_dev[0], ctx->scal + SC_COEF, &cnt);
+                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: cgs kernels not eligible");
+                break;
+            }
             default:
                 return fail(KH_ERR_ARG, "kh_bench_kernel: unknown kernel id %d", which);
         }
