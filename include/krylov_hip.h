@@ -35,6 +35,7 @@ extern "C" {
 typedef struct kh_ctx_s* kh_ctx;
 typedef struct kh_mat_s* kh_mat;
 typedef struct kh_vec_s* kh_vec;
+typedef struct kh_proj_s* kh_proj;
 
 typedef enum {
     KH_OK = 0,
@@ -143,14 +144,31 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
 int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
                     int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
                     double* hcol_out);
+/* ---- deflation projector (utils.Projection._apply / apply_complement, utils.py:522-627) ------- */
+/* Device image of a Projection with orthonormalised bases: W, V are (N, d) blocks, T = R^{-1} Q^H
+ * and WRH = WR^H are d x d row-major host matrices (NULL = identity), copied to the device.  One
+ * application z = a - P a is, per sweep, c = W^T z (panel product, all-reduced), c' = T c (tiny
+ * device kernel), z -= V c' (panel update); <Y,a> = WRH c of the FIRST sweep is what the reference
+ * returns as Ya.  Nothing goes through the host. */
+int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH,
+                   int iterations, kh_proj* out);
+int kh_proj_free(kh_proj p);
+/* Z[:, zcol] = complement projection of A[:, acol]  (Z may be the same column: in place);
+ * ya_out (d doubles, may be NULL) receives <Y, a>; synchronises only when ya_out != NULL */
+int kh_proj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_vec Z, int64_t zcol,
+                             double* ya_out);
+
 /* The same step split in two so that the host can process step k's Hessenberg column while the
  * device already runs step k+1 (whose kernels depend on device data only): _begin enqueues the
  * whole step plus an asynchronous copy of the H column into pinned slot `slot` (0..3) and records
- * an event; _end waits for that event only and returns `count` (= k+2) doubles.  Steps begun in
+ * an event; _end waits for that event only and returns `count` (= k+2) doubles.  With a
+ * projector `proj` (deflated solvers: operator = (I - P) A, deflation.py:127-143) the projection is
+ * applied to A v_k on the device and its d values <U, A v_k> (the new column of C) follow the H
+ * column: count = k+2+d.  Steps begun in
  * order on one context execute in order.  A speculative step past convergence/invariance only
  * writes V[:,k+1] (P[:,k+1]) and the work vector; the caller discards it. */
-int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W,
-                          int64_t wcol, int64_t k, int64_t start, int sweeps, int gs_mode,
+int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec V, kh_vec P,
+                          kh_vec W, int64_t wcol, int64_t k, int64_t start, int sweeps, int gs_mode,
                           double h_km1, int slot);
 int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out);
 

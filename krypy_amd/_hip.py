@@ -73,7 +73,10 @@ _SIGNATURES = {
     "kh_waxpby": [_H, _H, _I64, _D, _H, _I64, _D, _H, _I64],
     "kh_vdiv": [_H, _H, _I64, _H, _I64, _D],
     "kh_arnoldi_step": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _c_double_p],
-    "kh_arnoldi_step_begin": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _INT],
+    "kh_arnoldi_step_begin": [_H, _H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _D, _INT],
+    "kh_proj_create": [_H, _H, _H, _I64, _c_double_p, _c_double_p, _INT, ctypes.POINTER(_H)],
+    "kh_proj_free": [_H],
+    "kh_proj_apply_complement": [_H, _H, _H, _I64, _H, _I64, _c_double_p],
     "kh_arnoldi_step_end": [_H, _INT, _I64, _c_double_p],
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
@@ -146,6 +149,21 @@ class DeviceMatrix(object):
         try:
             if self.handle is not None and self.ctx._alive:
                 self.ctx._lib.kh_mat_free(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class DeviceProjector(object):
+    """Device image of a deflation projector (``kh_proj``); keeps its basis blocks alive."""
+
+    def __init__(self, ctx, handle, d, keep):
+        self.ctx, self.handle, self.d, self._keep = ctx, handle, d, keep
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx._alive:
+                self.ctx._lib.kh_proj_free(self.handle)
         except Exception:
             pass
         self.handle = None
@@ -410,11 +428,34 @@ class Context(object):
             gs_mode, h_km1, _dptr(out)), "kh_arnoldi_step")
         return out
 
-    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot):
+    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
+                           proj=None):
         _check(self._lib, self._lib.kh_arnoldi_step_begin(
-            self._h, A.handle if A is not None else None, Md.handle if Md is not None else None,
+            self._h, A.handle if A is not None else None,
+            proj.handle if proj is not None else None, Md.handle if Md is not None else None,
             V.handle, P.handle if P is not None else None, W.handle, wcol, k, start, sweeps,
             gs_mode, h_km1, slot), "kh_arnoldi_step_begin")
+
+    def proj_create(self, W, V, d, T, WRH, iterations):
+        """Device image of a Projection (``kh_proj``): T = R^{-1} Q^H, WRH = WR^H (d x d) or None."""
+        def mat(M):
+            if M is None:
+                return None, None
+            M = numpy.ascontiguousarray(M, dtype=numpy.float64)
+            return M, _dptr(M)
+        Tm, Tp = mat(T)
+        Wm, Wp = mat(WRH)
+        h = _H()
+        _check(self._lib, self._lib.kh_proj_create(self._h, W.handle, V.handle, d, Tp, Wp, iterations,
+                                                   ctypes.byref(h)), "kh_proj_create")
+        return DeviceProjector(self, h, d, (W, V))
+
+    def proj_apply_complement(self, proj, A, acol, Z, zcol, want_ya=False):
+        ya = numpy.empty(proj.d, dtype=numpy.float64) if want_ya else None
+        _check(self._lib, self._lib.kh_proj_apply_complement(
+            self._h, proj.handle, A.handle, acol, Z.handle, zcol,
+            _dptr(ya) if want_ya else None), "kh_proj_apply_complement")
+        return ya
 
     def arnoldi_step_end(self, slot, count):
         out = numpy.empty(count, dtype=numpy.float64)

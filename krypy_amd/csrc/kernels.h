@@ -531,4 +531,20 @@ __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_col
     if (lane == 0) y[row] = s;
 }
 
+// y = M x for a tiny dense row-major M (d x d, d <= 1024) held on the device: the projector's
+// R^{-1} Q^H and WR^H factors.  One workgroup, one row per thread, sequential sums (deterministic).
+__global__ __launch_bounds__(BS) void k_small_matvec(int d, const double* __restrict__ M,
+                                                     const double* __restrict__ x,
+                                                     double* __restrict__ y) {
+    for (int i = threadIdx.x; i < d; i += BS) {
+        double s = 0.0;
+        if (M == nullptr) {
+            s = x[i];
+        } else {
+            for (int j = 0; j < d; ++j) s += M[(int64_t)i * d + j] * x[j];
+        }
+        y[i] = s;
+    }
+}
+
 }  // namespace kh

@@ -106,6 +106,18 @@ struct kh_mat_s {
 // communicator in forced mode: the multi-rank code path is then testable on a single GPU)
 static inline bool kh_multi(const kh_ctx_s* ctx) { return ctx->nranks > 1 || ctx->force_multi; }
 
+struct kh_proj_s {
+    kh_ctx ctx;
+    kh_vec W, V;
+    int64_t d;
+    int iterations;
+    double* T = nullptr;     // d x d row-major, device (nullptr: identity)
+    double* WRH = nullptr;   // d x d row-major, device (nullptr: identity)
+    double* c0 = nullptr;    // d
+    double* c1 = nullptr;    // d
+    double* ya = nullptr;    // d
+};
+
 namespace kh {
 // comm.hip
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);

@@ -763,6 +763,23 @@ static int dot_panel_dev(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const 
     return 0;
 }
 
+// ---- deflation projector on the device ---------------------------------------------------------
+// z = complement projection of z (in place); ya_dev (d doubles on the device) gets <Y, z_in>
+static int proj_apply_dev(kh_ctx ctx, kh_proj p, double* z, double* ya_dev) {
+    const int d = (int)p->d;
+    for (int it = 0; it < p->iterations; ++it) {
+        KH_TRY(dot_panel_dev(ctx, p->W, 0, d, z, p->c0, 0));
+        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, d));
+        if (it == 0 && ya_dev != nullptr)
+            hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->WRH, p->c0, ya_dev);
+        hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->T, p->c0, p->c1);
+        KH_HIP(hipGetLastError());
+        KH_TRY(multiaxpy_cols(ctx, p->V, 0, d, p->c1, 1.0, 1.0, z, T_NONE, nullptr, nullptr));
+    }
+    return 0;
+}
+
+
 int kh_dot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol,
                  double* out) {
     KH_ARG(ctx && out, "kh_dot_panel: NULL");
@@ -879,8 +896,9 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
     hipLaunchKernelGGL((k_gs_link<ASRC, TAIL>), dim3(grid), dim3(BS), 0, ctx->stream, n, P, VN, w, DG, \
                        MW, PIN, grid, SIN, AARG, POUT, HS)
 
-int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
-                          int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1, int slot) {
+int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec V, kh_vec P, kh_vec W,
+                          int64_t wcol, int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
+                          int slot) {
     KH_ARG(ctx && V && W, "kh_arnoldi_step: NULL argument");
     KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_arnoldi_step: slot %d not in [0,%d)", slot, KH_NSLOT);
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_arnoldi_step: k=%lld needs %lld basis columns, have %lld",
@@ -888,7 +906,9 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     KH_ARG(start >= 0 && start <= k, "kh_arnoldi_step: start=%lld not in [0,k]", (long long)start);
     KH_ARG(sweeps >= 1 && sweeps <= 4, "kh_arnoldi_step: sweeps=%d", sweeps);
     // sized for the whole basis up front: never reallocated while steps of this basis are in flight
-    KH_TRY(ensure_hcap(ctx, std::max<int64_t>(k + 2, V->ncols + 1)));
+    const int64_t pd = proj ? proj->d : 0;
+    KH_ARG(proj == nullptr || (proj->W->n == V->n && A != nullptr), "kh_arnoldi_step: projector needs A and length N");
+    KH_TRY(ensure_hcap(ctx, std::max<int64_t>(k + 2, V->ncols + 1) + pd));
     KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_arnoldi_step: Md must be a diagonal operator");
     KH_ARG((Md == nullptr) == (P == nullptr), "kh_arnoldi_step: P and Md go together");
     KH_ARG(P == nullptr || (P->n == V->n && P->ncols >= V->ncols), "kh_arnoldi_step: P shape");
@@ -903,7 +923,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     const bool multi = kh_multi(ctx);
     double* hdev = ctx->hslot_dev[slot];
     double* tmp = ctx->scal + SC_TMP;
-    KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
+    KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
 
     const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
     // look-ahead Lanczos: h_km1 = NaN means "H[k,k-1] of the step begun just before this one",
@@ -915,7 +935,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
     const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) &&
                              chain_geometry(ctx, n, &cr2, &cg));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
-                            A->nblk > 0 && !want_chain);
+                            A->nblk > 0 && !want_chain && proj == nullptr);
     // 1. operator
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
@@ -924,6 +944,8 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
             KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_DOT, V->col(start), tmp, 0));
         else
             KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_NONE, nullptr, nullptr, 0));
+        // deflated solvers: w <- (I - P) w, and <U, A v_k> behind the H column (deflation.py:135-143)
+        if (proj != nullptr) KH_TRY(proj_apply_dev(ctx, proj, w, hdev + (k + 2)));
     }
 
     double* nrm_part = part_slot(ctx, SLOT_NRM);
@@ -1042,7 +1064,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, k
         }
         KH_HIP(hipGetLastError());
     }
-    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * (k + 2), hipMemcpyDeviceToHost,
+    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * (k + 2 + pd), hipMemcpyDeviceToHost,
                           ctx->stream));
     KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
     return 0;
@@ -1069,7 +1091,7 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
                     int64_t k, int64_t start, int sweeps, int gs_mode, double h_km1,
                     double* hcol_out) {
     KH_ARG(hcol_out != nullptr, "kh_arnoldi_step: NULL argument");
-    KH_TRY(kh_arnoldi_step_begin(ctx, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, 0));
+    KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, 0));
     return kh_arnoldi_step_end(ctx, 0, k + 2, hcol_out);
 }
 
@@ -1139,6 +1161,56 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     KH_HIP(hipGetLastError());
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
     return fetch_scalars(ctx, tmp, 1, rho_new);
+}
+
+int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH,
+                   int iterations, kh_proj* out) {
+    KH_ARG(ctx && W && V && out, "kh_proj_create: NULL");
+    KH_ARG(d >= 1 && d <= 1024 && W->ncols >= d && V->ncols >= d && W->n == V->n, "kh_proj_create: shapes");
+    KH_ARG(iterations >= 1, "kh_proj_create: iterations < 1");
+    kh_proj p = new kh_proj_s();
+    p->ctx = ctx;
+    p->W = W;
+    p->V = V;
+    p->d = d;
+    p->iterations = iterations;
+    KH_HIP(hipMalloc(&p->c0, sizeof(double) * 3 * d));
+    p->c1 = p->c0 + d;
+    p->ya = p->c0 + 2 * d;
+    if (T) {
+        KH_HIP(hipMalloc(&p->T, sizeof(double) * d * d));
+        KH_HIP(hipMemcpy(p->T, T, sizeof(double) * d * d, hipMemcpyHostToDevice));
+    }
+    if (WRH) {
+        KH_HIP(hipMalloc(&p->WRH, sizeof(double) * d * d));
+        KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * d * d, hipMemcpyHostToDevice));
+    }
+    *out = p;
+    return 0;
+}
+
+int kh_proj_free(kh_proj p) {
+    if (!p) return 0;
+    (void)hipStreamSynchronize(p->ctx->stream);
+    (void)hipFree(p->c0);
+    (void)hipFree(p->T);
+    (void)hipFree(p->WRH);
+    delete p;
+    return 0;
+}
+
+int kh_proj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_vec Z, int64_t zcol,
+                             double* ya_out) {
+    KH_ARG(ctx && p, "kh_proj_apply_complement: NULL");
+    KH_TRY(check_vec(A, acol, 1, "kh_proj_apply_complement(a)"));
+    KH_TRY(check_vec(Z, zcol, 1, "kh_proj_apply_complement(z)"));
+    KH_ARG(A->n == p->W->n && Z->n == A->n, "kh_proj_apply_complement: length mismatch");
+    if (!(A == Z && acol == zcol))
+        KH_HIP(hipMemcpyAsync(Z->col(zcol), A->col(acol), sizeof(double) * A->n, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+    KH_TRY(proj_apply_dev(ctx, p, Z->col(zcol), ya_out ? p->ya : nullptr));
+    if (ya_out) return fetch_scalars(ctx, p->ya, p->d, ya_out);
+    return 0;
 }
 
 // Timing harness for bench.py: `reps` back-to-back launches of one hot kernel between two HIP

@@ -4,8 +4,9 @@ Host-side mirror of the hot-path part of ``krypy/deflation.py`` (``ObliqueProjec
 ``_DeflationMixin``, ``DeflatedCg/Minres/Gmres``, ``Ritz``).  The deflation bases ``U``,
 ``AU`` and the orthonormalised projector bases ``V``, ``W`` are ``(N, d)`` device blocks; one
 application of the projected operator is, per refinement sweep, a tall-skinny ``W^T a`` panel
-product and a ``z -= V c`` panel update on the device plus a ``d x d`` triangular solve on the
-host.  ``Arnoldifyer`` / ``bound_pseudo`` (pseudospectral convergence prediction on small dense
+product, a ``d x d`` matrix-vector product with the precomputed ``R^{-1} Q^H`` and a ``z -= V c``
+panel update - all on the device (``kh_proj``), inside the fused Arnoldi step for
+DeflatedGmres/DeflatedMinres, so a deflated iteration needs no host round trip either.  ``Arnoldifyer`` / ``bound_pseudo`` (pseudospectral convergence prediction on small dense
 matrices) are outside the hot path and not provided.
 
 Reference lines are cited as ``deflation.py:<line>`` (= ``/root/reference/krypy/deflation.py``).
@@ -128,6 +129,11 @@ class _DeflationMixin(object):
         N = self.linear_system.N
         P = utils.LinearOperator((N, N), numpy.dtype(float), self._apply_projection)
         P._apply_dev = self._apply_projection_dev
+        if type(self)._store_UAv is _DeflationMixin._store_UAv:
+            # (I - P) A runs inside the fused Arnoldi step; DeflatedCg keeps the Python path: its
+            # C recurrence needs self.iter / self.rhos at application time
+            P._kh_proj = self.projection._device_projector()
+            P._on_ya = self._store_UAv
         self.MlAMr = P * self.linear_system.MlAMr
         super(_DeflationMixin, self)._solve()
 

@@ -838,6 +838,15 @@ class Arnoldi(object):
                 self._Md = md
         self._fused = self._euclid and (self.M is None or self._Md is not None)
         self._Amat = self.A._device_matrix() if self._fused else None
+        # deflated solvers hand in  P * MlAMr  with P the complement of a device projector: the
+        # projection then runs inside the fused step and <U, A v_k> comes back with the H column
+        self._proj = None
+        self._on_ya = None
+        if self._fused and self._Amat is None and isinstance(self.A, _ProductLinearOperator):
+            Pop, inner = self.A.args
+            kp = getattr(Pop, "_kh_proj", None)
+            if kp is not None and inner._device_matrix() is not None:
+                self._Amat, self._proj, self._on_ya = inner._device_matrix(), kp, Pop._on_ya
         # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
         # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU
         # never idles while the host does its O(k) work.  A speculative step past the end of the
@@ -884,7 +893,7 @@ class Arnoldi(object):
                 # to read H[k,k-1] from that step's device-side H column
                 h_km1 = float(self.H[k, k - 1]) if self.iter >= k else float("nan")
         self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
-                                     self._sweeps, self._gs_mode, h_km1, k % 4)
+                                     self._sweeps, self._gs_mode, h_km1, k % 4, proj=self._proj)
         self._enq = k + 1
 
     def _settle(self):
@@ -892,7 +901,7 @@ class Arnoldi(object):
         that the arrays look exactly like the reference's (untouched columns are zero)."""
         while self._enq > self.iter:
             k = self._enq - 1
-            self._ctx.arnoldi_step_end(k % 4, k + 2)
+            self._ctx.arnoldi_step_end(k % 4, k + 2 + (self._proj.d if self._proj is not None else 0))
             self._V.zero(k + 1, 1)
             if self._P is not None:
                 self._P.zero(k + 1, 1)
@@ -919,7 +928,11 @@ class Arnoldi(object):
                 last = min(k + self._lookahead, self.maxiter - 1)
                 while self._enq <= last:
                     self._begin()
-                hcol = ctx.arnoldi_step_end(k % 4, k + 2)
+                pd = self._proj.d if self._proj is not None else 0
+                hcol = ctx.arnoldi_step_end(k % 4, k + 2 + pd)
+                if pd:
+                    self._on_ya(hcol[k + 2:].reshape(-1, 1).copy())
+                    hcol = hcol[: k + 2]
             elif self._Amat is not None:
                 hcol = ctx.arnoldi_step(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
@@ -1142,15 +1155,38 @@ class Projection(object):
         a.ctx.gemm_nn(self._Vd, 0, self._k, c, 1.0, 0.0, out, 0)
         return (DVec(out), Ya) if return_Ya else DVec(out)
 
+    def _device_projector(self):
+        """The ``kh_proj`` image of this projection (Euclidean inner product only), or None.
+
+        ``T = R^{-1} Q^H`` is formed once on the host (a d x d triangular solve, d ~ 16) so that a
+        whole application - W^T z, T c, z -= V c, twice - runs on the device without a host round
+        trip; ``WR^H`` maps the first sweep's coefficients to ``<Y, a>``."""
+        if self._k == 0 or not (self.ip_B is None or isinstance(self.ip_B, IdentityLinearOperator)):
+            return None
+        if "_kh_proj" not in self.__dict__:
+            T = None
+            if self.Q is not None and self.R is not None:
+                T = scipy.linalg.solve_triangular(self.R, self.Q.T.conj())
+            WRH = None if self.WR is None else self.WR.T.conj()
+            self._kh_proj = self._Vd.ctx.proj_create(self._Wd, self._Vd, self._k, T, WRH,
+                                                     self.iterations)
+        return self._kh_proj
+
     def _apply_complement_dvec(self, a, return_Ya=False):
         """``z = a - P a`` with ``iterations-1`` refinement sweeps (utils.py:604-627).
 
         Each sweep is one tall-skinny ``W^T z`` panel product and one ``z -= V c`` panel
         update on the device; ``z`` is a fresh vector."""
         ctx = a.ctx
-        z = a.copy()
         if self._k == 0:
+            z = a.copy()
             return (z, numpy.zeros((0, 1))) if return_Ya else z
+        proj = self._device_projector()
+        if proj is not None:
+            z = DVec(ctx.alloc(self._N, 1))
+            Ya = ctx.proj_apply_complement(proj, a.block, a.col, z.block, z.col, want_ya=return_Ya)
+            return (z, Ya.reshape(-1, 1)) if return_Ya else z
+        z = a.copy()
         c, Ya = self._coeffs(a, return_Ya)
         ctx.axpy_panel(self._Vd, 0, self._k, c, z.block, z.col)
         for _ in range(self.iterations - 1):

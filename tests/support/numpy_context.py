@@ -205,12 +205,44 @@ class NumpyContext(object):
         hcol[k + 1] = hn
         return hcol
 
-    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot):
+    def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
+                           proj=None):
         if not hasattr(self, "_slots"):
             self._slots = {}
         if h_km1 != h_km1:      # NaN: H[k,k-1] of the step begun just before (device-side value)
             h_km1 = float(self._slots[(slot - 1) % 4][k])
-        self._slots[slot] = self.arnoldi_step(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+        if proj is None:
+            self._slots[slot] = self.arnoldi_step(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+            return
+        # projected operator: w = (I - P) A v_k, then the Gram-Schmidt part with A = None
+        W.a[:, wcol] = self._matvec(A, V.a[:, k])
+        ya = self.proj_apply_complement(proj, W, wcol, W, wcol, want_ya=True)
+        hcol = self.arnoldi_step(None, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+        self._slots[slot] = np.concatenate([hcol, ya])
+
+    def proj_create(self, W, V, d, T, WRH, iterations):
+        class _P(object):
+            pass
+        p = _P()
+        p.W, p.V, p.d, p.iterations, p.handle = W, V, d, iterations, None
+        p.T = None if T is None else np.array(T, dtype=float)
+        p.WRH = None if WRH is None else np.array(WRH, dtype=float)
+        return p
+
+    def proj_apply_complement(self, proj, A, acol, Z, zcol, want_ya=False):
+        self._count("proj_apply_complement")
+        d = proj.d
+        z = A.a[:, acol].copy()
+        ya = None
+        for it in range(proj.iterations):
+            c = self._allreduce(proj.W.a[:, :d].T.dot(z))
+            if it == 0 and want_ya:
+                ya = c.copy() if proj.WRH is None else proj.WRH.dot(c)
+            c = c if proj.T is None else proj.T.dot(c)
+            for j in range(d):
+                z = z - c[j] * proj.V.a[:, j]
+        Z.a[:, zcol] = z
+        return ya
 
     def arnoldi_step_end(self, slot, count):
         return self._slots[slot][:count].copy()
