@@ -1032,10 +1032,40 @@ def arnoldi(*args, **kwargs):
 # ----------------------------------------------------------------------------------------
 # QR and projections (utils.py:439-707)
 # ----------------------------------------------------------------------------------------
+def _qr_mgs_fused(Q, reorthos):
+    """Euclidean MGS-QR with one fused device call per column: column i is orthogonalised against
+    columns 0..i-1 in the reference's order, normed and normalised in place by the same kernels
+    that run an Arnoldi step (``kh_arnoldi_step`` with no operator).  Returns None if a column
+    turns out (numerically) dependent: the caller then takes the step-by-step path, which honours
+    the reference's ``R[i,i] >= 1e-15`` guard exactly."""
+    ctx = Q.ctx
+    k = Q.ncols
+    R = numpy.zeros((k, k))
+    for i in range(k):
+        if i == 0:
+            R[0, 0] = ctx.nrm2(Q, 0)
+            if not R[0, 0] >= 1e-15:
+                return None
+            ctx.vdiv(Q, 0, Q, 0, float(R[0, 0]))
+            continue
+        hcol = ctx.arnoldi_step(None, None, Q, None, Q, i, i - 1, 0, reorthos + 1, _hip.GS_MGS, 0.0)
+        R[: i + 1, i] = hcol[: i + 1]
+        if not hcol[i] >= 1e-15:
+            return None
+    return R
+
+
 def _qr_mgs_dev(Q, ip_B, reorthos):
     """In-place modified Gram-Schmidt of the device block ``Q`` (utils.py:694-707)."""
     ctx = Q.ctx
     k = Q.ncols
+    if (ip_B is None or isinstance(ip_B, IdentityLinearOperator)) and k > 1 and hasattr(ctx, "arnoldi_step"):
+        keep = ctx.alloc(Q.n, k)
+        keep.copy_from(0, Q, 0, k)
+        R = _qr_mgs_fused(Q, reorthos)
+        if R is not None:
+            return R
+        Q.copy_from(0, keep, 0, k)      # dependent column: redo with the guarded path
     R = numpy.zeros((k, k))
     for i in range(k):
         for _ in range(reorthos + 1):
