@@ -190,6 +190,7 @@ class NumpyContext(object):
                 hcol[start: k + 1] += h
                 for j in range(start, k + 1):
                     w = w - h[j - start] * B.a[:, j]
+        W.a[:, wcol] = w        # (before the store of v_{k+1}: W may alias the basis block, in-place QR)
         if Md is not None:
             mw = Md.mat * w
             W.a[:, wcol + 1] = mw
@@ -201,7 +202,6 @@ class NumpyContext(object):
             hn = float(np.sqrt(self._allreduce(np.array([np.dot(w, w)]))[0]))
             with np.errstate(divide="ignore", invalid="ignore"):
                 V.a[:, k + 1] = w / hn
-        W.a[:, wcol] = w
         hcol[k + 1] = hn
         return hcol
 
