@@ -427,37 +427,26 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
     double acc = 0.0;
     if (cnt <= tile) {
         if (cnt > 0) {
-            // 16-byte value loads / 8-byte index loads on pairs of consecutive entries: the pair grid
-            // starts at the even entry at or below nz0 (arrays are 256-B aligned and padded by two
-            // entries), so an odd nz0 costs one masked lane, never a misaligned load.  All
-            // index/value loads first, then all gathers: ITEMS independent loads in flight per lane
-            // (clamped addresses instead of predicated loads, which would serialise).
-            const int start = nz0 & ~1;
-            const int shift = nz0 - start;                    // 0 or 1
-            const int qmax = (nz1 - 1 - start) >> 1;          // last pair that holds a needed entry
-            const int2* __restrict__ ip2 = reinterpret_cast<const int2*>(indices) + (start >> 1);
-            const double2* __restrict__ dp2 = reinterpret_cast<const double2*>(data) + (start >> 1);
-            int2 c[ITEMS / 2];
-            double2 a[ITEMS / 2];
+            // all index/value loads first, then all gathers: ITEMS independent loads in flight per
+            // lane (clamped addresses instead of predicated loads, which would serialise)
+            int c[ITEMS];
+            double a[ITEMS];
 #pragma unroll
-            for (int i = 0; i < ITEMS / 2; ++i) {
-                const int q = threadIdx.x + i * BS;
-                const int qc = q < qmax ? q : qmax;
-                c[i] = ip2[qc];
-                a[i] = dp2[qc];
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                const int tc = t < cnt ? t : cnt - 1;
+                c[i] = indices[nz0 + tc];
+                a[i] = data[nz0 + tc];
             }
 #pragma unroll
-            for (int i = 0; i < ITEMS / 2; ++i) {
-                const double x0 = (c[i].x < nloc) ? x[c[i].x] : ghost[c[i].x - nloc];
-                const double x1 = (c[i].y < nloc) ? x[c[i].y] : ghost[c[i].y - nloc];
-                a[i].x = a[i].x * x0;
-                a[i].y = a[i].y * x1;
+            for (int i = 0; i < ITEMS; ++i) {
+                const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
+                a[i] = a[i] * xv;
             }
 #pragma unroll
-            for (int i = 0; i < ITEMS / 2; ++i) {
-                const int t = 2 * (threadIdx.x + i * BS) - shift;   // position of the pair's first entry
-                if (t >= 0 && t < cnt) prod[t] = a[i].x;
-                if (t + 1 >= 0 && t + 1 < cnt) prod[t + 1] = a[i].y;
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                if (t < cnt) prod[t] = a[i];
             }
         }
         __syncthreads();

@@ -634,7 +634,7 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
         int64_t acc = 0;
         while (r_end < n_rows && (r_end - r) < max_rows) {
             const int64_t nz = (int64_t)indptr[r_end + 1] - indptr[r_end];
-            if (acc + nz > tile - 1) break;   // tile-1: the aligned pair grid may start one entry early
+            if (acc + nz > tile) break;
             acc += nz;
             ++r_end;
         }
@@ -667,11 +667,8 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     build_rowblocks(indptr, n_rows, A->tile, blk);
     A->nblk = (int)blk.size() - 1;
     KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
-    // +2 entries of zeroed padding: the SpMV kernel loads aligned pairs (kernels.h)
-    KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * (nnz + 2)));
-    KH_HIP(hipMalloc(&A->data, sizeof(double) * (nnz + 2)));
-    KH_HIP(hipMemset(A->indices + nnz, 0, sizeof(int32_t) * 2));
-    KH_HIP(hipMemset(A->data + nnz, 0, sizeof(double) * 2));
+    KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
     KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
     KH_HIP(hipMalloc(&A->part, sizeof(double) * std::max(A->nblk, 1)));
     KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
