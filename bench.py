@@ -69,8 +69,8 @@ def laplace2d(nx, ny, row0=None, row1=None):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5, help="timed GMRES(100) restart cycles")
-    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up cycles")
+    ap.add_argument("--steps", type=int, default=8, help="timed GMRES(100) restart cycles")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up cycles")
     ap.add_argument("--nx", type=int, default=4000)
     ap.add_argument("--ny", type=int, default=2500)
     ap.add_argument("--restart", type=int, default=100)

@@ -121,7 +121,7 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
 // Every vector this kernel reads is a kh_vec / diag buffer allocated with CH_SLACK zeroed doubles
 // behind its last column, so loads need no clamping: an out-of-range lane reads finite data of a
 // neighbouring chunk/column (or zeros) and its w stays exactly 0 (select on registers).
-constexpr int64_t CH_SLACK = 2 * (int64_t)CH_GMAX * CH_BS + 64 * CH_BS;  // doubles
+constexpr int64_t CH_SLACK = 2 * 48 * (int64_t)CH_BS;  // doubles: one workgroup chunk (<= 40 rows of CH_BS double2) + margin
 
 // Software pipeline: the rows a thread owns are streamed in batches of PB rows through a two-deep
 // register ring.  The loads of batch b+1 are issued before batch b is consumed, and the ring runs
