@@ -85,7 +85,7 @@ def parse_args():
                     help="testing: take the multi-GPU code path (gloo init, RCCL communicator, "
                          "ShardedCSROperator, all-reduced reductions) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-steps", type=int, default=24)
+    ap.add_argument("--cpu-sample-steps", type=int, default=40)
     return ap.parse_args()
 
 
@@ -270,6 +270,22 @@ def _run():
         roof, extra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS)
     except Exception as exc:   # never lose the headline number to the instrumentation
         extra = {"roofline_error": repr(exc)}
+
+    # HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in separate runs of this same command, tools/profile.sh +
+    # tools/summarize_prof.py); bench.py cannot collect counters itself
+    if roof is not None and N == 10_000_000 and not sharded:
+        try:
+            import glob
+            key, pat = (("k_mgs_chain", "*_bench_mgs_chain_traffic.json") if ortho in ("mgs", "dmgs")
+                        else (None, None))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
+            if files and "k_mgs_chain" in roof["kernel"]:
+                tj = json.load(open(files[-1]))[key]
+                roof["traffic"] = tj["hbm_read_bytes_per_launch"] + tj["hbm_write_bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(files[-1], ROOT)
+        except Exception:
+            pass
 
     out = {
         "metric": "GMRES iterations/sec + SpMV HBM GB/s, n=10^7 5-pt Laplacian fp64",

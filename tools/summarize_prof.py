@@ -74,6 +74,31 @@ def main(src, dst):
             lines.append("| `%s` | %d | %.0f | %.0f | %.1f | %.1f | %.1f |" % (
                 short(name), f[0], f[1], w[1], rd, wr, rd + wr))
         lines.append("")
+    # per-launch HBM traffic of the roofline kernel in bench.py's own micro-measurement: the last
+    # launches of the run are kh_bench_kernel's identical 64-link (chain) launches
+    tj = {}
+    try:
+        fdb = os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")
+        wdb = os.path.join(src, "pmc_WRITE_SIZE", "pmc_results.db")
+        for key, pat in (("k_mgs_chain", "%k_mgs_chain%"), ("k_cgs_dots", "%k_cgs_dots%"),
+                         ("k_cgs_update", "%k_cgs_update%")):
+            f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and name like '%s' "
+                       "order by start desc limit 40" % pat)
+            w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and name like '%s' "
+                       "order by start desc limit 40" % pat)
+            if f and w:
+                rd = 2 * sum(x[0] for x in f) / len(f) * 1024
+                wr = sum(x[0] for x in w) / len(w) * 1024
+                tj[key] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                           "launches_averaged": len(f),
+                           "note": "last %d launches of the run = bench.py's kh_bench_kernel launches; "
+                                   "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
+    except Exception as exc:  # pragma: no cover
+        tj = {"error": repr(exc)}
+    if tj:
+        lines += ["## Roofline-kernel traffic (bench.py micro-launches)", "", "```json", json.dumps(tj, indent=1), "```", ""]
+        with open(os.path.splitext(dst)[0] + "_traffic.json", "w") as fh:
+            json.dump(tj, fh, indent=1)
     open(dst, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
