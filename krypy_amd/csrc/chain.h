@@ -43,7 +43,6 @@ struct ChainArgs {
     int sweeps;
     const double* w_in;
     const double* dg;  // Jacobi diagonal or nullptr
-    double* mw_out;    // unused scratch (kept for symmetry), may be nullptr
     double* vnext;     // V[:, k+1]
     double* pnext;     // P[:, k+1] or nullptr
     double* hdev;      // H column on the device (zeroed by the caller); hdev[j] += alpha

@@ -64,7 +64,6 @@ struct kh_ctx_s {
     int chain_debug = 0;
     double* cgs_part = nullptr;     // [CGS_MAXCOL][wave partials] of the register-resident panel GS
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
-    void* rccl_lib = nullptr;
     void* comm = nullptr;
     int rank = 0, nranks = 1;
     int force_multi = 0;   // tests: run the multi-rank code path on a 1-rank communicator

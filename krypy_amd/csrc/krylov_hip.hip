@@ -300,7 +300,6 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.sweeps = sweeps;
     a.w_in = w;
     a.dg = dg;
-    a.mw_out = nullptr;
     a.vnext = V->col(k + 1);
     a.pnext = P ? P->col(k + 1) : nullptr;
     a.hdev = hdev;

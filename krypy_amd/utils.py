@@ -29,7 +29,7 @@ __all__ = [
     "Arnoldi", "Givens", "IdentityLinearOperator", "LinearOperator", "MatrixLinearOperator",
     "ZeroLinearOperator", "Projection", "arnoldi", "arnoldi_res", "find_common_dtype",
     "get_linearoperator", "inner", "ip_euclid", "norm", "norm_squared", "orthonormality", "qr",
-    "shape_vec", "shape_vecs", "DVec", "Timer", "Timings", "TimedLinearOperator",
+    "shape_vec", "shape_vecs", "DVec", "Timer", "Timings", "TimedLinearOperator", "ritz",
 ]
 
 
@@ -1027,6 +1027,69 @@ def arnoldi(*args, **kwargs):
     while _arnoldi.iter < _arnoldi.maxiter and not _arnoldi.invariant:
         _arnoldi.advance()
     return _arnoldi.get()
+
+
+def ritz(H, V=None, hermitian=False, type="ritz"):
+    """Ritz, harmonic Ritz or improved harmonic Ritz pairs of an Arnoldi/Lanczos relation
+    (utils.py:1171-1286).
+
+    :param H: Hessenberg matrix ``(n+1, n)`` or ``(n, n)``.
+    :param V: (optional) Arnoldi vectors, ``(N, n+1)`` host array or device block; then the Ritz
+      vectors ``Z = V[:, :n] U`` are returned too (formed on the device).
+    :param hermitian: use ``eigh`` (``H[:n, :]`` must be Hermitian).
+    :param type: ``'ritz'`` | ``'harmonic'`` | ``'harmonic_improved'``.
+    :return: ``theta, U, resnorm`` and ``Z`` if ``V`` is given.
+
+    The eigenproblem is n x n host work; only ``V[:, :n] @ U`` touches N-vectors.
+    """
+    n = H.shape[1]
+    nv = None if V is None else (V.ncols if hasattr(V, "ncols") else V.shape[1])
+    if V is not None and nv != H.shape[0]:
+        raise ArgumentError("shape mismatch with V and H")
+    if not H.shape[0] in [n, n + 1]:
+        raise ArgumentError("H not of shape (n+1,n) or (n,n)")
+    Hn = H[:n, :]
+    symmres = numpy.linalg.norm(Hn - Hn.T.conj())
+    if hermitian and symmres >= 5e-14:
+        warnings.warn(f"Hessenberg matrix is not symmetric: |H-H^*|={symmres}")
+    eig = scipy.linalg.eigh if hermitian else scipy.linalg.eig
+
+    def residuals(theta, U):
+        res = []
+        for i in range(n):
+            resi = numpy.array(numpy.dot(H, U[:, i]), dtype=numpy.result_type(U.dtype, theta.dtype))
+            resi[:n] -= theta[i] * U[:, i]
+            res.append(numpy.linalg.norm(resi, 2))
+        return numpy.array(res)
+
+    if type == "ritz":
+        theta, U = eig(Hn)
+        beta = 0 if H.shape[0] == n else H[-1, -1]
+        resnorm = numpy.abs(beta * U[-1, :])
+    elif type in ("harmonic", "harmonic_improved"):
+        theta, U = eig(Hn.T.conj(), numpy.dot(H.T.conj(), H))
+        for i in range(n):
+            U[:, i] /= numpy.linalg.norm(U[:, i], 2)
+        if type == "harmonic":
+            theta = 1 / theta
+        else:
+            theta = numpy.array([numpy.dot(U[:, i].T.conj(), numpy.dot(Hn, U[:, i]))
+                                 for i in range(n)])
+        resnorm = residuals(theta, U)
+    else:
+        raise ArgumentError(f"unknown Ritz type {type}")
+    if V is None:
+        return theta, U, resnorm
+    Ur = U
+    if numpy.iscomplexobj(U):
+        if numpy.abs(U.imag).max() > 1e-12 * max(numpy.abs(U).max(), 1e-300):
+            _require_real(U.dtype, "Ritz vector coefficients")
+        Ur = U.real
+    Vd = _upload_block(V)
+    Z = Vd.ctx.alloc(Vd.n, n)
+    if n > 0:
+        Vd.ctx.gemm_nn(Vd, 0, n, Ur, 1.0, 0.0, Z, 0)
+    return theta, U, resnorm, numpy.ascontiguousarray(Z.download())
 
 
 # ----------------------------------------------------------------------------------------

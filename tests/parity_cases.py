@@ -610,3 +610,35 @@ def case_solver_zoo():
                                 assert rel(sol.xk[:, 0], o.xk) < 1e-9
                             n_checked += 1
     assert n_checked > 200
+
+
+# ---------------------------------------------------------------------------------------------
+# utils.ritz on a dmgs Arnoldi relation (reference: test_utils.py:554-621)
+# ---------------------------------------------------------------------------------------------
+def case_ritz():
+    A, b = lap2d_system(12, rhs="rng1")
+    N = A.shape[0]
+    n = 30
+    V, H = utils.arnoldi(A, b.reshape(-1, 1), maxiter=n, ortho="dmgs")
+    Ad = A.toarray()
+    for kind in ("ritz", "harmonic", "harmonic_improved"):
+        theta, U, resnorm, Z = utils.ritz(H, V, hermitian=True, type=kind)
+        assert Z.shape == (N, n) and U.shape == (n, n)
+        # Z = V_n U, unit Ritz vectors, residual norms as reported
+        assert np.allclose(Z, V[:, :n].dot(U), atol=1e-12)
+        for i in range(n):
+            z = Z[:, i]
+            assert abs(np.linalg.norm(z) - 1) < 1e-10
+            r = Ad.dot(z) - theta[i] * z
+            assert abs(np.linalg.norm(r) - resnorm[i]) < 1e-9
+        if kind == "ritz":
+            # Ritz values of a symmetric matrix interlace its spectrum
+            ev = np.linalg.eigvalsh(Ad)
+            assert theta.min() >= ev.min() - 1e-10 and theta.max() <= ev.max() + 1e-10
+    th2, U2, rn2 = utils.ritz(H, hermitian=True)
+    assert np.allclose(np.sort(th2), np.sort(utils.ritz(H, V, hermitian=True)[0]))
+    try:
+        utils.ritz(H, V[:, :5])
+        raise AssertionError
+    except utils.ArgumentError:
+        pass

@@ -19,7 +19,7 @@ SIMPLE = [
     pc.case_operator_algebra, pc.case_restart_failure, pc.case_minres_jacobi,
     pc.case_minres_cg_sparse, pc.case_cg_dense, pc.case_deflated_gmres_recycling,
     pc.case_recycling_gmres_lap3d, pc.case_recycling_factories_toy, pc.case_inner_product_matrix_B,
-    pc.case_solver_zoo,
+    pc.case_solver_zoo, pc.case_ritz,
 ]
 
 
@@ -176,6 +176,15 @@ def test_full_size_properties(hip):
     ls = linsys.LinearSystem(A, b)
     x = np.random.default_rng(1).standard_normal((N, 1))
     assert np.array_equal(ls.A * x, A.dot(x))
+    # first Arnoldi steps at full size against the CPU oracle, iterate for iterate (1e-10)
+    st = ref.arnoldi_init(A, b, 6)
+    ar = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=6, ortho="mgs")
+    for _ in range(6):
+        ref.arnoldi_step(st)
+        ar.advance()
+    assert np.linalg.norm(ar.H - st.H) < 1e-10 * np.linalg.norm(st.H)
+    assert np.linalg.norm(ar._V.download(6, 1)[:, 0] - st.V[:, 6]) < 1e-10
+    del st
     for ortho in ("mgs", "cgs2"):
         ar = utils.Arnoldi(A, b.reshape(-1, 1), maxiter=30, ortho=ortho)
         for _ in range(30):
@@ -318,3 +327,39 @@ def test_multi_rank_code_path_on_one_gpu(hip):
     r2 = want - 0.5 * b
     assert abs(rho - np.dot(r2, r2)) < 1e-12 * rho
     ctx.close()
+
+
+def test_sharded_deflated_gmres_through_rccl_path_on_one_gpu(hip):
+    """DeflatedGmres / Minres / Cg on a ShardedCSROperator with a 1-rank communicator in forced
+    multi-rank mode (every reduction goes through k_reduce_partials + ncclAllReduce, the projector's
+    W^T z panels included) equal the plain single-GPU solves."""
+    import os
+    from krypy_amd import _hip, deflation, dist as kdist, linsys
+
+    A, b = lap2d_system(60, rhs="rng1")
+    n = A.shape[0]
+    U = np.random.default_rng(4).standard_normal((n, 6))
+    ls0 = linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
+    want = (deflation.DeflatedGmres(ls0, U=U, tol=1e-9, maxiter=300, store_arnoldi=True),
+            linsys.Minres(ls0, tol=1e-9, maxiter=600), linsys.Cg(ls0, tol=1e-9, maxiter=600))
+    os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
+    try:
+        ctx = _hip.Context(0)
+        ctx.comm_init(0, 1, ctx.comm_unique_id())
+    finally:
+        del os.environ["KRYPY_AMD_FORCE_MULTI"]
+    old = _hip._install_context_for_testing(ctx)
+    try:
+        op = kdist.ShardedCSROperator(A, 0, n, ctx)
+        ls = linsys.LinearSystem(op, b, self_adjoint=True, positive_definite=True)
+        got = (deflation.DeflatedGmres(ls, U=U, tol=1e-9, maxiter=300, store_arnoldi=True),
+               linsys.Minres(ls, tol=1e-9, maxiter=600), linsys.Cg(ls, tol=1e-9, maxiter=600))
+        for g, w in zip(got, want):
+            assert len(g.resnorms) == len(w.resnorms)
+            assert np.allclose(g.resnorms[:40], w.resnorms[:40], rtol=1e-9)
+            assert np.linalg.norm(g.xk - w.xk) < 1e-8 * np.linalg.norm(w.xk)
+        assert np.allclose(got[0].E, want[0].E, rtol=1e-10, atol=1e-12)
+        assert np.allclose(got[0].C, want[0].C, rtol=1e-8, atol=1e-10)
+    finally:
+        _hip._install_context_for_testing(old)
+        ctx.close()
