@@ -177,6 +177,12 @@ def _run():
     import krypy_amd
     from krypy_amd import _hip, linsys, utils
 
+    if not os.path.exists(_hip.library_path()):     # fresh checkout: compile the HIP library once
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if dist is not None:
+            dist.barrier()
     ctx = _hip.get_context()
     nx, ny, m = args.nx, args.ny, args.restart
     N = nx * ny

@@ -45,6 +45,9 @@ def hip():
     from krypy_amd import _hip
 
     if not _real_ctx:
+        if not os.path.exists(_hip.library_path()):
+            import __graft_entry__
+            __graft_entry__.build()
         _hip._install_context_for_testing(None)
         _real_ctx.append(_hip.get_context())
     _hip._install_context_for_testing(_real_ctx[0])
