@@ -91,6 +91,12 @@ int kh_vec_upload(kh_vec v, int64_t col0, int64_t ncols, const double* host, int
 int kh_vec_download(kh_vec v, int64_t col0, int64_t ncols, double* host, int64_t host_ld);
 int kh_vec_zero(kh_vec v, int64_t col0, int64_t ncols);
 int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncols);
+/* a few consecutive entries of one column (Householder Arnoldi reads/writes single elements:
+ * utils.py:349-375, 973-983); synchronous */
+int kh_vec_get(kh_vec v, int64_t col, int64_t i0, int64_t count, double* out);
+int kh_vec_set(kh_vec v, int64_t col, int64_t i0, int64_t count, const double* in);
+/* zero entries [i0, i0+count) of one column */
+int kh_vec_zero_range(kh_vec v, int64_t col, int64_t i0, int64_t count);
 
 /* ---- operators (replace MatrixLinearOperator._dot -> A.dot(X), utils.py:1593-1594) --- */
 /* CSR as SciPy holds it: int32 indptr[n_rows+1], int32 indices[nnz] (sorted or not), fp64 data.

@@ -59,6 +59,9 @@ _SIGNATURES = {
     "kh_vec_download": [_H, _I64, _I64, _c_double_p, _I64],
     "kh_vec_zero": [_H, _I64, _I64],
     "kh_vec_copy": [_H, _I64, _H, _I64, _I64],
+    "kh_vec_get": [_H, _I64, _I64, _I64, _c_double_p],
+    "kh_vec_set": [_H, _I64, _I64, _I64, _c_double_p],
+    "kh_vec_zero_range": [_H, _I64, _I64, _I64],
     "kh_csr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
                       ctypes.POINTER(_H)],
     "kh_dense_upload": [_H, _I64, _I64, _c_double_p, _I64, ctypes.POINTER(_H)],
@@ -225,6 +228,22 @@ class DeviceVectors(object):
     def copy_from(self, dcol, src, scol, ncols=1):
         _check(self.ctx._lib, self.ctx._lib.kh_vec_copy(self.handle, dcol, src.handle, scol, ncols),
                "kh_vec_copy")
+
+    def get(self, col, i0, count=1):
+        """A few consecutive entries of one column as a host array."""
+        out = numpy.empty(max(count, 1), dtype=numpy.float64)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_get(self.handle, col, i0, count, _dptr(out)),
+               "kh_vec_get")
+        return out[:count]
+
+    def set(self, col, i0, values):
+        a = numpy.ascontiguousarray(values, dtype=numpy.float64).reshape(-1)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_set(self.handle, col, i0, a.size, _dptr(a)),
+               "kh_vec_set")
+
+    def zero_range(self, col, i0, count):
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_zero_range(self.handle, col, i0, count),
+               "kh_vec_zero_range")
 
 
 class Context(object):

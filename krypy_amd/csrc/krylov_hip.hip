@@ -619,6 +619,38 @@ int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncol
     return 0;
 }
 
+static int check_range(kh_vec v, int64_t col, int64_t i0, int64_t count, const char* what) {
+    KH_TRY(check_vec(v, col, 1, what));
+    KH_ARG(i0 >= 0 && count >= 0 && i0 + count <= v->n, "%s: entries [%lld, %lld) out of range (n=%lld)", what,
+           (long long)i0, (long long)(i0 + count), (long long)v->n);
+    return 0;
+}
+
+int kh_vec_get(kh_vec v, int64_t col, int64_t i0, int64_t count, double* out) {
+    KH_TRY(check_range(v, col, i0, count, "kh_vec_get"));
+    if (count == 0) return 0;
+    KH_ARG(out != nullptr, "kh_vec_get: NULL");
+    KH_HIP(hipMemcpyAsync(out, v->col(col) + i0, sizeof(double) * count, hipMemcpyDeviceToHost, v->ctx->stream));
+    KH_HIP(hipStreamSynchronize(v->ctx->stream));
+    return 0;
+}
+
+int kh_vec_set(kh_vec v, int64_t col, int64_t i0, int64_t count, const double* in) {
+    KH_TRY(check_range(v, col, i0, count, "kh_vec_set"));
+    if (count == 0) return 0;
+    KH_ARG(in != nullptr, "kh_vec_set: NULL");
+    KH_HIP(hipMemcpyAsync(v->col(col) + i0, in, sizeof(double) * count, hipMemcpyHostToDevice, v->ctx->stream));
+    KH_HIP(hipStreamSynchronize(v->ctx->stream));
+    return 0;
+}
+
+int kh_vec_zero_range(kh_vec v, int64_t col, int64_t i0, int64_t count) {
+    KH_TRY(check_range(v, col, i0, count, "kh_vec_zero_range"));
+    if (count == 0) return 0;
+    KH_HIP(hipMemsetAsync(v->col(col) + i0, 0, sizeof(double) * count, v->ctx->stream));
+    return 0;
+}
+
 // ---- operators --------------------------------------------------------------------------------
 static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
                            std::vector<int32_t>& blk) {

@@ -26,7 +26,7 @@ from ._hip import BackendError  # noqa: F401  (re-exported)
 __all__ = [
     "ArgumentError", "AssumptionError", "ConvergenceError", "LinearOperatorError",
     "InnerProductError", "RuntimeError", "BackendError",
-    "Arnoldi", "Givens", "IdentityLinearOperator", "LinearOperator", "MatrixLinearOperator",
+    "Arnoldi", "Givens", "House", "IdentityLinearOperator", "LinearOperator", "MatrixLinearOperator",
     "ZeroLinearOperator", "Projection", "arnoldi", "arnoldi_res", "find_common_dtype",
     "get_linearoperator", "inner", "ip_euclid", "norm", "norm_squared", "orthonormality", "qr",
     "shape_vec", "shape_vecs", "DVec", "Timer", "Timings", "TimedLinearOperator", "ritz",
@@ -280,6 +280,74 @@ def arnoldi_res(A, V, H, ip_B=None):
     A = get_linearoperator((N, N), A)
     res = A * (V if invariant else V[:, :-1]) - numpy.dot(V, H)
     return norm(res, ip_B=ip_B)
+
+
+# ----------------------------------------------------------------------------------------
+# Householder reflectors (utils.py:332-402)
+# ----------------------------------------------------------------------------------------
+def _house_scalars(gamma, sigma, n):
+    """The scalar part of Algorithm 5.1.1 (Golub, Van Loan) as the reference arranges it
+    (utils.py:349-377): returns (v0, xnorm, alpha, beta) for a real vector with first entry
+    ``gamma`` and ``sigma = ||x[1:]||``."""
+    if n == 1 or sigma == 0:
+        xnorm = abs(gamma)
+        return 1.0, xnorm, (1.0 if gamma == 0 else gamma / xnorm), 0
+    xnorm = numpy.sqrt(abs(gamma) ** 2 + sigma ** 2)
+    if gamma == 0:
+        return -sigma, xnorm, 1.0, 2
+    return gamma + gamma / abs(gamma) * xnorm, xnorm, -gamma / abs(gamma), 2
+
+
+class House(object):
+    def __init__(self, x):
+        """Householder transformation ``H`` with ``H x = alpha ||x||_2 e_1``, ``|alpha| = 1``
+        (utils.py:332-377), for a host ``(N,1)`` vector (real)."""
+        if len(x.shape) != 2 or x.shape[1] != 1:
+            raise ArgumentError("x is not a vector of dim (N,1)")
+        _require_real(x.dtype, "Householder vector")
+        v = numpy.array(x, dtype=float)
+        gamma = v[0].item()
+        sigma = 0.0 if x.shape[0] == 1 else numpy.linalg.norm(v[1:], 2)
+        v0, self.xnorm, self.alpha, self.beta = _house_scalars(gamma, sigma, x.shape[0])
+        v[0] = v0
+        self.v = v / numpy.sqrt(abs(v0) ** 2 + sigma ** 2)
+
+    def apply(self, x):
+        """Apply the transformation to a ``(N, m)`` array: ``x - beta v (v^* x)``."""
+        if len(x.shape) != 2:
+            raise ArgumentError("x is not a matrix of shape (N,*)")
+        if self.beta == 0:
+            return x
+        return x - self.beta * self.v * numpy.dot(self.v.T.conj(), x)
+
+    def matrix(self):
+        """Dense matrix ``I - beta v v^*`` (testing only)."""
+        n = self.v.shape[0]
+        return numpy.eye(n, n) - self.beta * numpy.dot(self.v, self.v.T.conj())
+
+
+class _DevHouse(object):
+    """A reflector for the sub-vector ``x[j:]`` of a device column, stored zero-padded as column
+    ``j`` of the reflector block, so that applying it is one dot and one axpy on whole columns."""
+
+    def __init__(self, ctx, Hv, j, X, xcol):
+        N = Hv.n
+        self.ctx, self.Hv, self.j = ctx, Hv, j
+        Hv.copy_from(j, X, xcol, 1)
+        Hv.zero_range(j, 0, j)
+        gamma = float(Hv.get(j, j, 1)[0])
+        Hv.set(j, j, [0.0])
+        sigma = 0.0 if N - j == 1 else ctx.nrm2(Hv, j)          # ||x[j+1:]||
+        v0, self.xnorm, self.alpha, self.beta = _house_scalars(gamma, sigma, N - j)
+        Hv.set(j, j, [v0])
+        ctx.vdiv(Hv, j, Hv, j, float(numpy.sqrt(abs(v0) ** 2 + sigma ** 2)))
+
+    def apply(self, X, xcol):
+        """``x[j:] -= beta v (v^* x[j:])`` in place (rows < j are untouched: v is zero there)."""
+        if self.beta == 0:
+            return
+        d = self.ctx.dot_panel(self.Hv, self.j, 1, X, xcol)[0]
+        self.ctx.axpy_panel(self.Hv, self.j, 1, [float(self.beta * d)], X, xcol)
 
 
 # ----------------------------------------------------------------------------------------
@@ -813,14 +881,14 @@ class Arnoldi(object):
         self.iter = 0
         self.invariant = False
         if ortho == "house":
-            raise NotImplementedError(
-                "ortho='house' (Householder Arnoldi) is a sequential host algorithm outside the "
-                "device hot path (SURVEY.md section 2, row 3)")
-        if ortho not in _GS_OF_ORTHO:
+            if self.M is not None or not (ip_B is None or isinstance(ip_B, IdentityLinearOperator)):
+                raise ArgumentError(
+                    "Only euclidean inner product allowed with Householder orthogonalization")
+        elif ortho not in _GS_OF_ORTHO:
             raise ArgumentError(
                 f"Invalid value '{ortho}' for argument 'ortho'. "
                 + "Valid are house, mgs, dmgs and lanczos.")
-        self._gs_mode, self._sweeps = _GS_OF_ORTHO[ortho]
+        self._gs_mode, self._sweeps = _GS_OF_ORTHO.get(ortho, (_hip.GS_MGS, 1))
         self.reorthos = self._sweeps - 1
 
         ctx = self._ctx = v.ctx if isinstance(v, DVec) else _hip.get_context()
@@ -854,9 +922,18 @@ class Arnoldi(object):
         # device-side H column, so it can run ahead as well.)
         self._lookahead = 1 if self._Amat is not None else 0
         self._enq = 0          # number of steps enqueued on the device so far
+        if ortho == "house":
+            # Householder Arnoldi (utils.py:910-922, 970-994): reflectors live zero-padded in their
+            # own (N, maxiter+2) block; every application is a device dot + axpy.  Sequential by
+            # nature (SURVEY: not a hot path), kept for its orthogonality guarantee.
+            self._fused, self._lookahead = False, 0
+            self._Hv = ctx.alloc(N, min(self.maxiter + 1, N) + 1)
 
         v = _as_dvec(v, ctx)
-        if self.M is not None:
+        if ortho == "house":
+            self.houses = [_DevHouse(ctx, self._Hv, 0, v.block, v.col)]
+            self.vnorm = norm(v)
+        elif self.M is not None:
             p = v
             v = (self.M * p) if Mv is None else _as_dvec(Mv, ctx)
             self.vnorm = norm(p, v, ip_B=ip_B) if Mv_norm is None else Mv_norm
@@ -942,6 +1019,8 @@ class Arnoldi(object):
                                         self._sweeps, self._gs_mode, h_km1)
             H[start: k + 1, k] += hcol[start: k + 1]
             hn = hcol[k + 1]
+        elif self.ortho == "house":
+            hn = self._advance_house(k)
         else:
             hn = self._advance_general(k, start, h_km1)
         H[k + 1, k] = hn
@@ -964,6 +1043,36 @@ class Arnoldi(object):
             self._V.zero(k + 1, 1)
             if self._P is not None:
                 self._P.zero(k + 1, 1)
+
+    def _advance_house(self, k):
+        """One Householder Arnoldi step (utils.py:970-994) on the device."""
+        ctx, V, W, H, N = self._ctx, self._V, self._W, self.H, self._V.n
+        self.A._apply_dev(V, k, W, 0, 1)
+        for j in range(k + 1):
+            hj = self.houses[j]
+            hj.apply(W, 0)
+            if hj.alpha != 1.0:                          # Av[j] *= conj(alpha_j), alpha = +-1
+                W.set(0, j, W.get(0, j, 1) * hj.alpha)
+        if k + 1 < N:
+            house = _DevHouse(ctx, self._Hv, k + 1, W, 0)
+            self.houses.append(house)
+            house.apply(W, 0)
+            col = W.get(0, 0, k + 2)
+            col[k + 1] *= house.alpha
+            H[: k + 2, k] = col
+            hn = abs(H[k + 1, k])
+        else:
+            H[: k + 1, k] = W.get(0, 0, k + 1)
+            hn = 0.0
+        if k + 1 < N and hn > 0:
+            # v_{k+1} = H_0 ... H_{k+1} e_{k+1} * alpha_{k+1}   (utils.py:990-994)
+            V.zero(k + 1, 1)
+            V.set(k + 1, k + 1, [1.0])
+            for j in range(k + 1, -1, -1):
+                self.houses[j].apply(V, k + 1)
+            if self.houses[-1].alpha != 1.0:
+                ctx.vdiv(V, k + 1, V, k + 1, float(self.houses[-1].alpha))
+        return hn
 
     def _advance_general(self, k, start, h_km1):
         """Arnoldi step for a non-Euclidean inner product or a general preconditioner ``M``:

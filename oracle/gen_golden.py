@@ -197,6 +197,13 @@ def gen_kernels(krypy):
             ar.advance()
         out["arn_%s_H" % ortho] = ar.H
         out["arn_%s_V" % ortho] = ar.V
+    # Householder Arnoldi incl. a Gmres run with it
+    ar = ku.Arnoldi(A, v, maxiter=12, ortho="house")
+    for _ in range(12):
+        ar.advance()
+    out["arn_house_H"], out["arn_house_V"] = ar.H, ar.V
+    sh = krypy.linsys.Gmres(krypy.linsys.LinearSystem(A, b), ortho="house", tol=1e-9, maxiter=200)
+    out["gmres_house_resnorms"], out["gmres_house_xk"] = np.array(sh.resnorms), sh.xk[:, 0]
     d = np.linspace(0.5, 1.5, A.shape[0])
     M = sp.diags(d).tocsr()
     ar = ku.Arnoldi(A, v, maxiter=12, ortho="lanczos", M=M)

@@ -642,3 +642,38 @@ def case_ritz():
         raise AssertionError
     except utils.ArgumentError:
         pass
+
+
+# ---------------------------------------------------------------------------------------------
+# Householder Arnoldi (ortho='house') on the device, against the reference
+# ---------------------------------------------------------------------------------------------
+def case_arnoldi_house():
+    g = golden("kernels")
+    A, b = lap2d_system(40, rhs="rng1")
+    v = b.reshape(-1, 1)
+    ar = utils.Arnoldi(A, v, maxiter=12, ortho="house")
+    for _ in range(12):
+        ar.advance()
+    assert rel(ar.H, g["arn_house_H"]) < RTOL
+    assert rel(ar.V, g["arn_house_V"]) < RTOL
+    V, H = ar.get()
+    N, k = A.shape[0], 12
+    eps = np.finfo(float).eps
+    # inequality (2.4) of Drkosova et al. as used by the reference's assert_arnoldi
+    assert np.linalg.norm(np.eye(k + 1) - V.T.dot(V), 2) <= (k ** 1.5) * N * eps
+    assert np.all(np.diag(H, -1) >= 0) and np.linalg.norm(np.tril(H, -2)) == 0
+    assert np.linalg.norm(A.dot(V[:, :k]) - V.dot(H)) <= k * N ** 1.5 * eps * 8
+    s = linsys.Gmres(linsys.LinearSystem(A, b), ortho="house", tol=1e-9, maxiter=200)
+    check_resnorms(s.resnorms, g["gmres_house_resnorms"], tol=1e-8, explicit_tol=1e-4)
+    assert rel(s.xk[:, 0], g["gmres_house_xk"]) < 1e-9
+    # the reference's test_house properties (test_utils.py:105-135) for the host class
+    x = np.random.default_rng(0).standard_normal((7, 1))
+    Hh = utils.House(x)
+    y = Hh.apply(x)
+    assert abs(abs(y[0, 0]) - np.linalg.norm(x)) < 1e-14 and np.linalg.norm(y[1:]) < 1e-14
+    assert np.linalg.norm(Hh.matrix().dot(Hh.matrix().T) - np.eye(7)) < 1e-14
+    try:
+        utils.Arnoldi(A, v, ortho="house", M=sp.identity(N).tocsr() * 2.0)
+        raise AssertionError
+    except utils.ArgumentError:
+        pass

@@ -40,6 +40,16 @@ class NumpyVectors(object):
         assert src.n == self.n
         self.a[:, dcol: dcol + ncols] = src.a[:, scol: scol + ncols]
 
+    def get(self, col, i0, count=1):
+        return self.a[i0: i0 + count, col].copy()
+
+    def set(self, col, i0, values):
+        v = np.asarray(values, dtype=float).reshape(-1)
+        self.a[i0: i0 + v.size, col] = v
+
+    def zero_range(self, col, i0, count):
+        self.a[i0: i0 + count, col] = 0.0
+
 
 class NumpyMatrix(object):
     def __init__(self, ctx, kind, mat, shape):
