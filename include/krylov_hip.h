@@ -198,6 +198,36 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
                  kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
                  double* rho_new);
 
+/* ---- complex (c128) twin of the hot path ------------------------------------------------- */
+/* KryPy's kernels are dtype-generic NumPy (H/V are allocated with the common dtype of A, v, M:
+ * utils.py:893-905, complex inner products are X^H Y: utils.py:183).  A complex N-vector block is
+ * a REAL kh_vec of length 2N (interleaved re, im), allocated / copied / zeroed / normed / scaled
+ * by a real with the entry points above; the entry points below are what is genuinely complex.
+ * Complex scalars cross the ABI as (re, im) pairs of doubles. */
+/* complex operators; kh_apply dispatches on the handle (X, Y are 2N-real views) */
+int kh_zcsr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
+                   const int32_t* indices, const double* data_re_im, kh_mat* out);
+int kh_zdense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a_re_im, int64_t lda,
+                     kh_mat* out);
+int kh_zdiag_upload(kh_ctx ctx, int64_t n, const double* d_re_im, kh_mat* out);
+/* Z[:, zcol..] (complex view) = X[:, xcol..] (real) + 0i: NumPy's upcast of a real operand */
+int kh_zfrom_real(kh_ctx ctx, kh_vec X, int64_t xcol, kh_vec Z, int64_t zcol, int64_t ncols);
+/* out[2j], out[2j+1] = <V[:, j0+j], W[:, wcol]> = conj(v)^T w   (utils.py:183, ncols <= 512) */
+int kh_zdot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol, double* out);
+/* W[:, wcol] -= sum_j h[j] V[:, j0+j], complex h, left to right (utils.py:1029) */
+int kh_zaxpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W,
+                   int64_t wcol);
+/* Y[:, y0..y0+nc) = beta*Y + X[:, x0..x0+k) C, C complex k x nc row-major (linsys.py:947) */
+int kh_zgemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc, double beta,
+                kh_vec Y, int64_t y0);
+/* z = alpha*x + beta*y with complex alpha, beta */
+int kh_zwaxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, const double alpha[2], kh_vec X, int64_t xcol,
+               const double beta[2], kh_vec Y, int64_t ycol);
+/* Arnoldi.advance for complex data (utils.py:954-1048; mgs / dmgs / lanczos / panel CGS, Euclidean
+ * inner product, no preconditioner): hcol_out receives k+2 complex numbers, the last (H[k+1,k], 0). */
+int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                     int sweeps, int gs_mode, const double h_km1[2], double* hcol_out);
+
 /* ---- measurement ----------------------------------------------------------------------- */
 /* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot
  * kernel, HIP events on the context's stream.  which: 0 Gram-Schmidt link (axpy+dot),

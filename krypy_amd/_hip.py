@@ -85,6 +85,17 @@ _SIGNATURES = {
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
     "kh_bench_kernel": [_H, _INT, _H, _H, _INT, _c_double_p],
+    # complex (c128) side: vectors are real blocks of length 2N (interleaved re, im)
+    "kh_zcsr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
+                       ctypes.POINTER(_H)],
+    "kh_zdense_upload": [_H, _I64, _I64, _c_double_p, _I64, ctypes.POINTER(_H)],
+    "kh_zdiag_upload": [_H, _I64, _c_double_p, ctypes.POINTER(_H)],
+    "kh_zfrom_real": [_H, _H, _I64, _H, _I64, _I64],
+    "kh_zdot_panel": [_H, _H, _I64, _I64, _H, _I64, _c_double_p],
+    "kh_zaxpy_panel": [_H, _H, _I64, _I64, _c_double_p, _H, _I64],
+    "kh_zgemm_nn": [_H, _H, _I64, _I64, _c_double_p, _I64, _D, _H, _I64],
+    "kh_zwaxpby": [_H, _H, _I64, _c_double_p, _H, _I64, _c_double_p, _H, _I64],
+    "kh_zarnoldi_step": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _c_double_p],
 }
 
 _lib = None
@@ -142,11 +153,51 @@ def _dptr(a):
     return a.ctypes.data_as(_c_double_p)
 
 
+_F64 = numpy.dtype(numpy.float64)
+_C128 = numpy.dtype(numpy.complex128)
+
+
+def _block_dtype(dtype):
+    """float64 for every real input type, complex128 for every complex one."""
+    return _C128 if numpy.dtype(dtype).kind == "c" else _F64
+
+
+def _zarr(values):
+    """contiguous complex128 copy of ``values`` and a pointer to its (re, im) doubles"""
+    a = numpy.ascontiguousarray(values, dtype=numpy.complex128)
+    return a, a.ctypes.data_as(_c_double_p)
+
+
+def _real_scalar(x, what):
+    if numpy.imag(x) != 0:
+        raise BackendError("%s: complex coefficient for real device blocks" % what)
+    return float(numpy.real(x))
+
+
+def _real_coeffs(h, what):
+    h = numpy.asarray(h)
+    if h.dtype.kind == "c":
+        if numpy.any(h.imag != 0):
+            raise BackendError("%s: complex coefficients for real device blocks" % what)
+        h = h.real
+    return numpy.ascontiguousarray(h, dtype=numpy.float64)
+
+
+def _same_dtype(what, *blocks):
+    dt = blocks[0].dtype
+    for b in blocks[1:]:
+        if b.dtype != dt:
+            raise BackendError("%s: real and complex device blocks mixed (%s)" % (
+                what, ", ".join(str(b.dtype) for b in blocks)))
+    return dt == _C128
+
+
 class DeviceMatrix(object):
     """An operator resident on the device (``kh_mat``)."""
 
-    def __init__(self, ctx, handle, kind, shape, nnz=0):
+    def __init__(self, ctx, handle, kind, shape, nnz=0, dtype=_F64):
         self.ctx, self.handle, self.kind, self.shape, self.nnz = ctx, handle, kind, shape, nnz
+        self.dtype = numpy.dtype(dtype)
 
     def __del__(self):
         try:
@@ -173,41 +224,48 @@ class DeviceProjector(object):
 
 
 class DeviceVectors(object):
-    """A block of ``ncols`` fp64 column vectors of length ``n`` in HBM (``kh_vec``).
+    """A block of ``ncols`` column vectors of length ``n`` in HBM (``kh_vec``), fp64 or c128.
 
     Column-contiguous, 256-byte aligned columns: the device image of the
-    reference's ``(N, k)`` ndarrays.
+    reference's ``(N, k)`` ndarrays.  A complex block is a real ``kh_vec`` of length ``2n``
+    (interleaved re, im): the real-linear kernels run on it unchanged.
     """
 
-    def __init__(self, ctx, n, ncols):
+    def __init__(self, ctx, n, ncols, dtype=_F64):
         self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
-        h = ctx._pool_take(self.n, self.ncols)
+        self.dtype = _block_dtype(dtype)
+        self._w = 2 if self.dtype == _C128 else 1      # doubles per entry
+        self._rn = self.n * self._w                    # length of the real kh_vec
+        h = ctx._pool_take(self._rn, self.ncols)
         if h is None:
             h = _H()
-            rc = ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h))
+            rc = ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h))
             if rc != 0 and ctx._pool_flush():
-                rc = ctx._lib.kh_vec_alloc(ctx._h, self.n, self.ncols, ctypes.byref(h))
-            _check(ctx._lib, rc, "kh_vec_alloc(%d x %d)" % (self.n, self.ncols))
+                rc = ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h))
+            _check(ctx._lib, rc, "kh_vec_alloc(%d x %d)" % (self._rn, self.ncols))
         self.handle = h
 
     def __del__(self):
         try:
             if self.handle is not None and self.ctx._alive:
-                self.ctx._pool_give(self.n, self.ncols, self.handle)
+                self.ctx._pool_give(self._rn, self.ncols, self.handle)
         except Exception:
             pass
         self.handle = None
 
     def upload(self, col0, arr):
         """Copy a host ``(n, k)`` (or ``(n,)``) array into columns ``col0 ..``."""
-        a = numpy.asarray(arr, dtype=numpy.float64)
+        a = numpy.asarray(arr)
+        if self._w == 1 and a.dtype.kind == "c":
+            raise BackendError("upload: complex data into a real device block")
+        a = numpy.asarray(a, dtype=self.dtype)
         if a.ndim == 1:
             a = a.reshape(-1, 1)
         if a.shape[0] != self.n:
             raise BackendError("upload: %d rows into a block of length %d" % (a.shape[0], self.n))
         a = numpy.asfortranarray(a)
         k = a.shape[1]
-        ld = max(a.strides[1] // 8, self.n) if k > 1 else max(self.n, 1)
+        ld = max(a.strides[1] // 8, self._rn) if k > 1 else max(self._rn, 1)
         _check(self.ctx._lib, self.ctx._lib.kh_vec_upload(self.handle, col0, k, _dptr(a), ld),
                "kh_vec_upload")
         return self
@@ -215,10 +273,10 @@ class DeviceVectors(object):
     def download(self, col0=0, ncols=None):
         """Return columns ``[col0, col0+ncols)`` as a fresh Fortran-ordered ``(n, ncols)`` array."""
         ncols = self.ncols - col0 if ncols is None else ncols
-        out = numpy.empty((self.n, ncols), dtype=numpy.float64, order="F")
+        out = numpy.empty((self.n, ncols), dtype=self.dtype, order="F")
         if self.n and ncols:
             _check(self.ctx._lib, self.ctx._lib.kh_vec_download(self.handle, col0, ncols, _dptr(out),
-                                                                max(self.n, 1)), "kh_vec_download")
+                                                                max(self._rn, 1)), "kh_vec_download")
         return out
 
     def zero(self, col0=0, ncols=None):
@@ -226,24 +284,28 @@ class DeviceVectors(object):
         _check(self.ctx._lib, self.ctx._lib.kh_vec_zero(self.handle, col0, ncols), "kh_vec_zero")
 
     def copy_from(self, dcol, src, scol, ncols=1):
+        _same_dtype("copy_from", self, src)
         _check(self.ctx._lib, self.ctx._lib.kh_vec_copy(self.handle, dcol, src.handle, scol, ncols),
                "kh_vec_copy")
 
     def get(self, col, i0, count=1):
         """A few consecutive entries of one column as a host array."""
-        out = numpy.empty(max(count, 1), dtype=numpy.float64)
-        _check(self.ctx._lib, self.ctx._lib.kh_vec_get(self.handle, col, i0, count, _dptr(out)),
-               "kh_vec_get")
+        out = numpy.empty(max(count, 1), dtype=self.dtype)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_get(self.handle, col, i0 * self._w,
+                                                       count * self._w, _dptr(out)), "kh_vec_get")
         return out[:count]
 
     def set(self, col, i0, values):
-        a = numpy.ascontiguousarray(values, dtype=numpy.float64).reshape(-1)
-        _check(self.ctx._lib, self.ctx._lib.kh_vec_set(self.handle, col, i0, a.size, _dptr(a)),
-               "kh_vec_set")
+        v = numpy.asarray(values)
+        if self._w == 1 and v.dtype.kind == "c":
+            raise BackendError("set: complex values into a real device block")
+        a = numpy.ascontiguousarray(v, dtype=self.dtype).reshape(-1)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_set(self.handle, col, i0 * self._w,
+                                                       a.size * self._w, _dptr(a)), "kh_vec_set")
 
     def zero_range(self, col, i0, count):
-        _check(self.ctx._lib, self.ctx._lib.kh_vec_zero_range(self.handle, col, i0, count),
-               "kh_vec_zero_range")
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_zero_range(self.handle, col, i0 * self._w,
+                                                              count * self._w), "kh_vec_zero_range")
 
 
 class Context(object):
@@ -361,54 +423,86 @@ class Context(object):
                                                     nrecv_prev, nrecv_next), "kh_mat_set_halo")
 
     # ---- allocation / transfer ----
-    def alloc(self, n, ncols=1):
-        return DeviceVectors(self, n, ncols)
+    def alloc(self, n, ncols=1, dtype=_F64):
+        return DeviceVectors(self, n, ncols, dtype)
 
-    def upload(self, arr):
-        a = numpy.asarray(arr, dtype=numpy.float64)
+    def upload(self, arr, dtype=None):
+        """Host array -> device block; ``dtype`` forces a complex block for real data."""
+        a = numpy.asarray(arr)
+        dt = _block_dtype(a.dtype if dtype is None else numpy.result_type(a.dtype, dtype))
         if a.ndim == 1:
             a = a.reshape(-1, 1)
-        return DeviceVectors(self, a.shape[0], a.shape[1]).upload(0, a)
+        return DeviceVectors(self, a.shape[0], a.shape[1], dt).upload(0, a)
 
-    def csr(self, A, n_cols=None):
-        """Upload a SciPy CSR matrix (int32 indices, fp64 data) without reordering its rows."""
+    def promote(self, X, xcol, Z, zcol, ncols=1):
+        """Z[:, zcol:zcol+ncols] (complex) = X[:, xcol:xcol+ncols] (real) + 0i, on the device."""
+        if X.dtype != _F64 or Z.dtype != _C128:
+            raise BackendError("promote: real source and complex destination expected")
+        _check(self._lib, self._lib.kh_zfrom_real(self._h, X.handle, xcol, Z.handle, zcol, ncols),
+               "kh_zfrom_real")
+
+    def csr(self, A, n_cols=None, dtype=None):
+        """Upload a SciPy CSR matrix (int32 indices, fp64 / c128 data) without reordering rows."""
         indptr = numpy.ascontiguousarray(A.indptr, dtype=numpy.int32)
         indices = numpy.ascontiguousarray(A.indices, dtype=numpy.int32)
-        data = numpy.ascontiguousarray(A.data, dtype=numpy.float64)
+        dt = _block_dtype(A.dtype if dtype is None else numpy.result_type(A.dtype, dtype))
+        data = numpy.ascontiguousarray(A.data, dtype=dt)
         n_rows = A.shape[0]
         n_cols = A.shape[1] if n_cols is None else n_cols
         h = _H()
-        _check(self._lib, self._lib.kh_csr_upload(
+        fn = self._lib.kh_zcsr_upload if dt == _C128 else self._lib.kh_csr_upload
+        _check(self._lib, fn(
             self._h, n_rows, n_cols, data.size, indptr.ctypes.data_as(_c_int32_p),
             indices.ctypes.data_as(_c_int32_p), _dptr(data), ctypes.byref(h)), "kh_csr_upload")
-        return DeviceMatrix(self, h, "csr", (n_rows, n_cols), data.size)
+        return DeviceMatrix(self, h, "csr", (n_rows, n_cols), data.size, dt)
 
-    def dense(self, A):
-        a = numpy.ascontiguousarray(A, dtype=numpy.float64)
+    def dense(self, A, dtype=None):
+        A = numpy.asarray(A)
+        dt = _block_dtype(A.dtype if dtype is None else numpy.result_type(A.dtype, dtype))
+        a = numpy.ascontiguousarray(A, dtype=dt)
         h = _H()
-        _check(self._lib, self._lib.kh_dense_upload(self._h, a.shape[0], a.shape[1], _dptr(a),
-                                                    a.shape[1], ctypes.byref(h)), "kh_dense_upload")
-        return DeviceMatrix(self, h, "dense", a.shape, a.size)
+        fn = self._lib.kh_zdense_upload if dt == _C128 else self._lib.kh_dense_upload
+        _check(self._lib, fn(self._h, a.shape[0], a.shape[1], _dptr(a), a.shape[1], ctypes.byref(h)),
+               "kh_dense_upload")
+        return DeviceMatrix(self, h, "dense", a.shape, a.size, dt)
 
-    def diag(self, d):
-        d = numpy.ascontiguousarray(d, dtype=numpy.float64)
+    def diag(self, d, dtype=None):
+        d = numpy.asarray(d)
+        dt = _block_dtype(d.dtype if dtype is None else numpy.result_type(d.dtype, dtype))
+        d = numpy.ascontiguousarray(d, dtype=dt)
         h = _H()
-        _check(self._lib, self._lib.kh_diag_upload(self._h, d.size, _dptr(d), ctypes.byref(h)),
-               "kh_diag_upload")
-        return DeviceMatrix(self, h, "diag", (d.size, d.size), d.size)
+        fn = self._lib.kh_zdiag_upload if dt == _C128 else self._lib.kh_diag_upload
+        _check(self._lib, fn(self._h, d.size, _dptr(d), ctypes.byref(h)), "kh_diag_upload")
+        return DeviceMatrix(self, h, "diag", (d.size, d.size), d.size, dt)
 
-    # ---- numerics (each is one C entry point) ----
+    # ---- numerics (each is one C entry point; complex blocks go to the kh_z* twin) ----
     def apply(self, A, X, xcol, Y, ycol, ncols=1):
+        if (A.dtype == _C128) != _same_dtype("apply", X, Y):
+            raise BackendError("apply: %s operator on %s blocks" % (A.dtype, X.dtype))
         _check(self._lib, self._lib.kh_apply(self._h, A.handle, X.handle, xcol, Y.handle, ycol,
                                              ncols), "kh_apply")
 
     def dot_panel(self, V, j0, ncols, W, wcol):
+        if _same_dtype("dot_panel", V, W):
+            out = numpy.empty(max(ncols, 1), dtype=numpy.complex128)
+            _check(self._lib, self._lib.kh_zdot_panel(self._h, V.handle, j0, ncols, W.handle, wcol,
+                                                      _dptr(out)), "kh_zdot_panel")
+            return out[:ncols]
         out = numpy.empty(max(ncols, 1), dtype=numpy.float64)
         _check(self._lib, self._lib.kh_dot_panel(self._h, V.handle, j0, ncols, W.handle, wcol,
                                                  _dptr(out)), "kh_dot_panel")
         return out[:ncols]
 
     def gemm_tn(self, X, x0, nx, Y, y0, ny):
+        if _same_dtype("gemm_tn", X, Y):
+            out = numpy.empty((nx, ny), dtype=numpy.complex128)
+            for c in range(ny):
+                done = 0
+                while done < nx:          # kh_zdot_panel takes at most 512 columns
+                    m = min(512, nx - done)
+                    out[done:done + m, c] = self.dot_panel(X, x0 + done, m, Y, y0 + c)
+                    done += m
+            return out
         out = numpy.empty((nx, ny), dtype=numpy.float64)
         if nx and ny:
             _check(self._lib, self._lib.kh_gemm_tn(self._h, X.handle, x0, nx, Y.handle, y0, ny,
@@ -416,30 +510,68 @@ class Context(object):
         return out
 
     def axpy_panel(self, V, j0, ncols, h, W, wcol):
-        h = numpy.ascontiguousarray(h, dtype=numpy.float64).reshape(-1)
+        if _same_dtype("axpy_panel", V, W):
+            h, hp = _zarr(numpy.asarray(h).reshape(-1))
+            _check(self._lib, self._lib.kh_zaxpy_panel(self._h, V.handle, j0, ncols, hp, W.handle,
+                                                       wcol), "kh_zaxpy_panel")
+            return
+        h = _real_coeffs(h, "axpy_panel").reshape(-1)
         _check(self._lib, self._lib.kh_axpy_panel(self._h, V.handle, j0, ncols, _dptr(h), W.handle,
                                                   wcol), "kh_axpy_panel")
 
     def gemm_nn(self, X, x0, k, C, alpha, beta, Y, y0):
-        C = numpy.ascontiguousarray(C, dtype=numpy.float64)
+        if _same_dtype("gemm_nn", X, Y):
+            C = numpy.asarray(C)
+            if C.ndim == 1:
+                C = C.reshape(-1, 1)
+            if numpy.imag(beta) != 0:
+                raise BackendError("gemm_nn: beta must be real")
+            C, cp = _zarr(C * alpha)
+            _check(self._lib, self._lib.kh_zgemm_nn(self._h, X.handle, x0, k, cp, C.shape[1],
+                                                    float(numpy.real(beta)), Y.handle, y0),
+                   "kh_zgemm_nn")
+            return
+        C = _real_coeffs(C, "gemm_nn")
         if C.ndim == 1:
             C = C.reshape(-1, 1)
         _check(self._lib, self._lib.kh_gemm_nn(self._h, X.handle, x0, k, _dptr(C), C.shape[1],
-                                               alpha, beta, Y.handle, y0), "kh_gemm_nn")
+                                               _real_scalar(alpha, "gemm_nn"),
+                                               _real_scalar(beta, "gemm_nn"), Y.handle, y0),
+               "kh_gemm_nn")
 
     def nrm2(self, W, wcol):
+        # complex: the 2-norm of the (re, im) view is the complex 2-norm
         out = _D(0.0)
         _check(self._lib, self._lib.kh_nrm2(self._h, W.handle, wcol, ctypes.byref(out)), "kh_nrm2")
         return out.value
 
     def waxpby(self, Z, zcol, alpha, X, xcol, beta, Y, ycol):
-        _check(self._lib, self._lib.kh_waxpby(self._h, Z.handle, zcol, alpha, X.handle, xcol, beta,
+        if _same_dtype("waxpby", Z, X, Y) and (numpy.imag(alpha) != 0 or numpy.imag(beta) != 0):
+            a, ap = _zarr([alpha])
+            b, bp = _zarr([beta])
+            _check(self._lib, self._lib.kh_zwaxpby(self._h, Z.handle, zcol, ap, X.handle, xcol, bp,
+                                                   Y.handle, ycol), "kh_zwaxpby")
+            return
+        _check(self._lib, self._lib.kh_waxpby(self._h, Z.handle, zcol, _real_scalar(alpha, "waxpby"),
+                                              X.handle, xcol, _real_scalar(beta, "waxpby"),
                                               Y.handle, ycol), "kh_waxpby")
 
     def vdiv(self, Z, zcol, X, xcol, s):
-        _check(self._lib, self._lib.kh_vdiv(self._h, Z.handle, zcol, X.handle, xcol, s), "kh_vdiv")
+        if _same_dtype("vdiv", Z, X) and numpy.imag(s) != 0:
+            return self.waxpby(Z, zcol, 1.0 / complex(s), X, xcol, 0.0, X, xcol)
+        _check(self._lib, self._lib.kh_vdiv(self._h, Z.handle, zcol, X.handle, xcol,
+                                            _real_scalar(s, "vdiv")), "kh_vdiv")
 
     def arnoldi_step(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
+        if _same_dtype("arnoldi_step", V, W):
+            if Md is not None or P is not None:
+                raise BackendError("arnoldi_step: the complex step takes no preconditioner")
+            out = numpy.empty(k + 2, dtype=numpy.complex128)
+            hk, hkp = _zarr([h_km1])
+            _check(self._lib, self._lib.kh_zarnoldi_step(
+                self._h, A.handle if A is not None else None, V.handle, W.handle, wcol, k, start,
+                sweeps, gs_mode, hkp, _dptr(out)), "kh_zarnoldi_step")
+            return out
         out = numpy.empty(k + 2, dtype=numpy.float64)
         _check(self._lib, self._lib.kh_arnoldi_step(
             self._h, A.handle if A is not None else None, Md.handle if Md is not None else None,
@@ -483,16 +615,29 @@ class Context(object):
         return out
 
     def residual(self, A, B, bcol, X, xcol, R, rcol):
+        if _same_dtype("residual", B, X, R):     # complex: operator, real-linear axpby, norm
+            self.apply(A, X, xcol, R, rcol, 1)
+            self.waxpby(R, rcol, 1.0, B, bcol, -1.0, R, rcol)
+            return self.nrm2(R, rcol)
         out = _D(0.0)
         _check(self._lib, self._lib.kh_residual(self._h, A.handle, B.handle, bcol, X.handle, xcol,
                                                 R.handle, rcol, ctypes.byref(out)), "kh_residual")
         return out.value
 
     def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
+        if _same_dtype("minres_update", V, Wk, YK):
+            # z = (V_k - r0 W0 - r1 W1)/r2 written over W0 (= column `slot`);  yk += y0 z
+            self.waxpby(Wk, slot, -complex(r0), Wk, slot, 1.0 + 0.0j, V, k)
+            self.axpy_panel(Wk, 1 - slot, 1, [r1], Wk, slot)
+            self.vdiv(Wk, slot, Wk, slot, r2)
+            self.waxpby(YK, ycol, complex(y0), Wk, slot, 1.0 + 0.0j, YK, ycol)
+            return
         _check(self._lib, self._lib.kh_minres_update(self._h, V.handle, k, Wk.handle, slot, r0, r1,
                                                      r2, y0, YK.handle, ycol), "kh_minres_update")
 
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
+        if _same_dtype("cg_update", Pd, AP, YK, R):
+            raise BackendError("cg_update is real only (complex CG runs the step by step path)")
         out = _D(0.0)
         _check(self._lib, self._lib.kh_cg_update(
             self._h, alpha, Pd.handle, pcol, AP.handle, apcol, YK.handle, ycol, R.handle, rcol,

@@ -77,7 +77,8 @@ struct kh_vec_s {
     double* col(int64_t j) const { return d + j * ld; }
 };
 
-enum { KH_MAT_CSR = 0, KH_MAT_DENSE = 1, KH_MAT_DIAG = 2 };
+enum { KH_MAT_CSR = 0, KH_MAT_DENSE = 1, KH_MAT_DIAG = 2,
+       KH_MAT_ZCSR = 3, KH_MAT_ZDENSE = 4, KH_MAT_ZDIAG = 5 };   // complex operators (zpath.h)
 
 struct kh_mat_s {
     kh_ctx ctx;

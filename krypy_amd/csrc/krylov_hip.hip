@@ -416,6 +416,9 @@ using namespace kh;
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// complex operators (zpath.h, included at the end of this file)
+static int zapply_cols(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols);
+
 extern "C" {
 
 const char* kh_last_error(void) { return g_err.c_str(); }
@@ -769,6 +772,7 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
     KH_ARG(ctx && A, "kh_apply: NULL handle");
     KH_TRY(check_vec(X, xcol, ncols, "kh_apply(X)"));
     KH_TRY(check_vec(Y, ycol, ncols, "kh_apply(Y)"));
+    if (A->kind >= KH_MAT_ZCSR) return zapply_cols(ctx, A, X, xcol, Y, ycol, ncols);
     const int64_t xneed = (A->kind == KH_MAT_CSR) ? A->n_cols - A->nrecv_prev - A->nrecv_next : A->n_cols;
     KH_ARG(X->n == xneed && Y->n == A->n_rows, "kh_apply: dimension mismatch (A %lldx%lld, x %lld, y %lld)",
            (long long)A->n_rows, (long long)A->n_cols, (long long)X->n, (long long)Y->n);
@@ -1325,3 +1329,5 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
 }
 
 }  // extern "C"
+
+#include "zpath.h"

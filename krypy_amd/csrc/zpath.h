@@ -1,0 +1,583 @@
+// Complex (c128) side of libkrylov_hip.
+//
+// A complex N-vector is held as a REAL kh_vec of length 2N (interleaved re, im): every operation
+// that is real-linear - copy, zero, 2-norm, scaling by a real, axpby with real coefficients, the
+// normalise-and-store of the Arnoldi step - is the existing real kernel on that view, untouched.
+// This file adds only what is genuinely complex: conj(V)^T w panel products, updates with complex
+// coefficients, complex CSR / dense / diagonal operators, and the Arnoldi step built from them.
+// Arithmetic follows NumPy's complex formulas ((ar*br - ai*bi), (ar*bi + ai*br), separate
+// roundings; -ffp-contract=off), CSR rows are summed left to right like scipy's csr_matvec.
+// Correctness first: per-column launches (no register-resident chain yet).
+#pragma once
+// included at the end of krylov_hip.hip (one translation unit: the kernels of kernels.h are shared)
+
+namespace kh {
+
+constexpr int ZMAXC = 8;   // complex columns per panel launch (2 partial-sum slots each)
+
+struct ZColPtrs {
+    const double2* c[ZMAXC];
+};
+
+// part_out[(2c) * pstride + wg] = Re partial, [(2c+1) * pstride + wg] = Im partial of <v_c, w>
+template <int C>
+__global__ __launch_bounds__(BS) void k_zmultidot(int64_t n, ZColPtrs cols, const double2* __restrict__ w,
+                                                  double* __restrict__ part_out, int pstride) {
+    __shared__ double sm[8];
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    double ar[C], ai[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ar[c] = ai[c] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double2 wv = w[i];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double2 v = cols.c[c][i];
+            ar[c] = fma(v.x, wv.x, ar[c]);     // conj(v) * w
+            ar[c] = fma(v.y, wv.y, ar[c]);
+            ai[c] = fma(v.x, wv.y, ai[c]);
+            ai[c] = fma(-v.y, wv.x, ai[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        double r = block_sum(ar[c], sm);
+        if (threadIdx.x == 0) part_out[(int64_t)(2 * c) * pstride + blockIdx.x] = r;
+        __syncthreads();
+        r = block_sum(ai[c], sm);
+        if (threadIdx.x == 0) part_out[(int64_t)(2 * c + 1) * pstride + blockIdx.x] = r;
+        __syncthreads();
+    }
+}
+
+// w = beta*w - sign * sum_c coef[c] * v_c (complex coefficients, left to right); optional <w,w> partials
+template <int C, bool NRM, int BETA>
+__global__ __launch_bounds__(BS) void k_zmultiaxpy(int64_t n, ZColPtrs cols, const double2* __restrict__ coef,
+                                                   double sign, double beta, double2* __restrict__ w,
+                                                   double* __restrict__ part_out) {
+    __shared__ double sm[8];
+    double2 h[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        h[c].x = sign * coef[c].x;
+        h[c].y = sign * coef[c].y;
+    }
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        double2 wv;
+        if (BETA == 0) {
+            wv.x = 0.0;
+            wv.y = 0.0;
+        } else {
+            wv = w[i];
+            if (BETA == 2) {
+                wv.x = beta * wv.x;
+                wv.y = beta * wv.y;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const double2 v = cols.c[c][i];
+            const double tr = h[c].x * v.x - h[c].y * v.y;
+            const double ti = h[c].x * v.y + h[c].y * v.x;
+            wv.x = wv.x - tr;
+            wv.y = wv.y - ti;
+        }
+        w[i] = wv;
+        if (NRM) {
+            acc = fma(wv.x, wv.x, acc);
+            acc = fma(wv.y, wv.y, acc);
+        }
+    }
+    if (NRM) {
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+__global__ __launch_bounds__(BS) void k_zwaxpby(int64_t n, double2* z, double2 alpha, const double2* x,
+                                                double2 beta, const double2* y) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    const bool b0 = (beta.x == 0.0 && beta.y == 0.0);
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double2 xv = x[i];
+        double2 r;
+        r.x = alpha.x * xv.x - alpha.y * xv.y;
+        r.y = alpha.x * xv.y + alpha.y * xv.x;
+        if (!b0) {
+            const double2 yv = y[i];
+            r.x = r.x + (beta.x * yv.x - beta.y * yv.y);
+            r.y = r.y + (beta.x * yv.y + beta.y * yv.x);
+        }
+        z[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(BS) void k_zdiag_apply(int64_t n, const double2* __restrict__ d,
+                                                    const double2* __restrict__ x, double2* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double2 a = d[i], b = x[i];
+        double2 r;
+        r.x = a.x * b.x - a.y * b.y;
+        r.y = a.x * b.y + a.y * b.x;
+        y[i] = r;
+    }
+}
+
+// complex CSR-stream SpMV: products parked in LDS as double2, rows summed left to right
+template <int ITEMS>
+__global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__ indptr,
+                                                     const int32_t* __restrict__ indices,
+                                                     const double2* __restrict__ data,
+                                                     const int32_t* __restrict__ rowblk, int nblk, int tile,
+                                                     const double2* __restrict__ x, double2* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) double2 zprod[];
+    __shared__ double sm[8];
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    const int nz0 = indptr[r0], nz1 = indptr[r1];
+    const int cnt = nz1 - nz0;
+    if (cnt <= tile) {
+        if (cnt > 0) {
+            int c[ITEMS];
+            double2 a[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                const int tc = t < cnt ? t : cnt - 1;
+                c[i] = indices[nz0 + tc];
+                a[i] = data[nz0 + tc];
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const double2 xv = x[c[i]];
+                double2 p;
+                p.x = a[i].x * xv.x - a[i].y * xv.y;
+                p.y = a[i].x * xv.y + a[i].y * xv.x;
+                a[i] = p;
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                if (t < cnt) zprod[t] = a[i];
+            }
+        }
+        __syncthreads();
+        for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+            const int p0 = indptr[r] - nz0, p1 = indptr[r + 1] - nz0;
+            double2 s;
+            s.x = 0.0;
+            s.y = 0.0;
+            for (int p = p0; p < p1; ++p) {
+                s.x += zprod[p].x;
+                s.y += zprod[p].y;
+            }
+            y[r] = s;
+        }
+    } else {  // one long row: tree reduction
+        double sr = 0.0, si = 0.0;
+        for (int t = threadIdx.x; t < cnt; t += BS) {
+            const double2 a = data[nz0 + t];
+            const double2 xv = x[indices[nz0 + t]];
+            sr += a.x * xv.x - a.y * xv.y;
+            si += a.x * xv.y + a.y * xv.x;
+        }
+        sr = block_sum(sr, sm);
+        __syncthreads();
+        si = block_sum(si, sm);
+        if (threadIdx.x == 0) {
+            double2 s;
+            s.x = sr;
+            s.y = si;
+            y[r0] = s;
+        }
+    }
+}
+
+__global__ __launch_bounds__(BS) void k_zgemv_dense(int64_t n_rows, int64_t n_cols, const double2* __restrict__ a,
+                                                    int64_t lda, const double2* __restrict__ x,
+                                                    double2* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const double2* __restrict__ ar = a + row * lda;
+    double sr = 0.0, si = 0.0;
+    for (int64_t i = lane; i < n_cols; i += 64) {
+        const double2 av = ar[i], xv = x[i];
+        sr = fma(av.x, xv.x, sr);
+        sr = fma(-av.y, xv.y, sr);
+        si = fma(av.x, xv.y, si);
+        si = fma(av.y, xv.x, si);
+    }
+    sr = wave_sum(sr);
+    si = wave_sum(si);
+    if (lane == 0) {
+        double2 s;
+        s.x = sr;
+        s.y = si;
+        y[row] = s;
+    }
+}
+
+// z = x + 0i (widen a real column to complex)
+__global__ __launch_bounds__(BS) void k_zfrom_real(int64_t n, const double* __restrict__ x, double2* __restrict__ z) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        double2 r;
+        r.x = x[i];
+        r.y = 0.0;
+        z[i] = r;
+    }
+}
+
+// hdev[2j..] += coef (complex accumulate of H[j,k]); tiny
+__global__ void k_zacc(int n2, double* __restrict__ dst, const double* __restrict__ src) {
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) dst[i] += src[i];
+}
+
+static inline int zgrid(kh_ctx ctx, int64_t n) {
+    int64_t need = (n + BS - 1) / BS;
+    if (need < 1) need = 1;
+    return (int)std::min<int64_t>(need, ctx->nb);
+}
+
+static int zcheck(kh_vec v, int64_t col, int64_t ncols, const char* what) {
+    KH_ARG(v != nullptr, "%s: NULL vector handle", what);
+    KH_ARG((v->n & 1) == 0, "%s: a complex vector is a real block of even length", what);
+    KH_ARG(col >= 0 && ncols >= 0 && col + ncols <= v->ncols, "%s: columns out of range", what);
+    return 0;
+}
+
+static inline const double2* zcol(kh_vec v, int64_t j) { return reinterpret_cast<const double2*>(v->col(j)); }
+static inline double2* zcolw(kh_vec v, int64_t j) { return reinterpret_cast<double2*>(v->col(j)); }
+
+// out_dev[2c], out_dev[2c+1] = <V_c, w> for c < nc (all-reduced when sharded)
+static int zdot_dev(kh_ctx ctx, kh_vec V, int64_t j0, int64_t nc, const double2* w, double* out_dev) {
+    const int64_t n = V->n / 2;
+    const int grid = zgrid(ctx, n);
+    int64_t done = 0;
+    while (done < nc) {
+        const int64_t left = nc - done;
+        const int c = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        ZColPtrs cp;
+        for (int i = 0; i < c; ++i) cp.c[i] = zcol(V, j0 + done + i);
+        switch (c) {
+            case 8: hipLaunchKernelGGL((k_zmultidot<8>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part, NB_MAX); break;
+            case 4: hipLaunchKernelGGL((k_zmultidot<4>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part, NB_MAX); break;
+            case 2: hipLaunchKernelGGL((k_zmultidot<2>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part, NB_MAX); break;
+            default: hipLaunchKernelGGL((k_zmultidot<1>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part, NB_MAX); break;
+        }
+        hipLaunchKernelGGL(k_reduce_partials, dim3(2 * c), dim3(BS), 0, ctx->stream, ctx->part, grid, NB_MAX,
+                           out_dev + 2 * done, 0);
+        KH_HIP(hipGetLastError());
+        done += c;
+    }
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, out_dev, 2 * nc));
+    return 0;
+}
+
+template <bool NRM, int BETA>
+static void zaxpy_launch(int c, int grid, hipStream_t st, int64_t n, const ZColPtrs& cp, const double2* cf,
+                         double sign, double beta, double2* w, double* part) {
+    switch (c) {
+        case 8: hipLaunchKernelGGL((k_zmultiaxpy<8, NRM, BETA>), dim3(grid), dim3(BS), 0, st, n, cp, cf, sign, beta, w, part); break;
+        case 4: hipLaunchKernelGGL((k_zmultiaxpy<4, NRM, BETA>), dim3(grid), dim3(BS), 0, st, n, cp, cf, sign, beta, w, part); break;
+        case 2: hipLaunchKernelGGL((k_zmultiaxpy<2, NRM, BETA>), dim3(grid), dim3(BS), 0, st, n, cp, cf, sign, beta, w, part); break;
+        default: hipLaunchKernelGGL((k_zmultiaxpy<1, NRM, BETA>), dim3(grid), dim3(BS), 0, st, n, cp, cf, sign, beta, w, part); break;
+    }
+}
+
+// w = beta*w - sign * sum coef_c X_c over nc columns; nrm: fuse <w,w> partials into the last chunk
+static int zaxpy_dev(kh_ctx ctx, kh_vec X, int64_t j0, int64_t nc, const double* coef_dev, double sign, double beta,
+                     double2* w, bool nrm, double* nrm_part) {
+    const int64_t n = X->n / 2;
+    const int grid = zgrid(ctx, n);
+    int64_t done = 0;
+    while (done < nc) {
+        const int64_t left = nc - done;
+        const int c = left >= 8 ? 8 : left >= 4 ? 4 : left >= 2 ? 2 : 1;
+        ZColPtrs cp;
+        for (int i = 0; i < c; ++i) cp.c[i] = zcol(X, j0 + done + i);
+        const bool last = (done + c == nc);
+        const bool tn = nrm && last;
+        const int b = (done > 0) ? 1 : (beta == 1.0 ? 1 : (beta == 0.0 ? 0 : 2));
+        const double2* cf = reinterpret_cast<const double2*>(coef_dev) + done;
+        if (tn) {
+            if (b == 1) zaxpy_launch<true, 1>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+            else if (b == 0) zaxpy_launch<true, 0>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+            else zaxpy_launch<true, 2>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+        } else {
+            if (b == 1) zaxpy_launch<false, 1>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+            else if (b == 0) zaxpy_launch<false, 0>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+            else zaxpy_launch<false, 2>(c, grid, ctx->stream, n, cp, cf, sign, beta, w, nrm_part);
+        }
+        KH_HIP(hipGetLastError());
+        done += c;
+    }
+    return 0;
+}
+
+static int zfetch(kh_ctx ctx, const double* dev, int64_t count, double* out) {
+    KH_HIP(hipMemcpyAsync(ctx->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->hpin, count * sizeof(double));
+    return 0;
+}
+
+static int zpush(kh_ctx ctx, const double* host, int64_t count, double* dev) {
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(ctx->hpin, host, count * sizeof(double));
+    KH_HIP(hipMemcpyAsync(dev, ctx->hpin, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+
+constexpr int ZSC_COEF = 6400;   // same scratch region as the real panel coefficients
+constexpr int ZSC_TMP = 6144;
+
+// y = A x for complex operators (real kh_vec views of length 2n)
+static int zapply_one(kh_ctx ctx, kh_mat A, const double* x, double* y) {
+    const double2* x2 = reinterpret_cast<const double2*>(x);
+    double2* y2 = reinterpret_cast<double2*>(y);
+    if (A->kind == KH_MAT_ZCSR) {
+        if (A->nblk == 0) return 0;
+        const size_t lds = (size_t)A->tile * sizeof(double2);
+        const double2* d2 = reinterpret_cast<const double2*>(A->data);
+        switch (A->tile / BS) {
+            case 4: hipLaunchKernelGGL((k_zspmv_stream<4>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
+            case 16: hipLaunchKernelGGL((k_zspmv_stream<16>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
+            default: hipLaunchKernelGGL((k_zspmv_stream<8>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
+        }
+    } else if (A->kind == KH_MAT_ZDENSE) {
+        const int grid = (int)((A->n_rows + BS / 64 - 1) / (BS / 64));
+        hipLaunchKernelGGL(k_zgemv_dense, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols,
+                           reinterpret_cast<const double2*>(A->a), A->lda, x2, y2);
+    } else {
+        hipLaunchKernelGGL(k_zdiag_apply, dim3(zgrid(ctx, A->n_rows)), dim3(BS), 0, ctx->stream, A->n_rows,
+                           reinterpret_cast<const double2*>(A->diag), x2, y2);
+    }
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace kh
+
+using namespace kh;
+
+static int zapply_cols(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols) {
+    KH_TRY(zcheck(X, xcol, ncols, "kh_apply(X, complex)"));
+    KH_TRY(zcheck(Y, ycol, ncols, "kh_apply(Y, complex)"));
+    KH_ARG(X->n == 2 * A->n_cols && Y->n == 2 * A->n_rows,
+           "kh_apply: dimension mismatch (complex A %lldx%lld, x %lld, y %lld reals)", (long long)A->n_rows,
+           (long long)A->n_cols, (long long)X->n, (long long)Y->n);
+    KH_ARG(!(X == Y && xcol == ycol), "kh_apply: in-place application is not supported");
+    for (int64_t c = 0; c < ncols; ++c) KH_TRY(zapply_one(ctx, A, X->col(xcol + c), Y->col(ycol + c)));
+    return 0;
+}
+
+extern "C" {
+
+int kh_zcsr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
+                   const int32_t* indices, const double* data, kh_mat* out) {
+    KH_ARG(ctx && out && indptr, "kh_zcsr_upload: NULL argument");
+    KH_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < 2147483647LL && nnz < 2147483647LL,
+           "kh_zcsr_upload: bad sizes");
+    KH_ARG(indptr[0] == 0 && indptr[n_rows] == nnz, "kh_zcsr_upload: inconsistent indptr");
+    for (int64_t i = 0; i < nnz; ++i)
+        KH_ARG(indices[i] >= 0 && indices[i] < n_cols, "kh_zcsr_upload: column index out of range");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_ZCSR;
+    A->n_rows = n_rows;
+    A->n_cols = n_cols;
+    A->nnz = nnz;
+    A->tile = std::min(ctx->spmv_tile, 2048);   // double2 products: 32 KB of LDS at 2048
+    // row blocks: same greedy rule as the real kernel
+    std::vector<int32_t> blk;
+    blk.push_back(0);
+    int64_t r = 0;
+    while (r < n_rows) {
+        int64_t r_end = r, acc = 0;
+        while (r_end < n_rows && (r_end - r) < BS * 4) {
+            const int64_t nz = (int64_t)indptr[r_end + 1] - indptr[r_end];
+            if (acc + nz > A->tile) break;
+            acc += nz;
+            ++r_end;
+        }
+        if (r_end == r) r_end = r + 1;
+        blk.push_back((int32_t)r_end);
+        r = r_end;
+    }
+    A->nblk = (int)blk.size() - 1;
+    KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
+    KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    KH_HIP(hipMalloc(&A->data, sizeof(double) * 2 * std::max<int64_t>(nnz, 1)));
+    KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
+    KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
+    if (nnz > 0) {
+        KH_HIP(hipMemcpy(A->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+        KH_HIP(hipMemcpy(A->data, data, sizeof(double) * 2 * nnz, hipMemcpyHostToDevice));
+    }
+    KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_zdense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a, int64_t lda, kh_mat* out) {
+    KH_ARG(ctx && out && a && lda >= n_cols, "kh_zdense_upload: bad argument");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_ZDENSE;
+    A->n_rows = n_rows;
+    A->n_cols = n_cols;
+    A->lda = n_cols;
+    KH_HIP(hipMalloc(&A->a, sizeof(double) * 2 * (size_t)std::max<int64_t>(n_rows * n_cols, 1)));
+    KH_HIP(hipMemcpy2D(A->a, A->lda * 16, a, lda * 16, n_cols * 16, n_rows, hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_zdiag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
+    KH_ARG(ctx && out && (d || n == 0), "kh_zdiag_upload: NULL argument");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_ZDIAG;
+    A->n_rows = A->n_cols = n;
+    KH_HIP(hipMalloc(&A->diag, sizeof(double) * 2 * std::max<int64_t>(n, 1)));
+    if (n > 0) KH_HIP(hipMemcpy(A->diag, d, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    *out = A;
+    return 0;
+}
+
+int kh_zfrom_real(kh_ctx ctx, kh_vec X, int64_t xcol, kh_vec Z, int64_t zcol_, int64_t ncols) {
+    KH_ARG(ctx && X, "kh_zfrom_real: NULL");
+    KH_ARG(xcol >= 0 && ncols >= 0 && xcol + ncols <= X->ncols, "kh_zfrom_real: columns out of range");
+    KH_TRY(zcheck(Z, zcol_, ncols, "kh_zfrom_real(Z)"));
+    KH_ARG(Z->n == 2 * X->n, "kh_zfrom_real: Z must hold 2*len(X) reals");
+    for (int64_t c = 0; c < ncols; ++c)
+        hipLaunchKernelGGL(k_zfrom_real, dim3(zgrid(ctx, X->n)), dim3(BS), 0, ctx->stream, X->n, X->col(xcol + c),
+                           zcolw(Z, zcol_ + c));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+int kh_zdot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol, double* out) {
+    KH_ARG(ctx && out, "kh_zdot_panel: NULL");
+    KH_TRY(zcheck(V, j0, ncols, "kh_zdot_panel(V)"));
+    KH_TRY(zcheck(W, wcol, 1, "kh_zdot_panel(W)"));
+    KH_ARG(V->n == W->n && ncols <= 512, "kh_zdot_panel: shapes");
+    if (ncols == 0) return 0;
+    double* dev = ctx->scal + ZSC_COEF;
+    KH_TRY(zdot_dev(ctx, V, j0, ncols, zcol(W, wcol), dev));
+    return zfetch(ctx, dev, 2 * ncols, out);
+}
+
+int kh_zaxpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W, int64_t wcol) {
+    KH_ARG(ctx && (h || ncols == 0), "kh_zaxpy_panel: NULL");
+    KH_TRY(zcheck(V, j0, ncols, "kh_zaxpy_panel(V)"));
+    KH_TRY(zcheck(W, wcol, 1, "kh_zaxpy_panel(W)"));
+    KH_ARG(V->n == W->n && ncols <= 512, "kh_zaxpy_panel: shapes");
+    if (ncols == 0) return 0;
+    double* dev = ctx->scal + ZSC_COEF;
+    KH_TRY(zpush(ctx, h, 2 * ncols, dev));
+    return zaxpy_dev(ctx, V, j0, ncols, dev, 1.0, 1.0, zcolw(W, wcol), false, nullptr);
+}
+
+int kh_zgemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc, double beta, kh_vec Y,
+                int64_t y0) {
+    KH_ARG(ctx && (C || k == 0 || nc == 0), "kh_zgemm_nn: NULL");
+    KH_TRY(zcheck(X, x0, k, "kh_zgemm_nn(X)"));
+    KH_TRY(zcheck(Y, y0, nc, "kh_zgemm_nn(Y)"));
+    KH_ARG(X->n == Y->n && k <= 512 && X != Y, "kh_zgemm_nn: shapes");
+    std::vector<double> coef((size_t)std::max<int64_t>(2 * k, 2));
+    double* dev = ctx->scal + ZSC_COEF;
+    for (int64_t c = 0; c < nc; ++c) {
+        if (k == 0) {
+            if (beta == 0.0) KH_TRY(kh_vec_zero(Y, y0 + c, 1));
+            continue;
+        }
+        for (int64_t i = 0; i < k; ++i) {
+            coef[2 * i] = C[2 * (i * nc + c)];
+            coef[2 * i + 1] = C[2 * (i * nc + c) + 1];
+        }
+        KH_TRY(zpush(ctx, coef.data(), 2 * k, dev));
+        KH_TRY(zaxpy_dev(ctx, X, x0, k, dev, -1.0, beta, zcolw(Y, y0 + c), false, nullptr));
+    }
+    return 0;
+}
+
+int kh_zwaxpby(kh_ctx ctx, kh_vec Z, int64_t zcol_, const double alpha[2], kh_vec X, int64_t xcol,
+               const double beta[2], kh_vec Y, int64_t ycol) {
+    KH_ARG(ctx && alpha && beta, "kh_zwaxpby: NULL");
+    KH_TRY(zcheck(Z, zcol_, 1, "kh_zwaxpby(Z)"));
+    KH_TRY(zcheck(X, xcol, 1, "kh_zwaxpby(X)"));
+    KH_TRY(zcheck(Y, ycol, 1, "kh_zwaxpby(Y)"));
+    KH_ARG(Z->n == X->n && Z->n == Y->n, "kh_zwaxpby: length mismatch");
+    const int64_t n = Z->n / 2;
+    double2 a, b;
+    a.x = alpha[0];
+    a.y = alpha[1];
+    b.x = beta[0];
+    b.y = beta[1];
+    hipLaunchKernelGGL(k_zwaxpby, dim3(zgrid(ctx, n)), dim3(BS), 0, ctx->stream, n, zcolw(Z, zcol_), a,
+                       zcol(X, xcol), b, zcol(Y, ycol));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+// One complex Arnoldi.advance() (utils.py:954-1048, mgs/dmgs/lanczos/cgs; no preconditioner):
+// hcol_out gets k+2 complex numbers (interleaved); the last one is (H[k+1,k], 0).
+int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                     int sweeps, int gs_mode, const double h_km1[2], double* hcol_out) {
+    KH_ARG(ctx && V && W && hcol_out, "kh_zarnoldi_step: NULL argument");
+    KH_TRY(zcheck(V, k, 2, "kh_zarnoldi_step(V)"));
+    KH_TRY(zcheck(W, wcol, 1, "kh_zarnoldi_step(W)"));
+    KH_ARG(V->n == W->n && start >= 0 && start <= k && sweeps >= 1 && sweeps <= 4, "kh_zarnoldi_step: arguments");
+    KH_ARG(2 * (k + 2) <= 4096, "kh_zarnoldi_step: k too large for the complex path");
+    const int64_t n = V->n / 2;
+    double* hdev = ctx->scal;                 // 2(k+2) doubles
+    double* tmp = ctx->scal + ZSC_TMP;
+    double* coef = ctx->scal + ZSC_COEF;
+    double2* w = zcolw(W, wcol);
+    KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * 2 * (k + 2), ctx->stream));
+    if (A != nullptr) {
+        KH_ARG(A->kind >= KH_MAT_ZCSR && A->n_rows == n, "kh_zarnoldi_step: complex operator of matching size needed");
+        KH_TRY(zapply_one(ctx, A, V->col(k), W->col(wcol)));
+    }
+    double* nrm_part = ctx->part + (int64_t)(2 * ZMAXC + 2) * NB_MAX;
+    const int grid = zgrid(ctx, n);
+    if (start > 0 && start == k) {   // Lanczos: w -= H[k,k-1] * v_{k-1}
+        KH_TRY(zpush(ctx, h_km1, 2, coef));
+        KH_TRY(zaxpy_dev(ctx, V, k - 1, 1, coef, 1.0, 1.0, w, false, nullptr));
+    }
+    const int64_t ncol = k - start + 1;
+    for (int s = 0; s < sweeps; ++s) {
+        const bool last_sweep = (s == sweeps - 1);
+        if (gs_mode == KH_GS_MGS) {
+            for (int64_t j = start; j <= k; ++j) {
+                KH_TRY(zdot_dev(ctx, V, j, 1, w, coef));
+                hipLaunchKernelGGL(k_zacc, dim3(1), dim3(64), 0, ctx->stream, 2, hdev + 2 * j, coef);
+                KH_TRY(zaxpy_dev(ctx, V, j, 1, coef, 1.0, 1.0, w, last_sweep && j == k, nrm_part));
+            }
+        } else {
+            KH_ARG(ncol <= 512, "kh_zarnoldi_step: panel mode handles at most 512 columns");
+            KH_TRY(zdot_dev(ctx, V, start, ncol, w, coef));
+            hipLaunchKernelGGL(k_zacc, dim3(1), dim3(256), 0, ctx->stream, (int)(2 * ncol), hdev + 2 * start, coef);
+            KH_TRY(zaxpy_dev(ctx, V, start, ncol, coef, 1.0, 1.0, w, last_sweep, nrm_part));
+        }
+    }
+    // norm (real) and normalise through the real kernels on the 2n view
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, grid, 0, tmp, 0);
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+    const int rgrid = (int)std::min<int64_t>(std::max<int64_t>(((V->n >> 1) + BS - 1) / BS, 1), ctx->nb);
+    hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(rgrid), dim3(BS), 0, ctx->stream, V->n, W->col(wcol), nullptr,
+                       V->col(k + 1), nullptr, nullptr, 0, tmp, hdev + 2 * (k + 1));
+    KH_HIP(hipGetLastError());
+    return zfetch(ctx, hdev, 2 * (k + 2), hcol_out);
+}
+
+}  // extern "C"

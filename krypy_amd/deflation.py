@@ -38,13 +38,15 @@ class ObliqueProjection(_Projection):
         """
         self.linear_system = linear_system
         ctx = linear_system._ctx
-        Ud = utils._upload_block(U, ctx)
+        udt = U.dtype if hasattr(U, "dtype") else numpy.dtype(float)
+        self._bdt = bdt = utils._bdt(linear_system.dtype, udt)
+        Ud = utils._upload_block(U, ctx, dtype=bdt)
         # orthogonalize U in the Minv-inner-product (deflation.py:40).  get_ip_Minv_B() is an
         # IdentityLinearOperator *instance* for the unpreconditioned system, so this is the
         # modified Gram-Schmidt branch of utils.qr, never scipy's Householder QR.
         self._Ud, _ = utils.qr(Ud, ip_B=linear_system.get_ip_Minv_B(), reorthos=qr_reorthos)
         d = self._Ud.ncols
-        self._AUd = ctx.alloc(linear_system.N, d)
+        self._AUd = ctx.alloc(linear_system.N, d, dtype=bdt)
         if d > 0:
             linear_system.MlAMr._apply_dev(self._Ud, 0, self._AUd, 0, d)
         self._MAUd = None
@@ -68,7 +70,7 @@ class ObliqueProjection(_Projection):
     def _MAU_dev(self):
         if self._MAUd is None:
             d = self._AUd.ncols
-            self._MAUd = self._AUd.ctx.alloc(self._AUd.n, d)
+            self._MAUd = self._AUd.ctx.alloc(self._AUd.n, d, dtype=self._bdt)
             if d > 0:
                 self.linear_system.M._apply_dev(self._AUd, 0, self._MAUd, 0, d)
         return self._MAUd
@@ -79,9 +81,12 @@ class ObliqueProjection(_Projection):
             return z
         ls = self.linear_system
         ctx = z.ctx
-        Az = ls.A * z
-        r = DVec(ctx.alloc(ls.N, 1))
-        ctx.waxpby(r.block, 0, 1.0, ls._b_dev.block, ls._b_dev.col, -1.0, Az.block, Az.col)
+        dt = utils._bdt(self._bdt, z.dtype)
+        z = z.astype(dt)
+        Az = (ls.A * z).astype(dt)
+        b = ls._b_dev.astype(dt)
+        r = DVec(ctx.alloc(ls.N, 1, dtype=dt))
+        ctx.waxpby(r.block, 0, 1.0, b.block, b.col, -1.0, Az.block, Az.col)
         c = ls.Ml * r
         c = utils._inner_dev(self._Wd, 0, self._k, c.block, c.col, 1, self.ip_B)
         if self.Q is not None and self.R is not None:
@@ -89,7 +94,8 @@ class ObliqueProjection(_Projection):
         if self.WR is not self.VR:
             c = self.WR.dot(scipy.linalg.solve_triangular(self.VR, c))
         out = z.copy()
-        ctx.gemm_nn(self._Wd, 0, self._k, c, 1.0, 1.0, out.block, out.col)
+        Wd = utils._promote_block(self._Wd, 0, self._k, dt)[0]
+        ctx.gemm_nn(Wd, 0, self._k, c, 1.0, 1.0, out.block, out.col)
         return out
 
     def correct(self, z):
@@ -110,7 +116,7 @@ class _DeflationMixin(object):
         if projection_kwargs is None:
             projection_kwargs = {}
         d = U.ncols if hasattr(U, "ncols") else U.shape[1]
-        udtype = numpy.dtype(float) if hasattr(U, "ncols") else U.dtype
+        udtype = U.dtype
         projection = ObliqueProjection(linear_system, U, **projection_kwargs)
         self.projection = projection
         # E = <U, Ml A Mr U> from the factors (deflation.py:104-111)
@@ -127,7 +133,7 @@ class _DeflationMixin(object):
 
     def _solve(self):
         N = self.linear_system.N
-        P = utils.LinearOperator((N, N), numpy.dtype(float), self._apply_projection)
+        P = utils.LinearOperator((N, N), self.projection._bdt, self._apply_projection)
         P._apply_dev = self._apply_projection_dev
         if type(self)._store_UAv is _DeflationMixin._store_UAv:
             # (I - P) A runs inside the fused Arnoldi step; DeflatedCg keeps the Python path: its
@@ -141,6 +147,7 @@ class _DeflationMixin(object):
         for c in range(ncols):
             PAv, UAv = self.projection._apply_complement_dvec(DVec(X, xcol + c), return_Ya=True)
             self._store_UAv(UAv)
+            PAv = PAv.astype(Y.dtype)
             Y.copy_from(ycol + c, PAv.block, PAv.col, 1)
 
     def _store_UAv(self, UAv):
@@ -148,8 +155,8 @@ class _DeflationMixin(object):
 
     def _apply_projection(self, Av):
         """Host-array form of the projected operator (deflation.py:135-143)."""
-        blk = _hip.get_context().upload(Av)
-        out = self.linear_system._ctx.alloc(Av.shape[0], Av.shape[1])
+        blk = _hip.get_context().upload(Av, dtype=self.projection._bdt)
+        out = self.linear_system._ctx.alloc(Av.shape[0], Av.shape[1], dtype=blk.dtype)
         self._apply_projection_dev(blk, 0, out, 0, Av.shape[1])
         return out.download()
 
@@ -160,9 +167,11 @@ class _DeflationMixin(object):
         if x0 is None:
             Mlr = linsys._dev_of(ls, "Mlb", ctx)
         else:
-            Ax = ls.A * x0
-            r = DVec(ctx.alloc(ls.N, 1))
-            ctx.waxpby(r.block, 0, 1.0, ls._b_dev.block, ls._b_dev.col, -1.0, Ax.block, Ax.col)
+            dt = utils._bdt(self.projection._bdt, x0.dtype)
+            Ax = (ls.A * x0.astype(dt)).astype(dt)
+            b = ls._b_dev.astype(dt)
+            r = DVec(ctx.alloc(ls.N, 1, dtype=dt))
+            ctx.waxpby(r.block, 0, 1.0, b.block, b.col, -1.0, Ax.block, Ax.col)
             Mlr = ls.Ml * r
         PMlr, self.UMlr = self.projection._apply_complement_dvec(Mlr, return_Ya=True)
         MPMlr = ls.M * PMlr
@@ -306,14 +315,18 @@ class Ritz(object):
         coeffs = numpy.asarray(coeffs)
         if coeffs.ndim == 1:
             coeffs = coeffs.reshape(-1, 1)
-        if numpy.iscomplexobj(coeffs):
-            if numpy.abs(coeffs.imag).max() > 1e-12 * max(numpy.abs(coeffs).max(), 1e-300):
-                utils._require_real(coeffs.dtype, "Ritz vector coefficients")
-            coeffs = coeffs.real
         Ud = s.projection._Ud
         Vd = s._basis_block()
         ctx = Vd.ctx
-        out = ctx.alloc(Vd.n, coeffs.shape[1])
+        dt = utils._bdt(Vd.dtype, Ud.dtype)
+        if numpy.iscomplexobj(coeffs) and coeffs.size:
+            if numpy.abs(coeffs.imag).max() > 1e-12 * max(numpy.abs(coeffs).max(), 1e-300):
+                dt = numpy.dtype(numpy.complex128)      # complex Ritz vectors
+            else:
+                coeffs = coeffs.real
+        Vd = utils._promote_block(Vd, 0, n, dt)[0] if n > 0 else Vd
+        Ud = utils._promote_block(Ud, 0, Ud.ncols, dt)[0] if Ud.ncols > 0 else Ud
+        out = ctx.alloc(Vd.n, coeffs.shape[1], dtype=dt)
         if coeffs.shape[1] == 0:
             return out
         ctx.gemm_nn(Vd, 0, n, coeffs[:n, :], 1.0, 0.0, out, 0)
@@ -329,7 +342,7 @@ class Ritz(object):
         """Explicitly computes the Ritz residual (deflation.py:849-855)."""
         vecs = self._get_vectors_dev(indices)
         ls = self._deflated_solver.linear_system
-        out = vecs.ctx.alloc(vecs.n, vecs.ncols)
+        out = vecs.ctx.alloc(vecs.n, vecs.ncols, dtype=vecs.dtype)
         ls.MlAMr._apply_dev(vecs, 0, out, 0, vecs.ncols)
         vals = self.values if indices is None else self.values[indices]
         return out.download() - vecs.download() * numpy.asarray(vals)

@@ -88,7 +88,9 @@ class ShardedCSROperator(utils.LinearOperator):
         self.row0, self.n_global = row0, n_global
         super(ShardedCSROperator, self).__init__((nloc, nloc), numpy.dtype(float), self._dot_host)
 
-    def _device_matrix(self, ctx=None):
+    def _device_matrix(self, ctx=None, dtype=None):
+        if dtype is not None and numpy.dtype(dtype).kind == "c":
+            return None   # real halo exchange only: complex operands take the generic path and fail loudly
         return self._dmat
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):

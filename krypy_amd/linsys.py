@@ -48,14 +48,21 @@ class _LazyHost(object):
             obj.__dict__[self.dev] = None
 
 
+def _pyscalar(x):
+    """numpy scalar -> Python float, or complex when it has an imaginary part"""
+    x = complex(x)
+    return x.real if x.imag == 0.0 else x
+
+
 def _dev_of(obj, name, ctx):
-    """Device view of a _LazyHost attribute (uploads a host-assigned value once)."""
+    """Device view of a _LazyHost attribute (uploads a host-assigned value once, in the owner's
+    block dtype ``_bdt`` when it has one)."""
     d = obj.__dict__.get("_" + name + "_dev")
     if d is None:
         h = obj.__dict__.get("_" + name + "_host")
         if h is None:
             return None
-        d = obj.__dict__["_" + name + "_dev"] = DVec.from_host(h, ctx)
+        d = obj.__dict__["_" + name + "_dev"] = DVec.from_host(h, ctx, dtype=obj.__dict__.get("_bdt"))
     return d
 
 
@@ -102,11 +109,11 @@ class LinearSystem(object):
             raise utils.ArgumentError("self-adjointness implies normality")
 
         self.dtype = utils.find_common_dtype(self.A, self.b, self.M, self.Ml, self.Mr, self.ip_B)
-        utils._require_real(self.dtype, "LinearSystem")
+        self._bdt = utils._bdt(self.dtype)     # float64 or complex128 device blocks
 
         # device-resident right hand side and its preconditioned forms (linsys.py:119-122)
         self._ctx = _hip.get_context()
-        self._b_dev = DVec.from_host(self.b, self._ctx)
+        self._b_dev = DVec.from_host(self.b, self._ctx, dtype=self._bdt)
         self._plain = all(isinstance(op, utils.IdentityLinearOperator) for op in (self.M, self.Ml))
         self.Mlb = self.Ml * self._b_dev
         self.MMlb = self.M * _dev_of(self, "Mlb", self._ctx)
@@ -120,16 +127,19 @@ class LinearSystem(object):
         if z is None:
             out = (_dev_of(self, "MMlb", ctx), _dev_of(self, "Mlb", ctx))
             return out + (self.MMlb_norm,) if compute_norm else out
-        Amat = self.A._device_matrix()
+        dt = utils._bdt(self._bdt, z.dtype)      # a complex guess makes a real system complex
+        z = z.astype(dt)
+        b = self._b_dev.astype(dt)
+        Amat = self.A._device_matrix(ctx, dt)
         euclid = self.ip_B is None or isinstance(self.ip_B, utils.IdentityLinearOperator)
         if self._plain and euclid and Amat is not None and compute_norm:
             # fused r = b - A z and ||r|| (one pass over the matrix, no extra vector pass)
-            r = DVec(ctx.alloc(self.N, 1))
-            nrm = ctx.residual(Amat, self._b_dev.block, self._b_dev.col, z.block, z.col, r.block, 0)
+            r = DVec(ctx.alloc(self.N, 1, dtype=dt))
+            nrm = ctx.residual(Amat, b.block, b.col, z.block, z.col, r.block, 0)
             return r, r, nrm
-        Az = self.A * z
-        r = DVec(ctx.alloc(self.N, 1))
-        ctx.waxpby(r.block, 0, 1.0, self._b_dev.block, self._b_dev.col, -1.0, Az.block, Az.col)
+        Az = (self.A * z).astype(dt)
+        r = DVec(ctx.alloc(self.N, 1, dtype=dt))
+        ctx.waxpby(r.block, 0, 1.0, b.block, b.col, -1.0, Az.block, Az.col)
         Mlr = self.Ml * r
         MMlr = self.M * Mlr
         if compute_norm:
@@ -145,7 +155,7 @@ class LinearSystem(object):
             if compute_norm:
                 return self.MMlb, self.Mlb, self.MMlb_norm
             return self.MMlb, self.Mlb
-        zd = z if isinstance(z, DVec) else DVec.from_host(z, self._ctx)
+        zd = z if isinstance(z, DVec) else DVec.from_host(z, self._ctx, dtype=self._bdt)
         res = self._residual_dev(zd, compute_norm)
         out = (res[0].download(), res[1].download())
         return out + (res[2],) if compute_norm else out
@@ -246,9 +256,11 @@ class _KrylovSolver(object):
         self._ctx = linear_system._ctx
         N = linear_system.N
         self.maxiter = N if maxiter is None else maxiter
+        # device blocks of this solve: complex as soon as the system, x0 or `dtype` is
+        self._bdt = utils._bdt(linear_system.dtype, getattr(x0, "dtype", None), dtype)
         if isinstance(x0, DVec):
             self.flat_vecs = False
-            self.x0 = x0
+            self.x0 = x0.astype(self._bdt)
         else:
             self.flat_vecs, (x0,) = utils.shape_vecs(x0)
             self.x0 = x0
@@ -260,19 +272,18 @@ class _KrylovSolver(object):
         self.MMlr0, self.Mlr0, self.MMlr0_norm = self._get_initial_residual(x0d)
 
         if x0d is None:
-            self.x0 = DVec.zeros(N, self._ctx)
+            self.x0 = DVec.zeros(N, self._ctx, dtype=self._bdt)
         self.tol = tol
         self.xk = None
 
-        x0dtype = numpy.dtype(float)
+        x0dtype = numpy.dtype(float) if x0 is None else getattr(x0, "dtype", numpy.dtype(float))
         self.dtype = utils._common_type([linear_system.dtype, x0dtype, dtype])
-        utils._require_real(self.dtype, "solver dtype")
         self.MlAMr = linear_system.MlAMr
         self.iter = 0
         self.resnorms = []
 
         if self.linear_system.MMlb_norm == 0:
-            z = DVec.zeros(N, self._ctx)
+            z = DVec.zeros(N, self._ctx, dtype=self._bdt)
             self.xk = z
             self.x0 = z
             self.resnorms.append(0.0)
@@ -292,7 +303,9 @@ class _KrylovSolver(object):
         if ex is None:
             ex = self.linear_system.__dict__["_exact_dev"] = DVec.from_host(
                 self.linear_system.exact_solution, ctx)
-        d = DVec(ctx.alloc(self.linear_system.N, 1))
+        dt = utils._bdt(ex.dtype, xk.dtype)
+        ex, xk = ex.astype(dt), xk.astype(dt)
+        d = DVec(ctx.alloc(self.linear_system.N, 1, dtype=dt))
         ctx.waxpby(d.block, 0, 1.0, ex.block, ex.col, -1.0, xk.block, xk.col)
         return utils.norm(d, ip_B=self.linear_system.ip_B)
 
@@ -308,8 +321,9 @@ class _KrylovSolver(object):
         """``x0 + Mr*yk`` as a device vector (linsys.py:423-428)."""
         x0 = _dev_of(self, "x0", self._ctx)
         if yk is not None:
-            Mryk = self.linear_system.Mr * yk
-            xk = DVec(self._ctx.alloc(self.linear_system.N, 1))
+            Mryk = (self.linear_system.Mr * yk).astype(self._bdt)
+            x0 = x0.astype(self._bdt)
+            xk = DVec(self._ctx.alloc(self.linear_system.N, 1, dtype=self._bdt))
             self._ctx.waxpby(xk.block, 0, 1.0, x0.block, x0.col, 1.0, Mryk.block, Mryk.col)
             return xk
         return x0
@@ -405,25 +419,28 @@ class Cg(_KrylovSolver):
         N = ls.N
         euclid = ls.ip_B is None or isinstance(ls.ip_B, utils.IdentityLinearOperator)
         M_id = isinstance(ls.M, utils.IdentityLinearOperator)
-        Md = None if M_id else ls.M._device_matrix()
-        fused = euclid and (M_id or (Md is not None and Md.kind == "diag"))
+        bdt = self._bdt
+        cplx = utils._is_c(bdt)
+        Md = None if (M_id or cplx) else ls.M._device_matrix()
+        # (kh_cg_update is real: complex CG takes the step by step branch below)
+        fused = not cplx and euclid and (M_id or (Md is not None and Md.kind == "diag"))
 
-        yk = DVec(ctx.alloc(N, 1))
+        yk = DVec(ctx.alloc(N, 1, dtype=bdt))
         self.rhos = rhos = [self.MMlr0_norm ** 2]
         # working copies (linsys.py:603-607)
-        self._Mlrk = _dev_of(self, "Mlr0", ctx).copy()
-        self._MMlrk = self._Mlrk if M_id else _dev_of(self, "MMlr0", ctx).copy()
-        p = _dev_of(self, "MMlr0", ctx).copy()
-        Ap = DVec(ctx.alloc(N, 1))
+        self._Mlrk = _dev_of(self, "Mlr0", ctx).astype(bdt).copy()
+        self._MMlrk = self._Mlrk if M_id else _dev_of(self, "MMlr0", ctx).astype(bdt).copy()
+        p = _dev_of(self, "MMlr0", ctx).astype(bdt).copy()
+        Ap = DVec(ctx.alloc(N, 1, dtype=bdt))
         self.iter = 0
 
         if self.store_arnoldi:
-            self._Vb = ctx.alloc(N, self.maxiter + 1)
+            self._Vb = ctx.alloc(N, self.maxiter + 1, dtype=bdt)
             if self.MMlr0_norm > 0:
                 ctx.vdiv(self._Vb, 0, self._MMlrk.block, self._MMlrk.col, float(self.MMlr0_norm))
             self._Pb = None
             if not M_id:
-                self._Pb = ctx.alloc(N, self.maxiter + 1)
+                self._Pb = ctx.alloc(N, self.maxiter + 1, dtype=bdt)
                 if self.MMlr0_norm > 0:
                     ctx.vdiv(self._Pb, 0, self._Mlrk.block, self._Mlrk.col, float(self.MMlr0_norm))
             self.H = numpy.zeros((self.maxiter + 1, self.maxiter))
@@ -462,7 +479,7 @@ class Cg(_KrylovSolver):
                 ctx.waxpby(yk.block, yk.col, 1.0, yk.block, yk.col, alpha, p.block, p.col)
                 ctx.waxpby(self._Mlrk.block, self._Mlrk.col, 1.0, self._Mlrk.block,
                            self._Mlrk.col, -alpha, Ap.block, Ap.col)
-                self._MMlrk = ls.M * self._Mlrk
+                self._MMlrk = (ls.M * self._Mlrk).astype(bdt)
                 MMlrk_norm = utils.norm(self._Mlrk, self._MMlrk, ip_B=ls.ip_B)
             rhos.append(MMlrk_norm ** 2)
 
@@ -559,15 +576,16 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             self.MlAMr, _dev_of(self, "Mlr0", ctx), maxiter=self.maxiter, ortho=self.ortho,
             M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B)
 
-        W = ctx.alloc(N, 2)     # the two remembered direction vectors (linsys.py:807)
+        bdt = self.lanczos.dtype
+        W = ctx.alloc(N, 2, dtype=bdt)     # the two remembered direction vectors (linsys.py:807)
         slot = 0                # column of W that currently holds W0
         y = [self.MMlr0_norm, 0.0]
         G2 = None
         G1 = None
-        yk = DVec(ctx.alloc(N, 1))
+        yk = DVec(ctx.alloc(N, 1, dtype=bdt))
 
-        def rot(G, u, v):
-            return G[0] * u + G[1] * v, -G[1] * u + G[0] * v
+        def rot(G, u, v):      # [[c, s], [-conj(s), c]] (utils.py:430)
+            return G[0] * u + G[1] * v, -G[1].conjugate() * u + G[0] * v
 
         while (self.resnorms[-1] > self.tol and self.lanczos.iter < self.lanczos.maxiter
                and not self.lanczos.invariant):
@@ -576,19 +594,19 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             H = self.lanczos.H
             # QR update of the Lanczos matrix (linsys.py:826-841), scalars only
             R0 = 0.0
-            R1 = float(H[k - 1, k])   # k == 0 reads H[-1, 0] like the reference: zero
+            R1 = H[k - 1, k].item()   # k == 0 reads H[-1, 0] like the reference: zero
             if G1 is not None:
                 R0, R1 = rot(G1, R0, R1)
-            R2, R3 = float(H[k, k]), float(H[k + 1, k])
+            R2, R3 = H[k, k].item(), H[k + 1, k].item()
             if G2 is not None:
                 R1, R2 = rot(G2, R1, R2)
             G1 = G2
             g = utils.Givens(numpy.array([[R2], [R3]]))
-            G2 = (float(g.c), float(g.s))
-            R2 = float(g.r)
+            G2 = (_pyscalar(g.c), _pyscalar(g.s))
+            R2 = _pyscalar(g.r)
             y = list(rot(G2, y[0], y[1]))
             # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
-            ctx.minres_update(self.lanczos._V, k, W, slot, R0, R1, R2, float(y[0]), yk.block, yk.col)
+            ctx.minres_update(self.lanczos._V, k, W, slot, R0, R1, R2, y[0], yk.block, yk.col)
             slot = 1 - slot
             y = [y[1], 0.0]
             self._finalize_iteration(yk, numpy.abs(y[0]))
@@ -639,7 +657,7 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
         if k > 0:
             yy = scipy.linalg.solve_triangular(self.R[:k, :k], y)
             ctx = self._ctx
-            yk = DVec(ctx.alloc(self.linear_system.N, 1))
+            yk = DVec(ctx.alloc(self.linear_system.N, 1, dtype=self.arnoldi.dtype))
             ctx.gemm_nn(self.arnoldi._V, 0, k, yy, 1.0, 0.0, yk.block, 0)
             return super(Gmres, self)._get_xk(yk)
         return _dev_of(self, "x0", self._ctx)
@@ -650,9 +668,10 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
         self.arnoldi = utils.Arnoldi(
             self.MlAMr, _dev_of(self, "Mlr0", ctx), maxiter=self.maxiter, ortho=self.ortho,
             M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B)
-        cs = []  # Givens rotations as (c, s) floats
-        self.R = numpy.zeros([self.maxiter + 1, self.maxiter], dtype=self.dtype)
-        y = numpy.zeros((self.maxiter + 1, 1), dtype=self.dtype)
+        cs = []  # Givens rotations as (c, s) Python scalars
+        rdt = utils._bdt(self.dtype, self.arnoldi.dtype)
+        self.R = numpy.zeros([self.maxiter + 1, self.maxiter], dtype=rdt)
+        y = numpy.zeros((self.maxiter + 1, 1), dtype=rdt)
         y[0] = self.MMlr0_norm
         R = self.R
 
@@ -667,17 +686,17 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
                 c, s = cs[i]
                 t0, t1 = col[i], col[i + 1]
                 col[i] = c * t0 + s * t1
-                col[i + 1] = -s * t0 + c * t1
+                col[i + 1] = -s.conjugate() * t0 + c * t1
             g = utils.Givens(numpy.array([[col[k]], [col[k + 1]]]))
-            c, s = float(g.c), float(g.s)
+            c, s = _pyscalar(g.c), _pyscalar(g.s)
             cs.append((c, s))
             t0, t1 = col[k], col[k + 1]
             col[k] = c * t0 + s * t1
-            col[k + 1] = -s * t0 + c * t1
+            col[k + 1] = -s.conjugate() * t0 + c * t1
             R[: k + 2, k] = col
-            t0, t1 = float(y[k, 0]), float(y[k + 1, 0])
+            t0, t1 = y[k, 0].item(), y[k + 1, 0].item()
             y[k, 0] = c * t0 + s * t1
-            y[k + 1, 0] = -s * t0 + c * t1
+            y[k + 1, 0] = -s.conjugate() * t0 + c * t1
             self._finalize_iteration(y[: k + 1], abs(y[k + 1, 0]))
 
         if self.xk is None:

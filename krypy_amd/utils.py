@@ -111,9 +111,30 @@ def shape_vecs(*args):
 def _require_real(dtype, what):
     if numpy.dtype(dtype).kind == "c":
         raise NotImplementedError(
-            "%s is complex: the MI355X kernels of this round are real fp64 only "
-            "(complex c128 kernels are a SURVEY.md 8(f) 'next' row); there is no CPU fallback."
-            % what)
+            "%s is complex: this part of the MI355X path is real fp64 only; there is no CPU "
+            "fallback." % what)
+
+
+def _bdt(*dtypes):
+    """Device block dtype for a mix of input dtypes: complex128 if any is complex, else float64."""
+    for t in dtypes:
+        if t is not None and numpy.dtype(t).kind == "c":
+            return numpy.dtype(numpy.complex128)
+    return numpy.dtype(numpy.float64)
+
+
+def _is_c(dtype):
+    return numpy.dtype(dtype).kind == "c"
+
+
+def _promote_block(X, c0, nc, dtype):
+    """``(block, col0)`` holding columns ``[c0, c0+nc)`` of ``X`` with block dtype ``dtype``
+    (a real block is widened to complex on the device; a complex one is never narrowed)."""
+    if not _is_c(dtype) or _is_c(X.dtype):
+        return X, c0
+    Z = X.ctx.alloc(X.n, nc, dtype=numpy.complex128)
+    X.ctx.promote(X, c0, Z, 0, nc)
+    return Z, 0
 
 
 # ----------------------------------------------------------------------------------------
@@ -123,10 +144,13 @@ class DVec(object):
     """One N-vector resident in HBM: column ``col`` of a DeviceVectors ``block``."""
 
     __slots__ = ("block", "col")
-    dtype = numpy.dtype(numpy.float64)
 
     def __init__(self, block, col=0):
         self.block, self.col = block, col
+
+    @property
+    def dtype(self):
+        return self.block.dtype
 
     @property
     def n(self):
@@ -145,37 +169,41 @@ class DVec(object):
         return numpy.ascontiguousarray(self.block.download(self.col, 1))
 
     def copy(self):
-        out = self.ctx.alloc(self.n, 1)
+        out = self.ctx.alloc(self.n, 1, dtype=self.dtype)
         out.copy_from(0, self.block, self.col, 1)
         return DVec(out, 0)
 
+    def astype(self, dtype):
+        """This vector with (at least) the given block dtype; real -> complex widens on the device."""
+        b, c = _promote_block(self.block, self.col, 1, dtype)
+        return self if b is self.block else DVec(b, c)
+
     @staticmethod
-    def from_host(x, ctx=None):
+    def from_host(x, ctx=None, dtype=None):
         ctx = _hip.get_context() if ctx is None else ctx
         x = numpy.asarray(x)
-        _require_real(x.dtype, "vector")
         if x.ndim == 2 and x.shape[1] != 1:
             raise ArgumentError("expected a single column, got shape %s" % (x.shape,))
-        return DVec(ctx.upload(x.reshape(-1, 1)), 0)
+        return DVec(ctx.upload(x.reshape(-1, 1), dtype=dtype), 0)
 
     @staticmethod
-    def zeros(n, ctx=None):
+    def zeros(n, ctx=None, dtype=None):
         ctx = _hip.get_context() if ctx is None else ctx
-        return DVec(ctx.alloc(n, 1), 0)
+        return DVec(ctx.alloc(n, 1, dtype=_bdt(dtype)), 0)
 
 
-def _as_dvec(x, ctx=None):
-    return x if isinstance(x, DVec) else DVec.from_host(x, ctx)
+def _as_dvec(x, ctx=None, dtype=None):
+    if isinstance(x, DVec):
+        return x if dtype is None else x.astype(dtype)
+    return DVec.from_host(x, ctx, dtype=dtype)
 
 
-def _upload_block(X, ctx=None):
-    """(N,k) host array or DeviceVectors -> DeviceVectors."""
+def _upload_block(X, ctx=None, dtype=None):
+    """(N,k) host array or DeviceVectors -> DeviceVectors (widened to ``dtype`` if given)."""
     if isinstance(X, _hip.DeviceVectors) or hasattr(X, "download") and hasattr(X, "ncols"):
-        return X
+        return X if dtype is None else _promote_block(X, 0, X.ncols, dtype)[0]
     ctx = _hip.get_context() if ctx is None else ctx
-    X = numpy.asarray(X)
-    _require_real(X.dtype, "array")
-    return ctx.upload(X)
+    return ctx.upload(numpy.asarray(X), dtype=dtype)
 
 
 # ----------------------------------------------------------------------------------------
@@ -189,20 +217,25 @@ def ip_euclid(X, Y):
 def _inner_dev(Xb, x0, nx, Yb, y0, ny, ip_B=None):
     """<X[:, x0:x0+nx], Y[:, y0:y0+ny]> for device blocks -> (nx, ny) host array."""
     ctx = Xb.ctx
-    if ip_B is None or isinstance(ip_B, IdentityLinearOperator):
-        return ctx.gemm_tn(Xb, x0, nx, Yb, y0, ny)
     N = Xb.n
-    try:
-        B = get_linearoperator((N, N), ip_B)
-    except TypeError:
-        # user callable (X, Y) -> (m, n): it gets host arrays, like in the reference (utils.py:189)
-        return numpy.asarray(ip_B(Xb.download(x0, nx), Yb.download(y0, ny)))
-    # operator B is applied to the thinner side (utils.py:190-193)
+    B = None
+    if not (ip_B is None or isinstance(ip_B, IdentityLinearOperator)):
+        try:
+            B = get_linearoperator((N, N), ip_B)
+        except TypeError:
+            # user callable (X, Y) -> (m, n): it gets host arrays, like in the reference (utils.py:189)
+            return numpy.asarray(ip_B(Xb.download(x0, nx), Yb.download(y0, ny)))
+    dt = _bdt(Xb.dtype, Yb.dtype, None if B is None else B.dtype)
+    Xb, x0 = _promote_block(Xb, x0, nx, dt)
+    Yb, y0 = _promote_block(Yb, y0, ny, dt)
+    if B is None:
+        return ctx.gemm_tn(Xb, x0, nx, Yb, y0, ny)
+    # operator B is applied to the thinner side (utils.py:190-193); <B x, y> = <x, B y>
     if nx > ny:
-        T = ctx.alloc(N, nx)
+        T = ctx.alloc(N, nx, dtype=dt)
         B._apply_dev(Xb, x0, T, 0, nx)
         return ctx.gemm_tn(T, 0, nx, Yb, y0, ny)
-    T = ctx.alloc(N, ny)
+    T = ctx.alloc(N, ny, dtype=dt)
     B._apply_dev(Yb, y0, T, 0, ny)
     return ctx.gemm_tn(Xb, x0, nx, T, 0, ny)
 
@@ -304,8 +337,7 @@ class House(object):
         (utils.py:332-377), for a host ``(N,1)`` vector (real)."""
         if len(x.shape) != 2 or x.shape[1] != 1:
             raise ArgumentError("x is not a vector of dim (N,1)")
-        _require_real(x.dtype, "Householder vector")
-        v = numpy.array(x, dtype=float)
+        v = numpy.array(x, dtype=_bdt(x.dtype))
         gamma = v[0].item()
         sigma = 0.0 if x.shape[0] == 1 else numpy.linalg.norm(v[1:], 2)
         v0, self.xnorm, self.alpha, self.beta = _house_scalars(gamma, sigma, x.shape[0])
@@ -335,7 +367,7 @@ class _DevHouse(object):
         self.ctx, self.Hv, self.j = ctx, Hv, j
         Hv.copy_from(j, X, xcol, 1)
         Hv.zero_range(j, 0, j)
-        gamma = float(Hv.get(j, j, 1)[0])
+        gamma = Hv.get(j, j, 1)[0].item()
         Hv.set(j, j, [0.0])
         sigma = 0.0 if N - j == 1 else ctx.nrm2(Hv, j)          # ||x[j+1:]||
         v0, self.xnorm, self.alpha, self.beta = _house_scalars(gamma, sigma, N - j)
@@ -347,7 +379,7 @@ class _DevHouse(object):
         if self.beta == 0:
             return
         d = self.ctx.dot_panel(self.Hv, self.j, 1, X, xcol)[0]
-        self.ctx.axpy_panel(self.Hv, self.j, 1, [float(self.beta * d)], X, xcol)
+        self.ctx.axpy_panel(self.Hv, self.j, 1, [self.beta * d], X, xcol)
 
 
 # ----------------------------------------------------------------------------------------
@@ -435,15 +467,16 @@ class LinearOperator(object):
         return _AdjointLinearOperator(self)
 
     # -- device API -------------------------------------------------------------------
-    def _device_matrix(self):
+    def _device_matrix(self, ctx=None, dtype=None):
         """The DeviceMatrix this operator *is* (plain matrices only), else None."""
         return None
 
-    def _scratch(self, ctx, n, ncols, key=0):
-        k = (id(ctx), n, ncols, key)
+    def _scratch(self, ctx, n, ncols, key=0, dtype=None):
+        dtype = _bdt(dtype)
+        k = (id(ctx), n, ncols, key, dtype.kind)
         buf = self._tmp.get(k)
         if buf is None:
-            buf = self._tmp[k] = ctx.alloc(n, ncols)
+            buf = self._tmp[k] = ctx.alloc(n, ncols, dtype=dtype)
         return buf
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
@@ -458,7 +491,8 @@ class LinearOperator(object):
     def _mul_dvec(self, x):
         if x.n != self.shape[1]:
             raise LinearOperatorError("dimension mismatch")
-        y = x.ctx.alloc(self.shape[0], 1)
+        x = x.astype(_bdt(x.dtype, self.dtype))   # a complex operator widens a real operand
+        y = x.ctx.alloc(self.shape[0], 1, dtype=x.dtype)
         self._apply_dev(x.block, x.col, y, 0, 1)
         return DVec(y, 0)
 
@@ -538,7 +572,7 @@ class _SumLinearOperator(LinearOperator):
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
         ctx = X.ctx
-        T = self._scratch(ctx, self.shape[0], 1)
+        T = self._scratch(ctx, self.shape[0], 1, dtype=X.dtype)
         for c in range(ncols):
             self.args[0]._apply_dev(X, xcol + c, Y, ycol + c, 1)
             self.args[1]._apply_dev(X, xcol + c, T, 0, 1)
@@ -562,7 +596,7 @@ class _ProductLinearOperator(LinearOperator):
         return self.args[1].dot_adj(self.args[0].dot_adj(X))
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
-        T = self._scratch(X.ctx, self.args[1].shape[0], ncols)
+        T = self._scratch(X.ctx, self.args[1].shape[0], ncols, dtype=X.dtype)
         self.args[1]._apply_dev(X, xcol, T, 0, ncols)
         self.args[0]._apply_dev(T, 0, Y, ycol, ncols)
 
@@ -584,10 +618,11 @@ class _ScaledLinearOperator(LinearOperator):
         return numpy.conj(self.args[1]) * self.args[0].dot_adj(X)
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
-        _require_real(numpy.asarray(self.args[1]).dtype, "scale factor")
         self.args[0]._apply_dev(X, xcol, Y, ycol, ncols)
+        alpha = self.args[1]
+        alpha = float(alpha.real) if numpy.imag(alpha) == 0 else complex(alpha)
         for c in range(ncols):
-            X.ctx.waxpby(Y, ycol + c, float(self.args[1]), Y, ycol + c, 0.0, Y, ycol + c)
+            X.ctx.waxpby(Y, ycol + c, alpha, Y, ycol + c, 0.0, Y, ycol + c)
 
 
 class _PowerLinearOperator(LinearOperator):
@@ -662,11 +697,11 @@ def _diagonal_of(A):
         return None
     if A.format == "dia":
         if len(A.offsets) == 1 and A.offsets[0] == 0:
-            return numpy.asarray(A.diagonal(), dtype=float)
+            return numpy.asarray(A.diagonal(), dtype=_bdt(A.dtype))
         return None
     C = A.tocoo()
     if C.nnz <= A.shape[0] and numpy.array_equal(C.row, C.col):
-        return numpy.asarray(A.diagonal(), dtype=float)
+        return numpy.asarray(A.diagonal(), dtype=_bdt(A.dtype))
     return None
 
 
@@ -682,33 +717,43 @@ class MatrixLinearOperator(LinearOperator):
         super(MatrixLinearOperator, self).__init__(A.shape, A.dtype, self._dot, self._dot_adj)
         self._A = A
         self._A_adj = None
-        self._dmat = None
+        self._dmats = {}
         self._adj_op = None
 
-    def _device_matrix(self, ctx=None):
-        if self._dmat is None:
+    def _device_matrix(self, ctx=None, dtype=None):
+        """Device image for blocks of ``dtype`` (default: the matrix' own): a real matrix is
+        uploaded a second time as c128 when it meets complex vectors."""
+        dt = _bdt(self.dtype, dtype)
+        dm = self._dmats.get(dt.kind)
+        if dm is None:
             ctx = _hip.get_context() if ctx is None else ctx
-            _require_real(self.dtype, "matrix")
             A = self._A
             if _is_sparse(A):
                 d = _diagonal_of(A)
                 if d is not None:
-                    self._dmat = ctx.diag(d)
+                    dm = ctx.diag(d, dtype=dt)
                 else:
-                    self._dmat = ctx.csr(scipy.sparse.csr_matrix(A))
+                    dm = ctx.csr(scipy.sparse.csr_matrix(A), dtype=dt)
             else:
-                self._dmat = ctx.dense(numpy.asarray(A))
-        return self._dmat
+                dm = ctx.dense(numpy.asarray(A), dtype=dt)
+            self._dmats[dt.kind] = dm
+        return dm
+
+    @property
+    def _dmat(self):
+        return self._dmats.get(_bdt(self.dtype).kind)
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
-        X.ctx.apply(self._device_matrix(X.ctx), X, xcol, Y, ycol, ncols)
+        if _is_c(self.dtype) and not _is_c(X.dtype):
+            raise LinearOperatorError("complex matrix applied to a real device block")
+        X.ctx.apply(self._device_matrix(X.ctx, X.dtype), X, xcol, Y, ycol, ncols)
 
     def _dot(self, X):
         X = numpy.asarray(X)
-        _require_real(X.dtype, "operand")
         ctx = _hip.get_context()
-        Xd = ctx.upload(X)
-        Yd = ctx.alloc(self.shape[0], X.shape[1])
+        dt = _bdt(self.dtype, X.dtype)
+        Xd = ctx.upload(X, dtype=dt)
+        Yd = ctx.alloc(self.shape[0], X.shape[1], dtype=dt)
         self._apply_dev(Xd, 0, Yd, 0, X.shape[1])
         return numpy.ascontiguousarray(Yd.download())
 
@@ -794,8 +839,8 @@ class TimedLinearOperator(LinearOperator):
         self._timer[-1] /= k
         return ret
 
-    def _device_matrix(self, ctx=None):
-        return self._linear_operator._device_matrix()
+    def _device_matrix(self, ctx=None, dtype=None):
+        return self._linear_operator._device_matrix(ctx, dtype)
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
         if ncols == 0:
@@ -875,9 +920,8 @@ class Arnoldi(object):
         if isinstance(self.M, IdentityLinearOperator):
             self.M = None
         self.ip_B = ip_B
-        self.dtype = find_common_dtype(A, v, M)
-        _require_real(self.dtype, "Arnoldi input")
-        self.dtype = numpy.dtype(numpy.float64)
+        self.dtype = bdt = _bdt(find_common_dtype(self.A, v, self.M))
+        cplx = _is_c(bdt)
         self.iter = 0
         self.invariant = False
         if ortho == "house":
@@ -892,20 +936,21 @@ class Arnoldi(object):
         self.reorthos = self._sweeps - 1
 
         ctx = self._ctx = v.ctx if isinstance(v, DVec) else _hip.get_context()
-        self._V = ctx.alloc(N, self.maxiter + 1)
-        self._P = ctx.alloc(N, self.maxiter + 1) if self.M is not None else None
-        self._W = ctx.alloc(N, 2)
+        self._V = ctx.alloc(N, self.maxiter + 1, dtype=bdt)
+        self._P = ctx.alloc(N, self.maxiter + 1, dtype=bdt) if self.M is not None else None
+        self._W = ctx.alloc(N, 2, dtype=bdt)
         self.H = numpy.zeros((self.maxiter + 1, self.maxiter), dtype=self.dtype)
         self._h2 = 0.0   # running sum of squares of H (Frobenius), for the invariance pre-test
         # fused device path: Euclidean inner product, M a plain diagonal (or absent)
         self._euclid = ip_B is None or isinstance(ip_B, IdentityLinearOperator)
         self._Md = None
-        if self.M is not None:
+        if self.M is not None and not cplx:
             md = self.M._device_matrix()
             if md is not None and md.kind == "diag":
                 self._Md = md
+        # (the complex step kernel takes no preconditioner: complex + M runs the general loop)
         self._fused = self._euclid and (self.M is None or self._Md is not None)
-        self._Amat = self.A._device_matrix() if self._fused else None
+        self._Amat = self.A._device_matrix(ctx, bdt) if self._fused else None
         # deflated solvers hand in  P * MlAMr  with P the complement of a device projector: the
         # projection then runs inside the fused step and <U, A v_k> comes back with the H column
         self._proj = None
@@ -913,29 +958,29 @@ class Arnoldi(object):
         if self._fused and self._Amat is None and isinstance(self.A, _ProductLinearOperator):
             Pop, inner = self.A.args
             kp = getattr(Pop, "_kh_proj", None)
-            if kp is not None and inner._device_matrix() is not None:
+            if kp is not None and not cplx and inner._device_matrix() is not None:
                 self._Amat, self._proj, self._on_ya = inner._device_matrix(), kp, Pop._on_ya
         # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
         # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU
         # never idles while the host does its O(k) work.  A speculative step past the end of the
         # iteration is discarded by _settle().  (A Lanczos step takes H[k,k-1] from the previous step's
         # device-side H column, so it can run ahead as well.)
-        self._lookahead = 1 if self._Amat is not None else 0
+        self._lookahead = 1 if (self._Amat is not None and not cplx) else 0
         self._enq = 0          # number of steps enqueued on the device so far
         if ortho == "house":
             # Householder Arnoldi (utils.py:910-922, 970-994): reflectors live zero-padded in their
             # own (N, maxiter+2) block; every application is a device dot + axpy.  Sequential by
             # nature (SURVEY: not a hot path), kept for its orthogonality guarantee.
             self._fused, self._lookahead = False, 0
-            self._Hv = ctx.alloc(N, min(self.maxiter + 1, N) + 1)
+            self._Hv = ctx.alloc(N, min(self.maxiter + 1, N) + 1, dtype=bdt)
 
-        v = _as_dvec(v, ctx)
+        v = _as_dvec(v, ctx, dtype=bdt)
         if ortho == "house":
             self.houses = [_DevHouse(ctx, self._Hv, 0, v.block, v.col)]
             self.vnorm = norm(v)
         elif self.M is not None:
             p = v
-            v = (self.M * p) if Mv is None else _as_dvec(Mv, ctx)
+            v = (self.M * p) if Mv is None else _as_dvec(Mv, ctx, dtype=bdt)
             self.vnorm = norm(p, v, ip_B=ip_B) if Mv_norm is None else Mv_norm
             if self.vnorm > 0:
                 ctx.vdiv(self._P, 0, p.block, p.col, float(self.vnorm))
@@ -999,7 +1044,7 @@ class Arnoldi(object):
             start = k
             if k > 0:
                 H[k - 1, k] = H[k, k - 1]
-                h_km1 = float(H[k, k - 1])
+                h_km1 = float(numpy.real(H[k, k - 1]))
         if self._fused:
             if self._lookahead:
                 last = min(k + self._lookahead, self.maxiter - 1)
@@ -1017,8 +1062,10 @@ class Arnoldi(object):
                 self.A._apply_dev(self._V, k, self._W, 0, 1)
                 hcol = ctx.arnoldi_step(None, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
+            if self.ortho == "lanczos" and hcol.dtype.kind == "c":
+                hcol = hcol.real       # alpha = real(alpha), utils.py:1024-1027
             H[start: k + 1, k] += hcol[start: k + 1]
-            hn = hcol[k + 1]
+            hn = float(numpy.real(hcol[k + 1]))
         elif self.ortho == "house":
             hn = self._advance_house(k)
         else:
@@ -1028,7 +1075,7 @@ class Arnoldi(object):
         # ||.||_2 <= ||.||_F, so the quotient by the Frobenius norm is a lower bound: only when
         # THAT is tiny is the exact 2-norm (an O(k^3) SVD) needed.  Same decisions, O(k) cost.
         col = H[: k + 2, k]
-        self._h2 += float(numpy.dot(col, col))
+        self._h2 += float(numpy.vdot(col, col).real)
         fro = numpy.sqrt(self._h2)
         is_inv = False
         if not (fro > 0) or not (hn / fro > 1e-14):
@@ -1051,14 +1098,14 @@ class Arnoldi(object):
         for j in range(k + 1):
             hj = self.houses[j]
             hj.apply(W, 0)
-            if hj.alpha != 1.0:                          # Av[j] *= conj(alpha_j), alpha = +-1
-                W.set(0, j, W.get(0, j, 1) * hj.alpha)
+            if hj.alpha != 1.0:                          # Av[j] *= conj(alpha_j)
+                W.set(0, j, W.get(0, j, 1) * numpy.conj(hj.alpha))
         if k + 1 < N:
             house = _DevHouse(ctx, self._Hv, k + 1, W, 0)
             self.houses.append(house)
             house.apply(W, 0)
             col = W.get(0, 0, k + 2)
-            col[k + 1] *= house.alpha
+            col[k + 1] *= numpy.conj(house.alpha)
             H[: k + 2, k] = col
             hn = abs(H[k + 1, k])
         else:
@@ -1070,8 +1117,10 @@ class Arnoldi(object):
             V.set(k + 1, k + 1, [1.0])
             for j in range(k + 1, -1, -1):
                 self.houses[j].apply(V, k + 1)
-            if self.houses[-1].alpha != 1.0:
-                ctx.vdiv(V, k + 1, V, k + 1, float(self.houses[-1].alpha))
+            a = self.houses[-1].alpha
+            if a != 1.0:
+                a = float(numpy.real(a)) if numpy.imag(a) == 0 else complex(a)
+                ctx.waxpby(V, k + 1, a, V, k + 1, 0.0, V, k + 1)
         return hn
 
     def _advance_general(self, k, start, h_km1):
@@ -1093,7 +1142,7 @@ class Arnoldi(object):
                             "Is your operator self-adjoint in the provided inner product?")
                     alpha = numpy.real(alpha)
                 H[j, k] += alpha
-                ctx.axpy_panel(B, j, 1, [float(alpha)], W, 0)
+                ctx.axpy_panel(B, j, 1, [alpha], W, 0)
         if self.M is not None:
             self.M._apply_dev(W, 0, W, 1, 1)
             ip = _inner_dev(W, 0, 1, W, 1, 1, self.ip_B)
@@ -1190,12 +1239,13 @@ def ritz(H, V=None, hermitian=False, type="ritz"):
     if V is None:
         return theta, U, resnorm
     Ur = U
-    if numpy.iscomplexobj(U):
-        if numpy.abs(U.imag).max() > 1e-12 * max(numpy.abs(U).max(), 1e-300):
-            _require_real(U.dtype, "Ritz vector coefficients")
-        Ur = U.real
     Vd = _upload_block(V)
-    Z = Vd.ctx.alloc(Vd.n, n)
+    if numpy.iscomplexobj(U) and n > 0:
+        if numpy.abs(U.imag).max() > 1e-12 * max(numpy.abs(U).max(), 1e-300):
+            Vd = _promote_block(Vd, 0, n, numpy.complex128)[0]   # complex Ritz vectors
+        else:
+            Ur = U.real
+    Z = Vd.ctx.alloc(Vd.n, n, dtype=Vd.dtype)
     if n > 0:
         Vd.ctx.gemm_nn(Vd, 0, n, Ur, 1.0, 0.0, Z, 0)
     return theta, U, resnorm, numpy.ascontiguousarray(Z.download())
@@ -1212,17 +1262,18 @@ def _qr_mgs_fused(Q, reorthos):
     the reference's ``R[i,i] >= 1e-15`` guard exactly."""
     ctx = Q.ctx
     k = Q.ncols
-    R = numpy.zeros((k, k))
+    R = numpy.zeros((k, k), dtype=Q.dtype)
     for i in range(k):
         if i == 0:
-            R[0, 0] = ctx.nrm2(Q, 0)
-            if not R[0, 0] >= 1e-15:
+            r00 = ctx.nrm2(Q, 0)
+            R[0, 0] = r00
+            if not r00 >= 1e-15:
                 return None
-            ctx.vdiv(Q, 0, Q, 0, float(R[0, 0]))
+            ctx.vdiv(Q, 0, Q, 0, float(r00))
             continue
         hcol = ctx.arnoldi_step(None, None, Q, None, Q, i, i - 1, 0, reorthos + 1, _hip.GS_MGS, 0.0)
         R[: i + 1, i] = hcol[: i + 1]
-        if not hcol[i] >= 1e-15:
+        if not hcol[i].real >= 1e-15:
             return None
     return R
 
@@ -1232,22 +1283,22 @@ def _qr_mgs_dev(Q, ip_B, reorthos):
     ctx = Q.ctx
     k = Q.ncols
     if (ip_B is None or isinstance(ip_B, IdentityLinearOperator)) and k > 1 and hasattr(ctx, "arnoldi_step"):
-        keep = ctx.alloc(Q.n, k)
+        keep = ctx.alloc(Q.n, k, dtype=Q.dtype)
         keep.copy_from(0, Q, 0, k)
         R = _qr_mgs_fused(Q, reorthos)
         if R is not None:
             return R
         Q.copy_from(0, keep, 0, k)      # dependent column: redo with the guarded path
-    R = numpy.zeros((k, k))
+    R = numpy.zeros((k, k), dtype=Q.dtype)
     for i in range(k):
         for _ in range(reorthos + 1):
             for j in range(i):
                 alpha = _inner_dev(Q, j, 1, Q, i, 1, ip_B)[0, 0]
                 R[j, i] += alpha
-                ctx.axpy_panel(Q, j, 1, [float(alpha)], Q, i)
+                ctx.axpy_panel(Q, j, 1, [alpha], Q, i)
         R[i, i] = numpy.sqrt(numpy.linalg.norm(_inner_dev(Q, i, 1, Q, i, 1, ip_B), 2))
-        if R[i, i] >= 1e-15:
-            ctx.vdiv(Q, i, Q, i, float(R[i, i]))
+        if R[i, i].real >= 1e-15:
+            ctx.vdiv(Q, i, Q, i, float(R[i, i].real))
     return R
 
 
@@ -1266,11 +1317,10 @@ def qr(X, ip_B=None, reorthos=1):
     if ip_B is None and not on_device and X.shape[1] > 0:
         return scipy.linalg.qr(X, mode="economic")
     if on_device:
-        Q = X.ctx.alloc(X.n, X.ncols)
+        Q = X.ctx.alloc(X.n, X.ncols, dtype=X.dtype)
         Q.copy_from(0, X, 0, X.ncols)
     else:
-        _require_real(numpy.asarray(X).dtype, "X")
-        Q = _hip.get_context().upload(numpy.asarray(X, dtype=float))
+        Q = _hip.get_context().upload(numpy.asarray(X))
     R = _qr_mgs_dev(Q, ip_B, reorthos)
     if on_device:
         return Q, R
@@ -1318,6 +1368,10 @@ class Projection(object):
             self._Wd, self.WR = self._Vd, self.VR
         else:
             Yd = _upload_block(Y, Xd.ctx)
+            if Yd.dtype != Xd.dtype:      # mixed real / complex bases: widen the real one
+                dt = _bdt(Xd.dtype, Yd.dtype)
+                Yd = _promote_block(Yd, 0, Yd.ncols, dt)[0]
+                self._Vd = _promote_block(self._Vd, 0, self._Vd.ncols, dt)[0]
             if orthogonalize:
                 if ip_B is None:
                     Qh, self.WR = scipy.linalg.qr(Yd.download(), mode="economic")
@@ -1352,9 +1406,11 @@ class Projection(object):
 
     def _apply_dvec(self, a, return_Ya=False):
         """Single application ``V c`` for a :class:`DVec` (utils.py:522-552)."""
+        a = a.astype(self._Vd.dtype)
         c, Ya = self._coeffs(a, return_Ya)
-        out = a.ctx.alloc(self._N, 1)
-        a.ctx.gemm_nn(self._Vd, 0, self._k, c, 1.0, 0.0, out, 0)
+        out = a.ctx.alloc(self._N, 1, dtype=a.dtype)
+        Vd = _promote_block(self._Vd, 0, self._k, a.dtype)[0]
+        a.ctx.gemm_nn(Vd, 0, self._k, c, 1.0, 0.0, out, 0)
         return (DVec(out), Ya) if return_Ya else DVec(out)
 
     def _device_projector(self):
@@ -1365,6 +1421,8 @@ class Projection(object):
         trip; ``WR^H`` maps the first sweep's coefficients to ``<Y, a>``."""
         if self._k == 0 or not (self.ip_B is None or isinstance(self.ip_B, IdentityLinearOperator)):
             return None
+        if _is_c(self._Vd.dtype) or _is_c(self._Wd.dtype):
+            return None     # kh_proj is real; complex projections run sweep by sweep (zdot/zaxpy)
         if "_kh_proj" not in self.__dict__:
             T = None
             if self.Q is not None and self.R is not None:
@@ -1383,23 +1441,24 @@ class Projection(object):
         if self._k == 0:
             z = a.copy()
             return (z, numpy.zeros((0, 1))) if return_Ya else z
-        proj = self._device_projector()
+        a = a.astype(self._Vd.dtype)
+        proj = self._device_projector() if not _is_c(a.dtype) else None
         if proj is not None:
             z = DVec(ctx.alloc(self._N, 1))
             Ya = ctx.proj_apply_complement(proj, a.block, a.col, z.block, z.col, want_ya=return_Ya)
             return (z, Ya.reshape(-1, 1)) if return_Ya else z
         z = a.copy()
+        Vd = _promote_block(self._Vd, 0, self._k, a.dtype)[0]
         c, Ya = self._coeffs(a, return_Ya)
-        ctx.axpy_panel(self._Vd, 0, self._k, c, z.block, z.col)
+        ctx.axpy_panel(Vd, 0, self._k, c, z.block, z.col)
         for _ in range(self.iterations - 1):
             c, _unused = self._coeffs(z, False)
-            ctx.axpy_panel(self._Vd, 0, self._k, c, z.block, z.col)
+            ctx.axpy_panel(Vd, 0, self._k, c, z.block, z.col)
         return (z, Ya) if return_Ya else z
 
     # -- host API (arrays in, arrays out) ---------------------------------------------
     def _columns(self, a, fn):
         a = numpy.asarray(a)
-        _require_real(a.dtype, "a")
         blk = _hip.get_context().upload(a)
         outs = [fn(DVec(blk, j)) for j in range(a.shape[1])]
         return outs
@@ -1422,6 +1481,7 @@ class Projection(object):
         ctx = _hip.get_context()
 
         def one(v):
+            v = v.astype(_bdt(self._Vd.dtype, self._Wd.dtype))
             if return_Ya:
                 x, Ya = self._apply_dvec(v, True)
             else:
@@ -1449,7 +1509,8 @@ class Projection(object):
         return numpy.column_stack([r.download() for r in res])
 
     def _get_operator(self, fun, fun_adj):
-        return LinearOperator((self._N, self._N), numpy.dtype(float), fun, fun_adj)
+        dt = numpy.dtype(float) if self._Vd is None else _bdt(self._Vd.dtype, self._Wd.dtype)
+        return LinearOperator((self._N, self._N), dt, fun, fun_adj)
 
     def operator(self):
         """``LinearOperator`` corresponding to :meth:`apply` (utils.py:645-654)."""

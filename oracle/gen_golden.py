@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import refshim  # noqa: E402
 from oracle.inputs import (  # noqa: E402
     toy_system, lap2d_system, minres_jacobi_system, dense_spd_system, lap3d_system,
-    kernel_panel,
+    kernel_panel, complex_systems, complex_panel,
 )
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -253,6 +253,93 @@ def gen_ipB(krypy, nx=24):
          iter=s.iter, arn_H=ar.H, arn_V=ar.V)
 
 
+def gen_complex(krypy, nx=24):
+    """Complex (c128) runs of the reference: kernels, Arnoldi in every ortho mode,
+    GMRES / MINRES / CG, mixed real-complex inputs, restarted and deflated GMRES."""
+    ku, kl = krypy.utils, krypy.linsys
+    c = complex_systems(nx)
+    N, b, x0, U = c["N"], c["b"], c["x0"], c["U"]
+    out = {}
+    # kernels
+    for n, k in ((1, 1), (65, 3), (4097, 16), (20000, 33)):
+        X, w = complex_panel(n, k, seed=n + k)
+        out["N%d_k%d_inner" % (n, k)] = ku.inner(X, w)
+        out["N%d_k%d_norm" % (n, k)] = ku.norm(w)
+    X, a = complex_panel(1500, 8, seed=3)
+    Y, _ = complex_panel(1500, 8, seed=4)
+    ipI = ku.IdentityLinearOperator((1500, 1500))
+    out["qr_Q"], out["qr_R"] = ku.qr(X, ip_B=ipI, reorthos=1)
+    P = ku.Projection(X, Y, ip_B=ipI)
+    out["proj_z"], out["proj_Ya"] = P.apply_complement(a, return_Ya=True)
+    out["proj_apply"] = P.apply(a)
+    g = []
+    fac = [0.0, 1.0, 1.0j, 1.0 + 1.0j, 1e8, 1e-8j, -3.0 + 4.0j]
+    for a_ in fac:
+        for b_ in fac:
+            G = ku.Givens(np.array([[a_], [b_]]))
+            g.append([a_, b_, G.c, G.s, G.r])
+    out["givens"] = np.array(g, dtype=complex)
+    # Arnoldi
+    v = b.reshape(-1, 1)
+    for ortho, A in (("mgs", c["nonh"]), ("dmgs", c["nonh"]), ("lanczos", c["hind"]), ("house", c["nonh"])):
+        ar = ku.Arnoldi(A, v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        out["arn_%s_H" % ortho], out["arn_%s_V" % ortho] = ar.H, ar.V
+    # real operator, complex start vector
+    ar = ku.Arnoldi(c["L"], v, maxiter=8, ortho="mgs")
+    for _ in range(8):
+        ar.advance()
+    out["arn_realA_H"], out["arn_realA_V"] = ar.H, ar.V
+    # solvers
+    def rec(tag, s):
+        out[tag + "_resnorms"], out[tag + "_xk"] = np.array(s.resnorms), s.xk[:, 0]
+        out[tag + "_iter"] = getattr(s, "iter", len(s.resnorms) - 1)
+
+    s = kl.Gmres(kl.LinearSystem(c["nonh"], b), tol=1e-10, maxiter=300, store_arnoldi=True)
+    rec("gmres", s)
+    out["gmres_H"], out["gmres_R"] = s.H, s.R
+    rec("gmres_x0", kl.Gmres(kl.LinearSystem(c["nonh"], b), x0=x0, tol=1e-10, maxiter=300))
+    rec("gmres_realA", kl.Gmres(kl.LinearSystem(c["L"], b), tol=1e-10, maxiter=300))
+    rec("gmres_realb", kl.Gmres(kl.LinearSystem(c["nonh"], b.real.copy()), tol=1e-10, maxiter=300))
+    rec("rgmres", kl.RestartedGmres(kl.LinearSystem(c["nonh"], b), tol=1e-9, maxiter=30, max_restarts=40))
+    s = kl.Minres(kl.LinearSystem(c["hind"], b, self_adjoint=True), tol=1e-10, maxiter=600,
+                  store_arnoldi=True)
+    rec("minres", s)
+    out["minres_H"] = s.H
+    d = np.asarray(c["hpd"].diagonal()).real
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    rec("cg", kl.Cg(kl.LinearSystem(c["hpd"], b, self_adjoint=True, positive_definite=True),
+                    tol=1e-10, maxiter=300))
+    rec("cg_jacobi", kl.Cg(kl.LinearSystem(c["hpd"], b, M=M, Minv=Minv, self_adjoint=True,
+                                           positive_definite=True), tol=1e-10, maxiter=300))
+    rec("minres_jacobi", kl.Minres(kl.LinearSystem(c["hind"], b, M=M, Minv=Minv, self_adjoint=True),
+                                   tol=1e-10, maxiter=600))
+    rec("gmres_jacobi", kl.Gmres(kl.LinearSystem(c["nonh"], b, M=M, Minv=Minv), tol=1e-10, maxiter=300))
+    # deflation with a complex basis
+    s = krypy.deflation.DeflatedGmres(kl.LinearSystem(c["nonh"], b), U=U, tol=1e-10, maxiter=300,
+                                      store_arnoldi=True)
+    rec("dgmres", s)
+    out["dgmres_E"], out["dgmres_C"], out["dgmres_B_"] = s.E, s.C, s.B_
+    rz = krypy.deflation.Ritz(s)
+    order = np.argsort(rz.values)           # numpy sorts complex numbers lexicographically
+    out["dgmres_ritz_values"] = rz.values[order]
+    out["dgmres_ritz_resnorms"] = rz.resnorms[order]
+    out["dgmres_ritz_explicit_resnorms"] = rz.get_explicit_resnorms()[order]
+    # (on the Hermitian positive definite matrix: with the indefinite one and a random U the oblique
+    # projector has norm ~50 and the reference's own Lanczos basis loses orthogonality within 15 steps)
+    s = krypy.deflation.DeflatedMinres(kl.LinearSystem(c["hpd"], b, self_adjoint=True), U=U, tol=1e-10,
+                                       maxiter=600)
+    rec("dminres", s)
+    s = krypy.deflation.DeflatedCg(kl.LinearSystem(c["hpd"], b, self_adjoint=True, positive_definite=True),
+                                   U=U, tol=1e-10, maxiter=300)
+    rec("dcg", s)
+    # real system deflated with a complex basis
+    s = krypy.deflation.DeflatedGmres(kl.LinearSystem(c["L"], b.real.copy()), U=U, tol=1e-10, maxiter=300)
+    rec("dgmres_realsys", s)
+    save("complex_nx%d" % nx, nx=nx, **out)
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -267,6 +354,7 @@ def main():
     gen_cg_dense(krypy)
     gen_deflation(krypy)
     gen_ipB(krypy)
+    gen_complex(krypy)
 
 
 if __name__ == "__main__":

@@ -52,3 +52,32 @@ def dense_spd_system(n):
 def kernel_panel(N, k, seed):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((N, k)), rng.standard_normal((N, 1))
+
+
+def complex_systems(nx=24):
+    """Complex (c128) systems on the 2-D Laplacian stencil: a Hermitian positive
+    definite, a Hermitian indefinite and a non-Hermitian sparse matrix, a complex right-hand side,
+    a complex initial guess and a complex deflation basis."""
+    L = laplace2d(nx).tocsr()
+    N = L.shape[0]
+    rng = np.random.default_rng(11)
+    K = sp.triu(L, 1).tocoo()
+    K = sp.coo_matrix((0.3 * rng.standard_normal(K.nnz), (K.row, K.col)), shape=L.shape).tocsr()
+    S = 1j * (K - K.T)                       # Hermitian: (iK - iK^T)^H = -iK^T + iK
+    hpd = (L + S + 0.5 * sp.identity(N)).tocsr()
+    # indefinite, well conditioned: diagonal +-4 (first / second half), half-weight off-diagonals:
+    # Gershgorin puts the spectrum in [-6.1, -1.9] u [1.9, 6.1]
+    sign = np.where(np.arange(N) < N // 2, 1.0, -1.0)
+    hind = (sp.diags(4.0 * sign) + 0.5 * (L - 4.0 * sp.identity(N) + S)).tocsr()
+    nonh = (L + sp.diags(1j * np.linspace(0.1, 1.0, N)) + 0.2 * sp.diags([np.ones(N - 1)], [1])).tocsr()
+    b = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    x0 = 0.1 * (rng.standard_normal(N) + 1j * rng.standard_normal(N))
+    U = rng.standard_normal((N, 4)) + 1j * rng.standard_normal((N, 4))
+    return dict(L=L, hpd=hpd, hind=hind, nonh=nonh, b=b, x0=x0, U=U, N=N)
+
+
+def complex_panel(N, k, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, k)) + 1j * rng.standard_normal((N, k))
+    w = rng.standard_normal((N, 1)) + 1j * rng.standard_normal((N, 1))
+    return X, w

@@ -180,9 +180,11 @@ def case_api_errors():
         raise AssertionError
     except utils.ArgumentError:
         pass
+    # complex data is supported (tests/parity_cases_complex.py); what stays real fails loudly
+    from krypy_amd import dist
     try:
-        linsys.LinearSystem(A.astype(complex), b)
-        raise AssertionError("complex must fail loudly")
+        dist.ShardedCSROperator(sp.csr_matrix(A.astype(complex)), 0, 100)
+        raise AssertionError("complex sharded matrix must fail loudly")
     except NotImplementedError:
         pass
     G = utils.Givens(np.array([[-3.0], [4.0]]))

@@ -1,0 +1,202 @@
+"""Complex (c128) parity cases - SURVEY.md 8(f) row f4 - shared by the CPU host-logic tests (NumPy
+test double) and the GPU tests (HIP library through the C ABI), like tests/parity_cases.py.
+
+Compared with tests/golden/complex_nx24.npz (outputs of the unmodified reference on the seeded
+inputs of oracle.inputs.complex_systems) and with the complex CPU oracle (oracle/krylov_ref_c.py).
+Tolerance 1e-10 relative on recurrence quantities, same iteration counts; a trailing explicit
+residual is pure cancellation and gets 1e-6 (see tests/test_oracle_golden.py).
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from krypy_amd import deflation, linsys, utils
+from oracle import krylov_ref_c as refc
+from oracle.inputs import complex_panel, complex_systems
+from tests.conftest import load_golden as golden
+
+RTOL = 1e-10
+
+
+def crel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300)
+
+
+def check_run(sol, g, tag, tol=RTOL, explicit_tol=1e-6, xtol=1e-9):
+    got, want = np.asarray(sol.resnorms), g[tag + "_resnorms"]
+    assert len(got) == len(want), (tag, len(got), len(want))
+    assert np.max(np.abs(got[:-1] - want[:-1]) / want[:-1]) < tol, tag
+    assert abs(got[-1] - want[-1]) / want[-1] < explicit_tol, tag
+    assert crel(sol.xk[:, 0], g[tag + "_xk"]) < xtol, tag
+
+
+def case_complex_kernels():
+    g = golden("complex_nx24")
+    for n, k in ((1, 1), (65, 3), (4097, 16), (20000, 33)):
+        X, w = complex_panel(n, k, seed=n + k)
+        ip = utils.inner(X, w)
+        assert ip.dtype.kind == "c" and crel(ip, g["N%d_k%d_inner" % (n, k)]) < 1e-13
+        assert abs(utils.norm(w) - g["N%d_k%d_norm" % (n, k)]) < 1e-13 * g["N%d_k%d_norm" % (n, k)]
+        # mixed real / complex operands widen like numpy
+        ipr = utils.inner(X.real.copy(), w)
+        assert crel(ipr, X.real.T.dot(w)) < 1e-13
+    X, a = complex_panel(1500, 8, seed=3)
+    Y, _ = complex_panel(1500, 8, seed=4)
+    ipI = utils.IdentityLinearOperator((1500, 1500))
+    Q, R = utils.qr(X, ip_B=ipI, reorthos=1)
+    assert crel(Q, g["qr_Q"]) < RTOL and crel(R, g["qr_R"]) < RTOL
+    P = utils.Projection(X, Y, ip_B=ipI)
+    z, Ya = P.apply_complement(a, return_Ya=True)
+    assert crel(z, g["proj_z"]) < RTOL and crel(Ya, g["proj_Ya"]) < RTOL
+    assert crel(P.apply(a), g["proj_apply"]) < 1e-9
+    # a real vector through a complex projection
+    zr = P.apply_complement(a.real.copy())
+    assert crel(zr, a.real - P.apply(a.real.copy())) < 1e-9
+    for row in g["givens"]:
+        G = utils.Givens(np.array([[row[0]], [row[1]]]))
+        assert abs(G.c - row[2]) < 1e-15 and abs(G.s - row[3]) < 1e-15
+        assert abs(G.r - row[4]) <= 1e-15 * max(1.0, abs(row[4]))
+
+
+def case_complex_operator_algebra():
+    c = complex_systems(24)
+    N = c["N"]
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((N, 3)) + 1j * rng.standard_normal((N, 3))
+    A = utils.get_linearoperator((N, N), c["nonh"])
+    L = utils.get_linearoperator((N, N), c["L"])
+    D = utils.get_linearoperator((N, N), sp.diags(np.linspace(1, 2, N) + 1j * np.linspace(0, 1, N)).tocsr())
+    Dn = np.diag(rng.standard_normal(6) + 1j * rng.standard_normal(6)) + rng.standard_normal((6, 6))
+    assert crel(A * X, c["nonh"].dot(X)) < 1e-14
+    assert crel(A * X.real.copy(), c["nonh"].dot(X.real)) < 1e-14        # complex op, real operand
+    assert crel(L * X, c["L"].dot(X)) < 1e-14                              # real op, complex operand
+    assert crel(D * X, D._A.dot(X)) < 1e-14
+    assert crel(utils.MatrixLinearOperator(Dn) * X[:6], Dn.dot(X[:6])) < 1e-14
+    op = (2.0 - 0.5j) * A * D + L - A
+    want = (2.0 - 0.5j) * c["nonh"].dot(D._A.dot(X)) + c["L"].dot(X) - c["nonh"].dot(X)
+    assert crel(op * X, want) < 1e-13
+    assert crel(A.adj * X, c["nonh"].T.conj().dot(X)) < 1e-14
+    # device vectors: widening, complex scaling
+    xd = utils.DVec.from_host(X[:, [0]].real.copy())
+    yd = (op * xd)
+    assert yd.dtype.kind == "c"
+    want0 = (2.0 - 0.5j) * c["nonh"].dot(D._A.dot(X[:, [0]].real)) + c["L"].dot(X[:, [0]].real) \
+        - c["nonh"].dot(X[:, [0]].real)
+    assert crel(yd.download(), want0) < 1e-13
+
+
+def case_complex_arnoldi():
+    g = golden("complex_nx24")
+    c = complex_systems(24)
+    v = c["b"].reshape(-1, 1)
+    for ortho, A in (("mgs", c["nonh"]), ("dmgs", c["nonh"]), ("lanczos", c["hind"]), ("house", c["nonh"])):
+        ar = utils.Arnoldi(A, v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        assert ar.H.dtype.kind == "c" and ar.V.dtype.kind == "c"
+        assert crel(ar.H, g["arn_%s_H" % ortho]) < RTOL, ortho
+        assert crel(ar.V, g["arn_%s_V" % ortho]) < RTOL, ortho
+        if ortho != "house":
+            Vo, Ho, _, _ = refc.arnoldi(A, c["b"], 12, ortho)
+            assert crel(ar.H, Ho) < RTOL and crel(ar.V, Vo) < RTOL
+    ar = utils.Arnoldi(c["L"], v, maxiter=8, ortho="mgs")       # real operator, complex start vector
+    for _ in range(8):
+        ar.advance()
+    assert crel(ar.H, g["arn_realA_H"]) < RTOL and crel(ar.V, g["arn_realA_V"]) < RTOL
+    # panel Gram-Schmidt extension: the Arnoldi relation and orthonormality
+    for ortho in ("cgs2",):
+        ar = utils.Arnoldi(c["nonh"], v, maxiter=12, ortho=ortho)
+        for _ in range(12):
+            ar.advance()
+        V, H = ar.get()
+        assert np.linalg.norm(np.eye(13) - V.T.conj().dot(V), 2) < 1e-13
+        assert np.linalg.norm(c["nonh"].dot(V[:, :12]) - V.dot(H)) < 1e-12
+    # preconditioned complex Lanczos / Arnoldi run the general loop
+    d = np.linspace(0.5, 1.5, c["N"])
+    M = sp.diags(d).tocsr()
+    for ortho, A in (("lanczos", c["hind"]), ("mgs", c["nonh"])):
+        ar = utils.Arnoldi(A, v, maxiter=10, ortho=ortho, M=M)
+        for _ in range(10):
+            ar.advance()
+        Vo, Ho, Po, _ = refc.arnoldi(A, c["b"], 10, ortho, M=M)
+        assert crel(ar.H, Ho) < RTOL and crel(ar.V, Vo) < RTOL and crel(ar.P, Po) < RTOL
+
+
+def case_complex_solvers():
+    g = golden("complex_nx24")
+    c = complex_systems(24)
+    b, x0 = c["b"], c["x0"]
+    s = linsys.Gmres(linsys.LinearSystem(c["nonh"], b), tol=1e-10, maxiter=300, store_arnoldi=True)
+    check_run(s, g, "gmres")
+    assert s.iter == int(g["gmres_iter"]) and s.xk.dtype.kind == "c"
+    k = 40        # the leading Hessenberg / R columns (late columns are ill-conditioned near convergence)
+    assert crel(s.H[: k + 1, :k], g["gmres_H"][: k + 1, :k]) < 1e-9
+    assert crel(s.R[:k, :k], g["gmres_R"][:k, :k]) < 1e-9
+    xo, reso, _, _ = refc.gmres(c["nonh"], b, tol=1e-10, maxiter=300)
+    assert len(reso) == len(s.resnorms) and crel(s.xk[:, 0], xo) < 1e-9
+    assert np.max(np.abs(np.array(s.resnorms[:-1]) - reso[:-1]) / reso[:-1]) < RTOL
+    check_run(linsys.Gmres(linsys.LinearSystem(c["nonh"], b), x0=x0, tol=1e-10, maxiter=300), g, "gmres_x0")
+    check_run(linsys.Gmres(linsys.LinearSystem(c["L"], b), tol=1e-10, maxiter=300), g, "gmres_realA")
+    check_run(linsys.Gmres(linsys.LinearSystem(c["nonh"], b.real.copy()), tol=1e-10, maxiter=300), g,
+              "gmres_realb")
+    # real system, complex initial guess: the solve turns complex
+    sr = linsys.Gmres(linsys.LinearSystem(c["L"], b.real.copy()), x0=x0, tol=1e-10, maxiter=300)
+    assert sr.xk.dtype.kind == "c"
+    assert np.linalg.norm(c["L"].dot(sr.xk[:, 0]) - b.real) / np.linalg.norm(b.real) < 1e-9
+    s = linsys.RestartedGmres(linsys.LinearSystem(c["nonh"], b), tol=1e-9, maxiter=30, max_restarts=40)
+    assert len(s.resnorms) == len(g["rgmres_resnorms"])
+    assert crel(s.xk[:, 0], g["rgmres_xk"]) < 1e-7
+    assert np.max(np.abs(np.array(s.resnorms) - g["rgmres_resnorms"]) / g["rgmres_resnorms"]) < 1e-6
+    s = linsys.Minres(linsys.LinearSystem(c["hind"], b, self_adjoint=True), tol=1e-10, maxiter=600,
+                      store_arnoldi=True)
+    check_run(s, g, "minres")
+    assert crel(s.H, g["minres_H"]) < 1e-9
+    d = np.asarray(c["hpd"].diagonal()).real
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    hpd = dict(self_adjoint=True, positive_definite=True)
+    check_run(linsys.Cg(linsys.LinearSystem(c["hpd"], b, **hpd), tol=1e-10, maxiter=300), g, "cg")
+    check_run(linsys.Cg(linsys.LinearSystem(c["hpd"], b, M=M, Minv=Minv, **hpd), tol=1e-10, maxiter=300),
+              g, "cg_jacobi")
+    check_run(linsys.Minres(linsys.LinearSystem(c["hind"], b, M=M, Minv=Minv, self_adjoint=True),
+                            tol=1e-10, maxiter=600), g, "minres_jacobi")
+    check_run(linsys.Gmres(linsys.LinearSystem(c["nonh"], b, M=M, Minv=Minv), tol=1e-10, maxiter=300), g,
+              "gmres_jacobi")
+    for ortho in ("dmgs", "cgs2", "house"):
+        s = linsys.Gmres(linsys.LinearSystem(c["nonh"], b), ortho=ortho, tol=1e-10, maxiter=300)
+        assert len(s.resnorms) == len(g["gmres_resnorms"]), ortho
+        assert crel(s.xk[:, 0], g["gmres_xk"]) < 1e-9
+
+
+def case_complex_deflation():
+    g = golden("complex_nx24")
+    c = complex_systems(24)
+    b, U = c["b"], c["U"]
+    s = deflation.DeflatedGmres(linsys.LinearSystem(c["nonh"], b), U=U, tol=1e-10, maxiter=300,
+                                store_arnoldi=True)
+    check_run(s, g, "dgmres")
+    # (late columns of C / rows of B_ inherit the loss of orthogonality of the basis: the leading
+    # 30 are compared at full precision, the rest loosely - same as the real case)
+    assert crel(s.E, g["dgmres_E"]) < 1e-9 and crel(s.C[:, :30], g["dgmres_C"][:, :30]) < 1e-9
+    assert crel(s.C, g["dgmres_C"]) < 1e-4
+    assert crel(s.B_[:30], g["dgmres_B_"][:30]) < 1e-9 and crel(s.B_, g["dgmres_B_"]) < 1e-4
+    r = deflation.Ritz(s)
+    order = np.argsort(r.values)
+    scale = np.max(np.abs(r.values))
+    assert np.max(np.abs(r.values[order] - g["dgmres_ritz_values"])) < 1e-6 * scale
+    assert np.max(np.abs(r.resnorms[order] - g["dgmres_ritz_resnorms"])) < 1e-6 * scale
+    vecs = r.get_vectors([0, 1])
+    assert vecs.dtype.kind == "c" and vecs.shape == (c["N"], 2)
+    assert np.max(np.abs(r.get_explicit_resnorms()[order] - g["dgmres_ritz_explicit_resnorms"])) < 1e-6 * scale
+    s = deflation.DeflatedMinres(linsys.LinearSystem(c["hpd"], b, self_adjoint=True), U=U, tol=1e-10,
+                                 maxiter=600)
+    check_run(s, g, "dminres", tol=1e-8)
+    s = deflation.DeflatedCg(linsys.LinearSystem(c["hpd"], b, self_adjoint=True, positive_definite=True),
+                             U=U, tol=1e-10, maxiter=300)
+    check_run(s, g, "dcg", tol=1e-8)
+    s = deflation.DeflatedGmres(linsys.LinearSystem(c["L"], b.real.copy()), U=U, tol=1e-10, maxiter=300)
+    check_run(s, g, "dgmres_realsys", tol=1e-8)
+
+
+CASES = [case_complex_kernels, case_complex_operator_algebra, case_complex_arnoldi, case_complex_solvers,
+         case_complex_deflation]

@@ -13,15 +13,43 @@ alternative backend, and the ``-m gpu`` tests never use it (they run the real HI
 import numpy as np
 import scipy.sparse as sp
 
+from krypy_amd._hip import BackendError
+
+
+def _bdt(dtype):
+    return np.dtype(np.complex128) if np.dtype(dtype).kind == "c" else np.dtype(np.float64)
+
+
+def _same(what, *blocks):
+    """As strict as the HIP library: real and complex blocks never mix in one call."""
+    dt = blocks[0].dtype
+    for b in blocks[1:]:
+        if b.dtype != dt:
+            raise BackendError("%s: real and complex device blocks mixed" % what)
+    return dt.kind == "c"
+
+
+def _coef(h, block, what):
+    h = np.asarray(h)
+    if block.dtype.kind != "c" and h.dtype.kind == "c":
+        if np.any(h.imag != 0):
+            raise BackendError("%s: complex coefficient for real device blocks" % what)
+        h = h.real
+    return h
+
 
 class NumpyVectors(object):
-    def __init__(self, ctx, n, ncols):
+    def __init__(self, ctx, n, ncols, dtype=float):
         self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
-        self.a = np.zeros((self.n, self.ncols), order="F")
+        self.dtype = _bdt(dtype)
+        self.a = np.zeros((self.n, self.ncols), order="F", dtype=self.dtype)
         self.handle = self
 
     def upload(self, col0, arr):
-        a = np.asarray(arr, dtype=float)
+        a = np.asarray(arr)
+        if self.dtype.kind != "c" and a.dtype.kind == "c":
+            raise BackendError("upload: complex data into a real device block")
+        a = np.asarray(a, dtype=self.dtype)
         if a.ndim == 1:
             a = a.reshape(-1, 1)
         assert a.shape[0] == self.n
@@ -37,6 +65,7 @@ class NumpyVectors(object):
         self.a[:, col0: col0 + ncols] = 0.0
 
     def copy_from(self, dcol, src, scol, ncols=1):
+        _same("copy_from", self, src)
         assert src.n == self.n
         self.a[:, dcol: dcol + ncols] = src.a[:, scol: scol + ncols]
 
@@ -44,7 +73,7 @@ class NumpyVectors(object):
         return self.a[i0: i0 + count, col].copy()
 
     def set(self, col, i0, values):
-        v = np.asarray(values, dtype=float).reshape(-1)
+        v = _coef(np.asarray(values).reshape(-1), self, "set")
         self.a[i0: i0 + v.size, col] = v
 
     def zero_range(self, col, i0, count):
@@ -54,6 +83,7 @@ class NumpyVectors(object):
 class NumpyMatrix(object):
     def __init__(self, ctx, kind, mat, shape):
         self.ctx, self.kind, self.mat, self.shape = ctx, kind, mat, shape
+        self.dtype = _bdt(mat.dtype)
         self.handle = self
         self.nnz = getattr(mat, "nnz", np.size(mat))
 
@@ -102,25 +132,34 @@ class NumpyContext(object):
         return self._allreduce(np.asarray(vals, dtype=float))
 
     # allocation
-    def alloc(self, n, ncols=1):
-        return NumpyVectors(self, n, ncols)
+    def alloc(self, n, ncols=1, dtype=float):
+        return NumpyVectors(self, n, ncols, dtype)
 
-    def upload(self, arr):
-        a = np.asarray(arr, dtype=float)
+    def upload(self, arr, dtype=None):
+        a = np.asarray(arr)
+        dt = _bdt(a.dtype if dtype is None else np.result_type(a.dtype, dtype))
         if a.ndim == 1:
             a = a.reshape(-1, 1)
-        return NumpyVectors(self, a.shape[0], a.shape[1]).upload(0, a)
+        return NumpyVectors(self, a.shape[0], a.shape[1], dt).upload(0, a)
 
-    def csr(self, A, n_cols=None):
+    def promote(self, X, xcol, Z, zcol, ncols=1):
+        if X.dtype.kind == "c" or Z.dtype.kind != "c":
+            raise BackendError("promote: real source and complex destination expected")
+        Z.a[:, zcol: zcol + ncols] = X.a[:, xcol: xcol + ncols]
+
+    def csr(self, A, n_cols=None, dtype=None):
         A = sp.csr_matrix(A)
+        A = A.astype(_bdt(A.dtype if dtype is None else np.result_type(A.dtype, dtype)))
         return NumpyMatrix(self, "csr", A, A.shape)
 
-    def dense(self, A):
-        A = np.ascontiguousarray(A, dtype=float)
+    def dense(self, A, dtype=None):
+        A = np.asarray(A)
+        A = np.ascontiguousarray(A, dtype=_bdt(A.dtype if dtype is None else np.result_type(A.dtype, dtype)))
         return NumpyMatrix(self, "dense", A, A.shape)
 
-    def diag(self, d):
-        d = np.ascontiguousarray(d, dtype=float)
+    def diag(self, d, dtype=None):
+        d = np.asarray(d)
+        d = np.ascontiguousarray(d, dtype=_bdt(d.dtype if dtype is None else np.result_type(d.dtype, dtype)))
         return NumpyMatrix(self, "diag", d, (d.size, d.size))
 
     # numerics
@@ -133,31 +172,38 @@ class NumpyContext(object):
 
     def apply(self, A, X, xcol, Y, ycol, ncols=1):
         self._count("apply")
+        if (A.dtype.kind == "c") != _same("apply", X, Y):
+            raise BackendError("apply: %s operator on %s blocks" % (A.dtype, X.dtype))
         for c in range(ncols):
             Y.a[:, ycol + c] = self._matvec(A, X.a[:, xcol + c])
 
     def dot_panel(self, V, j0, ncols, W, wcol):
         self._count("dot_panel")
-        return self._allreduce(V.a[:, j0: j0 + ncols].T.dot(W.a[:, wcol]))
+        _same("dot_panel", V, W)
+        return self._allreduce(V.a[:, j0: j0 + ncols].T.conj().dot(W.a[:, wcol]))
 
     def gemm_tn(self, X, x0, nx, Y, y0, ny):
         self._count("gemm_tn")
-        out = X.a[:, x0: x0 + nx].T.dot(Y.a[:, y0: y0 + ny])
+        _same("gemm_tn", X, Y)
+        out = X.a[:, x0: x0 + nx].T.conj().dot(Y.a[:, y0: y0 + ny])
         return self._allreduce(out.ravel()).reshape(nx, ny)
 
     def axpy_panel(self, V, j0, ncols, h, W, wcol):
         self._count("axpy_panel")
-        h = np.asarray(h, dtype=float).reshape(-1)
+        _same("axpy_panel", V, W)
+        h = _coef(np.asarray(h).reshape(-1), W, "axpy_panel")
         for j in range(ncols):
             W.a[:, wcol] = W.a[:, wcol] - h[j] * V.a[:, j0 + j]
 
     def gemm_nn(self, X, x0, k, C, alpha, beta, Y, y0):
         self._count("gemm_nn")
-        C = np.asarray(C, dtype=float)
+        _same("gemm_nn", X, Y)
+        C = _coef(C, Y, "gemm_nn")
+        alpha, beta = _coef(alpha, Y, "gemm_nn"), _coef(beta, Y, "gemm_nn")
         if C.ndim == 1:
             C = C.reshape(-1, 1)
         for c in range(C.shape[1]):
-            y = np.zeros(Y.n) if beta == 0.0 else beta * Y.a[:, y0 + c]
+            y = np.zeros(Y.n, dtype=Y.dtype) if beta == 0.0 else beta * Y.a[:, y0 + c]
             for i in range(k):
                 y = y + (alpha * C[i, c]) * X.a[:, x0 + i]
             Y.a[:, y0 + c] = y
@@ -165,10 +211,12 @@ class NumpyContext(object):
     def nrm2(self, W, wcol):
         self._count("nrm2")
         w = W.a[:, wcol]
-        return float(np.sqrt(self._allreduce(np.array([np.dot(w, w)]))[0]))
+        return float(np.sqrt(self._allreduce(np.array([np.vdot(w, w).real]))[0]))
 
     def waxpby(self, Z, zcol, alpha, X, xcol, beta, Y, ycol):
         self._count("waxpby")
+        _same("waxpby", Z, X, Y)
+        alpha, beta = _coef(alpha, Z, "waxpby"), _coef(beta, Z, "waxpby")
         a = X.a[:, xcol] if alpha == 1.0 else alpha * X.a[:, xcol]
         if beta == 0.0:
             Z.a[:, zcol] = a
@@ -177,14 +225,20 @@ class NumpyContext(object):
 
     def vdiv(self, Z, zcol, X, xcol, s):
         self._count("vdiv")
-        Z.a[:, zcol] = X.a[:, xcol] / s
+        _same("vdiv", Z, X)
+        Z.a[:, zcol] = X.a[:, xcol] / _coef(s, Z, "vdiv")
 
     def arnoldi_step(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
         """Semantics of kh_arnoldi_step (include/krylov_hip.h)."""
         self._count("arnoldi_step")
         B = P if P is not None else V
-        hcol = np.zeros(k + 2)
+        cplx = _same("arnoldi_step", V, W)
+        if cplx and (Md is not None or P is not None):
+            raise BackendError("arnoldi_step: the complex step takes no preconditioner")
+        hcol = np.zeros(k + 2, dtype=V.dtype)
         if A is not None:
+            if (A.dtype.kind == "c") != cplx:
+                raise BackendError("arnoldi_step: operator / block dtype mismatch")
             W.a[:, wcol] = self._matvec(A, V.a[:, k])
         w = W.a[:, wcol]
         if start > 0 and start == k:
@@ -192,11 +246,11 @@ class NumpyContext(object):
         for _ in range(sweeps):
             if gs_mode == 0:
                 for j in range(start, k + 1):
-                    alpha = self._allreduce(np.array([np.dot(V.a[:, j], w)]))[0]
+                    alpha = self._allreduce(np.array([np.vdot(V.a[:, j], w)]))[0]
                     hcol[j] += alpha
                     w = w - alpha * B.a[:, j]
             else:
-                h = self._allreduce(V.a[:, start: k + 1].T.dot(w))
+                h = self._allreduce(V.a[:, start: k + 1].T.conj().dot(w))
                 hcol[start: k + 1] += h
                 for j in range(start, k + 1):
                     w = w - h[j - start] * B.a[:, j]
@@ -209,7 +263,7 @@ class NumpyContext(object):
                 P.a[:, k + 1] = w / hn
                 V.a[:, k + 1] = mw / hn
         else:
-            hn = float(np.sqrt(self._allreduce(np.array([np.dot(w, w)]))[0]))
+            hn = float(np.sqrt(self._allreduce(np.array([np.vdot(w, w).real]))[0]))
             with np.errstate(divide="ignore", invalid="ignore"):
                 V.a[:, k + 1] = w / hn
         hcol[k + 1] = hn
@@ -231,6 +285,8 @@ class NumpyContext(object):
         self._slots[slot] = np.concatenate([hcol, ya])
 
     def proj_create(self, W, V, d, T, WRH, iterations):
+        if _same("proj_create", W, V):
+            raise BackendError("kh_proj is real only")
         class _P(object):
             pass
         p = _P()
@@ -259,18 +315,24 @@ class NumpyContext(object):
 
     def residual(self, A, B, bcol, X, xcol, R, rcol):
         self._count("residual")
+        if (A.dtype.kind == "c") != _same("residual", B, X, R):
+            raise BackendError("residual: operator / block dtype mismatch")
         r = B.a[:, bcol] - self._matvec(A, X.a[:, xcol])
         R.a[:, rcol] = r
-        return float(np.sqrt(self._allreduce(np.array([np.dot(r, r)]))[0]))
+        return float(np.sqrt(self._allreduce(np.array([np.vdot(r, r).real]))[0]))
 
     def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
         self._count("minres_update")
+        _same("minres_update", V, Wk, YK)
+        r0, r1, r2, y0 = (_coef(t, V, "minres_update") for t in (r0, r1, r2, y0))
         z = ((V.a[:, k] - r0 * Wk.a[:, slot]) - r1 * Wk.a[:, 1 - slot]) / r2
         Wk.a[:, slot] = z
         YK.a[:, ycol] = YK.a[:, ycol] + y0 * z
 
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
         self._count("cg_update")
+        if _same("cg_update", Pd, AP, YK, R):
+            raise BackendError("cg_update is real only")
         YK.a[:, ycol] = YK.a[:, ycol] + alpha * Pd.a[:, pcol]
         r = R.a[:, rcol] - alpha * AP.a[:, apcol]
         R.a[:, rcol] = r

@@ -1,0 +1,172 @@
+"""GPU tests of the complex (c128) kernels of libkrylov_hip (zpath.h), through the C ABI:
+edge sizes, mixed shapes, bit-level agreement of the complex CSR SpMV with SciPy, and the complex
+Arnoldi step against NumPy.  The solver-level complex parity cases run from tests/test_gpu_parity.py
+(tests/parity_cases_complex.py)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _crand(rng, *shape):
+    return rng.standard_normal(shape) + 1j * rng.standard_normal(shape)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 255, 4097, 100003, 1 << 20])
+def test_complex_vector_kernels_edge_sizes(hip, n):
+    rng = np.random.default_rng(n)
+    k = 19
+    X, w = _crand(rng, n, k), _crand(rng, n, 1)
+    Xd, Wd = hip.upload(X), hip.upload(w)
+    assert Xd.dtype == np.complex128 and Xd.n == n
+    assert np.array_equal(Xd.download(), X) and np.array_equal(Xd.download(3, 2), X[:, 3:5])
+    # <X, w> = X^H w
+    got = hip.dot_panel(Xd, 0, k, Wd, 0)
+    want = X.conj().T.dot(w)[:, 0]
+    assert np.allclose(got, want, rtol=1e-13, atol=1e-13 * np.sqrt(n) * 4)
+    G = hip.gemm_tn(Xd, 2, 5, Xd, 1, 3)
+    assert np.allclose(G, X[:, 2:7].conj().T.dot(X[:, 1:4]), rtol=1e-12, atol=1e-12 * n)
+    # 2-norm of the (re, im) view
+    assert abs(hip.nrm2(Wd, 0) - np.linalg.norm(w)) <= 1e-14 * np.linalg.norm(w) * 4
+    # w -= sum h_j X_j, left to right, NumPy's complex multiply (bit for bit)
+    h = _crand(rng, k)
+    ref = w[:, 0].copy()
+    for j in range(k):
+        ref = ref - h[j] * X[:, j]
+    hip.axpy_panel(Xd, 0, k, h, Wd, 0)
+    assert np.array_equal(Wd.download()[:, 0], ref)
+    # Y = beta Y + X C
+    C = _crand(rng, 7, 2)
+    Y0 = _crand(rng, n, 2)
+    Yd = hip.upload(Y0)
+    hip.gemm_nn(Xd, 4, 7, C, 1.0, 1.0, Yd, 0)
+    assert np.allclose(Yd.download(), Y0 + X[:, 4:11].dot(C), rtol=1e-13, atol=1e-13)
+    hip.gemm_nn(Xd, 4, 7, C, 2.0 - 1.0j, 0.0, Yd, 0)
+    assert np.allclose(Yd.download(), X[:, 4:11].dot((2.0 - 1.0j) * C), rtol=1e-13, atol=1e-13)
+    # z = alpha x + beta y, complex coefficients; real coefficients take the real kernel
+    a, b = 0.3 - 1.2j, -0.7 + 0.1j
+    Z = hip.alloc(n, 1, dtype=complex)
+    hip.waxpby(Z, 0, a, Xd, 0, b, Xd, 1)
+    assert np.allclose(Z.download()[:, 0], a * X[:, 0] + b * X[:, 1], rtol=1e-14, atol=1e-14)
+    hip.waxpby(Z, 0, 2.0, Xd, 0, -1.0, Xd, 1)
+    assert np.array_equal(Z.download()[:, 0], 2.0 * X[:, 0] - X[:, 1])
+    hip.vdiv(Z, 0, Xd, 2, 3.0)
+    assert np.array_equal(Z.download()[:, 0], X[:, 2] / 3.0)
+    hip.vdiv(Z, 0, Xd, 2, 1.0 + 2.0j)
+    assert np.allclose(Z.download()[:, 0], X[:, 2] / (1.0 + 2.0j), rtol=1e-14)
+    # widening a real block, element access, partial zero
+    R = rng.standard_normal((n, 2))
+    Rd = hip.upload(R)
+    hip.promote(Rd, 1, Z, 0, 1)
+    assert np.array_equal(Z.download()[:, 0], R[:, 1].astype(complex))
+    Z.set(0, n - 1, [5.0 - 2.0j])
+    assert Z.get(0, n - 1, 1)[0] == 5.0 - 2.0j
+    Z.zero_range(0, 0, n)
+    assert not Z.download().any()
+    with pytest.raises(Exception):
+        hip.dot_panel(Rd, 0, 1, Wd, 0)          # real and complex blocks never mix
+    with pytest.raises(Exception):
+        hip.axpy_panel(Rd, 0, 1, [1.0j], Rd, 1)  # complex coefficient for real blocks
+
+
+@pytest.mark.parametrize("kind", ["laplace", "random", "empty_rows", "long_row", "rect"])
+def test_complex_csr_spmv_bit_identical_to_scipy(hip, kind):
+    rng = np.random.default_rng(3)
+    if kind == "laplace":
+        from oracle.inputs import complex_systems
+        A = complex_systems(40)["nonh"]
+    elif kind == "random":
+        A = sp.random(3000, 3000, density=4e-3, random_state=3, format="csr")
+    elif kind == "empty_rows":
+        A = sp.random(5000, 5000, density=1e-3, random_state=4, format="csr")
+        A = sp.vstack([A[:100], sp.csr_matrix((300, 5000)), A[400:]]).tocsr()
+    elif kind == "long_row":
+        A = sp.random(300, 50000, density=1e-3, random_state=5, format="lil")
+        A[7, :] = rng.standard_normal(50000)
+        A = A.tocsr()
+    else:
+        A = sp.random(1000, 3000, density=5e-3, random_state=6, format="csr")
+    A = A.tocsr().astype(complex)
+    if kind != "laplace":
+        A.data = A.data + 1j * rng.standard_normal(A.nnz)
+    A.sort_indices()
+    x = _crand(rng, A.shape[1], 2)
+    Ad = hip.csr(A)
+    assert Ad.dtype == np.complex128
+    X, Y = hip.upload(x), hip.alloc(A.shape[0], 2, dtype=complex)
+    hip.apply(Ad, X, 0, Y, 0, 2)
+    got, want = Y.download(), A.dot(x)
+    if kind == "long_row":
+        mask = np.ones(A.shape[0], bool)
+        mask[7] = False
+        assert np.array_equal(got[mask], want[mask])
+        assert np.allclose(got[7], want[7], rtol=1e-12)
+    else:
+        assert np.array_equal(got, want)
+    # a real matrix uploaded for complex vectors
+    Ar = A.real.tocsr()
+    Ard = hip.csr(Ar, dtype=complex)
+    hip.apply(Ard, X, 0, Y, 0, 1)
+    assert np.allclose(Y.download()[:, 0], Ar.dot(x[:, 0]), rtol=1e-13, atol=1e-13)
+    with pytest.raises(Exception):
+        hip.apply(hip.csr(Ar), X, 0, Y, 0, 1)    # real operator, complex blocks
+
+
+def test_complex_dense_gemv_and_diag(hip):
+    rng = np.random.default_rng(2)
+    for n, m in ((1, 1), (37, 41), (512, 512), (1000, 999)):
+        A, x = _crand(rng, n, m), _crand(rng, m, 1)
+        Y = hip.alloc(n, 1, dtype=complex)
+        hip.apply(hip.dense(A), hip.upload(x), 0, Y, 0, 1)
+        assert np.allclose(Y.download(), A.dot(x), rtol=1e-13, atol=1e-12)
+    d, x = _crand(rng, 777), _crand(rng, 777, 1)
+    Y = hip.alloc(777, 1, dtype=complex)
+    hip.apply(hip.diag(d), hip.upload(x), 0, Y, 0, 1)
+    assert np.array_equal(Y.download()[:, 0], d * x[:, 0])
+
+
+@pytest.mark.parametrize("mode", ["mgs", "dmgs", "cgs", "lanczos"])
+def test_complex_arnoldi_step_against_numpy(hip, mode):
+    """kh_zarnoldi_step, step by step, against the same recurrence in NumPy (1e-12)."""
+    from krypy_amd import _hip
+    from oracle.inputs import complex_systems
+
+    c = complex_systems(40)
+    A = c["hind"] if mode == "lanczos" else c["nonh"]
+    N, m = A.shape[0], 20
+    rng = np.random.default_rng(1)
+    v = _crand(rng, N)
+    V = np.zeros((N, m + 1), dtype=complex, order="F")
+    V[:, 0] = v / np.linalg.norm(v)
+    Vd = hip.alloc(N, m + 1, dtype=complex)
+    Vd.upload(0, V[:, [0]])
+    Wd = hip.alloc(N, 2, dtype=complex)
+    Ad = hip.csr(A)
+    sweeps = 2 if mode == "dmgs" else 1
+    gs = _hip.GS_CGS if mode == "cgs" else _hip.GS_MGS
+    H = np.zeros((m + 1, m), dtype=complex)
+    for k in range(m):
+        start = k if mode == "lanczos" else 0
+        hk = H[k, k - 1] if (mode == "lanczos" and k > 0) else 0.0
+        hcol = hip.arnoldi_step(Ad, None, Vd, None, Wd, 0, k, start, sweeps, gs, hk)
+        w = A.dot(V[:, k])
+        if mode == "lanczos" and k > 0:
+            w = w - hk * V[:, k - 1]
+            H[k - 1, k] = hk
+        for _ in range(sweeps):
+            if mode == "cgs":
+                h = V[:, : k + 1].conj().T.dot(w)
+                H[: k + 1, k] += h
+                for j in range(k + 1):
+                    w = w - h[j] * V[:, j]
+            else:
+                for j in range(start, k + 1):
+                    a = np.vdot(V[:, j], w)
+                    H[j, k] += a
+                    w = w - a * V[:, j]
+        H[k + 1, k] = np.linalg.norm(w)
+        V[:, k + 1] = w / H[k + 1, k]
+        assert hcol.shape == (k + 2,) and hcol[k + 1].imag == 0.0
+        assert np.allclose(hcol[start:], H[start: k + 2, k], rtol=1e-11, atol=1e-12), (mode, k)
+    assert np.linalg.norm(Vd.download() - V) < 1e-10

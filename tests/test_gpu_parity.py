@@ -9,6 +9,7 @@ import scipy.sparse as sp
 from oracle import krylov_ref as ref
 from oracle.inputs import lap2d_system
 from tests import parity_cases as pc
+from tests import parity_cases_complex as pcc
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +21,7 @@ SIMPLE = [
     pc.case_minres_cg_sparse, pc.case_cg_dense, pc.case_deflated_gmres_recycling,
     pc.case_recycling_gmres_lap3d, pc.case_recycling_factories_toy, pc.case_inner_product_matrix_B,
     pc.case_solver_zoo, pc.case_ritz, pc.case_arnoldi_house,
-]
+] + pcc.CASES
 
 
 def test_native_library_is_the_one_running(hip):

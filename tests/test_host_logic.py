@@ -9,6 +9,7 @@ the kernels themselves are proven by the same cases in tests/test_gpu_parity.py 
 import pytest
 
 from tests import parity_cases as pc
+from tests import parity_cases_complex as pcc
 
 SIMPLE = [
     pc.case_toy_known_answers, pc.case_toy_custom_inner_product, pc.case_toy_deflated,
@@ -18,7 +19,7 @@ SIMPLE = [
     pc.case_minres_cg_sparse, pc.case_cg_dense, pc.case_deflated_gmres_recycling,
     pc.case_recycling_gmres_lap3d, pc.case_recycling_factories_toy, pc.case_inner_product_matrix_B,
     pc.case_solver_zoo, pc.case_ritz, pc.case_arnoldi_house,
-]
+] + pcc.CASES
 
 
 @pytest.mark.parametrize("case", SIMPLE, ids=lambda f: f.__name__)

@@ -230,3 +230,53 @@ def test_deflated_gmres_recycling(golden):
     assert rel(s1.C, g["s1_C"]) < 1e-8
     assert rel(s1.UMlr, g["s1_UMlr"][:, 0]) < RTOL
     assert rel(s1.xk, g["s1_xk"]) < 1e-9
+
+
+def test_complex_oracle_pinned(golden):
+    """The complex part of the oracle (oracle/krylov_ref_c.py) against the reference's outputs on the
+    seeded complex systems (tests/golden/complex_nx24.npz, made by oracle/gen_golden.py)."""
+    from oracle import krylov_ref_c as kc
+    from oracle.inputs import complex_systems
+
+    g = golden("complex_nx24")
+    c = complex_systems(24)
+    b = c["b"]
+
+    def check(tag, x, res, tol=RTOL):
+        want = g[tag + "_resnorms"]
+        assert len(res) == len(want), tag
+        assert np.max(np.abs(res[:-1] - want[:-1]) / want[:-1]) < tol, tag
+        assert abs(res[-1] - want[-1]) / want[-1] < 1e-6, tag            # explicit residual: cancellation
+        assert np.linalg.norm(x - g[tag + "_xk"]) / np.linalg.norm(x) < 1e-10, tag
+
+    x, res, H, R = kc.gmres(c["nonh"], b, tol=1e-10, maxiter=300)
+    check("gmres", x, res)
+    # (leading columns: the tiny top entries of late columns are rounding noise of MGS itself)
+    assert np.abs(H[:26, :25] - g["gmres_H"][:26, :25]).max() < 1e-10
+    assert np.abs(R[:25, :25] - g["gmres_R"][:25, :25]).max() < 1e-10
+    x, res, _, _ = kc.gmres(c["nonh"], b, x0=c["x0"], tol=1e-10, maxiter=300)
+    check("gmres_x0", x, res)
+    x, res, _, _ = kc.gmres(c["L"], b, tol=1e-10, maxiter=300)
+    check("gmres_realA", x, res)
+    x, res, _, _ = kc.gmres(c["nonh"], b.real.copy(), tol=1e-10, maxiter=300)
+    check("gmres_realb", x, res)
+    x, res = kc.minres(c["hind"], b, tol=1e-10, maxiter=600)
+    check("minres", x, res)
+    x, res = kc.cg(c["hpd"], b, tol=1e-10, maxiter=300)
+    check("cg", x, res)
+    d = np.asarray(c["hpd"].diagonal()).real
+    M = sp.diags(1.0 / d).tocsr()
+    x, res = kc.cg(c["hpd"], b, tol=1e-10, maxiter=300, M=M)
+    check("cg_jacobi", x, res)
+    x, res = kc.minres(c["hind"], b, tol=1e-10, maxiter=600, M=M)
+    check("minres_jacobi", x, res)
+    x, res, _, _ = kc.gmres(c["nonh"], b, tol=1e-10, maxiter=300, M=M)
+    check("gmres_jacobi", x, res)
+    for ortho, A in (("mgs", c["nonh"]), ("dmgs", c["nonh"]), ("lanczos", c["hind"])):
+        V, H, _, _ = kc.arnoldi(A, b, 12, ortho)
+        assert np.abs(V - g["arn_%s_V" % ortho]).max() < 1e-12
+        assert np.abs(H - g["arn_%s_H" % ortho]).max() < 1e-12
+    for row in g["givens"]:
+        cc, s, r = kc.givens(row[0], row[1])
+        assert abs(cc - row[2]) < 1e-15 and abs(s - row[3]) < 1e-15
+        assert abs(r - row[4]) <= 1e-15 * max(1.0, abs(row[4]))
