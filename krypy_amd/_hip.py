@@ -526,10 +526,16 @@ class Context(object):
                 C = C.reshape(-1, 1)
             if numpy.imag(beta) != 0:
                 raise BackendError("gemm_nn: beta must be real")
-            C, cp = _zarr(C * alpha)
-            _check(self._lib, self._lib.kh_zgemm_nn(self._h, X.handle, x0, k, cp, C.shape[1],
-                                                    float(numpy.real(beta)), Y.handle, y0),
-                   "kh_zgemm_nn")
+            C = numpy.asarray(C * alpha, dtype=numpy.complex128)
+            done, b = 0, float(numpy.real(beta))
+            while True:                       # kh_zgemm_nn takes at most 512 columns of X per call
+                m = min(512, k - done)
+                Cc, cp = _zarr(C[done:done + m])
+                _check(self._lib, self._lib.kh_zgemm_nn(self._h, X.handle, x0 + done, m, cp, C.shape[1],
+                                                        b, Y.handle, y0), "kh_zgemm_nn")
+                done, b = done + m, 1.0
+                if done >= k:
+                    break
             return
         C = _real_coeffs(C, "gemm_nn")
         if C.ndim == 1:
