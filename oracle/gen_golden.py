@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import refshim  # noqa: E402
 from oracle.inputs import (  # noqa: E402
     toy_system, lap2d_system, minres_jacobi_system, dense_spd_system, lap3d_system,
-    kernel_panel, complex_systems, complex_panel,
+    kernel_panel, complex_systems, complex_panel, run_solver_matrix,
 )
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -340,6 +340,20 @@ def gen_complex(krypy, nx=24):
     save("complex_nx%d" % nx, nx=nx, **out)
 
 
+def gen_solver_matrix(krypy):
+    """Outcome of every solve of the reference's solver test matrix (oracle.inputs.run_solver_matrix):
+    len(resnorms) (negated when the solve ended in a ConvergenceError) and the last residual norm."""
+    n_res, last = {}, {}
+
+    def visit(idx, name, Solver, ls, params, sol, failed, A, B, M, Ml):
+        n_res[idx] = -len(sol.resnorms) if failed else len(sol.resnorms)
+        last[idx] = sol.resnorms[-1]
+
+    total = run_solver_matrix(krypy.linsys, krypy.utils.ConvergenceError, visit)
+    save("solver_matrix", n_res=np.array([n_res[i] for i in range(total)], dtype=np.int32),
+         last=np.array([last[i] for i in range(total)]))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -355,6 +369,7 @@ def main():
     gen_deflation(krypy)
     gen_ipB(krypy)
     gen_complex(krypy)
+    gen_solver_matrix(krypy)
 
 
 if __name__ == "__main__":

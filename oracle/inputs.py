@@ -81,3 +81,86 @@ def complex_panel(N, k, seed):
     X = rng.standard_normal((N, k)) + 1j * rng.standard_normal((N, k))
     w = rng.standard_normal((N, 1)) + 1j * rng.standard_normal((N, 1))
     return X, w
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's solver test matrix (test/test_linsys.py:50-143, test/test_utils.py:14-58)
+# ---------------------------------------------------------------------------------------------
+def zoo_matrices():
+    """The six 10 x 10 matrices of the reference's tests (test_utils.py:14-58) with their flags."""
+    spd = np.linspace(1, 2, 10)
+    spd[-1] = 1e-2
+    hpd = np.array(np.linspace(1, 2, 10), dtype=complex)
+    hpd[0], hpd[-1] = 5, 1e-1
+    Ahpd = np.diag(hpd)
+    Ahpd[-1, 0], Ahpd[0, -1] = 1e-1j, -1e-1j
+    ind = np.linspace(1, 2, 10)
+    ind[-1] = -1
+    hind = np.array(np.linspace(1, 2, 10), dtype=complex)
+    hind[-1] = 1e-3
+    Ahind = np.diag(hind)
+    Ahind[-1, 0], Ahind[0, -1] = 10j, -10j
+    non = np.diag(np.arange(1, 11, dtype=float))
+    non[-1, -1], non[0, -1] = -1e1, 1e1
+    cnon = np.diag(np.arange(1, 11, dtype=complex))
+    cnon[-1, -1], cnon[0, -1] = -1e1, 1.0e1j
+    pd = dict(normal=True, self_adjoint=True, positive_definite=True)
+    sa = dict(normal=True, self_adjoint=True)
+    return [("spd", np.diag(spd), pd), ("hpd", Ahpd, pd), ("symm_indef", np.diag(ind), sa),
+            ("herm_indef", Ahind, sa), ("nonsymm", non, {}), ("comp_nonsymm", cnon, {})]
+
+
+def run_solver_matrix(linsys, ConvergenceError, visit, stride=1, offset=0):
+    """Drive ``linsys`` (the reference's module or krypy_amd's) through the reference's solver test
+    matrix - with the preconditioners really passed to LinearSystem, which the reference's own
+    generator forgets (test_linsys.py:91-97 yields **ls_kwargs) - and call
+    ``visit(idx, name, Solver, ls, params, sol, failed, A, B, M, Ml)`` for every solve.  Solve
+    ``idx`` is carried out only if ``idx % stride == offset``; returns the total number of cases."""
+    import itertools
+    import warnings
+
+    idx = 0
+    xs = [np.ones((10, 1)), np.ones((10,)), (1 + 1j) * np.ones((10, 1)), np.zeros((10, 1))]
+    for name, A0, flags in zoo_matrices():
+        for B, x in itertools.product([None, np.diag(np.arange(1.0, 11.0))], xs):
+            A = np.linalg.inv(B).dot(A0) if (B is not None and flags.get("self_adjoint")) else A0
+            Ainv = np.linalg.inv(A)
+            Ms, Mls, Mrs = [None], [None, Ainv], [None, Ainv]
+            if flags.get("positive_definite"):
+                Ms.append(Ainv)
+            if np.linalg.norm(np.diag(np.diag(A)) - A) == 0 and B is None:
+                Ms.append(np.diag(np.linspace(1, 10, 10)))
+            for exact in (None, x):
+                for M, Ml, Mr in itertools.product(Ms, Mls, Mrs):
+                    kw = dict(flags)
+                    kw.update(M=M, Ml=Ml, Mr=Mr)
+                    if M is not None:
+                        kw["Minv"] = np.linalg.inv(M)
+                    ls = None
+                    solvers = ["Gmres", "RestartedGmres"]
+                    if flags.get("self_adjoint"):
+                        solvers.append("Minres")
+                    if flags.get("positive_definite"):
+                        solvers.append("Cg")
+                    b = A.dot(x)
+                    x0s = [None, np.zeros(b.shape), np.ones(b.shape)]
+                    if exact is not None:
+                        x0s.append(exact)
+                    for sname, x0, tol in itertools.product(solvers, x0s, (1e-13, 1e-2)):
+                        if idx % stride == offset:
+                            if ls is None:
+                                ls = linsys.LinearSystem(A, b, ip_B=B, exact_solution=exact, **kw)
+                            Solver = getattr(linsys, sname)
+                            params = dict(x0=x0, tol=tol, maxiter=15)
+                            if sname == "RestartedGmres":
+                                params.update(maxiter=7, max_restarts=20)
+                            failed = False
+                            with warnings.catch_warnings():
+                                warnings.simplefilter("ignore")
+                                try:
+                                    sol = Solver(ls, **params)
+                                except ConvergenceError as e:
+                                    sol, failed = e.solver, True
+                            visit(idx, name, Solver, ls, params, sol, failed, A, B, M, Ml)
+                        idx += 1
+    return idx

@@ -365,3 +365,11 @@ def test_sharded_deflated_gmres_through_rccl_path_on_one_gpu(hip):
     finally:
         _hip._install_context_for_testing(old)
         ctx.close()
+
+
+def test_reference_solver_matrix(hip):
+    """All 13,216 solves of the reference's solver test matrix (6 matrices, 3 of them complex, x inner
+    products x right-hand sides x preconditioners x solvers x parameters) against the reference's own
+    outcomes (tests/golden/solver_matrix.npz)."""
+    stats = pcc.case_reference_solver_matrix()
+    assert stats["n"] == 13216

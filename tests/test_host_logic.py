@@ -52,3 +52,11 @@ def test_gmres_issues_one_device_call_per_iteration(cpu_double):
         pass
     assert cpu_double.calls.get("arnoldi_step") == 30
     assert cpu_double.calls.get("dot_panel", 0) == 0 and cpu_double.calls.get("axpy_panel", 0) == 0
+
+
+def test_reference_solver_matrix(cpu_double):
+    """All 13,216 solves of the reference's solver test matrix (6 matrices, 3 of them complex, x inner
+    products x right-hand sides x preconditioners x solvers x parameters) against the reference's own
+    outcomes (tests/golden/solver_matrix.npz)."""
+    stats = pcc.case_reference_solver_matrix()
+    assert stats["n"] == 13216
