@@ -110,12 +110,14 @@ def zoo_matrices():
             ("herm_indef", Ahind, sa), ("nonsymm", non, {}), ("comp_nonsymm", cnon, {})]
 
 
-def run_solver_matrix(linsys, ConvergenceError, visit, stride=1, offset=0):
+def run_solver_matrix(linsys, ConvergenceError, visit, stride=1, offset=0, perturb=0.0):
     """Drive ``linsys`` (the reference's module or krypy_amd's) through the reference's solver test
     matrix - with the preconditioners really passed to LinearSystem, which the reference's own
     generator forgets (test_linsys.py:91-97 yields **ls_kwargs) - and call
     ``visit(idx, name, Solver, ls, params, sol, failed, A, B, M, Ml)`` for every solve.  Solve
-    ``idx`` is carried out only if ``idx % stride == offset``; returns the total number of cases."""
+    ``idx`` is carried out only if ``idx % stride == offset``; returns the total number of cases.
+    ``perturb`` scales entry i of every right-hand side by ``1 + perturb*i`` (the fixture generator
+    uses 1e-15 to find the solves whose outcome is rounding-chaotic in the reference itself)."""
     import itertools
     import warnings
 
@@ -143,6 +145,8 @@ def run_solver_matrix(linsys, ConvergenceError, visit, stride=1, offset=0):
                     if flags.get("positive_definite"):
                         solvers.append("Cg")
                     b = A.dot(x)
+                    if perturb:
+                        b = b * (1.0 + perturb * np.arange(10).reshape(b.shape))
                     x0s = [None, np.zeros(b.shape), np.ones(b.shape)]
                     if exact is not None:
                         x0s.append(exact)
