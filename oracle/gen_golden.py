@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import refshim  # noqa: E402
 from oracle.inputs import (  # noqa: E402
     toy_system, lap2d_system, minres_jacobi_system, dense_spd_system, lap3d_system,
-    kernel_panel, complex_systems, complex_panel, run_solver_matrix,
+    kernel_panel, complex_systems, complex_panel, run_solver_matrix, run_deflation_matrix,
 )
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -363,6 +363,29 @@ def gen_solver_matrix(krypy):
     save("solver_matrix", n_res=n0, last=l0, stable=stable)
 
 
+def gen_deflation_matrix(krypy):
+    """Outcomes of the reference on its deflated-solver test matrix: len(resnorms) (negative:
+    ConvergenceError), last residual norm, Frobenius norms of E, C, B_ and the Ritz values."""
+    rows = {}
+
+    def visit(idx, name, Solver, ls, sol, failed, A, B):
+        n = -len(sol.resnorms) if failed else len(sol.resnorms)
+        rv = np.sort(np.abs(krypy.deflation.Ritz(sol, mode="ritz").values)) if sol.H.shape[1] + \
+            sol.projection.U.shape[1] > 0 else np.zeros(0)
+        rows[idx] = (n, sol.resnorms[-1], np.linalg.norm(sol.E), np.linalg.norm(sol.C),
+                     np.linalg.norm(sol.B_[: sol.H.shape[1]]), rv)   # (last row: a noise direction
+        #                                   when the Krylov space is numerically invariant)
+
+    total = run_deflation_matrix(krypy.linsys, krypy.deflation, krypy.utils.ConvergenceError, visit)
+    ritz = np.full((total, 12), np.nan)
+    for i in range(total):
+        rv = rows[i][5]
+        ritz[i, : len(rv)] = rv[:12]
+    save("deflation_matrix", n_res=np.array([rows[i][0] for i in range(total)], dtype=np.int32),
+         last=np.array([rows[i][1] for i in range(total)]),
+         norms=np.array([rows[i][2:5] for i in range(total)]), ritz_abs=ritz)
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -379,6 +402,7 @@ def main():
     gen_ipB(krypy)
     gen_complex(krypy)
     gen_solver_matrix(krypy)
+    gen_deflation_matrix(krypy)
 
 
 if __name__ == "__main__":

@@ -168,3 +168,39 @@ def run_solver_matrix(linsys, ConvergenceError, visit, stride=1, offset=0, pertu
                             visit(idx, name, Solver, ls, params, sol, failed, A, B, M, Ml)
                         idx += 1
     return idx
+
+
+def run_deflation_matrix(linsys, deflation, ConvergenceError, visit):
+    """The reference's deflated-solver test matrix (test/test_deflation.py:13-41): the six matrices
+    x inner products x right-hand sides x exact solution x U in {None, e_1, e_1 + 1e-3} x
+    Deflated{Gmres,Minres,Cg}, tol 1e-6, maxiter 15, store_arnoldi.  (Unpreconditioned, exactly as
+    the reference's generator produces them.)  Calls ``visit(idx, name, Solver, ls, sol, failed, A, B)``;
+    returns the number of cases."""
+    import itertools
+    import warnings
+
+    idx = 0
+    xs = [np.ones((10, 1)), np.ones((10,)), (1 + 1j) * np.ones((10, 1)), np.zeros((10, 1))]
+    Us = [None, np.eye(10, 1), np.eye(10, 1) + 1e-3 * np.ones((10, 1))]
+    for name, A0, flags in zoo_matrices():
+        for B, x in itertools.product([None, np.diag(np.arange(1.0, 11.0))], xs):
+            A = np.linalg.inv(B).dot(A0) if (B is not None and flags.get("self_adjoint")) else A0
+            for exact in (None, x):
+                ls = linsys.LinearSystem(A, A.dot(x), ip_B=B, exact_solution=exact, **flags)
+                solvers = ["DeflatedGmres"]
+                if flags.get("self_adjoint"):
+                    solvers.append("DeflatedMinres")
+                if flags.get("positive_definite"):
+                    solvers.append("DeflatedCg")
+                for U, sname in itertools.product(Us, solvers):
+                    Solver = getattr(deflation, sname)
+                    failed = False
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        try:
+                            sol = Solver(ls, U=U, x0=None, tol=1e-6, maxiter=15, store_arnoldi=True)
+                        except ConvergenceError as e:
+                            sol, failed = e.solver, True
+                    visit(idx, name, Solver, ls, sol, failed, A, B)
+                    idx += 1
+    return idx

@@ -281,3 +281,64 @@ def case_reference_solver_matrix(stride=1, offset=0):
     assert stats["loose"] <= max(3, stats["n"] // 200), stats
     print("solver matrix:", stats)
     return stats
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's deflated-solver test matrix (test/test_deflation.py:13-125): 576 solves, real and
+# complex, against the reference's recorded outcomes + the identities its test asserts
+# (E = <U, A U>, C = <U, A V_n>, B_ = <V, AU>, Ritz pairs), recomputed in NumPy.
+# ---------------------------------------------------------------------------------------------
+def case_reference_deflation_matrix():
+    from oracle.inputs import run_deflation_matrix
+
+    g = golden("deflation_matrix")
+    stats = dict(n=0, borderline=0)
+
+    def ipB(X, Y, B):
+        return X.conj().T.dot(Y if B is None else B.dot(Y))
+
+    def check(idx, name, Solver, ls, sol, failed, A, B):
+        tag = (idx, name, Solver.__name__, B is not None)
+        n_res = -len(sol.resnorms) if failed else len(sol.resnorms)
+        if n_res != g["n_res"][idx]:
+            # a residual sitting on tol = 1e-6 may stop one step earlier / later
+            assert abs(abs(n_res) - abs(int(g["n_res"][idx]))) <= 1, (tag, n_res, int(g["n_res"][idx]))
+            stats["borderline"] += 1
+        else:
+            # (a final residual far below tol = 1e-6 is the rounding floor of the last step)
+            assert abs(sol.resnorms[-1] - g["last"][idx]) <= 1e-5 * g["last"][idx] + 1e-10, \
+                (tag, sol.resnorms[-1], g["last"][idx])
+            want = g["norms"][idx]
+            got = np.array([np.linalg.norm(sol.E), np.linalg.norm(sol.C),
+                            np.linalg.norm(sol.B_[: sol.H.shape[1]])])
+            # (short recurrences lose orthogonality on the ill-conditioned matrices: C, B_ of
+            # DeflatedMinres / DeflatedCg carry that drift; full orthogonalisation does not)
+            rt = 1e-6 if isinstance(sol, linsys.Gmres) else 2e-3
+            assert np.all(np.abs(got - want) <= rt * (1.0 + np.abs(want))), (tag, got, want)
+        stats["n"] += 1
+        # test_deflation.py:49-73
+        U, AU, V = sol.projection.U, sol.projection.AU, sol.V
+        n_, n = sol.H.shape
+        assert np.allclose(sol.E, ipB(U, A.dot(U), B), atol=1e-6), tag
+        assert np.allclose(sol.C, ipB(U, A.dot(V[:, :n]), B), atol=1e-6), tag
+        assert np.allclose(sol.B_, ipB(V, AU, B), atol=1e-6), tag
+        assert np.allclose(AU, A.dot(U), atol=1e-12), tag
+        # Ritz pairs (test_deflation.py:76-125): values against the reference's, vectors have unit
+        # coefficient norm and the claimed residuals
+        m = U.shape[1]
+        if n + m > 0:
+            r = deflation.Ritz(sol, mode="ritz")
+            mine = np.sort(np.abs(r.values))[:12]
+            want = g["ritz_abs"][idx][: len(mine)]
+            if n_res == g["n_res"][idx] and isinstance(sol, linsys.Gmres):
+                assert np.allclose(mine, want, rtol=1e-5, atol=1e-7), (tag, mine, want)
+            Z = r.get_vectors()
+            assert Z.shape == (10, n + m) and np.all(np.isfinite(Z)), tag
+            Zc = np.column_stack([V[:, :n], U]).dot(r.coeffs)
+            assert np.allclose(Z, Zc, atol=1e-10), tag
+
+    total = run_deflation_matrix(linsys, deflation, utils.ConvergenceError, check)
+    assert total == len(g["n_res"]) == 576
+    assert stats["borderline"] <= 6, stats
+    print("deflation matrix:", stats)
+    return stats

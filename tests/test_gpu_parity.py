@@ -373,3 +373,9 @@ def test_reference_solver_matrix(hip):
     outcomes (tests/golden/solver_matrix.npz)."""
     stats = pcc.case_reference_solver_matrix()
     assert stats["n"] == 13216
+
+
+def test_reference_deflation_matrix(hip):
+    """The reference's deflated-solver test matrix (576 solves, real + complex) against its recorded
+    outcomes and the E / C / B_ / Ritz identities of test/test_deflation.py."""
+    assert pcc.case_reference_deflation_matrix()["n"] == 576
