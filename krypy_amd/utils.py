@@ -30,6 +30,7 @@ __all__ = [
     "ZeroLinearOperator", "Projection", "arnoldi", "arnoldi_res", "find_common_dtype",
     "get_linearoperator", "inner", "ip_euclid", "norm", "norm_squared", "orthonormality", "qr",
     "shape_vec", "shape_vecs", "DVec", "Timer", "Timings", "TimedLinearOperator", "ritz",
+    "hegedus", "angles",
 ]
 
 
@@ -313,6 +314,75 @@ def arnoldi_res(A, V, H, ip_B=None):
     A = get_linearoperator((N, N), A)
     res = A * (V if invariant else V[:, :-1]) - numpy.dot(V, H)
     return norm(res, ip_B=ip_B)
+
+
+def hegedus(A, b, x0, M=None, Ml=None, ip_B=None):
+    r"""Rescale an initial guess (Hegedues trick, utils.py:812-851).
+
+    Returns :math:`\gamma_{\min} x_0` with
+    :math:`\gamma_{\min} = \langle z, M M_l b\rangle_{M^{-1}} / \|z\|_{M^{-1}}^2`, :math:`z = M M_l A x_0`,
+    which minimises :math:`\|M M_l (b - A \gamma x_0)\|_{M^{-1}}` over :math:`\gamma`; the zero
+    vector if :math:`\|z\|^2 \le 10^{-15}`.  Same arguments as the solvers take.  The three operator
+    applications and the two inner products run on the device; the result is a host ``(N,1)`` array.
+    """
+    N = len(b)
+    A = get_linearoperator((N, N), A)
+    M = get_linearoperator((N, N), M)
+    Ml = get_linearoperator((N, N), Ml)
+    x0 = numpy.asarray(x0)
+    dt = _bdt(A.dtype, M.dtype, Ml.dtype, x0.dtype, numpy.asarray(b).dtype)
+    MlAx0 = Ml * (A * DVec.from_host(x0, dtype=dt))
+    z = M * MlAx0
+    znorm2 = inner(z, MlAx0, ip_B=ip_B)
+    if znorm2 <= 1e-15:
+        return numpy.zeros((N, 1))
+    gamma = inner(z, Ml * DVec.from_host(shape_vec(numpy.asarray(b)) if numpy.ndim(b) == 1 else b,
+                                         dtype=dt), ip_B=ip_B) / znorm2
+    return gamma * x0
+
+
+def angles(F, G, ip_B=None, compute_vectors=False):
+    r"""Principal angles between the subspaces spanned by ``F`` (N,k) and ``G`` (N,l)
+    (utils.py:710-809; Knyazev & Argentati 2002, algorithm 6.2: cosines for large angles, sines
+    of the residual for small ones).
+
+    :return: ``theta`` (``max(k,l)`` angles, ascending, in :math:`[0,\pi/2]`), and with
+      ``compute_vectors`` also the principal vectors ``U`` (from F) and ``V`` (from G).
+
+    Orthonormalisations and the Gram matrices go through :func:`qr` / :func:`inner` (device); the
+    SVDs are of ``k x l`` matrices on the host.
+    """
+    swapped = F.shape[1] < G.shape[1]
+    if swapped:                      # work with the wider block first
+        F, G = G, F
+    k, l = F.shape[1], G.shape[1]
+    QF, _ = qr(F, ip_B=ip_B)
+    QG, _ = qr(G, ip_B=ip_B)
+    half_pi = numpy.pi / 2
+    if l == 0:
+        theta, U, V = numpy.full(k, half_pi), QF, QG
+    else:
+        Y, cosines, Zh = scipy.linalg.svd(inner(QF, QG, ip_B=ip_B))
+        Vcos = QG.dot(Zh.T.conj())
+        small = int(numpy.count_nonzero(cosines ** 2 >= 0.5))       # angles below 45 degrees
+        theta = numpy.concatenate([numpy.arccos(cosines[small:]), numpy.full(k - l, half_pi)])
+        if compute_vectors:
+            Ucos = QF.dot(Y)
+            U, V = Ucos[:, small:], Vcos[:, small:]
+        if small > 0:
+            # small angles from the sines: the part of the G-side vectors outside span(F)
+            RG = Vcos[:, :small]
+            _, Rs = qr(RG - QF.dot(inner(QF, RG, ip_B=ip_B)), ip_B=ip_B)
+            _, sines, Zh2 = scipy.linalg.svd(Rs)
+            theta = numpy.concatenate([numpy.arcsin(sines[::-1][:small]), theta])
+            if compute_vectors:
+                c = cosines[:small]
+                rot = numpy.diag(1.0 / c).dot(Zh2.T.conj().dot(numpy.diag(c)))
+                U = numpy.column_stack([Ucos[:, :small].dot(rot), U])
+                V = numpy.column_stack([RG.dot(Zh2.T.conj()), V])
+    if not compute_vectors:
+        return theta
+    return (theta, V, U) if swapped else (theta, U, V)
 
 
 # ----------------------------------------------------------------------------------------

@@ -10,6 +10,7 @@ from oracle import krylov_ref as ref
 from oracle.inputs import lap2d_system
 from tests import parity_cases as pc
 from tests import parity_cases_complex as pcc
+from tests import parity_cases_utils as pcu
 
 pytestmark = pytest.mark.gpu
 
@@ -379,3 +380,10 @@ def test_reference_deflation_matrix(hip):
     """The reference's deflated-solver test matrix (576 solves, real + complex) against its recorded
     outcomes and the E / C / B_ / Ritz identities of test/test_deflation.py."""
     assert pcc.case_reference_deflation_matrix()["n"] == 576
+
+
+@pytest.mark.parametrize("case", pcu.CASES, ids=lambda f: f.__name__)
+def test_reference_utils_matrix(hip, case):
+    """The reference's utils test matrix (test/test_utils.py: House, Givens, Projection, qr, angles,
+    hegedus, Arnoldi in every ortho mode, Ritz pairs) on real AND complex matrices."""
+    assert case() > 20

@@ -10,6 +10,7 @@ import pytest
 
 from tests import parity_cases as pc
 from tests import parity_cases_complex as pcc
+from tests import parity_cases_utils as pcu
 
 SIMPLE = [
     pc.case_toy_known_answers, pc.case_toy_custom_inner_product, pc.case_toy_deflated,
@@ -66,3 +67,10 @@ def test_reference_deflation_matrix(cpu_double):
     """The reference's deflated-solver test matrix (576 solves, real + complex) against its recorded
     outcomes and the E / C / B_ / Ritz identities of test/test_deflation.py."""
     assert pcc.case_reference_deflation_matrix()["n"] == 576
+
+
+@pytest.mark.parametrize("case", pcu.CASES, ids=lambda f: f.__name__)
+def test_reference_utils_matrix(cpu_double, case):
+    """The reference's utils test matrix (test/test_utils.py: House, Givens, Projection, qr, angles,
+    hegedus, Arnoldi in every ortho mode, Ritz pairs) on real AND complex matrices."""
+    assert case() > 20
