@@ -198,6 +198,15 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
                  kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
                  double* rho_new);
 
+/* One whole CG iteration (linsys.py:622-665) in one call, one host synchronisation:
+ *   p = z + omega*p (skipped when `first`);  Ap = A p;  pAp = <p, Ap>;  alpha = rho / pAp (on the
+ *   device);  yk += alpha p;  r -= alpha Ap;  z = Md r (z is r when Md == NULL);  rho_new = <r, z>
+ * out[0] = <p, Ap>, out[1] = rho_new.  omega = rho/rho_prev and rho are the host's values (the host
+ * may have replaced rho by an explicit residual, linsys.py:667-669). */
+int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol,
+               kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first,
+               double omega, double rho, double* out);
+
 /* ---- complex (c128) twin of the hot path ------------------------------------------------- */
 /* KryPy's kernels are dtype-generic NumPy (H/V are allocated with the common dtype of A, v, M:
  * utils.py:893-905, complex inner products are X^H Y: utils.py:183).  A complex N-vector block is

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
+    "kh_cg_step": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _INT, _D, _D,
+                   _c_double_p],
     "kh_bench_kernel": [_H, _INT, _H, _H, _INT, _c_double_p],
     # complex (c128) side: vectors are real blocks of length 2N (interleaved re, im)
     "kh_zcsr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
@@ -651,6 +653,17 @@ class Context(object):
             ctypes.byref(out)), "kh_cg_update")
         return out.value
 
+
+    def cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
+        """One CG iteration in one call; returns ``(<p, Ap>, rho_new)``."""
+        if _same_dtype("cg_step", Pd, AP, YK, R):
+            raise BackendError("cg_step is real only (complex CG runs the step by step path)")
+        out = numpy.empty(2, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_cg_step(
+            self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle,
+            apcol, YK.handle, ycol, R.handle, rcol, Z.handle if Z is not None else None, zcol,
+            1 if first else 0, omega, rho, _dptr(out)), "kh_cg_step")
+        return float(out[0]), float(out[1])
 
     def bench_kernel(self, which, V, W, reps):
         ms = _D(0.0)

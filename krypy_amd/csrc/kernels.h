@@ -368,9 +368,13 @@ __global__ __launch_bounds__(BS) void k_cg_update(int64_t n, double alpha,
                                                   double* __restrict__ yk, double* __restrict__ r,
                                                   const double* __restrict__ dg,
                                                   double* __restrict__ z,
-                                                  double* __restrict__ part_out) {
+                                                  double* __restrict__ part_out,
+                                                  const double* __restrict__ pap = nullptr) {
     __shared__ double sm[8];
     const int64_t stride = (int64_t)gridDim.x * BS;
+    // kh_cg_step: `alpha` carries rho and the step length is rho / <p, Ap> with the inner product
+    // still on the device (same IEEE division the host would do)
+    if (pap != nullptr) alpha = alpha / pap[0];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
         yk[i] = yk[i] + alpha * p[i];

@@ -1198,6 +1198,48 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     return fetch_scalars(ctx, tmp, 1, rho_new);
 }
 
+int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
+               int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega,
+               double rho, double* out) {
+    KH_ARG(ctx && A && out, "kh_cg_step: NULL");
+    KH_TRY(check_vec(Pd, pcol, 1, "kh_cg_step(p)"));
+    KH_TRY(check_vec(AP, apcol, 1, "kh_cg_step(Ap)"));
+    KH_TRY(check_vec(YK, ycol, 1, "kh_cg_step(yk)"));
+    KH_TRY(check_vec(R, rcol, 1, "kh_cg_step(r)"));
+    KH_ARG(A->kind <= KH_MAT_DIAG, "kh_cg_step: real operator expected");
+    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_step: Md must be diagonal");
+    if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_step(z)"));
+    const int64_t n = R->n;
+    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && A->n_rows == n, "kh_cg_step: length mismatch");
+    KH_ARG(!(Pd == AP && pcol == apcol), "kh_cg_step: p and Ap must be different columns");
+    double* p = Pd->col(pcol);
+    double* ap = AP->col(apcol);
+    double* r = R->col(rcol);
+    double* z = Md ? Z->col(zcol) : r;
+    const int grid = grid_lin(ctx, n);
+    double* tmp = ctx->scal + SC_TMP;       // tmp[0] = <p, Ap>, tmp[1] = rho_new
+    if (!first)                             // p = z + omega p   (linsys.py:627)
+        hipLaunchKernelGGL(k_waxpby, dim3(grid), dim3(BS), 0, ctx->stream, n, p, 1.0, z, omega, p);
+    if (A->kind == KH_MAT_CSR) {            // Ap = A p with <p, Ap> fused into the SpMV
+        KH_TRY(apply_one(ctx, A, p, ap, EPI_DOT, p, tmp, 0));
+    } else {
+        KH_TRY(apply_one(ctx, A, p, ap, EPI_NONE, nullptr, nullptr, 0));
+        KH_TRY(dot_panel_dev(ctx, Pd, pcol, 1, ap, tmp, 0));
+    }
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+    double* part = part_slot(ctx, SLOT_NRM);
+    if (Md)
+        hipLaunchKernelGGL((k_cg_update<true>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
+                           YK->col(ycol), r, Md->diag, z, part, tmp);
+    else
+        hipLaunchKernelGGL((k_cg_update<false>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
+                           YK->col(ycol), r, nullptr, nullptr, part, tmp);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp + 1, 0);
+    KH_HIP(hipGetLastError());
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
+    return fetch_scalars(ctx, tmp, 2, out);
+}
+
 int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH,
                    int iterations, kh_proj* out) {
     KH_ARG(ctx && W && V && out, "kh_proj_create: NULL");

@@ -446,15 +446,28 @@ class Cg(_KrylovSolver):
             self.H = numpy.zeros((self.maxiter + 1, self.maxiter))
             alpha_old = 0
 
+        # whole iteration in one device call (one host synchronisation) when the operator is a plain
+        # device matrix as well: direction update, A p, <p, Ap>, the fused update, <r, z>
+        Amat = self.MlAMr._device_matrix(ctx, bdt) if fused else None
+        one_call = Amat is not None and hasattr(ctx, "cg_step")
+
         while self.resnorms[-1] > self.tol and self.iter < self.maxiter:
             k = self.iter
             if k > 0:
                 # p = MMlrk + rhos[-1]/rhos[-2] * p   (linsys.py:627)
                 omega = rhos[-1] / rhos[-2]
-                ctx.waxpby(p.block, p.col, 1.0, self._MMlrk.block, self._MMlrk.col, float(omega),
-                           p.block, p.col)
-            self.MlAMr._apply_dev(p.block, p.col, Ap.block, Ap.col, 1)
-            pAp = utils._inner_dev(p.block, p.col, 1, Ap.block, Ap.col, 1, ls.ip_B)[0, 0]
+            if one_call:
+                pAp, rho_new = ctx.cg_step(
+                    Amat, None if M_id else Md, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
+                    self._Mlrk.block, self._Mlrk.col, None if M_id else self._MMlrk.block,
+                    0 if M_id else self._MMlrk.col, k == 0, float(omega) if k > 0 else 0.0,
+                    float(rhos[-1]))
+            else:
+                if k > 0:
+                    ctx.waxpby(p.block, p.col, 1.0, self._MMlrk.block, self._MMlrk.col, float(omega),
+                               p.block, p.col)
+                self.MlAMr._apply_dev(p.block, p.col, Ap.block, Ap.col, 1)
+                pAp = utils._inner_dev(p.block, p.col, 1, Ap.block, Ap.col, 1, ls.ip_B)[0, 0]
             alpha = rhos[-1] / pAp
             if abs(numpy.imag(alpha)) > 1e-12:
                 warnings.warn(
@@ -469,7 +482,9 @@ class Cg(_KrylovSolver):
                 else:
                     self.H[k, k] = 1.0 / alpha
 
-            if fused:
+            if one_call:
+                MMlrk_norm = numpy.sqrt(abs(rho_new))
+            elif fused:
                 rho_new = ctx.cg_update(alpha, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
                                         self._Mlrk.block, self._Mlrk.col, None if M_id else Md,
                                         None if M_id else self._MMlrk.block,

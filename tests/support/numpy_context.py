@@ -343,6 +343,32 @@ class NumpyContext(object):
         return float(self._allreduce(np.array([np.dot(r, z)]))[0])
 
 
+def _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
+    """Semantics of kh_cg_step (include/krylov_hip.h)."""
+    self._count("cg_step")
+    if _same("cg_step", Pd, AP, YK, R):
+        raise BackendError("cg_step is real only")
+    z = Z.a[:, zcol] if Md is not None else R.a[:, rcol]
+    if not first:
+        Pd.a[:, pcol] = z + omega * Pd.a[:, pcol]
+    p = Pd.a[:, pcol]
+    ap = self._matvec(A, p)
+    AP.a[:, apcol] = ap
+    pap = float(self._allreduce(np.array([np.dot(p, ap)]))[0])
+    alpha = rho / pap
+    YK.a[:, ycol] = YK.a[:, ycol] + alpha * p
+    r = R.a[:, rcol] - alpha * ap
+    R.a[:, rcol] = r
+    zz = r
+    if Md is not None:
+        zz = Md.mat * r
+        Z.a[:, zcol] = zz
+    return pap, float(self._allreduce(np.array([np.dot(r, zz)]))[0])
+
+
+NumpyContext.cg_step = _cg_step
+
+
 class GlooComm(object):
     """torch.distributed (gloo, CPU) stand-in for the RCCL calls of libkrylov_hip: sum
     all-reduce of small panels and the nearest-neighbour halo exchange.  world_size-2 tests only."""
