@@ -311,6 +311,7 @@ struct CgsArgs {
     int pstride;
     const double* dg;      // update: Jacobi diagonal or nullptr
     double* mw;            // update: D w
+    int reverse;           // update: walk the columns last to first (see k_cgs_update)
 };
 
 template <int R2, bool MASKED>
@@ -385,18 +386,24 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         w[r].y = CH_OK(r) ? v.y : 0.0;
         if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
     }
+    // reverse: the dots pass has just streamed the columns first to last, so the LAST ones are what
+    // the 256 MB Infinity Cache still holds - walking them last to first turns the head of this
+    // pass into cache hits (it matters when the local basis is a few hundred MB: sharded runs)
+    const int tfirst = a.reverse ? a.ncol - 1 : 0, tstep = a.reverse ? -1 : 1;
     {
-        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + a.col0 * a.ld) + first;
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + (a.col0 + tfirst) * a.ld) + first;
 #pragma unroll
         for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
         CH_ISSUE_FENCE();
     }
-    for (int t = 0; t < a.ncol; ++t) {
+    for (int it = 0; it < a.ncol; ++it) {
+        const int t = tfirst + it * tstep;
+        const int tn = (it + 1 < a.ncol) ? t + tstep : t;
         const double h = a.coef[t];
         const double2* __restrict__ b2 =
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
         const double2* __restrict__ bn =
-            reinterpret_cast<const double2*>(a.Vb + (a.col0 + (t + 1 < a.ncol ? t + 1 : t)) * a.ld) + first;
+            reinterpret_cast<const double2*>(a.Vb + (a.col0 + tn) * a.ld) + first;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : bn;

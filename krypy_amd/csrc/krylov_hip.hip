@@ -373,6 +373,11 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
     a.pstride = CGS_PSTRIDE;
     a.dg = nullptr;
     a.mw = nullptr;
+    static const int rev_env = [] {
+        const char* e = getenv("KRYPY_AMD_CGS_REVERSE");
+        return e ? atoi(e) : 1;
+    }();
+    a.reverse = rev_env;
 #define KH_CGS(R, UPD) (padded ? launch_cgs<R, false>(ctx, G, a, UPD) : launch_cgs<R, true>(ctx, G, a, UPD))
 #define KH_CGS_ANY(UPD)                                                                        \
     (r2 == 4 ? KH_CGS(4, UPD) : r2 == 8 ? KH_CGS(8, UPD) : r2 == 16 ? KH_CGS(16, UPD)            \
