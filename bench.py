@@ -85,6 +85,8 @@ def parse_args():
                     help="testing: take the multi-GPU code path (gloo init, RCCL communicator, "
                          "ShardedCSROperator, all-reduced reductions) even with one rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the kernel micro-benchmarks (profiling runs that want the solver's kernels only)")
     ap.add_argument("--cpu-sample-steps", type=int, default=40)
     return ap.parse_args()
 
@@ -273,6 +275,8 @@ def _run():
     extra = {}
     try:
         from krypy_amd import _bench
+        if args.no_roofline:
+            raise RuntimeError("skipped (--no-roofline)")
         roof, extra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS)
     except Exception as exc:   # never lose the headline number to the instrumentation
         extra = {"roofline_error": repr(exc)}

@@ -340,7 +340,9 @@ class Context(object):
     # (8 GB at N = 10^7, m = 100); hipMalloc/hipFree of that size costs tens of ms, so released
     # blocks are parked (at most _POOL_PER_SHAPE per shape, _POOL_FRACTION of device memory in
     # total) and handed out again zero-filled, which is what kh_vec_alloc guarantees. ----
-    _POOL_PER_SHAPE = 2
+    _POOL_PER_SHAPE = 2          # big blocks (a basis)
+    _POOL_PER_SHAPE_SMALL = 12   # blocks below _POOL_SMALL_BYTES (single vectors, W pairs, panels):
+    _POOL_SMALL_BYTES = 1 << 30  # a cycle allocates and drops about ten of them
     _POOL_FRACTION = 0.35
 
     def _pool_take(self, n, ncols):
@@ -362,7 +364,8 @@ class Context(object):
                 self._pool_cap = 0
         nbytes = 8 * n * max(ncols, 1)
         lst = pool.setdefault((n, ncols), [])
-        if len(lst) < self._POOL_PER_SHAPE and self._pool_bytes + nbytes <= self._pool_cap:
+        cap = self._POOL_PER_SHAPE_SMALL if nbytes < self._POOL_SMALL_BYTES else self._POOL_PER_SHAPE
+        if len(lst) < cap and self._pool_bytes + nbytes <= self._pool_cap:
             lst.append(h)
             self._pool_bytes += nbytes
         else:

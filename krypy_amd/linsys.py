@@ -267,7 +267,14 @@ class _KrylovSolver(object):
         self.explicit_residual = explicit_residual
         self.store_arnoldi = store_arnoldi
 
-        self.x0 = self._get_initial_guess(self.x0)
+        # the hook sees the guess as it is held - a device vector stays on the device (reading the
+        # `x0` attribute would download it: 80 MB over PCIe per restart cycle at N = 10^7)
+        x0_cur = self.__dict__.get("_x0_dev")
+        if x0_cur is None:
+            x0_cur = self.__dict__.get("_x0_host")
+        x0_new = self._get_initial_guess(x0_cur)
+        if x0_new is not x0_cur:
+            self.x0 = x0_new
         x0d = _dev_of(self, "x0", self._ctx)
         self.MMlr0, self.Mlr0, self.MMlr0_norm = self._get_initial_residual(x0d)
 
