@@ -1006,8 +1006,13 @@ class Arnoldi(object):
         self.reorthos = self._sweeps - 1
 
         ctx = self._ctx = v.ctx if isinstance(v, DVec) else _hip.get_context()
-        self._V = ctx.alloc(N, self.maxiter + 1, dtype=bdt)
-        self._P = ctx.alloc(N, self.maxiter + 1, dtype=bdt) if self.M is not None else None
+        # The reference allocates (N, maxiter+1) up front and lives on lazily committed host pages
+        # (maxiter defaults to N).  Device memory is committed at once, so the basis starts with what
+        # a fixed share of HBM allows and doubles when the iteration gets there (_grow); a restarted
+        # or short run - anything that fits - gets its whole basis up front and never grows.
+        self._cols = self._initial_cols(ctx, N, self.maxiter + 1, 2 if self.M is not None else 1, bdt)
+        self._V = ctx.alloc(N, self._cols, dtype=bdt)
+        self._P = ctx.alloc(N, self._cols, dtype=bdt) if self.M is not None else None
         self._W = ctx.alloc(N, 2, dtype=bdt)
         self.H = numpy.zeros((self.maxiter + 1, self.maxiter), dtype=self.dtype)
         self._h2 = 0.0   # running sum of squares of H (Frobenius), for the invariance pre-test
@@ -1061,18 +1066,59 @@ class Arnoldi(object):
         else:
             self.invariant = True
 
+    _BASIS_SHARE = 0.30      # share of device memory the first allocation of V (and P) may take
+    _max_initial_cols = None  # tests: force a small first allocation to exercise _grow()
+
+    @classmethod
+    def _initial_cols(cls, ctx, N, want, nblocks, bdt):
+        if cls._max_initial_cols is not None:
+            return max(2, min(want, cls._max_initial_cols))
+        try:
+            total = ctx.info()["mem_total"]
+        except Exception:
+            total = 0
+        if total <= 0:
+            return want
+        per_col = 8 * (2 if _is_c(bdt) else 1) * max(N, 1) * nblocks
+        fit = int(cls._BASIS_SHARE * total // per_col)
+        return want if want <= fit else max(16, fit)
+
+    def _grow(self, need):
+        """Make room for ``need`` basis columns: double the blocks (at most maxiter+1 columns) and copy
+        what has been computed.  Steps in flight are discarded first (they are re-enqueued)."""
+        self._settle()
+        cols = min(self.maxiter + 1, max(need, 2 * self._cols))
+        done = self.iter + 1
+        for name in ("_V", "_P"):
+            old = getattr(self, name)
+            if old is None:
+                continue
+            new = self._ctx.alloc(old.n, cols, dtype=old.dtype)
+            new.copy_from(0, old, 0, min(done, old.ncols))
+            setattr(self, name, new)
+        self._cols = cols
+
+    def _padded(self, block):
+        """Host copy with the reference's (N, maxiter+1) shape (columns never reached are zero)."""
+        out = block.download()
+        if out.shape[1] == self.maxiter + 1:
+            return out
+        full = numpy.zeros((out.shape[0], self.maxiter + 1), dtype=out.dtype)
+        full[:, : out.shape[1]] = out
+        return full
+
     # the reference exposes ndarrays; here they are downloaded on demand
     @property
     def V(self):
         self._settle()
-        return self._V.download()
+        return self._padded(self._V)
 
     @property
     def P(self):
         if self._P is None:
             raise AttributeError("P")
         self._settle()
-        return self._P.download()
+        return self._padded(self._P)
 
     def _begin(self):
         """Enqueue Arnoldi step ``self._enq`` on the device (no host synchronisation)."""
@@ -1110,6 +1156,9 @@ class Arnoldi(object):
         H = self.H
         start = 0
         h_km1 = 0.0
+        need = min(k + self._lookahead, self.maxiter - 1) + 2
+        if need > self._cols:
+            self._grow(need)
         if self.ortho == "lanczos":
             start = k
             if k > 0:

@@ -679,3 +679,45 @@ def case_arnoldi_house():
         raise AssertionError
     except utils.ArgumentError:
         pass
+
+
+# ---------------------------------------------------------------------------------------------
+# Basis growth: the device basis starts smaller than (N, maxiter+1) when that would not fit and
+# doubles on demand (utils.Arnoldi._grow).  Forced here with a 4-column start: same iterates.
+# ---------------------------------------------------------------------------------------------
+def case_basis_growth():
+    g = golden("kernels")
+    A, b = lap2d_system(40, rhs="rng1")
+    v = b.reshape(-1, 1)
+    old = utils.Arnoldi._max_initial_cols
+    utils.Arnoldi._max_initial_cols = 4
+    try:
+        for ortho in ("mgs", "dmgs", "lanczos"):
+            ar = utils.Arnoldi(A, v, maxiter=12, ortho=ortho)
+            assert ar._cols == 4
+            for _ in range(12):
+                ar.advance()
+            assert ar._cols == 13 and ar.V.shape == (A.shape[0], 13)
+            assert rel(ar.H, g["arn_%s_H" % ortho]) < RTOL
+            assert rel(ar.V, g["arn_%s_V" % ortho]) < RTOL
+        d = np.linspace(0.5, 1.5, A.shape[0])
+        ar = utils.Arnoldi(A, v, maxiter=12, ortho="lanczos", M=sp.diags(d).tocsr())
+        for _ in range(12):
+            ar.advance()
+        assert rel(ar.H, g["arn_lanczosM_H"]) < RTOL and rel(ar.V, g["arn_lanczosM_V"]) < RTOL
+        assert rel(ar.P, g["arn_lanczosM_P"]) < RTOL
+        # whole solves: the default maxiter = N would need an (N, N+1) basis
+        gt = golden("toy")
+        At, bt = toy_system()
+        x, sol = krypy_amd.gmres(At, bt)
+        check_resnorms(sol.resnorms, gt["gmres_resnorms"])
+        assert rel(x, gt["gmres_x"]) < RTOL
+        x, sol = krypy_amd.minres(At, bt)
+        check_resnorms(sol.resnorms, gt["minres_resnorms"])
+        gm = golden("lap2d_minres_cg_nx100")
+        A2, b2 = lap2d_system(100, rhs="rng1")
+        s = linsys.Minres(linsys.LinearSystem(A2, b2, self_adjoint=True), tol=1e-8, maxiter=2000)
+        assert s.iter == int(gm["minres_iter"]) and s.lanczos._cols < 2001
+        assert rel(s.xk[:, 0], gm["minres_xk"]) < 1e-8
+    finally:
+        utils.Arnoldi._max_initial_cols = old
