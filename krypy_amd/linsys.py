@@ -553,17 +553,14 @@ class _ArnoldiBasisMixin(object):
         v = self.__dict__.get("_V_trim")
         if v is not None:
             return v
-        return self._basis_source()._V.download()
+        return self._basis_source().V
 
     @property
     def P(self):
         p = self.__dict__.get("_P_trim")
         if p is not None:
             return p
-        src = self._basis_source()
-        if src._P is None:
-            raise AttributeError("P")
-        return src._P.download()
+        return self._basis_source().P
 
 
 class Minres(_ArnoldiBasisMixin, _KrylovSolver):
@@ -594,9 +591,11 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
         ls = self.linear_system
         ctx = self._ctx
         N = ls.N
+        # (without store_arnoldi nobody reads the Lanczos basis afterwards: a sliding window of it)
         self.lanczos = utils.Arnoldi(
             self.MlAMr, _dev_of(self, "Mlr0", ctx), maxiter=self.maxiter, ortho=self.ortho,
-            M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B)
+            M=ls.M, Mv=_dev_of(self, "MMlr0", ctx), Mv_norm=self.MMlr0_norm, ip_B=ls.ip_B,
+            _window=not self.store_arnoldi)
 
         bdt = self.lanczos.dtype
         W = ctx.alloc(N, 2, dtype=bdt)     # the two remembered direction vectors (linsys.py:807)
@@ -628,7 +627,8 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             R2 = _pyscalar(g.r)
             y = list(rot(G2, y[0], y[1]))
             # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
-            ctx.minres_update(self.lanczos._V, k, W, slot, R0, R1, R2, y[0], yk.block, yk.col)
+            ctx.minres_update(self.lanczos._V, k - self.lanczos._base, W, slot, R0, R1, R2, y[0],
+                              yk.block, yk.col)
             slot = 1 - slot
             y = [y[1], 0.0]
             self._finalize_iteration(yk, numpy.abs(y[0]))

@@ -966,7 +966,8 @@ _GS_OF_ORTHO = {  # ortho -> (gs_mode, sweeps)
 
 
 class Arnoldi(object):
-    def __init__(self, A, v, maxiter=None, ortho="mgs", M=None, Mv=None, Mv_norm=None, ip_B=None):
+    def __init__(self, A, v, maxiter=None, ortho="mgs", M=None, Mv=None, Mv_norm=None, ip_B=None,
+                 _window=False):
         """Arnoldi algorithm: ``A V_n = V_{n+1} H_n`` (utils.py:855-952), basis in HBM.
 
         :param A: linear operator (anything :func:`get_linearoperator` accepts).
@@ -1011,6 +1012,15 @@ class Arnoldi(object):
         # a fixed share of HBM allows and doubles when the iteration gets there (_grow); a restarted
         # or short run - anything that fits - gets its whole basis up front and never grows.
         self._cols = self._initial_cols(ctx, N, self.maxiter + 1, 2 if self.M is not None else 1, bdt)
+        # Lanczos needs v_{k-1}, v_k, v_{k+1} only.  A caller that does not want the basis afterwards
+        # (Minres without store_arnoldi) asks for a sliding WINDOW of _WINDOW_COLS columns instead of
+        # maxiter+1: logical column j lives at j - _base, and when the window is full its last two
+        # columns move to the front.  Nothing to zero-fill, nothing that grows with maxiter.
+        self._base = 0
+        self._win = (bool(_window) and ortho == "lanczos" and self._WINDOW_COLS < self._cols
+                     and self._window_ok(ctx, bdt))
+        if self._win:
+            self._cols = self._WINDOW_COLS
         self._V = ctx.alloc(N, self._cols, dtype=bdt)
         self._P = ctx.alloc(N, self._cols, dtype=bdt) if self.M is not None else None
         self._W = ctx.alloc(N, 2, dtype=bdt)
@@ -1041,6 +1051,7 @@ class Arnoldi(object):
         # iteration is discarded by _settle().  (A Lanczos step takes H[k,k-1] from the previous step's
         # device-side H column, so it can run ahead as well.)
         self._lookahead = 1 if (self._Amat is not None and not cplx) else 0
+        assert not self._win or (self._fused and self._lookahead), "sliding window outside the look-ahead path"
         self._enq = 0          # number of steps enqueued on the device so far
         if ortho == "house":
             # Householder Arnoldi (utils.py:910-922, 970-994): reflectors live zero-padded in their
@@ -1066,8 +1077,25 @@ class Arnoldi(object):
         else:
             self.invariant = True
 
+    _WINDOW_COLS = 66        # columns of the sliding Lanczos window (re-based every 64 steps)
     _BASIS_SHARE = 0.30      # share of device memory the first allocation of V (and P) may take
     _max_initial_cols = None  # tests: force a small first allocation to exercise _grow()
+
+    def _window_ok(self, ctx, bdt):
+        """The window lives in the look-ahead path only: Euclidean inner product, plain device
+        matrix (possibly behind a device projector), M absent or diagonal, real data."""
+        if _is_c(bdt) or not (self.ip_B is None or isinstance(self.ip_B, IdentityLinearOperator)):
+            return False
+        if self.M is not None:
+            md = self.M._device_matrix()
+            if md is None or md.kind != "diag":
+                return False
+        if self.A._device_matrix(ctx, bdt) is not None:
+            return True
+        if isinstance(self.A, _ProductLinearOperator):
+            Pop, inner = self.A.args
+            return getattr(Pop, "_kh_proj", None) is not None and inner._device_matrix() is not None
+        return False
 
     @classmethod
     def _initial_cols(cls, ctx, N, want, nblocks, bdt):
@@ -1087,6 +1115,16 @@ class Arnoldi(object):
         """Make room for ``need`` basis columns: double the blocks (at most maxiter+1 columns) and copy
         what has been computed.  Steps in flight are discarded first (they are re-enqueued)."""
         self._settle()
+        if self._win:
+            # slide: the two columns the next step reads (k-1, k) move to the front
+            k = self.iter
+            src = max(k - 1, 0) - self._base
+            if src > 0:
+                for blk in (self._V, self._P):
+                    if blk is not None:
+                        blk.copy_from(0, blk, src, 2 if k >= 1 else 1)
+                self._base = max(k - 1, 0)
+            return
         cols = min(self.maxiter + 1, max(need, 2 * self._cols))
         done = self.iter + 1
         for name in ("_V", "_P"):
@@ -1110,6 +1148,8 @@ class Arnoldi(object):
     # the reference exposes ndarrays; here they are downloaded on demand
     @property
     def V(self):
+        if self._win:
+            raise AttributeError("V: this Lanczos run keeps a sliding window, not the basis")
         self._settle()
         return self._padded(self._V)
 
@@ -1117,6 +1157,8 @@ class Arnoldi(object):
     def P(self):
         if self._P is None:
             raise AttributeError("P")
+        if self._win:
+            raise AttributeError("P: this Lanczos run keeps a sliding window, not the basis")
         self._settle()
         return self._padded(self._P)
 
@@ -1130,8 +1172,9 @@ class Arnoldi(object):
                 # the previous step has been begun but maybe not fetched yet: NaN tells the library
                 # to read H[k,k-1] from that step's device-side H column
                 h_km1 = float(self.H[k, k - 1]) if self.iter >= k else float("nan")
-        self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
-                                     self._sweeps, self._gs_mode, h_km1, k % 4, proj=self._proj)
+        self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k - self._base,
+                                     start - self._base if start else 0, self._sweeps, self._gs_mode,
+                                     h_km1, k % 4, proj=self._proj)
         self._enq = k + 1
 
     def _settle(self):
@@ -1139,10 +1182,11 @@ class Arnoldi(object):
         that the arrays look exactly like the reference's (untouched columns are zero)."""
         while self._enq > self.iter:
             k = self._enq - 1
-            self._ctx.arnoldi_step_end(k % 4, k + 2 + (self._proj.d if self._proj is not None else 0))
-            self._V.zero(k + 1, 1)
+            kp = k - self._base
+            self._ctx.arnoldi_step_end(k % 4, kp + 2 + (self._proj.d if self._proj is not None else 0))
+            self._V.zero(kp + 1, 1)
             if self._P is not None:
-                self._P.zero(k + 1, 1)
+                self._P.zero(kp + 1, 1)
             self._enq = k
 
     def advance(self):
@@ -1156,7 +1200,7 @@ class Arnoldi(object):
         H = self.H
         start = 0
         h_km1 = 0.0
-        need = min(k + self._lookahead, self.maxiter - 1) + 2
+        need = min(k + self._lookahead, self.maxiter - 1) + 2 - self._base
         if need > self._cols:
             self._grow(need)
         if self.ortho == "lanczos":
@@ -1170,10 +1214,12 @@ class Arnoldi(object):
                 while self._enq <= last:
                     self._begin()
                 pd = self._proj.d if self._proj is not None else 0
-                hcol = ctx.arnoldi_step_end(k % 4, k + 2 + pd)
+                kp = k - self._base
+                hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd)
                 if pd:
-                    self._on_ya(hcol[k + 2:].reshape(-1, 1).copy())
-                    hcol = hcol[: k + 2]
+                    self._on_ya(hcol[kp + 2:].reshape(-1, 1).copy())
+                    hcol = hcol[: kp + 2]
+
             elif self._Amat is not None:
                 hcol = ctx.arnoldi_step(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
@@ -1183,8 +1229,9 @@ class Arnoldi(object):
                                         self._sweeps, self._gs_mode, h_km1)
             if self.ortho == "lanczos" and hcol.dtype.kind == "c":
                 hcol = hcol.real       # alpha = real(alpha), utils.py:1024-1027
-            H[start: k + 1, k] += hcol[start: k + 1]
-            hn = float(numpy.real(hcol[k + 1]))
+            off = self._base          # (window: the column arrives in window coordinates)
+            H[start: k + 1, k] += hcol[start - off: k + 1 - off]
+            hn = float(numpy.real(hcol[k + 1 - off]))
         elif self.ortho == "house":
             hn = self._advance_house(k)
         else:
@@ -1206,9 +1253,9 @@ class Arnoldi(object):
             # the reference leaves column k+1 untouched (zeros); undo the stores of this step and
             # of any step enqueued ahead of it
             self._settle()
-            self._V.zero(k + 1, 1)
+            self._V.zero(k + 1 - self._base, 1)
             if self._P is not None:
-                self._P.zero(k + 1, 1)
+                self._P.zero(k + 1 - self._base, 1)
 
     def _advance_house(self, k):
         """One Householder Arnoldi step (utils.py:970-994) on the device."""
@@ -1279,6 +1326,8 @@ class Arnoldi(object):
     def get(self):
         """``(V, H[, P])`` trimmed to the computed part (utils.py:1050-1061)."""
         k = self.iter
+        if self._win:
+            raise ArgumentError("this Lanczos run keeps a sliding window, not the basis (get() needs it)")
         self._settle()
         nv, hr = (k, k) if self.invariant else (k + 1, k + 1)
         V, H = self._V.download(0, nv), self.H[:hr, :k]
@@ -1292,9 +1341,9 @@ class Arnoldi(object):
         if self.invariant:
             V, H = None, self.H[:k, [k - 1]]
             return (V, H, None) if self.M is not None else (V, H)
-        V, H = self._V.download(k, 1), self.H[: k + 1, [k - 1]]
+        V, H = self._V.download(k - self._base, 1), self.H[: k + 1, [k - 1]]
         if self.M is not None:
-            return V, H, self._P.download(k, 1)
+            return V, H, self._P.download(k - self._base, 1)
         return V, H
 
 

@@ -721,3 +721,34 @@ def case_basis_growth():
         assert rel(s.xk[:, 0], gm["minres_xk"]) < 1e-8
     finally:
         utils.Arnoldi._max_initial_cols = old
+
+
+# ---------------------------------------------------------------------------------------------
+# MINRES without store_arnoldi keeps a sliding window of the Lanczos basis (utils.Arnoldi._win)
+# ---------------------------------------------------------------------------------------------
+def case_lanczos_window():
+    gm = golden("lap2d_minres_cg_nx100")
+    A2, b2 = lap2d_system(100, rhs="rng1")
+    s = linsys.Minres(linsys.LinearSystem(A2, b2, self_adjoint=True), tol=1e-8, maxiter=2000)
+    assert s.iter == int(gm["minres_iter"])
+    assert rel(s.xk[:, 0], gm["minres_xk"]) < 1e-8
+    # ... and that long Lanczos run kept a sliding window of the basis only (re-based many times)
+    assert s.lanczos._win and s.lanczos._base > 64 and s.iter > 130
+    check_resnorms(s.resnorms, gm["minres_resnorms"], tol=1e-8, explicit_tol=1e-5)
+    try:
+        s.V
+        raise AssertionError("no basis is kept without store_arnoldi")
+    except AttributeError:
+        pass
+    s2 = linsys.Minres(linsys.LinearSystem(A2, b2, self_adjoint=True), tol=1e-8, maxiter=2000,
+                       store_arnoldi=True)
+    assert not s2.lanczos._win and s2.V.shape[1] == s2.H.shape[0]
+    assert rel(s2.xk[:, 0], s.xk[:, 0]) < 1e-12
+    # deflated MINRES through the window (projector inside the fused step)
+    U = np.linalg.qr(np.random.default_rng(4).standard_normal((A2.shape[0], 4)))[0]
+    sd = deflation.DeflatedMinres(linsys.LinearSystem(A2, b2, self_adjoint=True), U=U, tol=1e-8,
+                                  maxiter=2000)
+    sd2 = deflation.DeflatedMinres(linsys.LinearSystem(A2, b2, self_adjoint=True), U=U, tol=1e-8,
+                                   maxiter=2000, store_arnoldi=True)
+    assert sd.lanczos._win and not sd2.lanczos._win and sd.iter == sd2.iter
+    assert rel(sd.xk[:, 0], sd2.xk[:, 0]) < 1e-10 and rel(sd.C, sd2.C) < 1e-10
