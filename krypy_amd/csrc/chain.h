@@ -142,7 +142,12 @@ struct ChainShape {
 // is zero and stays zero, so the hot loops carry no predicate at all (out-of-range lanes hold
 // w = 0 and read p = 0); only the final store is masked.  MASKED=true is the general kernel for
 // small or unpadded vectors.  `rem` = number of valid double2 starting at this thread's first.
-template <int R2, bool MASKED>
+//
+// CPLX: the same kernel for complex (c128) vectors.  A complex N-vector is a real block of 2N doubles
+// (re, im interleaved), i.e. exactly one double2 row per element, so geometry, pipeline and padding
+// are unchanged; the dot is conj(v).w (two grid reductions per link: re, im), the update the complex
+// multiply of NumPy (separate roundings), H entries are (re, im) pairs in hdev.
+template <int R2, bool MASKED, bool CPLX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
@@ -204,13 +209,30 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const double2 v = ring[b & 1][i];
-                acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                if (CPLX) {               // conj(v) * w: acc0 = re, acc1 = im
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc0 = fma(v.y, w[b * PB + i].y, acc0);
+                    acc1 = fma(v.x, w[b * PB + i].y, acc1);
+                    acc1 = fma(-v.y, w[b * PB + i].x, acc1);
+                } else {
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                }
             }
         }
-        const double alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                            : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
-        if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+        double alpha, alpha_i = 0.0;
+        if (CPLX) {
+            alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
+            alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
+            if (blockIdx.x == 0 && tid == 0) {
+                a.hdev[2 * j] += alpha;
+                a.hdev[2 * j + 1] += alpha_i;
+            }
+        } else {
+            alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+            if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+        }
         // ---- update phase: w -= alpha * b_j ----
         const int64_t jn = a.col0 + ((t + 1) % a.ncol);
         const double2* __restrict__ vn = (t + 1 < total)
@@ -227,8 +249,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             for (int i = 0; i < PB; ++i) {
                 const double2 p = ring[b & 1][i];
                 const int r = b * PB + i;
-                w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-                w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+                if (CPLX) {               // (alpha + i alpha_i) * (p.x + i p.y), NumPy's formula
+                    const double tr = alpha * p.x - alpha_i * p.y;
+                    const double ti = alpha * p.y + alpha_i * p.x;
+                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
+                } else {
+                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+                }
             }
         }
     }

@@ -228,17 +228,17 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
 // is what matters for the in-kernel grid reduction, and it is identical for plain and cooperative
 // launches: it is checked here against the occupancy of this instantiation, and every spin in the
 // kernel is bounded.
-template <int R2, bool MASKED>
+template <int R2, bool MASKED, bool CPLX = false>
 static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
     if (blocks_per_cu < 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED>, CH_BS, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CPLX>, CH_BS, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CPLX>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -272,8 +272,10 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 // kernels), negative on error
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
-                     const double* h_km1_dev, double* hdev, int slot) {
+                     const double* h_km1_dev, double* hdev, int slot, bool cplx = false) {
+    // cplx: V, B, w are (re, im) views of complex vectors (zpath.h); hdev holds (re, im) pairs
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
+    if (cplx && (dg != nullptr || P != nullptr)) return 0;
     const int64_t n = V->n;
     const int64_t n2 = (n + 1) >> 1;
     int r2 = 0, G = 0;
@@ -303,7 +305,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.vnext = V->col(k + 1);
     a.pnext = P ? P->col(k + 1) : nullptr;
     a.hdev = hdev;
-    a.hnext = k + 1;
+    a.hnext = cplx ? 2 * (k + 1) : k + 1;
     a.gran = ctx->chain_gran;
     a.epoch0 = ctx->chain_epoch;
     a.err = ctx->chain_err;
@@ -313,7 +315,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.h_km1_dev = h_km1_dev;
     a.bprev = presub ? B->col(k - 1) : nullptr;
     hipError_t e;
-#define KH_CHAIN(R) (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a))
+#define KH_CHAIN(R)                                                                                   \
+    (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
+          : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
     if (r2 == 4) e = KH_CHAIN(4);
     else if (r2 == 8) e = KH_CHAIN(8);
     else if (r2 == 16) e = KH_CHAIN(16);
@@ -327,7 +331,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         ctx->chain_enabled = 0;
         return 0;
     }
-    ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);
+    ctx->chain_epoch += (unsigned)((cplx ? 2 : 1) * a.ncol * a.sweeps + 1);
     KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                           ctx->stream));
     return 1;

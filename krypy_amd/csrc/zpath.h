@@ -555,6 +555,26 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
         KH_TRY(zaxpy_dev(ctx, V, k - 1, 1, coef, 1.0, 1.0, w, false, nullptr));
     }
     const int64_t ncol = k - start + 1;
+    // reference-order MGS with w in registers for the whole chain (chain.h, CPLX instantiation):
+    // one launch instead of 4 per column
+    if (gs_mode == KH_GS_MGS) {
+        const bool presub = (start > 0 && start == k);
+        const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, false, 0.0,
+                                 nullptr, hdev, 0, true);
+        (void)presub;   // (the Lanczos pre-subtraction has been applied above with its complex coefficient)
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            KH_TRY(zfetch(ctx, hdev, 2 * (k + 2), hcol_out));
+            if (*ctx->chain_err_pin[0] != 0) {
+                *ctx->chain_err_pin[0] = 0;
+                ctx->chain_enabled = 0;
+                (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
+                return fail(KH_ERR_HIP, "grid-wide reduction of the complex MGS chain kernel timed out; the "
+                                        "chain path is now disabled for this context");
+            }
+            return 0;
+        }
+    }
     for (int s = 0; s < sweeps; ++s) {
         const bool last_sweep = (s == sweeps - 1);
         if (gs_mode == KH_GS_MGS) {

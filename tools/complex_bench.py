@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""GMRES(100) on a complex (c128) shifted 2-D Laplacian, N = 5*10^6 (same bytes per vector as the real
+bench): python tools/complex_bench.py [ortho ...]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+import bench  # noqa: E402
+from krypy_amd import _hip, linsys, utils  # noqa: E402
+
+ctx = _hip.get_context()
+A = bench.laplace2d(2500, 2000).astype(complex)
+N = A.shape[0]
+A = (A + sp.diags(1j * np.linspace(0.1, 1.0, N))).tocsr()
+rng = np.random.default_rng(0)
+b = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+ls = linsys.LinearSystem(A, b)
+for ortho in (sys.argv[1:] or ["mgs", "cgs"]):
+    for it in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        try:
+            s = linsys.RestartedGmres(ls, maxiter=100, max_restarts=1, tol=1e-14, ortho=ortho)
+        except utils.ConvergenceError as e:
+            s = e.solver
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    n_it = len(s.resnorms) - 1
+    print(json.dumps({"config": "complex GMRES(100), N=%d, ortho=%s" % (N, ortho), "iterations_per_s": n_it / dt,
+                      "ms_per_cycle": dt / 2 * 1e3, "relres": float(s.resnorms[-1])}))
