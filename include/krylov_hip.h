@@ -236,6 +236,11 @@ int kh_zwaxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, const double alpha[2], kh_vec
  * inner product, no preconditioner): hcol_out receives k+2 complex numbers, the last (H[k+1,k], 0). */
 int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
                      int sweeps, int gs_mode, const double h_km1[2], double* hcol_out);
+/* ... and split for look-ahead like kh_arnoldi_step_begin: collect the column with
+ * kh_arnoldi_step_end(ctx, slot, 2*(k+2), out).  h_km1[0] = NaN takes the Lanczos coefficient from
+ * the previous slot's device-side column. */
+int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
+                           int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 /* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "kh_zgemm_nn": [_H, _H, _I64, _I64, _c_double_p, _I64, _D, _H, _I64],
     "kh_zwaxpby": [_H, _H, _I64, _c_double_p, _H, _I64, _c_double_p, _H, _I64],
     "kh_zarnoldi_step": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _c_double_p],
+    "kh_zarnoldi_step_begin": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
 }
 
 _lib = None
@@ -592,6 +593,14 @@ class Context(object):
 
     def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
                            proj=None):
+        if _same_dtype("arnoldi_step_begin", V, W):
+            if Md is not None or P is not None or proj is not None:
+                raise BackendError("arnoldi_step_begin: the complex step takes no preconditioner / projector")
+            hk = numpy.array([h_km1, 0.0], dtype=numpy.float64)
+            _check(self._lib, self._lib.kh_zarnoldi_step_begin(
+                self._h, A.handle if A is not None else None, V.handle, W.handle, wcol, k, start, sweeps,
+                gs_mode, _dptr(hk), slot), "kh_zarnoldi_step_begin")
+            return
         _check(self._lib, self._lib.kh_arnoldi_step_begin(
             self._h, A.handle if A is not None else None,
             proj.handle if proj is not None else None, Md.handle if Md is not None else None,
@@ -619,10 +628,11 @@ class Context(object):
             _dptr(ya) if want_ya else None), "kh_proj_apply_complement")
         return ya
 
-    def arnoldi_step_end(self, slot, count):
-        out = numpy.empty(count, dtype=numpy.float64)
-        _check(self._lib, self._lib.kh_arnoldi_step_end(self._h, slot, count, _dptr(out)),
-               "kh_arnoldi_step_end")
+    def arnoldi_step_end(self, slot, count, cplx=False):
+        """The H column of the step begun in ``slot``: ``count`` numbers (complex ones with ``cplx``)."""
+        out = numpy.empty(count, dtype=numpy.complex128 if cplx else numpy.float64)
+        _check(self._lib, self._lib.kh_arnoldi_step_end(self._h, slot, count * (2 if cplx else 1),
+                                                        _dptr(out)), "kh_arnoldi_step_end")
         return out
 
     def residual(self, A, B, bcol, X, xcol, R, rcol):

@@ -529,17 +529,18 @@ int kh_zwaxpby(kh_ctx ctx, kh_vec Z, int64_t zcol_, const double alpha[2], kh_ve
     return 0;
 }
 
-// One complex Arnoldi.advance() (utils.py:954-1048, mgs/dmgs/lanczos/cgs; no preconditioner):
-// hcol_out gets k+2 complex numbers (interleaved); the last one is (H[k+1,k], 0).
-int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
-                     int sweeps, int gs_mode, const double h_km1[2], double* hcol_out) {
-    KH_ARG(ctx && V && W && hcol_out, "kh_zarnoldi_step: NULL argument");
+}  // extern "C"
+
+// One complex Arnoldi.advance() (utils.py:954-1048, mgs/dmgs/lanczos/cgs; no preconditioner), enqueued
+// on the context's stream: the H column (k+2 complex numbers, the last one (H[k+1,k], 0)) lands in
+// `hdev`.  h_km1_dev: Lanczos coefficient still on the device (look-ahead), else h_km1 from the host.
+static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                         int sweeps, int gs_mode, const double h_km1[2], const double* h_km1_dev, double* hdev,
+                         int slot) {
     KH_TRY(zcheck(V, k, 2, "kh_zarnoldi_step(V)"));
     KH_TRY(zcheck(W, wcol, 1, "kh_zarnoldi_step(W)"));
     KH_ARG(V->n == W->n && start >= 0 && start <= k && sweeps >= 1 && sweeps <= 4, "kh_zarnoldi_step: arguments");
-    KH_ARG(2 * (k + 2) <= 4096, "kh_zarnoldi_step: k too large for the complex path");
     const int64_t n = V->n / 2;
-    double* hdev = ctx->scal;                 // 2(k+2) doubles
     double* tmp = ctx->scal + ZSC_TMP;
     double* coef = ctx->scal + ZSC_COEF;
     double2* w = zcolw(W, wcol);
@@ -551,29 +552,20 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
     double* nrm_part = ctx->part + (int64_t)(2 * ZMAXC + 2) * NB_MAX;
     const int grid = zgrid(ctx, n);
     if (start > 0 && start == k) {   // Lanczos: w -= H[k,k-1] * v_{k-1}
-        KH_TRY(zpush(ctx, h_km1, 2, coef));
-        KH_TRY(zaxpy_dev(ctx, V, k - 1, 1, coef, 1.0, 1.0, w, false, nullptr));
+        const double* cf = h_km1_dev;
+        if (cf == nullptr) {
+            KH_TRY(zpush(ctx, h_km1, 2, coef));
+            cf = coef;
+        }
+        KH_TRY(zaxpy_dev(ctx, V, k - 1, 1, cf, 1.0, 1.0, w, false, nullptr));
     }
     const int64_t ncol = k - start + 1;
     // reference-order MGS with w in registers for the whole chain (chain.h, CPLX instantiation):
     // one launch instead of 4 per column
     if (gs_mode == KH_GS_MGS) {
-        const bool presub = (start > 0 && start == k);
         const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, false, 0.0,
-                                 nullptr, hdev, 0, true);
-        (void)presub;   // (the Lanczos pre-subtraction has been applied above with its complex coefficient)
-        if (rc < 0) return rc;
-        if (rc == 1) {
-            KH_TRY(zfetch(ctx, hdev, 2 * (k + 2), hcol_out));
-            if (*ctx->chain_err_pin[0] != 0) {
-                *ctx->chain_err_pin[0] = 0;
-                ctx->chain_enabled = 0;
-                (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
-                return fail(KH_ERR_HIP, "grid-wide reduction of the complex MGS chain kernel timed out; the "
-                                        "chain path is now disabled for this context");
-            }
-            return 0;
-        }
+                                 nullptr, hdev, slot, true);
+        if (rc != 0) return rc < 0 ? rc : 0;
     }
     for (int s = 0; s < sweeps; ++s) {
         const bool last_sweep = (s == sweeps - 1);
@@ -597,7 +589,47 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
     hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(rgrid), dim3(BS), 0, ctx->stream, V->n, W->col(wcol), nullptr,
                        V->col(k + 1), nullptr, nullptr, 0, tmp, hdev + 2 * (k + 1));
     KH_HIP(hipGetLastError());
-    return zfetch(ctx, hdev, 2 * (k + 2), hcol_out);
+    return 0;
+}
+
+extern "C" {
+
+int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                     int sweeps, int gs_mode, const double h_km1[2], double* hcol_out) {
+    KH_ARG(ctx && V && W && hcol_out && h_km1, "kh_zarnoldi_step: NULL argument");
+    KH_ARG(2 * (k + 2) <= 4096, "kh_zarnoldi_step: k too large for the synchronous complex step");
+    double* hdev = ctx->scal;                 // 2(k+2) doubles
+    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, nullptr, hdev, 0));
+    KH_TRY(zfetch(ctx, hdev, 2 * (k + 2), hcol_out));
+    if (*ctx->chain_err_pin[0] != 0) {
+        *ctx->chain_err_pin[0] = 0;
+        ctx->chain_enabled = 0;
+        (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
+        return fail(KH_ERR_HIP, "grid-wide reduction of the complex MGS chain kernel timed out; the chain "
+                                "path is now disabled for this context");
+    }
+    return 0;
+}
+
+// The same step split like kh_arnoldi_step_begin / _end (look-ahead): results are collected with
+// kh_arnoldi_step_end(ctx, slot, 2*(k+2), out).  h_km1[0] = NaN: Lanczos coefficient H[k,k-1] of the
+// step begun just before this one, still in the previous H-column slot on the device.
+int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                           int sweeps, int gs_mode, const double h_km1[2], int slot) {
+    KH_ARG(ctx && V && W && h_km1, "kh_zarnoldi_step_begin: NULL argument");
+    KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_zarnoldi_step_begin: slot %d not in [0,%d)", slot, KH_NSLOT);
+    KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_zarnoldi_step_begin: k=%lld needs %lld basis columns, have %lld",
+           (long long)k, (long long)(k + 2), (long long)V->ncols);
+    KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1))));
+    double* hdev = ctx->hslot_dev[slot];
+    const double* hk_dev = nullptr;
+    if (start > 0 && start == k && h_km1[0] != h_km1[0])
+        hk_dev = ctx->hslot_dev[(slot + KH_NSLOT - 1) % KH_NSLOT] + 2 * k;
+    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, hk_dev, hdev, slot));
+    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * 2 * (k + 2), hipMemcpyDeviceToHost,
+                          ctx->stream));
+    KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+    return 0;
 }
 
 }  // extern "C"

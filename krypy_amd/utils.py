@@ -1050,7 +1050,8 @@ class Arnoldi(object):
         # never idles while the host does its O(k) work.  A speculative step past the end of the
         # iteration is discarded by _settle().  (A Lanczos step takes H[k,k-1] from the previous step's
         # device-side H column, so it can run ahead as well.)
-        self._lookahead = 1 if (self._Amat is not None and not cplx) else 0
+        self._lookahead = 1 if self._Amat is not None else 0
+        self._cplx = cplx
         assert not self._win or (self._fused and self._lookahead), "sliding window outside the look-ahead path"
         self._enq = 0          # number of steps enqueued on the device so far
         if ortho == "house":
@@ -1171,7 +1172,7 @@ class Arnoldi(object):
             if k > 0:
                 # the previous step has been begun but maybe not fetched yet: NaN tells the library
                 # to read H[k,k-1] from that step's device-side H column
-                h_km1 = float(self.H[k, k - 1]) if self.iter >= k else float("nan")
+                h_km1 = float(numpy.real(self.H[k, k - 1])) if self.iter >= k else float("nan")
         self._ctx.arnoldi_step_begin(self._Amat, self._Md, self._V, self._P, self._W, 0, k - self._base,
                                      start - self._base if start else 0, self._sweeps, self._gs_mode,
                                      h_km1, k % 4, proj=self._proj)
@@ -1183,7 +1184,8 @@ class Arnoldi(object):
         while self._enq > self.iter:
             k = self._enq - 1
             kp = k - self._base
-            self._ctx.arnoldi_step_end(k % 4, kp + 2 + (self._proj.d if self._proj is not None else 0))
+            self._ctx.arnoldi_step_end(k % 4, kp + 2 + (self._proj.d if self._proj is not None else 0),
+                                       cplx=self._cplx)
             self._V.zero(kp + 1, 1)
             if self._P is not None:
                 self._P.zero(kp + 1, 1)
@@ -1215,7 +1217,7 @@ class Arnoldi(object):
                     self._begin()
                 pd = self._proj.d if self._proj is not None else 0
                 kp = k - self._base
-                hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd)
+                hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd, cplx=self._cplx)
                 if pd:
                     self._on_ya(hcol[kp + 2:].reshape(-1, 1).copy())
                     hcol = hcol[: kp + 2]

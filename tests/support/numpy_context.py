@@ -274,7 +274,7 @@ class NumpyContext(object):
         if not hasattr(self, "_slots"):
             self._slots = {}
         if h_km1 != h_km1:      # NaN: H[k,k-1] of the step begun just before (device-side value)
-            h_km1 = float(self._slots[(slot - 1) % 4][k])
+            h_km1 = float(np.real(self._slots[(slot - 1) % 4][k]))
         if proj is None:
             self._slots[slot] = self.arnoldi_step(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
             return
@@ -310,7 +310,7 @@ class NumpyContext(object):
         Z.a[:, zcol] = z
         return ya
 
-    def arnoldi_step_end(self, slot, count):
+    def arnoldi_step_end(self, slot, count, cplx=False):
         return self._slots[slot][:count].copy()
 
     def residual(self, A, B, bcol, X, xcol, R, rcol):
