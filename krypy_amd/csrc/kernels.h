@@ -535,6 +535,86 @@ __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_col
     if (lane == 0) y[row] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// Dense A times a PANEL of up to 16 vectors on the FP64 matrix cores (v_mfma_f64_16x16x4_f64):
+// Y[:, 0:nc] = A X[:, 0:nc].  The one GEMM-shaped operation of the path (A U of the deflation set-up,
+// multi-column LinearOperator.dot, Ritz residuals with a dense operator): A is streamed once for
+// all columns instead of once per column.  A wave owns RT tiles of 16 rows; per 64-column chunk
+// every lane loads 8 double2 of its row (lane = (row r, quarter q): columns c0 + 8i + 2q, +1 - the
+// four lanes of a row read 64 contiguous bytes per instruction) and the matching 8 double2 of its
+// X column; the k index of an MFMA only has to agree between the A and the B operand, so this
+// interleaved order needs no shuffles.  MFMA f64 layouts: A[l&15][l>>4], B[l>>4][l&15],
+// D: col = l&15, row = (l>>4) + 4*reg.
+// ------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+template <int RT>
+__global__ __launch_bounds__(BS) void k_gemm_dense_mfma(int64_t n_rows, int64_t n_cols,
+                                                        const double* __restrict__ a, int64_t lda,
+                                                        const double* __restrict__ X, int64_t ldx, int nc,
+                                                        double* __restrict__ Y, int64_t ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t row_base = ((int64_t)blockIdx.x * (BS / 64) + wave) * (16 * RT);
+    if (row_base >= n_rows) return;
+    v4f64 acc[RT];
+    const double* __restrict__ arow[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) {
+        acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+        int64_t row = row_base + 16 * t + r;
+        row = row < n_rows ? row : n_rows - 1;          // tail tiles re-read the last row (never stored)
+        arow[t] = a + row * lda;
+    }
+    const bool colok = r < nc;
+    const double* __restrict__ xcol = X + (int64_t)(colok ? r : 0) * ldx;
+    const int64_t full = n_cols & ~(int64_t)63;
+    for (int64_t c0 = 0; c0 < full; c0 += 64) {
+        double2 bv[8], av[RT][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = *reinterpret_cast<const double2*>(xcol + c0 + 8 * i + 2 * q);
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) av[t][i] = *reinterpret_cast<const double2*>(arow[t] + c0 + 8 * i + 2 * q);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double bx = colok ? bv[i].x : 0.0, by = colok ? bv[i].y : 0.0;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][i].x, bx, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[t][i].y, by, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (full < n_cols) {   // last, partial chunk: guarded scalar loads
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t kk = full + 8 * i + 2 * q + h;
+                const bool ok = kk < n_cols;
+                const double bx = (ok && colok) ? xcol[kk] : 0.0;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const double ax = ok ? arow[t][kk] : 0.0;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (colok) {
+        double* __restrict__ ycol = Y + (int64_t)r * ldy;
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = row_base + 16 * t + q + 4 * i;
+                if (row < n_rows) ycol[row] = acc[t][i];
+            }
+    }
+}
+
 // y = M x for a tiny dense row-major M (d x d, d <= 1024) held on the device: the projector's
 // R^{-1} Q^H and WR^H factors.  One workgroup, one row per thread, sequential sums (deterministic).
 __global__ __launch_bounds__(BS) void k_small_matvec(int d, const double* __restrict__ M,

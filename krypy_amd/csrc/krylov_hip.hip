@@ -786,6 +786,18 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
     KH_ARG(X->n == xneed && Y->n == A->n_rows, "kh_apply: dimension mismatch (A %lldx%lld, x %lld, y %lld)",
            (long long)A->n_rows, (long long)A->n_cols, (long long)X->n, (long long)Y->n);
     KH_ARG(!(X == Y && xcol == ycol), "kh_apply: in-place application is not supported");
+    if (A->kind == KH_MAT_DENSE && ncols >= 2 && A->n_rows >= 1024 && X != Y) {
+        // a panel: stream A once per 16 columns on the FP64 matrix cores (k_gemm_dense_mfma)
+        constexpr int RT = 2;
+        const int grid = (int)((A->n_rows + (BS / 64) * 16 * RT - 1) / ((BS / 64) * 16 * RT));
+        for (int64_t c = 0; c < ncols; c += 16) {
+            const int nc = (int)std::min<int64_t>(16, ncols - c);
+            hipLaunchKernelGGL((k_gemm_dense_mfma<RT>), dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols,
+                               A->a, A->lda, X->col(xcol + c), X->ld, nc, Y->col(ycol + c), Y->ld);
+        }
+        KH_HIP(hipGetLastError());
+        return 0;
+    }
     for (int64_t c = 0; c < ncols; ++c)
         KH_TRY(apply_one(ctx, A, X->col(xcol + c), Y->col(ycol + c), EPI_NONE, nullptr, nullptr, 0));
     return 0;

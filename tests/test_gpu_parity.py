@@ -388,3 +388,31 @@ def test_reference_utils_matrix(hip, case):
     """The reference's utils test matrix (test/test_utils.py: House, Givens, Projection, qr, angles,
     hegedus, Arnoldi in every ortho mode, Ritz pairs) on real AND complex matrices."""
     assert case() > 20
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (1500, 1111), (4100, 777), (2048, 64), (1030, 63)])
+def test_dense_panel_apply_on_matrix_cores(hip, shape):
+    """kh_apply of a dense operator to a panel (k_gemm_dense_mfma, v_mfma_f64_16x16x4_f64): ragged row
+    and column counts, 2..33 columns, an asymmetric panel (a transposed tile write would show)."""
+    n, m = shape
+    rng = np.random.default_rng(n + m)
+    A = rng.standard_normal((n, m))
+    Ad = hip.dense(A)
+    for nc in (2, 5, 16, 17, 33):
+        X = rng.standard_normal((m, nc)) * np.arange(1, nc + 1)
+        Xd = hip.upload(X)
+        Yd = hip.alloc(n, nc + 1)
+        Yd.upload(0, np.full((n, nc + 1), 7.0))
+        hip.apply(Ad, Xd, 0, Yd, 0, nc)
+        got = Yd.download()
+        want = A.dot(X)
+        assert np.allclose(got[:, :nc], want, rtol=1e-12, atol=1e-11 * np.abs(want).max())
+        assert np.all(got[:, nc] == 7.0)          # the column behind the panel is untouched
+    # the single-column GEMV and the panel kernel agree
+    x = rng.standard_normal((m, 2))
+    Y1, Y2 = hip.alloc(n, 2), hip.alloc(n, 2)
+    Xd = hip.upload(x)
+    hip.apply(Ad, Xd, 0, Y1, 0, 2)
+    hip.apply(Ad, Xd, 0, Y2, 0, 1)
+    hip.apply(Ad, Xd, 1, Y2, 1, 1)
+    assert np.allclose(Y1.download(), Y2.download(), rtol=1e-12, atol=1e-11)
