@@ -54,6 +54,11 @@ def _pyscalar(x):
     return x.real if x.imag == 0.0 else x
 
 
+def _is_set(obj, name):
+    """True if a _LazyHost attribute holds a value (device or host) - without downloading it."""
+    return obj.__dict__.get("_" + name + "_dev") is not None or obj.__dict__.get("_" + name + "_host") is not None
+
+
 def _dev_of(obj, name, ctx):
     """Device view of a _LazyHost attribute (uploads a host-assigned value once, in the owner's
     block dtype ``_bdt`` when it has one)."""
@@ -518,7 +523,7 @@ class Cg(_KrylovSolver):
                 rhos[-1] = rkn ** 2
             self.iter += 1
 
-        if self.xk is None:
+        if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(yk)
 
     # the reference keeps Mlrk / MMlrk as ndarray attributes
@@ -633,7 +638,7 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             y = [y[1], 0.0]
             self._finalize_iteration(yk, numpy.abs(y[0]))
 
-        if self.xk is None:
+        if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(yk)
 
     def _finalize(self):
@@ -721,7 +726,7 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
             y[k + 1, 0] = -s.conjugate() * t0 + c * t1
             self._finalize_iteration(y[: k + 1], abs(y[k + 1, 0]))
 
-        if self.xk is None:
+        if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(y[: self.arnoldi.iter])
 
     def _finalize(self):
