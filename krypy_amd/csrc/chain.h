@@ -314,6 +314,222 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_mgs_chain_lds: the chain kernel with the head of every basis column parked in LDS.
+//
+// A link reads its column twice - v_j for the dot, then (without a preconditioner) the same v_j for
+// the update, after the grid-wide reduction.  The workgroup owns a whole CU (512 threads, 160 KB of
+// LDS, ~4 KB used), so the first LB batches of the column (LB*PB rows x 512 lanes x 16 B = up to
+// 128 KB) are copied into LDS while the dot phase streams them and the update phase takes them from
+// there: 16 of the 40 rows at N = 10^7, i.e. 20 % less HBM/Infinity-Cache traffic per link (all of the
+// second read when the vectors are short enough for R2 <= 16).  Only for B == V (no preconditioner);
+// batches of 4 rows so that the ring parity still resets every phase (NB - LB even).
+// ------------------------------------------------------------------------------------------
+// R2 = 40 (the N = 10^7 shape) is at the VGPR limit: batches of 5 rows like the plain kernel and 2 of
+// the 8 batches in LDS is what fits without noticeable spilling (4 VGPRs); measured alternatives:
+// PB=4/LB=4 spills 29 VGPRs and is slower than no LDS at all, PB=2/LB=8 27.3 us per column.
+#ifndef KH_LDS40_PB
+#define KH_LDS40_PB 5
+#endif
+#ifndef KH_LDS40_LB
+#define KH_LDS40_LB 2
+#endif
+template <int R2>
+struct ChainShapeLds {
+    static constexpr int PB = (R2 == 40) ? KH_LDS40_PB : ((R2 == 4) ? 2 : 4);
+    static constexpr int NB = R2 / PB;
+    static constexpr int LB = (R2 == 40) ? KH_LDS40_LB : (NB < 4 ? NB : 4);   // batches kept in LDS
+    static constexpr int NG = NB - LB;                        // update batches that still come from memory
+    static_assert(NB * PB == R2 && (NB % 2) == 0 && (NG % 2) == 0, "ring parity must reset every phase");
+    static constexpr size_t LDS_BYTES = (size_t)LB * PB * CH_BS * sizeof(double2);
+};
+
+template <int R2, bool MASKED, bool CPLX = false>
+__global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
+    constexpr int PB = ChainShapeLds<R2>::PB;
+    constexpr int NB = ChainShapeLds<R2>::NB;
+    constexpr int LB = ChainShapeLds<R2>::LB;
+    constexpr int NG = ChainShapeLds<R2>::NG;
+    extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB][CH_BS]
+    __shared__ double smd[CH_BS / 64];
+    __shared__ unsigned smu[2 * CH_GMAX];
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    double2 w[R2];
+    double2 ring[2][PB];
+    {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = win2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    }
+    if (a.presub) {
+        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 p = p2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    }
+    unsigned epoch = a.epoch0;
+    const int total = a.ncol * a.sweeps;
+    {
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld) + first;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        CH_ISSUE_FENCE();
+    }
+    for (int t = 0; t < total; ++t) {
+        const int64_t j = a.col0 + (t % a.ncol);
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + j * a.ld) + first;
+        const int64_t jn = a.col0 + ((t + 1) % a.ncol);
+        const double2* __restrict__ vn = (t + 1 < total)
+            ? reinterpret_cast<const double2*>(a.V + jn * a.ld) + first
+            : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
+        // ---- dot phase: <v_j, w>; the first LB batches are parked in LDS on the way ----
+        double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            // next: v_j batch b+1; after the last one the first update batch that is not in LDS
+            // (or, if the whole column is, the next column's first batch)
+            const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS
+                                                            : (NG > 0 ? v2 + (int64_t)LB * PB * CH_BS : vn);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 v = ring[b & 1][i];
+                if (b < LB) vlds[(b * PB + i) * CH_BS + tid] = v;
+                if (CPLX) {
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc0 = fma(v.y, w[b * PB + i].y, acc0);
+                    acc1 = fma(v.x, w[b * PB + i].y, acc1);
+                    acc1 = fma(-v.y, w[b * PB + i].x, acc1);
+                } else {
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                }
+            }
+        }
+        double alpha, alpha_i = 0.0;
+        if (CPLX) {
+            alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
+            alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
+            if (blockIdx.x == 0 && tid == 0) {
+                a.hdev[2 * j] += alpha;
+                a.hdev[2 * j + 1] += alpha_i;
+            }
+        } else {
+            alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+            if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+        }
+        // ---- update phase: w -= alpha * v_j, head from LDS (own entries: no barrier needed) ----
+#pragma unroll
+        for (int b = 0; b < LB; ++b) {
+            CH_ISSUE_FENCE();     // one batch of LDS reads at a time (they would all be hoisted: spills)
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = vlds[(b * PB + i) * CH_BS + tid];
+                const int r = b * PB + i;
+                if (CPLX) {
+                    const double tr = alpha * p.x - alpha_i * p.y;
+                    const double ti = alpha * p.y + alpha_i * p.x;
+                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
+                } else {
+                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int b = LB + g;
+            const double2* __restrict__ nx = (g + 1 < NG) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[(g + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = ring[g & 1][i];
+                const int r = b * PB + i;
+                if (CPLX) {
+                    const double tr = alpha * p.x - alpha_i * p.y;
+                    const double ti = alpha * p.y + alpha_i * p.x;
+                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
+                } else {
+                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+                }
+            }
+        }
+    }
+    // norm: <w,w> or <w, D w>
+    double acc = 0.0;
+    if (a.dg != nullptr) {
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 d = d2[(int64_t)r * CH_BS];
+            acc = fma(w[r].x, d.x * w[r].x, acc);
+            acc = fma(w[r].y, d.y * w[r].y, acc);
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            acc = fma(w[r].x, w[r].x, acc);
+            acc = fma(w[r].y, w[r].y, acc);
+        }
+    }
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu);
+    const double h = sqrt(fabs(h2));
+    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+    if (a.dg != nullptr) {
+        double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                const double2 d = d2[(int64_t)r * CH_BS];
+                double2 o, m;
+                o.x = w[r].x / h;
+                o.y = w[r].y / h;
+                m.x = (d.x * w[r].x) / h;
+                m.y = (d.y * w[r].y) / h;
+                pn2[(int64_t)r * CH_BS] = o;
+                vn2[(int64_t)r * CH_BS] = m;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                double2 o;
+                o.x = w[r].x / h;
+                o.y = w[r].y / h;
+                vn2[(int64_t)r * CH_BS] = o;
+            }
+        }
+    }
+#undef CH_OK
+}
+
+// ------------------------------------------------------------------------------------------
 // Register-resident PANEL (classical) Gram-Schmidt: two launches per sweep, any number of ranks.
 //
 //   k_cgs_dots    w in registers; streams ALL columns once; per column one wave64 partial per

@@ -242,6 +242,25 @@ static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// the variant that parks the head of every column in LDS between its dot and its update (B == V)
+template <int R2, bool MASKED, bool CPLX = false>
+static hipError_t launch_chain_lds(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = ChainShapeLds<R2>::LDS_BYTES;
+    if (blocks_per_cu < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_lds<R2, MASKED, CPLX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain_lds<R2, MASKED, CPLX>, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((k_mgs_chain_lds<R2, MASKED, CPLX>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
 static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
     if (n < 2) return false;
@@ -315,9 +334,20 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.h_km1_dev = h_km1_dev;
     a.bprev = presub ? B->col(k - 1) : nullptr;
     hipError_t e;
-#define KH_CHAIN(R)                                                                                   \
+    static const int lds_env = [] {
+        const char* ev = getenv("KRYPY_AMD_CHAIN_LDS");
+        return ev ? atoi(ev) : 1;
+    }();
+    // (the complex instantiations with 32 / 40 rows per lane are beyond the VGPR budget with the LDS
+    // traffic on top - 81 / 199 spilled registers - and stay on the plain kernel)
+    const bool use_lds = lds_env && B == V && dg == nullptr && ctx->chain_debug == 0 && !(cplx && r2 >= 32);
+#define KH_CHAIN_PLAIN(R)                                                                             \
     (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
+#define KH_CHAIN_LDS(R)                                                                                       \
+    (cplx ? (padded ? launch_chain_lds<R, false, true>(ctx, G, a) : launch_chain_lds<R, true, true>(ctx, G, a)) \
+          : (padded ? launch_chain_lds<R, false>(ctx, G, a) : launch_chain_lds<R, true>(ctx, G, a)))
+#define KH_CHAIN(R) (use_lds ? KH_CHAIN_LDS(R) : KH_CHAIN_PLAIN(R))
     if (r2 == 4) e = KH_CHAIN(4);
     else if (r2 == 8) e = KH_CHAIN(8);
     else if (r2 == 16) e = KH_CHAIN(16);
@@ -325,6 +355,8 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     else if (r2 == 32) e = KH_CHAIN(32);
     else e = KH_CHAIN(40);
 #undef KH_CHAIN
+#undef KH_CHAIN_LDS
+#undef KH_CHAIN_PLAIN
     if (e != hipSuccess) {
         // e.g. hipErrorCooperativeLaunchTooLarge: not all workgroups can be co-resident
         (void)hipGetLastError();
