@@ -320,26 +320,20 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 // the update, after the grid-wide reduction.  The workgroup owns a whole CU (512 threads, 160 KB of
 // LDS, ~4 KB used), so the first LB batches of the column (LB*PB rows x 512 lanes x 16 B = up to
 // 128 KB) are copied into LDS while the dot phase streams them and the update phase takes them from
-// there: 16 of the 40 rows at N = 10^7, i.e. 20 % less HBM/Infinity-Cache traffic per link (all of the
-// second read when the vectors are short enough for R2 <= 16).  Only for B == V (no preconditioner);
-// batches of 4 rows so that the ring parity still resets every phase (NB - LB even).
+// there.  The update phase also walks the batches in REVERSE order, so the last batch of the dot phase
+// is still in the register ring and is used again without any load.  At N = 10^7 (R2 = 40, batches
+// of 5 rows): 15 rows from LDS + 5 from the ring = half of the second read, 25 % less HBM traffic per
+// link; for R2 <= 16 the second read disappears altogether.  Only for B == V (no preconditioner).
+// Ring parity: batch NB-1 sits in ring[1]; the NG = NB - LB - 1 batches that still come from memory
+// start in ring[0] and NG is even, so the next column's first batch lands in ring[0] again.
 // ------------------------------------------------------------------------------------------
-// R2 = 40 (the N = 10^7 shape) is at the VGPR limit: batches of 5 rows like the plain kernel and 2 of
-// the 8 batches in LDS is what fits without noticeable spilling (4 VGPRs); measured alternatives:
-// PB=4/LB=4 spills 29 VGPRs and is slower than no LDS at all, PB=2/LB=8 27.3 us per column.
-#ifndef KH_LDS40_PB
-#define KH_LDS40_PB 5
-#endif
-#ifndef KH_LDS40_LB
-#define KH_LDS40_LB 2
-#endif
 template <int R2>
 struct ChainShapeLds {
-    static constexpr int PB = (R2 == 40) ? KH_LDS40_PB : ((R2 == 4) ? 2 : 4);
-    static constexpr int NB = R2 / PB;
-    static constexpr int LB = (R2 == 40) ? KH_LDS40_LB : (NB < 4 ? NB : 4);   // batches kept in LDS
-    static constexpr int NG = NB - LB;                        // update batches that still come from memory
-    static_assert(NB * PB == R2 && (NB % 2) == 0 && (NG % 2) == 0, "ring parity must reset every phase");
+    static constexpr int PB = ChainShape<R2>::PB;             // 5 rows per batch for R2 = 40, like the plain kernel
+    static constexpr int NB = ChainShape<R2>::NB;
+    static constexpr int LB = NB >= 4 ? 3 : 1;                // leading batches kept in LDS
+    static constexpr int NG = NB - LB - 1;                    // update batches that still come from memory
+    static_assert((NB % 2) == 0 && NG >= 0 && (NG % 2) == 0, "ring parity must reset every phase");
     static constexpr size_t LDS_BYTES = (size_t)LB * PB * CH_BS * sizeof(double2);
 };
 
@@ -403,7 +397,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             // next: v_j batch b+1; after the last one the first update batch that is not in LDS
             // (or, if the whole column is, the next column's first batch)
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS
-                                                            : (NG > 0 ? v2 + (int64_t)LB * PB * CH_BS : vn);
+                                                            : (NG > 0 ? v2 + (int64_t)(NB - 2) * PB * CH_BS : vn);
 #pragma unroll
             for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
@@ -435,47 +429,45 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                                    : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
             if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
         }
-        // ---- update phase: w -= alpha * v_j, head from LDS (own entries: no barrier needed) ----
+        // ---- update phase: w -= alpha * v_j, batches in reverse order ----
+#define CH_UPD(r, p)                                              \
+    do {                                                          \
+        if (CPLX) {                                               \
+            const double tr = alpha * (p).x - alpha_i * (p).y;    \
+            const double ti = alpha * (p).y + alpha_i * (p).x;    \
+            w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;                \
+            w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;                \
+        } else {                                                  \
+            w[r].x = CH_OK(r) ? w[r].x - alpha * (p).x : 0.0;     \
+            w[r].y = CH_OK(r) ? w[r].y - alpha * (p).y : 0.0;     \
+        }                                                         \
+    } while (0)
+        // (a) the last batch of the dot phase is still in ring[1]
 #pragma unroll
-        for (int b = 0; b < LB; ++b) {
-            CH_ISSUE_FENCE();     // one batch of LDS reads at a time (they would all be hoisted: spills)
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const double2 p = vlds[(b * PB + i) * CH_BS + tid];
-                const int r = b * PB + i;
-                if (CPLX) {
-                    const double tr = alpha * p.x - alpha_i * p.y;
-                    const double ti = alpha * p.y + alpha_i * p.x;
-                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
-                } else {
-                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
-                }
-            }
-        }
+        for (int i = 0; i < PB; ++i) CH_UPD((NB - 1) * PB + i, ring[1][i]);
+        // (b) batches NB-2 ... LB from memory through the ring
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int b = LB + g;
-            const double2* __restrict__ nx = (g + 1 < NG) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+            const int b = NB - 2 - g;
+            const double2* __restrict__ nx = (g + 1 < NG) ? v2 + (int64_t)(b - 1) * PB * CH_BS : vn;
 #pragma unroll
             for (int i = 0; i < PB; ++i) ring[(g + 1) & 1][i] = nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
+            for (int i = 0; i < PB; ++i) CH_UPD(b * PB + i, ring[g & 1][i]);
+        }
+        // (c) the head of the column from LDS (own entries: no barrier needed), one batch of reads at
+        //     a time (hoisted all together they would spill)
+#pragma unroll
+        for (int b = LB - 1; b >= 0; --b) {
+            CH_ISSUE_FENCE();
+#pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 p = ring[g & 1][i];
-                const int r = b * PB + i;
-                if (CPLX) {
-                    const double tr = alpha * p.x - alpha_i * p.y;
-                    const double ti = alpha * p.y + alpha_i * p.x;
-                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
-                } else {
-                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
-                }
+                const double2 p = vlds[(b * PB + i) * CH_BS + tid];
+                CH_UPD(b * PB + i, p);
             }
         }
+#undef CH_UPD
     }
     // norm: <w,w> or <w, D w>
     double acc = 0.0;
