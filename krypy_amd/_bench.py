@@ -44,7 +44,7 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         # register-resident MGS chain: one launch = load w (8N) + 64 links x (v_j read for the dot +
         # b_j read for the update = 16N, the SURVEY 8d per-column figure) + store v_{k+1} (8N)
         nb = 16.0 * n * CHAIN_LINKS + 16.0 * n
-        run(K_CHAIN, nb, "k_mgs_chain (64 links/launch)", nb)
+        run(K_CHAIN, nb, "k_mgs_chain (64 links/launch)", 8.0 * n * CHAIN_LINKS * 1.5 + 16.0 * n)
         chain = kernels["k_mgs_chain (64 links/launch)"]
         chain["us_per_link"] = chain["avg_ms"] * 1e3 / CHAIN_LINKS
     except Exception as exc:   # not eligible (odd n, w larger than the register file, multi-GPU)
@@ -81,7 +81,7 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         ms = d["avg_ms"] + a["avg_ms"]
         name = "k_multidot<16>+k_multiaxpy<16>"
     elif chain is not None:
-        nb, ms, name = chain["algorithmic_bytes"], chain["avg_ms"], "k_mgs_chain<40,false> (64 links per launch)"
+        nb, ms, name = chain["algorithmic_bytes"], chain["avg_ms"], "k_mgs_chain_lds (64 links per launch)"
     else:
         d = kernels["k_gs_link<A_PART,T_DOT>"]
         nb, ms, name = d["algorithmic_bytes"], d["avg_ms"], "k_gs_link<A_PART,T_DOT>"
@@ -89,4 +89,9 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
     roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": peak_gbs, "unit": "GB/s",
             "frac": ach / peak_gbs, "traffic": None, "avg_launch_ms": ms,
             "algorithmic_bytes_per_launch": nb}
+    if chain is not None and name.startswith("k_mgs_chain"):
+        roof["note"] = ("algorithmic bytes = SURVEY 8(d): 16 N per basis column (the column is read for the "
+                        "projection and again for the update).  The kernel serves half of that second read "
+                        "from LDS / the register ring, so its HBM traffic (`traffic`, PMC) is below the "
+                        "algorithmic bytes and `frac` can exceed 1; traffic / avg_launch_ms is the HBM rate.")
     return roof, extra
