@@ -352,13 +352,17 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    // a batch that will be read again (update phase) is loaded normally so that the Infinity Cache
+    // keeps it; everything that is used once (the batches that live on in LDS / the ring, the second
+    // read itself, w) is loaded non-temporally and does not evict it
+#define CH_LD(ptr, reuse) ((reuse) ? *(ptr) : ld_nt2(ptr))
     double2 w[R2];
     double2 ring[2][PB];
     {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            const double2 v = win2[(int64_t)r * CH_BS];
+            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
             w[r].x = CH_OK(r) ? v.x : 0.0;
             w[r].y = CH_OK(r) ? v.y : 0.0;
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
@@ -380,7 +384,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     {
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld) + first;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        for (int i = 0; i < PB; ++i) ring[0][i] = CH_LD(v2 + (int64_t)i * CH_BS, false);
         CH_ISSUE_FENCE();
     }
     for (int t = 0; t < total; ++t) {
@@ -399,7 +403,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS
                                                             : (NG > 0 ? v2 + (int64_t)(NB - 2) * PB * CH_BS : vn);
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i)
+                ring[(b + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, (b + 1 < NB) && (b + 1 >= LB) && (b + 1 <= NB - 2));
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
@@ -451,7 +456,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             const int b = NB - 2 - g;
             const double2* __restrict__ nx = (g + 1 < NG) ? v2 + (int64_t)(b - 1) * PB * CH_BS : vn;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(g + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i) ring[(g + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, false);
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) CH_UPD(b * PB + i, ring[g & 1][i]);
@@ -518,6 +523,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             }
         }
     }
+#undef CH_LD
 #undef CH_OK
 }
 
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            const double2 v = win2[(int64_t)r * CH_BS];
+            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);   // (the columns stay normal loads: the update pass re-reads them)
             w[r].x = CH_OK(r) ? v.x : 0.0;
             w[r].y = CH_OK(r) ? v.y : 0.0;
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
@@ -618,7 +624,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
     double2* __restrict__ w2 = reinterpret_cast<double2*>(a.w) + first;
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
-        const double2 v = w2[(int64_t)r * CH_BS];
+        const double2 v = ld_nt2(w2 + (int64_t)r * CH_BS);
         w[r].x = CH_OK(r) ? v.x : 0.0;
         w[r].y = CH_OK(r) ? v.y : 0.0;
         if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
     {
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + (a.col0 + tfirst) * a.ld) + first;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        for (int i = 0; i < PB; ++i) ring[0][i] = ld_nt2(v2 + (int64_t)i * CH_BS);
         CH_ISSUE_FENCE();
     }
     for (int it = 0; it < a.ncol; ++it) {
@@ -645,7 +651,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : bn;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = ld_nt2(nx + (int64_t)i * CH_BS);
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {

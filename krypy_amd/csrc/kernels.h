@@ -47,6 +47,16 @@ __device__ __forceinline__ double bcast_sum_partials(const double* __restrict__ 
     return r;
 }
 
+// 16-byte non-temporal load (streams that are used once: keep them out of the way of what is reused)
+typedef double v2f64_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 ld_nt2(const double2* p) {
+    const v2f64_t v = __builtin_nontemporal_load(reinterpret_cast<const v2f64_t*>(p));
+    double2 r;
+    r.x = v.x;
+    r.y = v.y;
+    return r;
+}
+
 // where a kernel takes the coefficient of its axpy from
 enum { A_NONE = 0, A_PART = 1, A_SCAL = 2, A_ARG = 3 };
 // what a kernel reduces after the axpy
@@ -439,8 +449,10 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = threadIdx.x + i * BS;
                 const int tc = t < cnt ? t : cnt - 1;
-                c[i] = indices[nz0 + tc];
-                a[i] = data[nz0 + tc];
+                // read-once streams: non-temporal, so that they do not push the x lines that the
+                // gathers below (and the neighbouring row blocks) need out of L2
+                c[i] = __builtin_nontemporal_load(indices + nz0 + tc);
+                a[i] = __builtin_nontemporal_load(data + nz0 + tc);
             }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
@@ -510,7 +522,9 @@ __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_col
         int64_t i = lane;
         // four independent 16-byte row loads in flight per lane (1 KB per wave instruction)
         for (; i + 192 < n2; i += 256) {
-            const double2 a0 = a2[i], a1 = a2[i + 64], a2v = a2[i + 128], a3 = a2[i + 192];
+            // the matrix is streamed once: non-temporal, x stays in L2
+            const double2 a0 = ld_nt2(a2 + i), a1 = ld_nt2(a2 + i + 64), a2v = ld_nt2(a2 + i + 128),
+                          a3 = ld_nt2(a2 + i + 192);
             const double2 x0 = x2[i], x1 = x2[i + 64], x2v = x2[i + 128], x3 = x2[i + 192];
             acc0 = fma(a0.x, x0.x, acc0);
             acc0 = fma(a0.y, x0.y, acc0);
