@@ -215,7 +215,7 @@ __global__ __launch_bounds__(BS) void k_multidot(int64_t n, ColPtrs cols,
         const double2 wv = w2[i];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double2 vv = reinterpret_cast<const double2*>(cols.c[c])[i];
+            const double2 vv = ld_nt2(reinterpret_cast<const double2*>(cols.c[c]) + i);   // column: used once
             acc[c] = fma(vv.x, wv.x, acc[c]);
             acc[c] = fma(vv.y, wv.y, acc[c]);
         }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(BS) void k_multiaxpy(int64_t n, ColPtrs cols,
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double2 vv = reinterpret_cast<const double2*>(cols.c[c])[i];
+            const double2 vv = ld_nt2(reinterpret_cast<const double2*>(cols.c[c]) + i);   // column: used once
             wv.x = wv.x - h[c] * vv.x;
             wv.y = wv.y - h[c] * vv.y;
         }

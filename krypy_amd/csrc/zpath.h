@@ -32,7 +32,7 @@ __global__ __launch_bounds__(BS) void k_zmultidot(int64_t n, ZColPtrs cols, cons
         const double2 wv = w[i];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double2 v = cols.c[c][i];
+            const double2 v = ld_nt2(cols.c[c] + i);    // column: used once per launch
             ar[c] = fma(v.x, wv.x, ar[c]);     // conj(v) * w
             ar[c] = fma(v.y, wv.y, ar[c]);
             ai[c] = fma(v.x, wv.y, ai[c]);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(BS) void k_zmultiaxpy(int64_t n, ZColPtrs cols, con
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const double2 v = cols.c[c][i];
+            const double2 v = ld_nt2(cols.c[c] + i);    // column: used once per launch
             const double tr = h[c].x * v.x - h[c].y * v.y;
             const double ti = h[c].x * v.y + h[c].y * v.x;
             wv.x = wv.x - tr;
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__
             for (int i = 0; i < ITEMS; ++i) {
                 const int t = threadIdx.x + i * BS;
                 const int tc = t < cnt ? t : cnt - 1;
-                c[i] = indices[nz0 + tc];
-                a[i] = data[nz0 + tc];
+                c[i] = __builtin_nontemporal_load(indices + nz0 + tc);   // read-once streams
+                a[i] = ld_nt2(data + nz0 + tc);
             }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
