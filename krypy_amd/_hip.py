@@ -234,12 +234,15 @@ class DeviceVectors(object):
     (interleaved re, im): the real-linear kernels run on it unchanged.
     """
 
-    def __init__(self, ctx, n, ncols, dtype=_F64):
+    def __init__(self, ctx, n, ncols, dtype=_F64, zero=True):
+        """``zero=False``: the caller writes every column before it reads it (a Krylov basis), so a
+        recycled block is handed out as it is - only its padding is guaranteed to be zero (no kernel
+        ever writes there).  A fresh allocation is zero-filled either way."""
         self.ctx, self.n, self.ncols = ctx, int(n), int(ncols)
         self.dtype = _block_dtype(dtype)
         self._w = 2 if self.dtype == _C128 else 1      # doubles per entry
         self._rn = self.n * self._w                    # length of the real kh_vec
-        h = ctx._pool_take(self._rn, self.ncols)
+        h = ctx._pool_take(self._rn, self.ncols, zero)
         if h is None:
             h = _H()
             rc = ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h))
@@ -346,13 +349,14 @@ class Context(object):
     _POOL_SMALL_BYTES = 1 << 30  # a cycle allocates and drops about ten of them
     _POOL_FRACTION = 0.35
 
-    def _pool_take(self, n, ncols):
+    def _pool_take(self, n, ncols, zero=True):
         lst = self.__dict__.setdefault("_pool", {}).get((n, ncols))
         if not lst:
             return None
         h = lst.pop()
         self._pool_bytes -= 8 * n * max(ncols, 1)
-        _check(self._lib, self._lib.kh_vec_zero(h, 0, ncols), "kh_vec_zero(pool)")
+        if zero:
+            _check(self._lib, self._lib.kh_vec_zero(h, 0, ncols), "kh_vec_zero(pool)")
         return h
 
     def _pool_give(self, n, ncols, h):
@@ -429,8 +433,8 @@ class Context(object):
                                                     nrecv_prev, nrecv_next), "kh_mat_set_halo")
 
     # ---- allocation / transfer ----
-    def alloc(self, n, ncols=1, dtype=_F64):
-        return DeviceVectors(self, n, ncols, dtype)
+    def alloc(self, n, ncols=1, dtype=_F64, zero=True):
+        return DeviceVectors(self, n, ncols, dtype, zero)
 
     def upload(self, arr, dtype=None):
         """Host array -> device block; ``dtype`` forces a complex block for real data."""

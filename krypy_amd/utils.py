@@ -1021,8 +1021,10 @@ class Arnoldi(object):
                      and self._window_ok(ctx, bdt))
         if self._win:
             self._cols = self._WINDOW_COLS
-        self._V = ctx.alloc(N, self._cols, dtype=bdt)
-        self._P = ctx.alloc(N, self._cols, dtype=bdt) if self.M is not None else None
+        # (zero=False: every basis column is written before it is read, and V / P / get() download the
+        # computed columns only - a recycled 8 GB block is not zero-filled again)
+        self._V = ctx.alloc(N, self._cols, dtype=bdt, zero=False)
+        self._P = ctx.alloc(N, self._cols, dtype=bdt, zero=False) if self.M is not None else None
         self._W = ctx.alloc(N, 2, dtype=bdt)
         self.H = numpy.zeros((self.maxiter + 1, self.maxiter), dtype=self.dtype)
         self._h2 = 0.0   # running sum of squares of H (Frobenius), for the invariance pre-test
@@ -1132,18 +1134,20 @@ class Arnoldi(object):
             old = getattr(self, name)
             if old is None:
                 continue
-            new = self._ctx.alloc(old.n, cols, dtype=old.dtype)
+            new = self._ctx.alloc(old.n, cols, dtype=old.dtype, zero=False)
             new.copy_from(0, old, 0, min(done, old.ncols))
             setattr(self, name, new)
         self._cols = cols
 
     def _padded(self, block):
-        """Host copy with the reference's (N, maxiter+1) shape (columns never reached are zero)."""
-        out = block.download()
-        if out.shape[1] == self.maxiter + 1:
-            return out
-        full = numpy.zeros((out.shape[0], self.maxiter + 1), dtype=out.dtype)
-        full[:, : out.shape[1]] = out
+        """Host copy with the reference's (N, maxiter+1) shape: the computed columns, zeros behind them
+        (the device block is not zero-filled when it is recycled, and may be shorter than maxiter+1)."""
+        done = min(self.iter + 1, block.ncols)
+        if self.invariant:
+            done = min(self.iter, block.ncols)      # the reference leaves the last column untouched
+        full = numpy.zeros((block.n, self.maxiter + 1), dtype=block.dtype, order="F")
+        if done > 0:
+            full[:, :done] = block.download(0, done)
         return full
 
     # the reference exposes ndarrays; here they are downloaded on demand

@@ -132,8 +132,11 @@ class NumpyContext(object):
         return self._allreduce(np.asarray(vals, dtype=float))
 
     # allocation
-    def alloc(self, n, ncols=1, dtype=float):
-        return NumpyVectors(self, n, ncols, dtype)
+    def alloc(self, n, ncols=1, dtype=float, zero=True):
+        v = NumpyVectors(self, n, ncols, dtype)
+        if not zero:
+            v.a[:] = np.nan      # a recycled block holds garbage: whoever reads before writing shows up
+        return v
 
     def upload(self, arr, dtype=None):
         a = np.asarray(arr)
