@@ -340,7 +340,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     }();
     // (the complex instantiations with 32 / 40 rows per lane are beyond the VGPR budget with the LDS
     // traffic on top - 81 / 199 spilled registers - and stay on the plain kernel)
-    const bool use_lds = lds_env && B == V && dg == nullptr && ctx->chain_debug == 0 && !(cplx && r2 >= 32);
+    static thread_local bool lds_failed = false;   // the LDS variant could not be launched once: plain kernel from then on
+    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
+                   !(cplx && r2 >= 32);
 #define KH_CHAIN_PLAIN(R)                                                                             \
     (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
@@ -348,12 +350,18 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     (cplx ? (padded ? launch_chain_lds<R, false, true>(ctx, G, a) : launch_chain_lds<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain_lds<R, false>(ctx, G, a) : launch_chain_lds<R, true>(ctx, G, a)))
 #define KH_CHAIN(R) (use_lds ? KH_CHAIN_LDS(R) : KH_CHAIN_PLAIN(R))
-    if (r2 == 4) e = KH_CHAIN(4);
-    else if (r2 == 8) e = KH_CHAIN(8);
-    else if (r2 == 16) e = KH_CHAIN(16);
-    else if (r2 == 24) e = KH_CHAIN(24);
-    else if (r2 == 32) e = KH_CHAIN(32);
-    else e = KH_CHAIN(40);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (r2 == 4) e = KH_CHAIN(4);
+        else if (r2 == 8) e = KH_CHAIN(8);
+        else if (r2 == 16) e = KH_CHAIN(16);
+        else if (r2 == 24) e = KH_CHAIN(24);
+        else if (r2 == 32) e = KH_CHAIN(32);
+        else e = KH_CHAIN(40);
+        if (e == hipSuccess || !use_lds) break;
+        (void)hipGetLastError();     // e.g. the 120 KB of dynamic LDS were refused: fall back to the plain kernel
+        lds_failed = true;
+        use_lds = false;
+    }
 #undef KH_CHAIN
 #undef KH_CHAIN_LDS
 #undef KH_CHAIN_PLAIN
