@@ -225,13 +225,14 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
             alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
             if (blockIdx.x == 0 && tid == 0) {
-                a.hdev[2 * j] += alpha;
-                a.hdev[2 * j + 1] += alpha_i;
+                // first sweep assigns (the caller does not clear the H column for a chain launch)
+                a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
+                a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
                                    : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
-            if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+            if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
         // ---- update phase: w -= alpha * b_j ----
         const int64_t jn = a.col0 + ((t + 1) % a.ncol);
@@ -426,13 +427,14 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
             alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
             if (blockIdx.x == 0 && tid == 0) {
-                a.hdev[2 * j] += alpha;
-                a.hdev[2 * j + 1] += alpha_i;
+                // first sweep assigns (the caller does not clear the H column for a chain launch)
+                a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
+                a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
                                    : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
-            if (blockIdx.x == 0 && tid == 0) a.hdev[j] += alpha;
+            if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
         // ---- update phase: w -= alpha * v_j, batches in reverse order ----
 #define CH_UPD(r, p)                                              \

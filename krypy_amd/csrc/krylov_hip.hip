@@ -1019,7 +1019,6 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     const bool multi = kh_multi(ctx);
     double* hdev = ctx->hslot_dev[slot];
     double* tmp = ctx->scal + SC_TMP;
-    KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
 
     const bool presub = (start > 0 && start == k);  // Lanczos three-term recurrence
     // look-ahead Lanczos: h_km1 = NaN means "H[k,k-1] of the step begun just before this one",
@@ -1032,6 +1031,9 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                              chain_geometry(ctx, n, &cr2, &cg));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
                             A->nblk > 0 && !want_chain && proj == nullptr);
+    // the H column accumulates over sweeps, so it starts from zero - except under the chain kernel, whose
+    // first sweep assigns (one memset launch and its queue bubble less per step)
+    if (!want_chain) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
     // 1. operator
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
@@ -1051,6 +1053,9 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot);
         if (rc < 0) return rc;
         chained = (rc == 1);
+        if (!chained) {   // not eligible after all: clear the column now, nothing has been accumulated yet
+            KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
+        }
     }
     if (chained) {
         // the whole Gram-Schmidt chain, the norm and the normalised store ran in one launch
