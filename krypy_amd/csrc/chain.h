@@ -55,6 +55,11 @@ struct ChainArgs {
     double h_km1;
     const double* h_km1_dev;   // when non-null the coefficient is read from the device (look-ahead)
     const double* bprev;
+    // when hpin != nullptr workgroup 0 finally copies the H column (hcount doubles) and the error word
+    // straight into pinned host memory: no device-to-host copies behind the launch
+    double* hpin;
+    int hcount;
+    int* errpin;
 };
 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
@@ -311,6 +316,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             }
         }
     }
+    if (blockIdx.x == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by thread 0 of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #undef CH_OK
 }
 
@@ -524,6 +535,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                 vn2[(int64_t)r * CH_BS] = o;
             }
         }
+    }
+    if (blockIdx.x == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by thread 0 of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #undef CH_LD
 #undef CH_OK

@@ -156,11 +156,20 @@ __global__ __launch_bounds__(BS) void k_scale_store(int64_t n, const double* __r
                                                     double* __restrict__ pnext,
                                                     const double* __restrict__ part_in, int nb_in,
                                                     const double* __restrict__ scal_in,
-                                                    double* __restrict__ hslot) {
+                                                    double* __restrict__ hslot,
+                                                    const double* hcol = nullptr, int hcount = 0,
+                                                    double* hpin = nullptr) {
     __shared__ double sm[8];
     double h2 = (HSRC == A_PART) ? bcast_sum_partials(part_in, nb_in, sm) : scal_in[0];
     const double h = sqrt(fabs(h2));
     if (hslot != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *hslot = h;
+    if (hpin != nullptr && blockIdx.x == 0) {
+        // last kernel of an Arnoldi step: workgroup 0 puts the finished H column (hcount doubles,
+        // *hslot among them) straight into pinned host memory - no device-to-host copy behind it
+        __syncthreads();
+        for (int i = threadIdx.x; i < hcount; i += BS)
+            hpin[i] = __hip_atomic_load(hcol + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const int64_t n2 = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * BS;
     const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);

@@ -291,7 +291,8 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 // kernels), negative on error
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
-                     const double* h_km1_dev, double* hdev, int slot, bool cplx = false) {
+                     const double* h_km1_dev, double* hdev, int slot, bool cplx = false, double* hpin = nullptr,
+                     int hcount = 0) {
     // cplx: V, B, w are (re, im) views of complex vectors (zpath.h); hdev holds (re, im) pairs
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     if (cplx && (dg != nullptr || P != nullptr)) return 0;
@@ -333,6 +334,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.h_km1 = h_km1;
     a.h_km1_dev = h_km1_dev;
     a.bprev = presub ? B->col(k - 1) : nullptr;
+    a.hpin = hpin;
+    a.hcount = hcount;
+    a.errpin = ctx->chain_err_pin[slot];
     hipError_t e;
     static const int lds_env = [] {
         const char* ev = getenv("KRYPY_AMD_CHAIN_LDS");
@@ -372,8 +376,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         return 0;
     }
     ctx->chain_epoch += (unsigned)((cplx ? 2 : 1) * a.ncol * a.sweeps + 1);
-    KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    if (hpin == nullptr)      // (otherwise workgroup 0 has written the error word to the pinned slot itself)
+        KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                              ctx->stream));
     return 1;
 }
 
@@ -1050,7 +1055,8 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     int nrm_count = grid;     // number of partial sums the norm arrives in
     bool chained = false;
     if (want_chain) {
-        const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot);
+        const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot,
+                                 false, ctx->hslot_pin[slot], (int)(k + 2 + pd));
         if (rc < 0) return rc;
         chained = (rc == 1);
         if (!chained) {   // not eligible after all: clear the column now, nothing has been accumulated yet
@@ -1158,15 +1164,14 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                                tmp + 1, 0);
             KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
             hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
-                               pn, nullptr, 0, tmp + 1, hs);
+                               pn, nullptr, 0, tmp + 1, hs, hdev, (int)(k + 2 + pd), ctx->hslot_pin[slot]);
         } else {
             hipLaunchKernelGGL((k_scale_store<A_PART>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
-                               pn, nrm_part, nrm_count, nullptr, hs);
+                               pn, nrm_part, nrm_count, nullptr, hs, hdev, (int)(k + 2 + pd), ctx->hslot_pin[slot]);
         }
         KH_HIP(hipGetLastError());
     }
-    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * (k + 2 + pd), hipMemcpyDeviceToHost,
-                          ctx->stream));
+    // (the last kernel of the step - chain or scale-store - has written the H column to the pinned slot)
     KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
     return 0;
 }
