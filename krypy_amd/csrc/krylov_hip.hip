@@ -436,12 +436,16 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         a.coef = nullptr;
         a.part = ctx->cgs_part;
         KH_HIP(KH_CGS_ANY(false));
+        // one sweep: the coefficients ARE the H entries - reduce (and all-reduce) straight into the H
+        // column, which the caller then need not clear, and skip the accumulate launch
+        if (sweeps == 1) coef = hdev + start;
         hipLaunchKernelGGL(k_reduce_partials, dim3((int)ncol), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
                            CGS_PSTRIDE, coef, 0);
         KH_HIP(hipGetLastError());
         if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
-        hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0, hdev + start,
-                           1.0, coef);
+        if (sweeps > 1)
+            hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0, hdev + start,
+                               1.0, coef);
         a.Vb = B->d;
         a.ld = B->ld;
         a.coef = coef;
@@ -1038,7 +1042,9 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                             A->nblk > 0 && !want_chain && proj == nullptr);
     // the H column accumulates over sweeps, so it starts from zero - except under the chain kernel, whose
     // first sweep assigns (one memset launch and its queue bubble less per step)
-    if (!want_chain) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
+    // (nor under the single-sweep register-resident panel kernels, which write the entries directly)
+    const bool want_cgs1 = (gs_mode == KH_GS_CGS && sweeps == 1 && ctx->chain_enabled);
+    if (!want_chain && !want_cgs1) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
     // 1. operator
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
@@ -1143,6 +1149,8 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         const int rc = try_cgs_reg(ctx, V, B, w, W->ld, dg, mw, start, ncol, sweeps, multi, hdev, coef,
                                    &nrm_count);
         if (rc < 0) return rc;
+        if (rc == 0 && want_cgs1)     // not eligible after all: the chunked path accumulates, clear the column now
+            KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
         for (int s = 0; rc == 0 && s < sweeps; ++s) {     // chunked panel kernels (w streamed)
             KH_TRY(dot_panel_dev(ctx, V, start, ncol, w, coef, 0));
             if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
