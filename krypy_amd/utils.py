@@ -1682,6 +1682,51 @@ class Projection(object):
                     numpy.column_stack([r[1] for r in res]))
         return numpy.column_stack([r.download() for r in res])
 
+    # -- adjoint projection (utils.py:554-564, 593-603, 629-638) ------------------------------
+    def _apply_adj_dvec(self, a):
+        """Single application of the adjoint: ``W Q R^{-H} <V, a>``."""
+        a = a.astype(_bdt(self._Vd.dtype, self._Wd.dtype))
+        c = _inner_dev(self._Vd, 0, self._k, a.block, a.col, 1, self.ip_B)
+        if self.Q is not None and self.R is not None:
+            c = self.Q.dot(scipy.linalg.solve_triangular(self.R.T.conj(), c, lower=True))
+        out = a.ctx.alloc(self._N, 1, dtype=a.dtype)
+        Wd = _promote_block(self._Wd, 0, self._k, a.dtype)[0]
+        a.ctx.gemm_nn(Wd, 0, self._k, c, 1.0, 0.0, out, 0)
+        return DVec(out)
+
+    def _axpy(self, z, alpha, x):
+        """z += alpha * x for device vectors (real alpha)."""
+        z.ctx.waxpby(z.block, z.col, 1.0, z.block, z.col, alpha, x.block, x.col)
+
+    def apply_adj(self, a):
+        """Apply the adjoint projection, ``iterations`` sweeps (utils.py:593-603)."""
+        if self._k == 0:
+            return numpy.zeros(a.shape)
+
+        def one(v):
+            v = v.astype(_bdt(self._Vd.dtype, self._Wd.dtype))
+            x = self._apply_adj_dvec(v)
+            for _ in range(self.iterations - 1):
+                z = v.copy()
+                self._axpy(z, -1.0, x)
+                self._axpy(x, 1.0, self._apply_adj_dvec(z))
+            return x
+        return numpy.column_stack([r.download() for r in self._columns(a, one)])
+
+    def apply_complement_adj(self, a):
+        """Apply the adjoint of the complementary projection (utils.py:629-638)."""
+        if self._k == 0:
+            return a.copy()
+
+        def one(v):
+            v = v.astype(_bdt(self._Vd.dtype, self._Wd.dtype))
+            z = v.copy()
+            self._axpy(z, -1.0, self._apply_adj_dvec(v))
+            for _ in range(self.iterations - 1):
+                self._axpy(z, -1.0, self._apply_adj_dvec(z))
+            return z
+        return numpy.column_stack([r.download() for r in self._columns(a, one)])
+
     def _get_operator(self, fun, fun_adj):
         dt = numpy.dtype(float) if self._Vd is None else _bdt(self._Vd.dtype, self._Wd.dtype)
         return LinearOperator((self._N, self._N), dt, fun, fun_adj)
@@ -1690,13 +1735,13 @@ class Projection(object):
         """``LinearOperator`` corresponding to :meth:`apply` (utils.py:645-654)."""
         if self._k == 0:
             return ZeroLinearOperator((self._N, self._N))
-        return self._get_operator(self.apply, None)
+        return self._get_operator(self.apply, self.apply_adj)
 
     def operator_complement(self):
         """``LinearOperator`` corresponding to :meth:`apply_complement` (utils.py:656-665)."""
         if self._k == 0:
             return IdentityLinearOperator((self._N, self._N))
-        op = self._get_operator(self.apply_complement, None)
+        op = self._get_operator(self.apply_complement, self.apply_complement_adj)
         op._apply_dev = self._complement_apply_dev
         return op
 

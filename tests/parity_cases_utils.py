@@ -85,6 +85,19 @@ def case_projection():
         assert np.linalg.norm(P.operator() * z - P.apply(z)) == 0
         assert np.linalg.norm(P.operator_complement() * z - P.apply_complement(z)) == 0
         assert np.linalg.norm(P.matrix() - PI, 2) < 1e-13
+        # adjoint (utils.py:554-638): <P x, y> = <x, P^* y> in the inner product used, same for the
+        # complement, and the operators expose it
+        if k > 0:
+            rngp = np.random.default_rng(n)
+            xa, ya = rngp.standard_normal((N, 2)), rngp.standard_normal((N, 2))
+            lhs = _ip(P.apply(xa), ya, ipi > 0)
+            rhs = _ip(xa, P.apply_adj(ya), ipi > 0)
+            assert np.linalg.norm(lhs - rhs) < 1e-10 * max(1.0, np.linalg.norm(lhs))
+            lhs = _ip(P.apply_complement(xa), ya, ipi > 0)
+            rhs = _ip(xa, P.apply_complement_adj(ya), ipi > 0)
+            assert np.linalg.norm(lhs - rhs) < 1e-10 * max(1.0, np.linalg.norm(lhs))
+            assert np.linalg.norm(P.operator().adj * ya - P.apply_adj(ya)) == 0
+            assert np.linalg.norm(P.operator_complement().adj * ya - P.apply_complement_adj(ya)) == 0
         a = np.ones((N, 1))
         want = _ip(X if Y is None else Y, a, ipi > 0)
         _, Ya = P.apply(a, return_Ya=True)
