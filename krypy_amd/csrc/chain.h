@@ -574,9 +574,10 @@ struct CgsArgs {
     const double* dg;      // update: Jacobi diagonal or nullptr
     double* mw;            // update: D w
     int reverse;           // update: walk the columns last to first (see k_cgs_update)
+    int nt_cols;           // dots: non-temporal column loads (a panel far larger than the Infinity Cache)
 };
 
-template <int R2, bool MASKED>
+template <int R2, bool MASKED, bool NTC>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
@@ -600,7 +601,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
     {
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + a.col0 * a.ld) + first;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) ring[0][i] = v2[(int64_t)i * CH_BS];
+        for (int i = 0; i < PB; ++i) ring[0][i] = NTC ? ld_nt2(v2 + (int64_t)i * CH_BS) : v2[(int64_t)i * CH_BS];
         CH_ISSUE_FENCE();
     }
     const int slot = blockIdx.x * (CH_BS / 64) + wid;
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i)
+                ring[(b + 1) & 1][i] = NTC ? ld_nt2(nx + (int64_t)i * CH_BS) : nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {

@@ -390,8 +390,10 @@ template <int R2, bool MASKED>
 static hipError_t launch_cgs(kh_ctx ctx, int G, CgsArgs& a, bool update) {
     if (update)
         hipLaunchKernelGGL((k_cgs_update<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    else if (a.nt_cols)
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, true>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -427,6 +429,13 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         return e ? atoi(e) : 1;
     }();
     a.reverse = rev_env;
+    // the update pass re-reads what the dots pass read last from the Infinity Cache (256 MB); when the
+    // panel is many times larger than that, streaming it non-temporally is worth more
+    static const double nt_gb = [] {
+        const char* e = getenv("KRYPY_AMD_CGS_NT_GB");
+        return e ? atof(e) : 0.75;       // GB; measured: N = 10^7 668 -> 703 it/s, N/2 1315 -> 1441, N/4 2504 -> 2576, N/8 equal
+    }();
+    a.nt_cols = ((double)ncol * (double)n * 8.0 > nt_gb * 1e9) ? 1 : 0;
 #define KH_CGS(R, UPD) (padded ? launch_cgs<R, false>(ctx, G, a, UPD) : launch_cgs<R, true>(ctx, G, a, UPD))
 #define KH_CGS_ANY(UPD)                                                                        \
     (r2 == 4 ? KH_CGS(4, UPD) : r2 == 8 ? KH_CGS(8, UPD) : r2 == 16 ? KH_CGS(16, UPD)            \
