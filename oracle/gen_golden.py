@@ -386,6 +386,70 @@ def gen_deflation_matrix(krypy):
          norms=np.array([rows[i][2:5] for i in range(total)]), ritz_abs=ritz)
 
 
+def gen_api_surface(krypy):
+    """Smaller pieces of the API the other fixtures do not touch: utils.arnoldi_res / orthonormality /
+    norm_squared / Arnoldi.get_last, explicit_residual=True, the convenience wrappers with every keyword,
+    TimedLinearSystem / ConvertedTimedLinearSystem, UnionFactory, operations()."""
+    ku, kl = krypy.utils, krypy.linsys
+    out = {}
+    A, b = lap2d_system(20, rhs="rng1")
+    N = A.shape[0]
+    v = b.reshape(-1, 1)
+    ar = ku.Arnoldi(A, v, maxiter=10, ortho="mgs")
+    for _ in range(10):
+        ar.advance()
+    V, H = ar.get()
+    out["arnoldi_res"] = ku.arnoldi_res(A, V, H)
+    out["orthonormality"] = ku.orthonormality(V)
+    out["norm_squared"] = ku.norm_squared(v)
+    Vl, Hl = ar.get_last()
+    out["get_last_V"], out["get_last_H"] = Vl, Hl
+    Bd = np.linspace(0.5, 2.0, N)
+    B = sp.diags(Bd).tocsr()
+    out["arnoldi_res_B"] = ku.arnoldi_res(A, V, H, ip_B=B)
+    out["orthonormality_B"] = ku.orthonormality(V, ip_B=B)
+    # explicit residual in every iteration
+    for name, Solver, kw in (("gmres", kl.Gmres, {}), ("minres", kl.Minres, dict(self_adjoint=True)),
+                             ("cg", kl.Cg, dict(self_adjoint=True, positive_definite=True))):
+        sol = Solver(kl.LinearSystem(A, b, **kw), tol=1e-9, maxiter=200, explicit_residual=True)
+        out["expl_%s_resnorms" % name], out["expl_%s_xk" % name] = np.array(sol.resnorms), sol.xk[:, 0]
+        out["ops_%s" % name] = np.array([Solver.operations(7)[k] for k in ("A", "M", "Ml", "Mr", "ip_B", "axpy")], dtype=float)
+    # convenience wrappers with the whole keyword set
+    d = np.asarray(A.diagonal())
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    x0 = 0.1 * np.ones(N)
+    U = np.zeros((N, 2))
+    U[0, 0] = U[1, 1] = 1.0
+    exact = np.linalg.solve(A.toarray(), b)
+    for name, fn, extra in (("cg", krypy.cg, {}), ("minres", krypy.minres, dict(ortho="dmgs")),
+                            ("gmres", krypy.gmres, dict(ortho="dmgs"))):
+        x, sol = fn(A, b, M=M, Minv=Minv, exact_solution=exact, x0=x0, U=U, tol=1e-9, maxiter=300,
+                    use_explicit_residual=True, store_arnoldi=True, **extra)
+        out["conv_%s_x" % name], out["conv_%s_resnorms" % name] = x, np.array(sol.resnorms)
+        out["conv_%s_errnorms" % name], out["conv_%s_H" % name] = np.array(sol.errnorms), sol.H
+    x, sol = krypy.gmres(A, b, inner_product=lambda x_, y_: np.dot(x_.conj(), Bd * y_), tol=1e-9, maxiter=300)
+    out["conv_gmres_ip_x"], out["conv_gmres_ip_resnorms"] = x, np.array(sol.resnorms)
+    # timed systems
+    tls = kl.TimedLinearSystem(A, b, M=M, Minv=Minv, self_adjoint=True)
+    sol = kl.Minres(tls, tol=1e-9, maxiter=300)
+    out["timed_resnorms"] = np.array(sol.resnorms)
+    out["timed_keys"] = np.array(sorted(k for k in tls.timings if len(tls.timings[k]) > 0))
+    cls = kl.ConvertedTimedLinearSystem(kl.LinearSystem(A, b, self_adjoint=True))
+    out["converted_resnorms"] = np.array(kl.Minres(cls, tol=1e-9, maxiter=300).resnorms)
+    # UnionFactory of two simple Ritz factories through the recycling driver
+    fac = krypy.recycling.factories.UnionFactory([
+        krypy.recycling.factories.RitzFactorySimple(n_vectors=2, which="sm"),
+        krypy.recycling.factories.RitzFactorySimple(n_vectors=2, which="lm")])
+    rec = krypy.recycling.RecyclingMinres()
+    ls = kl.LinearSystem(A, b, self_adjoint=True)
+    its = []
+    for _ in range(3):
+        s = rec.solve(ls, vector_factory=fac, tol=1e-9, maxiter=300)
+        its.append(len(s.resnorms) - 1)
+    out["union_iters"], out["union_xk"] = np.array(its), s.xk[:, 0]
+    save("api_surface", **out)
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -403,6 +467,7 @@ def main():
     gen_complex(krypy)
     gen_solver_matrix(krypy)
     gen_deflation_matrix(krypy)
+    gen_api_surface(krypy)
 
 
 if __name__ == "__main__":
