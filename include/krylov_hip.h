@@ -109,6 +109,10 @@ int kh_dense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a,
 /* diagonal operator (Jacobi M / Minv given as scipy.sparse.diags) */
 int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out);
 int kh_mat_free(kh_mat A);
+/* number of diagonals of the banded copy kh_csr_upload built for this operator (square, sorted
+ * columns, no stored zeros, <= 32 diagonals at least 70 % full; KRYPY_AMD_SPMV_DIA=0 disables it),
+ * 0 when the CSR kernel serves.  Same results bit for bit either way. */
+int kh_mat_diagonals(kh_mat A);
 /* Y[:, ycol:ycol+nc] = A * X[:, xcol:xcol+nc].  CSR rows are summed left to right in storage
  * order with separate multiply and add, i.e. bit-identical to scipy's csr_matvec(s). */
 int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols);

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "kh_dense_upload": [_H, _I64, _I64, _c_double_p, _I64, ctypes.POINTER(_H)],
     "kh_diag_upload": [_H, _I64, _c_double_p, ctypes.POINTER(_H)],
     "kh_mat_free": [_H],
+    "kh_mat_diagonals": [_H],
     "kh_apply": [_H, _H, _H, _I64, _H, _I64, _I64],
     "kh_dot_panel": [_H, _H, _I64, _I64, _H, _I64, _c_double_p],
     "kh_gemm_tn": [_H, _H, _I64, _I64, _H, _I64, _I64, _c_double_p],
@@ -201,6 +202,13 @@ class DeviceMatrix(object):
     def __init__(self, ctx, handle, kind, shape, nnz=0, dtype=_F64):
         self.ctx, self.handle, self.kind, self.shape, self.nnz = ctx, handle, kind, shape, nnz
         self.dtype = numpy.dtype(dtype)
+
+    @property
+    def diagonals(self):
+        """Diagonals of the banded copy the library built for a CSR operator (0: CSR kernel)."""
+        if self.kind != "csr" or self.dtype != _F64:
+            return 0
+        return int(self.ctx._lib.kh_mat_diagonals(self.handle))
 
     def __del__(self):
         try:

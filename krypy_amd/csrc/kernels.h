@@ -511,6 +511,118 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// Banded ("DIA") SpMV for CSR operators whose entries sit on a few diagonals (finite-difference /
+// stencil matrices: configs 2, 3, 5).  kh_csr_upload detects the structure and k_dia_fill builds
+// the diagonal-major copy on the device: dia[d * ld + i] = A[i, i + off[d]] (0.0 where the row has
+// no entry there; operators that store explicit zeros keep the CSR kernel, so "a == 0" <=> "no
+// entry").  Per row 8 B per diagonal instead of 12 B per entry + indptr, no index stream, no LDS
+// stage, and the x gather becomes nd coalesced streams.  A lane owns RPT pairs of neighbouring
+// rows (16-byte value loads); the diagonals are visited in ascending offset = the storage order of
+// a CSR row with sorted columns, separate multiply and add: the same bits as scipy's csr_matvec
+// and as k_spmv_stream.  Same epilogues and the same XCD-aware block order as the CSR kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int KH_DIA_MAX = 32;
+struct DiaOffs {
+    int nd;
+    int off[KH_DIA_MAX];
+};
+
+__global__ __launch_bounds__(BS) void k_dia_fill(const int32_t* __restrict__ indptr,
+                                                 const int32_t* __restrict__ indices,
+                                                 const double* __restrict__ data, int64_t n_rows,
+                                                 DiaOffs o, double* __restrict__ dia, int64_t ld) {
+    const int64_t r = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (r >= n_rows) return;
+    for (int p = indptr[r]; p < indptr[r + 1]; ++p) {
+        const int off = indices[p] - (int)r;
+        int d = 0;
+        while (d < o.nd - 1 && o.off[d] != off) ++d;
+        dia[(int64_t)d * ld + r] = data[p];
+    }
+}
+
+template <int EPI, int ND, int RPT>
+__global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __restrict__ dia,
+                                                 int64_t ld, int64_t n, int nblk,
+                                                 const double* __restrict__ x,
+                                                 double* __restrict__ y,
+                                                 const double* __restrict__ aux,
+                                                 double* __restrict__ part_out) {
+    __shared__ double sm[8];
+    const int64_t base = (int64_t)xcd_remap(blockIdx.x, nblk) * (2 * BS * RPT);
+    const int64_t last = n - 1;
+    const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    double s0[RPT], s1[RPT];
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) s0[u] = s1[u] = 0.0;
+    auto diagonal = [&](int d) {
+        const int64_t off = o.off[d];
+        const bool even = ((off & 1) == 0) && xal;
+        const double* __restrict__ dd = dia + (int64_t)d * ld;
+        double2 a[RPT];
+        double x0[RPT], x1[RPT];
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t r = base + 2 * (threadIdx.x + u * BS);   // ld covers the whole grid
+            a[u] = ld_nt2(reinterpret_cast<const double2*>(dd + r));
+            int64_t c0 = r + off, c1 = r + 1 + off;
+            if (even && c0 >= 0 && c1 <= last) {            // aligned pair of x: one 16-byte load
+                const double2 xv = *reinterpret_cast<const double2*>(x + c0);
+                x0[u] = xv.x;
+                x1[u] = xv.y;
+            } else {
+                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+                x0[u] = x[c0];
+                x1[u] = x[c1];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const double p0 = a[u].x * x0[u], p1 = a[u].y * x1[u];
+            s0[u] = (a[u].x != 0.0) ? s0[u] + p0 : s0[u];
+            s1[u] = (a[u].y != 0.0) ? s1[u] + p1 : s1[u];
+        }
+    };
+    if constexpr (ND > 0) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) diagonal(d);
+    } else {
+        for (int d = 0; d < o.nd; ++d) diagonal(d);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < RPT; ++u) {
+        const int64_t r = base + 2 * (threadIdx.x + u * BS);
+        double v0 = s0[u], v1 = s1[u];
+        if (r + 1 < n) {
+            if (EPI == EPI_RES) {
+                v0 = aux[r] - v0;
+                v1 = aux[r + 1] - v1;
+                acc = fma(v0, v0, acc);
+                acc = fma(v1, v1, acc);
+            }
+            if (EPI == EPI_DOT) {
+                acc = fma(aux[r], v0, acc);
+                acc = fma(aux[r + 1], v1, acc);
+            }
+            *reinterpret_cast<double2*>(y + r) = make_double2(v0, v1);
+        } else if (r < n) {
+            if (EPI == EPI_RES) {
+                v0 = aux[r] - v0;
+                acc = fma(v0, v0, acc);
+            }
+            if (EPI == EPI_DOT) acc = fma(aux[r], v0, acc);
+            y[r] = v0;
+        }
+    }
+    if (EPI != EPI_NONE) {
+        const double r = block_sum(acc, sm);
+        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Dense row-major GEMV (config 4: A 32768^2 fp64 = 8.6 GB streamed once per CG step).
 // One wave64 per row: lanes stride the row with double2 loads, x stays in L2 (256 KB).
 // HBM-bound (0.25 flop/B); MFMA cannot help a single right-hand side.

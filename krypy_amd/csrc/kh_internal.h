@@ -91,7 +91,12 @@ struct kh_mat_s {
     int32_t* rowblk = nullptr;  // row-block boundaries of the CSR-stream kernel
     int nblk = 0;
     int tile = 0;
-    double* part = nullptr;     // nblk partial sums for the fused dot / norm epilogues
+    double* part = nullptr;     // max(nblk, dia_nblk) partial sums for the fused dot / norm epilogues
+    // banded copy of a CSR operator whose entries sit on <= KH_DIA_MAX diagonals (k_spmv_dia)
+    double* dia = nullptr;      // [dia_nd][dia_ld], 0.0 = no entry
+    int64_t dia_ld = 0;
+    int dia_nd = 0, dia_nblk = 0, dia_rpt = 0;
+    int dia_off[32] = {0};
     // dense
     double* a = nullptr;
     int64_t lda = 0;

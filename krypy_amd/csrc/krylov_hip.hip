@@ -179,8 +179,38 @@ static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, 
                        A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part);
 }
 
+template <int EPI, int ND, int RPT>
+static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* x, double* y, const double* aux) {
+    hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT>), dim3(A->dia_nblk), dim3(BS), 0, ctx->stream, o, A->dia,
+                       A->dia_ld, A->n_rows, A->dia_nblk, x, y, aux, A->part);
+}
+
+template <int EPI>
+static void launch_dia(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+    DiaOffs o;
+    o.nd = A->dia_nd;
+    for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < A->dia_nd ? A->dia_off[d] : 0;
+    // rows per workgroup = 2 * BS * RPT (fixed at upload: dia_ld covers whole workgroups)
+#define KH_DIA_RPT(R)                                                            \
+    switch (A->dia_nd) {                                                         \
+        case 3: launch_dia_nd<EPI, 3, R>(ctx, A, o, x, y, aux); break;           \
+        case 5: launch_dia_nd<EPI, 5, R>(ctx, A, o, x, y, aux); break;           \
+        case 7: launch_dia_nd<EPI, 7, R>(ctx, A, o, x, y, aux); break;           \
+        case 9: launch_dia_nd<EPI, 9, R>(ctx, A, o, x, y, aux); break;           \
+        default: launch_dia_nd<EPI, 0, R>(ctx, A, o, x, y, aux); break;          \
+    }
+    if (A->dia_rpt == 4) { KH_DIA_RPT(4) }
+    else if (A->dia_rpt == 2) { KH_DIA_RPT(2) }
+    else { KH_DIA_RPT(1) }
+#undef KH_DIA_RPT
+}
+
 template <int EPI>
 static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+    if (A->dia != nullptr && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+        launch_dia<EPI>(ctx, A, x, y, aux);
+        return;
+    }
     switch (A->tile / BS) {      // tile is one of 1024 / 2048 / 4096 (kh_ctx_tune)
         case 4: launch_spmv_items<EPI, 4>(ctx, A, x, y, aux); break;
         case 16: launch_spmv_items<EPI, 16>(ctx, A, x, y, aux); break;
@@ -201,8 +231,9 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
         if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux);
         KH_HIP(hipGetLastError());
         if (epi != EPI_NONE) {
+            const bool dia = A->dia != nullptr && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, A->part,
-                               A->nblk, 0, scal_out, rmode);
+                               dia ? A->dia_nblk : A->nblk, 0, scal_out, rmode);
             KH_HIP(hipGetLastError());
         }
         return 0;
@@ -746,6 +777,73 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
     return 0;
 }
 
+// Banded structure (k_spmv_dia): square, columns strictly ascending within each row, no stored
+// zeros, at most KH_DIA_MAX distinct diagonals, and those at least 70 % full (8 B per slot against
+// 12 B per CSR entry).  One pass over the host arrays; gives up at the first violation.
+static bool detect_dia(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
+                       const int32_t* indices, const double* data, std::vector<int>& offs) {
+    offs.clear();
+    if (n_rows != n_cols || n_rows < 2 || nnz == 0 || data == nullptr) return false;
+    if (nnz > (int64_t)KH_DIA_MAX * n_rows) return false;
+    int tab[KH_DIA_MAX];
+    int nd = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        int prev = -1;
+        for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+            const int c = indices[p];
+            if (c <= prev || data[p] == 0.0) return false;
+            prev = c;
+            const int off = c - (int)r;
+            int d = 0;
+            while (d < nd && tab[d] != off) ++d;
+            if (d == nd) {
+                if (nd == KH_DIA_MAX) return false;
+                tab[nd++] = off;
+            } else if (d > 0) {            // move-to-front keeps the common offsets cheap to find
+                std::swap(tab[d], tab[d - 1]);
+            }
+        }
+    }
+    if ((double)nnz < 0.7 * (double)nd * (double)n_rows) return false;
+    offs.assign(tab, tab + nd);
+    std::sort(offs.begin(), offs.end());
+    return true;
+}
+
+static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs) {
+    static int mode = -2;     // KRYPY_AMD_SPMV_DIA: 0 = off, 1/2/4 = row pairs per lane (default 4)
+    if (mode == -2) {
+        const char* e = getenv("KRYPY_AMD_SPMV_DIA");
+        mode = e ? atoi(e) : 4;
+        if (mode != 0 && mode != 1 && mode != 2 && mode != 4) mode = 4;
+    }
+    if (mode == 0) return 0;
+    const int64_t rows_per_wg = 2 * (int64_t)BS * mode;
+    const int64_t nblk = (A->n_rows + rows_per_wg - 1) / rows_per_wg;
+    const int64_t ld = nblk * rows_per_wg;
+    const size_t bytes = sizeof(double) * (size_t)ld * offs.size();
+    double* dia = nullptr;
+    if (hipMalloc(&dia, bytes) != hipSuccess) {     // no room for the copy: the CSR kernel serves
+        (void)hipGetLastError();
+        return 0;
+    }
+    KH_HIP(hipMemsetAsync(dia, 0, bytes, ctx->stream));
+    DiaOffs o;
+    o.nd = (int)offs.size();
+    for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < o.nd ? offs[d] : 0;
+    hipLaunchKernelGGL(k_dia_fill, dim3((unsigned)((A->n_rows + BS - 1) / BS)), dim3(BS), 0, ctx->stream,
+                       A->indptr, A->indices, A->data, A->n_rows, o, dia, ld);
+    KH_HIP(hipGetLastError());
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    A->dia = dia;
+    A->dia_ld = ld;
+    A->dia_nd = o.nd;
+    A->dia_nblk = (int)nblk;
+    A->dia_rpt = mode;
+    for (int d = 0; d < o.nd; ++d) A->dia_off[d] = offs[d];
+    return 0;
+}
+
 int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
                   const int32_t* indices, const double* data, kh_mat* out) {
     KH_ARG(ctx && out && indptr, "kh_csr_upload: NULL argument");
@@ -771,13 +869,17 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
     KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
     KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
-    KH_HIP(hipMalloc(&A->part, sizeof(double) * std::max(A->nblk, 1)));
+    std::vector<int> offs;
+    const bool banded = detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs);
+    const int64_t npart = std::max<int64_t>(std::max(A->nblk, 1), banded ? (n_rows + 2 * BS - 1) / (2 * BS) : 1   /* RPT >= 1 */);
+    KH_HIP(hipMalloc(&A->part, sizeof(double) * npart));
     KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
     if (nnz > 0) {
         KH_HIP(hipMemcpy(A->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
         KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
     }
     KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    if (banded) KH_TRY(build_dia(ctx, A, offs));
     *out = A;
     return 0;
 }
@@ -828,12 +930,15 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->data);
     (void)hipFree(A->rowblk);
     (void)hipFree(A->part);
+    (void)hipFree(A->dia);
     (void)hipFree(A->a);
     (void)hipFree(A->diag);
     (void)hipFree(A->ghost);
     delete A;
     return 0;
 }
+
+int kh_mat_diagonals(kh_mat A) { return (A != nullptr && A->dia != nullptr) ? A->dia_nd : 0; }
 
 int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols) {
     KH_ARG(ctx && A, "kh_apply: NULL handle");

@@ -2,6 +2,8 @@
 C ABI, plus kernel-level checks against SciPy/NumPy on the same seeded inputs, and
 size-independent properties at BASELINE.json's full size (N = 10^7).
 """
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -120,6 +122,86 @@ def test_csr_spmv_bit_identical_to_scipy(hip, kind):
         assert np.allclose(got[7], want[7], rtol=1e-12)    # tree-reduced row: not bit-ordered
     else:
         assert np.array_equal(got, want)
+
+
+def _banded(n, offsets, seed, holes=0.0):
+    rng = np.random.default_rng(seed)
+    diags = []
+    for o in offsets:
+        d = rng.standard_normal(n - abs(o))
+        d[d == 0.0] = 1.0
+        if holes:
+            d[rng.random(d.size) < holes] = 0.0
+        diags.append(d)
+    A = sp.diags(diags, offsets, shape=(n, n)).tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("kind,nd", [
+    ("tridiag", 3), ("lap2d", 5), ("lap3d", 7), ("nine", 9), ("holes", 5), ("generic11", 11), ("two", 2),
+    ("edge1023", 5), ("edge1025", 5), ("tiny", 3), ("wide", 4), ("corners", 0), ("explicit_zero", 0), ("sparse_diags", 0),
+    ("too_many", 0)])
+def test_banded_spmv_bit_identical_to_scipy(hip, kind, nd):
+    """k_spmv_dia (banded copy of a CSR operator): detection, and the same bits as csr_matvec."""
+    if kind == "tridiag":
+        A = _banded(30011, (-1, 0, 1), 1)
+    elif kind == "lap2d":
+        A = ref.laplace2d(97, 53)
+    elif kind == "lap3d":
+        A = ref.laplace3d(23).tocsr()
+    elif kind == "nine":
+        A = _banded(40000, (-201, -200, -199, -1, 0, 1, 199, 200, 201), 2)
+    elif kind == "holes":
+        A = _banded(25000, (-150, -1, 0, 1, 150), 3, holes=0.2)
+    elif kind == "generic11":
+        A = _banded(9000, (-900, -30, -3, -2, -1, 0, 1, 2, 3, 30, 900), 4)
+    elif kind == "two":
+        A = _banded(5000, (0, 17), 5)
+    elif kind == "edge1023":
+        A = _banded(1023, (-31, -1, 0, 1, 31), 6)
+    elif kind == "edge1025":
+        A = _banded(1025, (-31, -1, 0, 1, 31), 7)
+    elif kind == "tiny":
+        A = _banded(3, (-1, 0, 1), 8)
+    elif kind == "wide":
+        A = _banded(4096, (-1000, 0, 1, 1000), 9)
+    elif kind == "corners":
+        A = _banded(4096, (-4095, -1, 0, 1, 4095), 13)    # periodic tridiagonal: 60 % full, CSR serves
+    elif kind == "explicit_zero":
+        A = _banded(3000, (-1, 0, 1), 10)
+        A.data[7] = 0.0                                   # a stored zero: the CSR kernel must serve
+    elif kind == "sparse_diags":
+        A = _banded(3000, (-7, 0, 7), 11, holes=0.5)      # less than 70 % full
+    else:
+        A = _banded(3000, tuple(range(-20, 21)), 12)      # 41 diagonals > 32
+    n = A.shape[0]
+    rng = np.random.default_rng(99)
+    x = rng.standard_normal((n, 3))
+    Ad = hip.csr(A)
+    if os.environ.get("KRYPY_AMD_SPMV_DIA", "") != "0":
+        assert Ad.diagonals == nd
+    X, Y = hip.upload(x), hip.alloc(n, 3)
+    hip.apply(Ad, X, 0, Y, 0, 3)
+    assert np.array_equal(Y.download(), A.dot(x))
+    # fused epilogues of the banded kernel: explicit residual + norm, first MGS coefficient
+    b = rng.standard_normal((n, 1))
+    R = hip.alloc(n, 1)
+    nrm = hip.residual(Ad, hip.upload(b), 0, X, 1, R, 0)
+    want = b[:, 0] - A.dot(x[:, 1])
+    assert np.array_equal(R.download()[:, 0], want)
+    assert abs(nrm - np.linalg.norm(want)) <= 1e-14 * np.linalg.norm(want)
+    if n >= 8:
+        V, W = hip.alloc(n, 4), hip.alloc(n, 2)
+        v0 = x[:, [0]] / np.linalg.norm(x[:, 0])
+        V.upload(0, v0)
+        h = hip.arnoldi_step(Ad, None, V, None, W, 0, 0, 0, 1, 0)
+        w = A.dot(v0[:, 0])
+        a0 = float(np.dot(v0[:, 0], w))
+        assert abs(h[0] - a0) <= 1e-13 * np.linalg.norm(w)
+        w = w - a0 * v0[:, 0]
+        assert abs(h[1] - np.linalg.norm(w)) <= 1e-13 * np.linalg.norm(w)
 
 
 def test_dense_gemv_and_diag(hip):

@@ -76,7 +76,8 @@ def config5(ctx, nx=200, m=100, d=16):
         s0 = e.solver
     ritz = deflation.Ritz(s0)
     U = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:d])
-    for it in range(2):
+    dts = []
+    for it in range(6):          # first pass = warm-up; best of the rest (a solve is only ~0.2 s)
         ctx.sync()
         t0 = time.perf_counter()
         try:
@@ -84,10 +85,12 @@ def config5(ctx, nx=200, m=100, d=16):
         except utils.ConvergenceError as e:
             s1 = e.solver
         ctx.sync()
-        dt = time.perf_counter() - t0
+        dts.append(time.perf_counter() - t0)
+    dt = min(dts[1:])
     n_it = len(s1.resnorms) - 1
     return dict(config="5 (one-GPU shape): 3-D 7-pt %d^3 (N=%d), DeflatedGmres(%d) with %d Ritz vectors"
                        % (nx, N, m, d), iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+                solve_ms=[round(x * 1e3, 1) for x in dts],
                 plain_relres=float(s0.resnorms[-1]), deflated_relres=float(s1.resnorms[-1]))
 
 

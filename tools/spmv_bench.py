@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """SpMV timing on the bench matrix (and a 3-D 7-point one): python tools/spmv_bench.py
-(KRYPY_AMD_SPMV_WIN=0 selects the plain gather kernel)"""
+(KRYPY_AMD_SPMV_DIA=0 selects the CSR kernel, 1/2/4 the row pairs per lane of the banded one)"""
 import os
 import sys
 
@@ -26,5 +26,7 @@ for name, A in (("lap2d 4000x2500", bench.laplace2d(4000, 2500)), ("lap3d 200^3"
         ctx.apply(Ad, X, 0, Y, 0, 1)
     ms = ctx.timer_stop() / 50
     ok = np.array_equal(Y.download()[:, 0], want)
-    print("win=%s %s: %.1f us  %.0f GB/s (CSR bytes)  bit-identical=%s" % (
-        os.environ.get("KRYPY_AMD_SPMV_WIN", "default"), name, ms * 1e3, nb / ms / 1e6, ok))
+    nd = Ad.diagonals
+    moved = (8.0 * nd * n + 16.0 * n) if nd else nb
+    print("dia=%s %s: diagonals=%d  %.1f us  %.0f GB/s (CSR bytes)  %.0f GB/s (bytes of the format used)  bit-identical=%s" % (
+        os.environ.get("KRYPY_AMD_SPMV_DIA", "default"), name, nd, ms * 1e3, nb / ms / 1e6, moved / ms / 1e6, ok))
