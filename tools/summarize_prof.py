@@ -34,7 +34,7 @@ def main(src, dst):
         try:
             b = json.loads(open(bj).read().strip().splitlines()[-1])
             lines += ["Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d "
-                      "--no-cpu-baseline --ortho %s` on one MI355X." % (b["steps"], b["warmup"], b["config"]["ortho"]),
+                      "--no-cpu-baseline --ortho %s --other-modes none` (tools/profile.sh) on one MI355X." % (b["steps"], b["warmup"], b["config"]["ortho"]),
                       "", "bench.py under the profiler: **%.1f iterations/s** (%.1f ms per GMRES(100) cycle); "
                       "live HIP-event average of the dominant kernel `%s`: **%.3f us**." % (
                           b["value"], b["ms_per_step"], b["roofline"]["kernel"],
