@@ -81,6 +81,9 @@ int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count);
  * matrix' column indices must address [local rows | ghosts from prev | ghosts from next]. */
 int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next,
                     int64_t nrecv_prev, int64_t nrecv_next);
+/* diagnostic: write the nrecv_prev + nrecv_next ghost entries directly (what the halo exchange would
+ * deliver); lets a single process check a shard's SpMV against the global operator */
+int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count);
 
 /* ---- vectors ---------------------------------------------------------------------- */
 int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out);   /* zero-filled */

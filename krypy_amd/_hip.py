@@ -52,6 +52,7 @@ _SIGNATURES = {
     "kh_comm_destroy": [_H],
     "kh_comm_allreduce_host": [_H, _c_double_p, _I64],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
+    "kh_mat_set_ghost": [_H, _c_double_p, _I64],
     "kh_vec_alloc": [_H, _I64, _I64, ctypes.POINTER(_H)],
     "kh_vec_free": [_H],
     "kh_vec_shape": [_H, _c_int64_p, _c_int64_p, _c_int64_p],
@@ -435,6 +436,11 @@ class Context(object):
         _check(self._lib, self._lib.kh_comm_allreduce_host(self._h, _dptr(a), a.size),
                "kh_comm_allreduce_host")
         return a
+
+    def set_ghost(self, A, values):
+        """Diagnostic: the ghost entries a halo exchange would deliver (``kh_mat_set_ghost``)."""
+        v = numpy.ascontiguousarray(values, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_mat_set_ghost(A.handle, _dptr(v), v.size), "kh_mat_set_ghost")
 
     def set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
         _check(self._lib, self._lib.kh_mat_set_halo(self._h, A.handle, nsend_prev, nsend_next,

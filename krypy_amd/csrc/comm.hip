@@ -173,7 +173,7 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
         KH_HIP(hipMalloc(&A->ghost, sizeof(double) * ng));
         KH_HIP(hipMemset(A->ghost, 0, sizeof(double) * ng));
     }
-    return 0;
+    return kh::dia_rebuild_for_halo(ctx, A);
 }
 
 }  // extern "C"

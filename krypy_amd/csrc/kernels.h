@@ -527,25 +527,34 @@ struct DiaOffs {
     int off[KH_DIA_MAX];
 };
 
+// Column of a block-row shard on the axis of its own rows: local columns stay, the ghost columns
+// (CSR ids nloc .. nloc+nprev+nnext, krypy_amd/dist.py) are the rows just before / after the slab:
+// -nprev .. -1 and nloc .. nloc+nnext-1.  With it a sharded stencil matrix is banded again.
+__host__ __device__ __forceinline__ int dia_virtual_col(int c, int nloc, int nprev) {
+    return c < nloc ? c : (c < nloc + nprev ? c - nloc - nprev : c - nprev);
+}
+
 __global__ __launch_bounds__(BS) void k_dia_fill(const int32_t* __restrict__ indptr,
                                                  const int32_t* __restrict__ indices,
                                                  const double* __restrict__ data, int64_t n_rows,
-                                                 DiaOffs o, double* __restrict__ dia, int64_t ld) {
+                                                 int nprev, DiaOffs o, double* __restrict__ dia,
+                                                 int64_t ld) {
     const int64_t r = (int64_t)blockIdx.x * BS + threadIdx.x;
     if (r >= n_rows) return;
     for (int p = indptr[r]; p < indptr[r + 1]; ++p) {
-        const int off = indices[p] - (int)r;
+        const int off = dia_virtual_col(indices[p], (int)n_rows, nprev) - (int)r;
         int d = 0;
         while (d < o.nd - 1 && o.off[d] != off) ++d;
         dia[(int64_t)d * ld + r] = data[p];
     }
 }
 
-template <int EPI, int ND, int RPT>
+template <int EPI, int ND, int RPT, bool HALO>
 __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __restrict__ dia,
                                                  int64_t ld, int64_t n, int nblk,
                                                  const double* __restrict__ x,
-                                                 double* __restrict__ y,
+                                                 const double* __restrict__ ghost, int nprev,
+                                                 int nnext, double* __restrict__ y,
                                                  const double* __restrict__ aux,
                                                  double* __restrict__ part_out) {
     __shared__ double sm[8];
@@ -570,6 +579,12 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                 const double2 xv = *reinterpret_cast<const double2*>(x + c0);
                 x0[u] = xv.x;
                 x1[u] = xv.y;
+            } else if (HALO) {                              // rows of the neighbouring slabs: ghost[]
+                const int64_t lo = -(int64_t)nprev, hi = last + nnext;
+                c0 = c0 < lo ? lo : (c0 > hi ? hi : c0);
+                c1 = c1 < lo ? lo : (c1 > hi ? hi : c1);
+                x0[u] = c0 < 0 ? ghost[c0 + nprev] : (c0 > last ? ghost[nprev + (c0 - n)] : x[c0]);
+                x1[u] = c1 < 0 ? ghost[c1 + nprev] : (c1 > last ? ghost[nprev + (c1 - n)] : x[c1]);
             } else {
                 c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
                 c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);

@@ -127,4 +127,6 @@ namespace kh {
 // comm.hip
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
 int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x);
+// krylov_hip.hip
+int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
 }  // namespace kh

@@ -179,10 +179,11 @@ static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, 
                        A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part);
 }
 
-template <int EPI, int ND, int RPT>
+template <int EPI, int ND, int RPT, bool HALO>
 static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* x, double* y, const double* aux) {
-    hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT>), dim3(A->dia_nblk), dim3(BS), 0, ctx->stream, o, A->dia,
-                       A->dia_ld, A->n_rows, A->dia_nblk, x, y, aux, A->part);
+    hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT, HALO>), dim3(A->dia_nblk), dim3(BS), 0, ctx->stream, o, A->dia,
+                       A->dia_ld, A->n_rows, A->dia_nblk, x, A->ghost, (int)A->nrecv_prev, (int)A->nrecv_next, y,
+                       aux, A->part);
 }
 
 template <int EPI>
@@ -191,17 +192,18 @@ static void launch_dia(kh_ctx ctx, kh_mat A, const double* x, double* y, const d
     o.nd = A->dia_nd;
     for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < A->dia_nd ? A->dia_off[d] : 0;
     // rows per workgroup = 2 * BS * RPT (fixed at upload: dia_ld covers whole workgroups)
-#define KH_DIA_RPT(R)                                                            \
-    switch (A->dia_nd) {                                                         \
-        case 3: launch_dia_nd<EPI, 3, R>(ctx, A, o, x, y, aux); break;           \
-        case 5: launch_dia_nd<EPI, 5, R>(ctx, A, o, x, y, aux); break;           \
-        case 7: launch_dia_nd<EPI, 7, R>(ctx, A, o, x, y, aux); break;           \
-        case 9: launch_dia_nd<EPI, 9, R>(ctx, A, o, x, y, aux); break;           \
-        default: launch_dia_nd<EPI, 0, R>(ctx, A, o, x, y, aux); break;          \
+#define KH_DIA_RPT(R, H)                                                            \
+    switch (A->dia_nd) {                                                            \
+        case 3: launch_dia_nd<EPI, 3, R, H>(ctx, A, o, x, y, aux); break;           \
+        case 5: launch_dia_nd<EPI, 5, R, H>(ctx, A, o, x, y, aux); break;           \
+        case 7: launch_dia_nd<EPI, 7, R, H>(ctx, A, o, x, y, aux); break;           \
+        case 9: launch_dia_nd<EPI, 9, R, H>(ctx, A, o, x, y, aux); break;           \
+        default: launch_dia_nd<EPI, 0, R, H>(ctx, A, o, x, y, aux); break;          \
     }
-    if (A->dia_rpt == 4) { KH_DIA_RPT(4) }
-    else if (A->dia_rpt == 2) { KH_DIA_RPT(2) }
-    else { KH_DIA_RPT(1) }
+    if (A->nrecv_prev + A->nrecv_next > 0) { KH_DIA_RPT(4, true) }      // shard with ghost rows: dia_rpt == 4
+    else if (A->dia_rpt == 4) { KH_DIA_RPT(4, false) }
+    else if (A->dia_rpt == 2) { KH_DIA_RPT(2, false) }
+    else { KH_DIA_RPT(1, false) }
 #undef KH_DIA_RPT
 }
 
@@ -781,17 +783,19 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
 // zeros, at most KH_DIA_MAX distinct diagonals, and those at least 70 % full (8 B per slot against
 // 12 B per CSR entry).  One pass over the host arrays; gives up at the first violation.
 static bool detect_dia(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
-                       const int32_t* indices, const double* data, std::vector<int>& offs) {
+                       const int32_t* indices, const double* data, std::vector<int>& offs,
+                       int64_t nprev = 0, int64_t nnext = 0) {
+    // nprev / nnext: ghost columns of a block-row shard, taken as the rows before / after the slab
     offs.clear();
-    if (n_rows != n_cols || n_rows < 2 || nnz == 0 || data == nullptr) return false;
+    if (n_rows + nprev + nnext != n_cols || n_rows < 2 || nnz == 0 || data == nullptr) return false;
     if (nnz > (int64_t)KH_DIA_MAX * n_rows) return false;
     int tab[KH_DIA_MAX];
     int nd = 0;
     for (int64_t r = 0; r < n_rows; ++r) {
-        int prev = -1;
+        int prev = 0;
         for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
-            const int c = indices[p];
-            if (c <= prev || data[p] == 0.0) return false;
+            const int c = dia_virtual_col(indices[p], (int)n_rows, (int)nprev);
+            if ((p > indptr[r] && c <= prev) || data[p] == 0.0) return false;
             prev = c;
             const int off = c - (int)r;
             int d = 0;
@@ -810,7 +814,7 @@ static bool detect_dia(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_
     return true;
 }
 
-static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs) {
+static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs, bool halo = false) {
     static int mode = -2;     // KRYPY_AMD_SPMV_DIA: 0 = off, 1/2/4 = row pairs per lane (default 4)
     if (mode == -2) {
         const char* e = getenv("KRYPY_AMD_SPMV_DIA");
@@ -818,7 +822,8 @@ static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs) {
         if (mode != 0 && mode != 1 && mode != 2 && mode != 4) mode = 4;
     }
     if (mode == 0) return 0;
-    const int64_t rows_per_wg = 2 * (int64_t)BS * mode;
+    const int rpt = halo ? 4 : mode;                 // the ghost-row variant exists for 4 row pairs per lane
+    const int64_t rows_per_wg = 2 * (int64_t)BS * rpt;
     const int64_t nblk = (A->n_rows + rows_per_wg - 1) / rows_per_wg;
     const int64_t ld = nblk * rows_per_wg;
     const size_t bytes = sizeof(double) * (size_t)ld * offs.size();
@@ -832,15 +837,57 @@ static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs) {
     o.nd = (int)offs.size();
     for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < o.nd ? offs[d] : 0;
     hipLaunchKernelGGL(k_dia_fill, dim3((unsigned)((A->n_rows + BS - 1) / BS)), dim3(BS), 0, ctx->stream,
-                       A->indptr, A->indices, A->data, A->n_rows, o, dia, ld);
+                       A->indptr, A->indices, A->data, A->n_rows, (int)A->nrecv_prev, o, dia, ld);
     KH_HIP(hipGetLastError());
     KH_HIP(hipStreamSynchronize(ctx->stream));
     A->dia = dia;
     A->dia_ld = ld;
     A->dia_nd = o.nd;
     A->dia_nblk = (int)nblk;
-    A->dia_rpt = mode;
+    A->dia_rpt = rpt;
     for (int d = 0; d < o.nd; ++d) A->dia_off[d] = offs[d];
+    return 0;
+}
+
+extern "C++" {
+namespace kh {
+// kh_mat_set_halo: the ghost columns are known now - look for the banded structure of the shard
+int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A) {
+    const int64_t ng = A->nrecv_prev + A->nrecv_next;
+    if (ng == 0) return 0;                       // square operator: what kh_csr_upload found stands
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(A->dia);
+    A->dia = nullptr;
+    A->dia_nd = 0;
+    if (A->nnz == 0) return 0;
+    std::vector<int32_t> indptr(A->n_rows + 1), indices(A->nnz);
+    std::vector<double> data(A->nnz);
+    KH_HIP(hipMemcpy(indptr.data(), A->indptr, sizeof(int32_t) * indptr.size(), hipMemcpyDeviceToHost));
+    KH_HIP(hipMemcpy(indices.data(), A->indices, sizeof(int32_t) * indices.size(), hipMemcpyDeviceToHost));
+    KH_HIP(hipMemcpy(data.data(), A->data, sizeof(double) * data.size(), hipMemcpyDeviceToHost));
+    std::vector<int> offs;
+    if (!detect_dia(A->n_rows, A->n_cols, A->nnz, indptr.data(), indices.data(), data.data(), offs,
+                    A->nrecv_prev, A->nrecv_next))
+        return 0;
+    const int64_t need = (A->n_rows + 2 * BS - 1) / (2 * BS);
+    if (need > std::max(A->nblk, 1)) {           // partial sums of the fused epilogues: one per workgroup
+        (void)hipFree(A->part);
+        A->part = nullptr;
+        KH_HIP(hipMalloc(&A->part, sizeof(double) * need));
+    }
+    return build_dia(ctx, A, offs, true);
+}
+}  // namespace kh
+}  // extern "C++"
+
+int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count) {
+    KH_ARG(A && (values || count == 0), "kh_mat_set_ghost: NULL");
+    KH_ARG(A->kind == KH_MAT_CSR && count == A->nrecv_prev + A->nrecv_next,
+           "kh_mat_set_ghost: %lld values for %lld ghost columns", (long long)count,
+           (long long)(A->nrecv_prev + A->nrecv_next));
+    if (count == 0) return 0;
+    KH_HIP(hipMemcpyAsync(A->ghost, values, sizeof(double) * count, hipMemcpyHostToDevice, A->ctx->stream));
+    KH_HIP(hipStreamSynchronize(A->ctx->stream));
     return 0;
 }
 

@@ -204,6 +204,45 @@ def test_banded_spmv_bit_identical_to_scipy(hip, kind, nd):
         assert abs(h[1] - np.linalg.norm(w)) <= 1e-13 * np.linalg.norm(w)
 
 
+@pytest.mark.parametrize("kind", ["lap2d", "lap3d", "nonsym", "random"])
+def test_shard_spmv_with_ghost_rows_on_one_gpu(hip, kind):
+    """A block-row shard's SpMV (ghost columns, krypy_amd/dist.py) on the one GPU: every slab of a
+    3-way split, ghost entries written with kh_mat_set_ghost instead of the halo exchange, must
+    reproduce its rows of the global product bit for bit - through the banded kernel's ghost-row
+    variant for the stencil matrices, through the CSR kernel for the random one."""
+    from krypy_amd import dist
+
+    if kind == "lap2d":
+        A, align = ref.laplace2d(64, 45), 64
+    elif kind == "lap3d":
+        A, align = ref.laplace3d(18).tocsr(), 18 * 18
+    elif kind == "nonsym":
+        A, align = _banded(30000, (-300, -2, -1, 0, 1, 300), 21), 1      # even and odd offsets, one-sided -2
+    else:
+        A = (sp.random(6000, 6000, density=2e-3, random_state=8, format="csr") + sp.eye(6000)).tocsr()
+        A.sort_indices()
+        align = 1
+    n = A.shape[0]
+    x = np.random.default_rng(5).standard_normal(n)
+    want = A.dot(x)
+    b = np.random.default_rng(6).standard_normal(n)
+    cuts = dist.slab_cuts(n, 3, align)
+    for p in range(3):
+        r0, r1 = cuts[p], cuts[p + 1]
+        A_local, nrp, nrn = dist.localize_columns(A[r0:r1], r0, n)
+        Ad = hip.csr(A_local, n_cols=A_local.shape[1])
+        hip.set_halo(Ad, 0, 0, nrp, nrn)                      # no communicator: nothing is sent
+        hip.set_ghost(Ad, np.concatenate([x[r0 - nrp:r0], x[r1:r1 + nrn]]))
+        if os.environ.get("KRYPY_AMD_SPMV_DIA", "") != "0":
+            assert (Ad.diagonals > 0) == (kind != "random"), (kind, p, Ad.diagonals)
+        X, Y = hip.upload(x[r0:r1]), hip.alloc(r1 - r0, 1)
+        hip.apply(Ad, X, 0, Y, 0, 1)
+        assert np.array_equal(Y.download()[:, 0], want[r0:r1]), (kind, p)
+        R = hip.alloc(r1 - r0, 1)
+        hip.residual(Ad, hip.upload(b[r0:r1]), 0, X, 0, R, 0)
+        assert np.array_equal(R.download()[:, 0], b[r0:r1] - want[r0:r1]), (kind, p)
+
+
 def test_dense_gemv_and_diag(hip):
     rng = np.random.default_rng(2)
     for n, m in ((1, 1), (37, 41), (512, 512), (1000, 999)):
