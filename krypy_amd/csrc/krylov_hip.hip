@@ -898,6 +898,8 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     KH_ARG(n_rows < 2147483647LL && nnz < 2147483647LL, "kh_csr_upload: int32 CSR limits exceeded");
     KH_ARG(indptr[0] == 0 && indptr[n_rows] == nnz, "kh_csr_upload: indptr[0]=%d indptr[n]=%d nnz=%lld",
            indptr[0], indptr[n_rows], (long long)nnz);
+    for (int64_t r = 0; r < n_rows; ++r)
+        KH_ARG(indptr[r] <= indptr[r + 1], "kh_csr_upload: indptr decreases at row %lld", (long long)r);
     for (int64_t i = 0; i < nnz; ++i)
         KH_ARG(indices[i] >= 0 && indices[i] < n_cols, "kh_csr_upload: column index %d out of range at %lld",
                indices[i], (long long)i);
