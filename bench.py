@@ -287,12 +287,13 @@ def _run():
     if roof is not None and N == 10_000_000 and not sharded:
         try:
             import glob
-            key, pat = (("k_mgs_chain", "*_bench_mgs_chain_traffic.json") if ortho in ("mgs", "dmgs")
-                        else (None, None))
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
-            if files and "k_mgs_chain" in roof["kernel"]:
-                tj = json.load(open(files[-1]))[key]
-                roof["traffic"] = tj["hbm_read_bytes_per_launch"] + tj["hbm_write_bytes_per_launch"]
+            keys, pat = ((("k_mgs_chain",), "*_bench_mgs_chain_traffic.json") if ortho in ("mgs", "dmgs")
+                         else (("k_cgs_dots", "k_cgs_update"), "*_bench_cgs_traffic.json"))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+            if files and roof["kernel"].startswith(keys[0]):
+                tj = json.load(open(files[-1]))
+                roof["traffic"] = sum(tj[k]["hbm_read_bytes_per_launch"] + tj[k]["hbm_write_bytes_per_launch"]
+                                      for k in keys)
                 roof["traffic_source"] = os.path.relpath(files[-1], ROOT)
         except Exception:
             pass
