@@ -243,6 +243,32 @@ def test_shard_spmv_with_ghost_rows_on_one_gpu(hip, kind):
         assert np.array_equal(R.download()[:, 0], b[r0:r1] - want[r0:r1]), (kind, p)
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_banded_spmv_measurement_modes(hip, mode):
+    """KRYPY_AMD_SPMV_DIA is read once per process: the non-default settings (CSR kernel, 1 and 2
+    row pairs per lane) are checked in a child process - same bits as SciPy in every mode."""
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, scipy.sparse as sp\n"
+        "from krypy_amd import _hip\n"
+        "from oracle import krylov_ref as ref\n"
+        "ctx = _hip.get_context()\n"
+        "for A in (ref.laplace2d(97, 53), ref.laplace3d(21).tocsr(), ref.laplace2d(1500, 700)):\n"
+        "    x = np.random.default_rng(1).standard_normal((A.shape[0], 2))\n"
+        "    Ad = ctx.csr(A)\n"
+        "    assert (Ad.diagonals > 0) == (%r != '0')\n"
+        "    Y = ctx.alloc(A.shape[0], 2)\n"
+        "    ctx.apply(Ad, ctx.upload(x), 0, Y, 0, 2)\n"
+        "    assert np.array_equal(Y.download(), A.dot(x))\n"
+        "print('ok')\n" % mode)
+    env = dict(os.environ, KRYPY_AMD_SPMV_DIA=mode)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_dense_gemv_and_diag(hip):
     rng = np.random.default_rng(2)
     for n, m in ((1, 1), (37, 41), (512, 512), (1000, 999)):
