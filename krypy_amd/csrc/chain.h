@@ -122,6 +122,72 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     return s;
 }
 
+// Two sums in one round (the real and imaginary part of a complex coefficient): four granules per
+// workgroup, one publish, one sweep.  Needs 4*G <= 2*CH_GMAX words per parity (checked by the
+// launcher); same protocol, same fixed summation order as grid_sum.
+__device__ __forceinline__ void grid_sum2(double& p0, double& p1, unsigned epoch, unsigned long long* gran,
+                                          int G, int* err, double* smd, unsigned* smu) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = CH_BS / 64;
+    const double a0 = wave_sum(p0), a1 = wave_sum(p1);
+    if (lane == 0) {
+        smd[wid] = a0;
+        smd[NW + wid] = a1;
+    }
+    __syncthreads();
+    unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
+    if (tid < 2) {
+        double s = smd[tid * NW];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += smd[tid * NW + i];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        st_agent(slot + 4 * blockIdx.x + 2 * tid, tag | (bits & 0xffffffffull));
+        st_agent(slot + 4 * blockIdx.x + 2 * tid + 1, tag | (bits >> 32));
+    }
+    for (int g = tid; g < 4 * G; g += CH_BS) {
+        unsigned long long x = ld_agent(slot + g);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            x = ld_agent(slot + g);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1u << 22)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        smu[g] = (unsigned)x;
+    }
+    __syncthreads();
+    double v0 = 0.0, v1 = 0.0;
+    for (int b = tid; b < G; b += CH_BS) {
+        const unsigned long long b0 = ((unsigned long long)smu[4 * b + 1] << 32) | smu[4 * b];
+        const unsigned long long b1 = ((unsigned long long)smu[4 * b + 3] << 32) | smu[4 * b + 2];
+        v0 += __longlong_as_double((long long)b0);
+        v1 += __longlong_as_double((long long)b1);
+    }
+    v0 = wave_sum(v0);
+    v1 = wave_sum(v1);
+    __syncthreads();          // smd reuse
+    if (lane == 0) {
+        smd[wid] = v0;
+        smd[NW + wid] = v1;
+    }
+    __syncthreads();
+    double s0 = smd[0], s1 = smd[NW];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) {
+        s0 += smd[i];
+        s1 += smd[NW + i];
+    }
+    __syncthreads();
+    p0 = s0;
+    p1 = s1;
+}
+
 // Every vector this kernel reads is a kh_vec / diag buffer allocated with CH_SLACK zeroed doubles
 // behind its last column, so loads need no clamping: an out-of-range lane reads finite data of a
 // neighbouring chunk/column (or zeros) and its w stays exactly 0 (select on registers).
@@ -156,7 +222,7 @@ template <int R2, bool MASKED, bool CPLX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
-    __shared__ double smd[CH_BS / 64];
+    __shared__ double smd[2 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     const int tid = threadIdx.x;
     const int G = gridDim.x;
@@ -227,8 +293,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         }
         double alpha, alpha_i = 0.0;
         if (CPLX) {
-            alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
-            alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
+            alpha = acc0;
+            alpha_i = acc1;
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
             if (blockIdx.x == 0 && tid == 0) {
                 // first sweep assigns (the caller does not clear the H column for a chain launch)
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
@@ -339,10 +406,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 // Ring parity: batch NB-1 sits in ring[1]; the NG = NB - LB - 1 batches that still come from memory
 // start in ring[0] and NG is even, so the next column's first batch lands in ring[0] again.
 // ------------------------------------------------------------------------------------------
-template <int R2>
+template <int R2, bool CPLX = false>
 struct ChainShapeLds {
-    static constexpr int PB = ChainShape<R2>::PB;             // 5 rows per batch for R2 = 40, like the plain kernel
-    static constexpr int NB = ChainShape<R2>::NB;
+    // 5 rows per batch for R2 = 40, like the plain kernel (the complex instantiation spills 36 registers
+    // with it and is still 14 % faster than the plain kernel; 4-row batches spill 42)
+    static constexpr int PB = ChainShape<R2>::PB;
+    static constexpr int NB = R2 / PB;
     static constexpr int LB = NB >= 4 ? 3 : 1;                // leading batches kept in LDS
     static constexpr int NG = NB - LB - 1;                    // update batches that still come from memory
     static_assert((NB % 2) == 0 && NG >= 0 && (NG % 2) == 0, "ring parity must reset every phase");
@@ -351,12 +420,12 @@ struct ChainShapeLds {
 
 template <int R2, bool MASKED, bool CPLX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
-    constexpr int PB = ChainShapeLds<R2>::PB;
-    constexpr int NB = ChainShapeLds<R2>::NB;
-    constexpr int LB = ChainShapeLds<R2>::LB;
-    constexpr int NG = ChainShapeLds<R2>::NG;
+    constexpr int PB = ChainShapeLds<R2, CPLX>::PB;
+    constexpr int NB = ChainShapeLds<R2, CPLX>::NB;
+    constexpr int LB = ChainShapeLds<R2, CPLX>::LB;
+    constexpr int NG = ChainShapeLds<R2, CPLX>::NG;
     extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB][CH_BS]
-    __shared__ double smd[CH_BS / 64];
+    __shared__ double smd[2 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     const int tid = threadIdx.x;
     const int G = gridDim.x;
@@ -435,8 +504,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         }
         double alpha, alpha_i = 0.0;
         if (CPLX) {
-            alpha = grid_sum(acc0, epoch++, a.gran, G, a.err, smd, smu);
-            alpha_i = grid_sum(acc1, epoch++, a.gran, G, a.err, smd, smu);
+            alpha = acc0;
+            alpha_i = acc1;
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
             if (blockIdx.x == 0 && tid == 0) {
                 // first sweep assigns (the caller does not clear the H column for a chain launch)
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;

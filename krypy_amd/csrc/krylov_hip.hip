@@ -279,7 +279,7 @@ static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
 template <int R2, bool MASKED, bool CPLX = false>
 static hipError_t launch_chain_lds(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
-    constexpr size_t lds = ChainShapeLds<R2>::LDS_BYTES;
+    constexpr size_t lds = ChainShapeLds<R2, CPLX>::LDS_BYTES;
     if (blocks_per_cu < 0) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_lds<R2, MASKED, CPLX>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -333,6 +333,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     const int64_t n2 = (n + 1) >> 1;
     int r2 = 0, G = 0;
     if (!chain_geometry(ctx, n, &r2, &G)) return 0;
+    if (cplx && 4 * G > 2 * CH_GMAX) return 0;      // grid_sum2: four granules per workgroup
     if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n || (P && P->ld <= n))) return 0;
     const int64_t chunk2 = (int64_t)r2 * CH_BS;
     // predicate-free kernel iff every block involved is padded to G whole chunks
@@ -375,11 +376,11 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         const char* ev = getenv("KRYPY_AMD_CHAIN_LDS");
         return ev ? atoi(ev) : 1;
     }();
-    // (the complex instantiations with 32 / 40 rows per lane are beyond the VGPR budget with the LDS
-    // traffic on top - 81 / 199 spilled registers - and stay on the plain kernel)
+    // (the complex instantiation with 40 rows per lane spills 36 registers with the LDS traffic on top
+    // and still beats the plain kernel, 769 vs 677 it/s at N = 5*10^6; 32 rows fit without spills since
+    // both parts of the coefficient share one grid reduction)
     static thread_local bool lds_failed = false;   // the LDS variant could not be launched once: plain kernel from then on
-    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
-                   !(cplx && r2 >= 32);
+    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0;
 #define KH_CHAIN_PLAIN(R)                                                                             \
     (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
@@ -408,7 +409,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         ctx->chain_enabled = 0;
         return 0;
     }
-    ctx->chain_epoch += (unsigned)((cplx ? 2 : 1) * a.ncol * a.sweeps + 1);
+    ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);   // one grid reduction per link (complex: both parts in it) + the norm
     if (hpin == nullptr)      // (otherwise workgroup 0 has written the error word to the pinned slot itself)
         KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                               ctx->stream));

@@ -437,6 +437,41 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
+@pytest.mark.parametrize("rows", [8, 16, 24, 32, 40])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_mgs_chain_every_register_shape(hip, rows, cplx):
+    """The chain kernel is instantiated for 4 ... 40 `double2` rows of w per lane; the vector length
+    picks the instantiation.  One size per shape (real and complex, i.e. the LDS-parking kernel in both
+    flavours): chain == per-column link kernels up to the order of the partial sums, and the
+    Arnoldi relation A V_m = V_{m+1} H holds."""
+    n2 = {8: 700_000, 16: 1_500_000, 24: 2_800_000, 32: 3_900_000, 40: 5_000_000}[rows]   # double2 per vector
+    n = n2 if cplx else 2 * n2                     # complex entries are one double2 each
+    rng = np.random.default_rng(rows)
+    A = sp.diags([np.full(n - 1, -1.0), np.linspace(2.0, 3.0, n), np.full(n - 1, -1.0)], [-1, 0, 1]).tocsr()
+    if cplx:
+        A = (A + sp.diags(1j * np.linspace(0.1, 0.5, n))).tocsr()
+    b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0.0)
+    m = 5
+    dt = complex if cplx else float
+    res = []
+    for chain in (True, False):
+        ctx = _second_context(chain)
+        Ad = ctx.csr(A)
+        V, W = ctx.alloc(n, m + 1, dtype=dt), ctx.alloc(n, 2, dtype=dt)
+        V.upload(0, b / np.linalg.norm(b))
+        H = np.zeros((m + 1, m), dtype=dt)
+        for k in range(m):
+            H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 0)
+        res.append((H, V.download()))
+        ctx.close()
+    (Hc, Vc), (Hl, Vl) = res
+    assert np.linalg.norm(Hc - Hl) < 1e-12 * np.linalg.norm(Hl)
+    assert np.linalg.norm(Vc - Vl) < 1e-11 * np.sqrt(m)
+    assert np.linalg.norm(A.dot(Vc[:, :m]) - Vc.dot(Hc)) < 1e-12 * np.linalg.norm(Hc)
+    G = Vc.conj().T.dot(Vc)
+    assert np.linalg.norm(G - np.eye(m + 1)) < 1e-12
+
+
 def test_multi_rank_code_path_on_one_gpu(hip):
     """The code path libkrylov_hip takes on N > 1 GPUs (partial sums -> k_reduce_partials -> device
     scalar -> ncclAllReduce -> consumer kernels reading the scalar; halo exchange hook; panel

@@ -14,7 +14,8 @@ import bench  # noqa: E402
 from krypy_amd import _hip, linsys, utils  # noqa: E402
 
 ctx = _hip.get_context()
-A = bench.laplace2d(2500, 2000).astype(complex)
+NX, NY = (int(os.environ.get('ZNX', 2500)), int(os.environ.get('ZNY', 2000)))
+A = bench.laplace2d(NX, NY).astype(complex)
 N = A.shape[0]
 A = (A + sp.diags(1j * np.linspace(0.1, 1.0, N))).tocsr()
 rng = np.random.default_rng(0)
