@@ -380,7 +380,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // and still beats the plain kernel, 769 vs 677 it/s at N = 5*10^6; 32 rows fit without spills since
     // both parts of the coefficient share one grid reduction)
     static thread_local bool lds_failed = false;   // the LDS variant could not be launched once: plain kernel from then on
-    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0;
+    // (an unpadded block of a long vector - not what kh_vec_alloc produces - takes the plain kernel: the
+    // masked LDS instantiations with 32 / 40 rows spill)
+    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
+                   (padded || r2 <= 24);
 #define KH_CHAIN_PLAIN(R)                                                                             \
     (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
