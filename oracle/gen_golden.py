@@ -450,6 +450,28 @@ def gen_api_surface(krypy):
     save("api_surface", **out)
 
 
+def gen_recycling_toy(krypy):
+    """test/test_recycling.py:17-39 run on the reference: 3 recycling solvers x 7 Ritz selections x 3
+    consecutive solves of the 100x100 diagonal system - iteration counts, last residual norm, and
+    the recycled basis' projector U^T U deviation (orthonormality of what the factory hands on)."""
+    N = 100
+    d = np.linspace(1, 2, N)
+    d[:5] = [1e-8, 1e-4, 1e-2, 2e-2, 3e-2]
+    ls = krypy.linsys.LinearSystem(np.diag(d), np.ones((N, 1)), normal=True, self_adjoint=True,
+                                   positive_definite=True)
+    iters, last, ncols = [], [], []
+    for Solver in (krypy.recycling.RecyclingCg, krypy.recycling.RecyclingMinres, krypy.recycling.RecyclingGmres):
+        for which in ("lm", "sm", "lr", "sr", "li", "si", "smallest_res"):
+            fac = krypy.recycling.factories.RitzFactorySimple(n_vectors=3, which=which)
+            rs = Solver()
+            for _ in range(3):
+                s = rs.solve(ls, vector_factory=fac, maxiter=50, tol=1e-5, x0=None)
+                iters.append(len(s.resnorms))
+                last.append(s.resnorms[-1])
+                ncols.append(s.projection.U.shape[1])
+    save("recycling_toy", iters=np.array(iters), last=np.array(last), ncols=np.array(ncols))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -468,6 +490,7 @@ def main():
     gen_solver_matrix(krypy)
     gen_deflation_matrix(krypy)
     gen_api_surface(krypy)
+    gen_recycling_toy(krypy)
 
 
 if __name__ == "__main__":

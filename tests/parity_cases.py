@@ -487,6 +487,8 @@ def case_recycling_factories_toy():
     d[:5] = [1e-8, 1e-4, 1e-2, 2e-2, 3e-2]
     ls = linsys.LinearSystem(np.diag(d), np.ones((N, 1)), normal=True, self_adjoint=True,
                              positive_definite=True)
+    g = golden("recycling_toy")
+    row = 0
     for Solver in (recycling.RecyclingCg, recycling.RecyclingMinres, recycling.RecyclingGmres):
         for which in ("lm", "sm", "lr", "sr", "li", "si", "smallest_res"):
             fac = recycling.factories.RitzFactorySimple(n_vectors=3, which=which)
@@ -494,6 +496,13 @@ def case_recycling_factories_toy():
             sols = [rs.solve(ls, vector_factory=fac, maxiter=50, tol=1e-5, x0=None) for _ in range(3)]
             for s in sols:
                 assert s.resnorms[-1] <= 1e-5 and s.projection.U.shape[0] == N
+                # the reference's run of the same sequence (tests/golden/recycling_toy.npz)
+                assert len(s.resnorms) == int(g["iters"][row]), (Solver.__name__, which, row)
+                assert s.projection.U.shape[1] == int(g["ncols"][row])
+                # last entry = explicit residual b - A x_k at 7e-6 |b| with cond(A) = 2e8: it carries
+                # eps * cond * |b| / |r| ~ 3e-3 of cancellation noise in the reference itself
+                assert abs(s.resnorms[-1] - float(g["last"][row])) < 1e-2 * float(g["last"][row])
+                row += 1
             for s in sols[1:]:
                 assert len(s.resnorms) <= len(sols[0].resnorms)
 
