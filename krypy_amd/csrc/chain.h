@@ -25,6 +25,7 @@
 // Residency: one 512-thread workgroup per CU (<= 256 VGPRs per lane); the launch is cooperative
 // so that a grid that cannot be co-resident is rejected instead of deadlocking.
 #pragma once
+#include <type_traits>
 #include "kernels.h"
 
 namespace kh {
@@ -631,6 +632,19 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 // that scales over xGMI (one all-reduce per sweep) and keeps launch count flat when the shards
 // get short.
 // ------------------------------------------------------------------------------------------
+// Batches of the panel kernels: no phase structure to respect here, so short vectors (R2 <= 16, i.e.
+// the N/4 and N/8 shards of the bench problem) stream 8-row batches through the ring instead of the
+// chain's 4: more bytes in flight per workgroup where there are few workgroups (153 for 256 CUs at
+// N/8).  Measured (cgs GMRES(100), tools/shard_sweep.sh): N/8 4778 -> 5100 it/s, N/4 2647 -> 2680;
+// 12-row batches at R2 = 24 (N/2) lost 2.5 %, 16-row batches at R2 = 16 gained nothing.  NB may be odd:
+// the ring parity then alternates from column to column and the column loop is unrolled by two.
+template <int R2>
+struct CgsShape {
+    static constexpr int PB = R2 <= 8 ? R2 : (R2 == 16 ? 8 : ChainShape<R2>::PB);
+    static constexpr int NB = R2 / PB;
+    static_assert(NB * PB == R2, "batches must tile the rows");
+};
+
 struct CgsArgs {
     int64_t n2, chunk2;
     const double* Vb;      // column base: Vb + j*ld  (V for the dots, B for the update)
@@ -649,8 +663,8 @@ struct CgsArgs {
 
 template <int R2, bool MASKED, bool NTC>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
-    constexpr int PB = ChainShape<R2>::PB;
-    constexpr int NB = ChainShape<R2>::NB;
+    constexpr int PB = CgsShape<R2>::PB;
+    constexpr int NB = CgsShape<R2>::NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
@@ -675,7 +689,9 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         CH_ISSUE_FENCE();
     }
     const int slot = blockIdx.x * (CH_BS / 64) + wid;
-    for (int t = 0; t < a.ncol; ++t) {
+    // one column, the ring slot its first batch sits in given as a compile-time constant
+    auto column = [&](auto par, int t) {
+        constexpr int P0 = decltype(par)::value;
         const double2* __restrict__ v2 =
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
         const double2* __restrict__ vn =
@@ -686,25 +702,35 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                ring[(b + 1) & 1][i] = NTC ? ld_nt2(nx + (int64_t)i * CH_BS) : nx[(int64_t)i * CH_BS];
+                ring[(P0 + b + 1) & 1][i] = NTC ? ld_nt2(nx + (int64_t)i * CH_BS) : nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 v = ring[b & 1][i];
+                const double2 v = ring[(P0 + b) & 1][i];
                 acc0 = fma(v.x, w[b * PB + i].x, acc0);
                 acc1 = fma(v.y, w[b * PB + i].y, acc1);
             }
         }
         const double s = wave_sum(acc0 + acc1);
         if (lane == 0) a.part[(int64_t)t * a.pstride + slot] = s;
+    };
+    if constexpr ((NB & 1) == 0) {
+        for (int t = 0; t < a.ncol; ++t) column(std::integral_constant<int, 0>{}, t);
+    } else {                                    // odd NB: two columns bring the ring parity back to 0
+        int t = 0;
+        for (; t + 1 < a.ncol; t += 2) {
+            column(std::integral_constant<int, 0>{}, t);
+            column(std::integral_constant<int, 1>{}, t + 1);
+        }
+        if (t < a.ncol) column(std::integral_constant<int, 0>{}, t);
     }
 #undef CH_OK
 }
 
 template <int R2, bool MASKED>
 __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
-    constexpr int PB = ChainShape<R2>::PB;
-    constexpr int NB = ChainShape<R2>::NB;
+    constexpr int PB = CgsShape<R2>::PB;
+    constexpr int NB = CgsShape<R2>::NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
@@ -730,7 +756,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         for (int i = 0; i < PB; ++i) ring[0][i] = ld_nt2(v2 + (int64_t)i * CH_BS);
         CH_ISSUE_FENCE();
     }
-    for (int it = 0; it < a.ncol; ++it) {
+    auto column = [&](auto par, int it) {
+        constexpr int P0 = decltype(par)::value;
         const int t = tfirst + it * tstep;
         const int tn = (it + 1 < a.ncol) ? t + tstep : t;
         const double h = a.coef[t];
@@ -742,16 +769,26 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : bn;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = ld_nt2(nx + (int64_t)i * CH_BS);
+            for (int i = 0; i < PB; ++i) ring[(P0 + b + 1) & 1][i] = ld_nt2(nx + (int64_t)i * CH_BS);
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 p = ring[b & 1][i];
+                const double2 p = ring[(P0 + b) & 1][i];
                 const int r = b * PB + i;
                 w[r].x = CH_OK(r) ? w[r].x - h * p.x : 0.0;
                 w[r].y = CH_OK(r) ? w[r].y - h * p.y : 0.0;
             }
         }
+    };
+    if constexpr ((NB & 1) == 0) {
+        for (int it = 0; it < a.ncol; ++it) column(std::integral_constant<int, 0>{}, it);
+    } else {
+        int it = 0;
+        for (; it + 1 < a.ncol; it += 2) {
+            column(std::integral_constant<int, 0>{}, it);
+            column(std::integral_constant<int, 1>{}, it + 1);
+        }
+        if (it < a.ncol) column(std::integral_constant<int, 0>{}, it);
     }
     // write w back with the wave partials of its (M-)norm
     double acc = 0.0;
