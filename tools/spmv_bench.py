@@ -12,7 +12,32 @@ from krypy_amd import _hip  # noqa: E402
 from oracle.krylov_ref import laplace3d  # noqa: E402
 
 ctx = _hip.get_context()
-for name, A in (("lap2d 4000x2500", bench.laplace2d(4000, 2500)), ("lap3d 200^3", laplace3d(200).tocsr())):
+import scipy.sparse as sp  # noqa: E402
+
+
+def banded(n, offsets, fill=1.0, seed=0):
+    rng = np.random.default_rng(seed)
+    diags = []
+    for o in offsets:
+        d = rng.standard_normal(n - abs(o)) + 3.0
+        if fill < 1.0:
+            d[rng.random(d.size) > fill] = 0.0
+        diags.append(d)
+    A = sp.diags(diags, offsets, shape=(n, n)).tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A
+
+
+mats = [("lap2d 4000x2500", bench.laplace2d(4000, 2500)), ("lap3d 200^3", laplace3d(200).tocsr())]
+if "--wide" in sys.argv:     # the generic (not unrolled) instantiation and partially filled diagonals
+    n = 4_000_000
+    o27 = [a * 160 * 160 + b * 160 + c for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1)]
+    mats = [("11 diagonals", banded(n, (-2000, -40, -3, -2, -1, 0, 1, 2, 3, 40, 2000))),
+            ("27-point 160^3 pattern", banded(160 ** 3, sorted(o27))),
+            ("9 diagonals 75% full", banded(n, (-2001, -2000, -1999, -1, 0, 1, 1999, 2000, 2001), 0.75)),
+            ("27 diagonals 72% full", banded(160 ** 3, sorted(o27), 0.72))]
+for name, A in mats:
     n = A.shape[0]
     x = np.random.default_rng(0).standard_normal(n)
     want = A.dot(x)
