@@ -22,28 +22,26 @@ class RitzFactorySimple(_DeflationVectorFactory):
         self.n_vectors = n_vectors
         self.which = which
 
+    # criterion -> (sort key of the Ritz values, take from the large end?)
+    _BY_VALUE = {"lm": (numpy.abs, True), "sm": (numpy.abs, False),
+                 "lr": (numpy.real, True), "sr": (numpy.real, False),
+                 "li": (numpy.imag, True), "si": (numpy.imag, False)}
+
     def get(self, solver):
         ritz = deflation.Ritz(solver, mode=self.mode)
-        values, which, n_vectors = ritz.values, self.which, self.n_vectors
-        if which == "lm":
-            indices = numpy.argsort(numpy.abs(values))[-n_vectors:]
-        elif which == "sm":
-            indices = numpy.argsort(numpy.abs(values))[:n_vectors]
-        elif which == "lr":
-            indices = numpy.argsort(numpy.real(values))[-n_vectors:]
-        elif which == "sr":
-            indices = numpy.argsort(numpy.real(values))[:n_vectors]
-        elif which == "li":
-            indices = numpy.argsort(numpy.imag(values))[-n_vectors:]
-        elif which == "si":
-            indices = numpy.argsort(numpy.imag(values))[:n_vectors]
-        elif which == "smallest_res":
-            indices = numpy.argsort(ritz.resnorms)[:n_vectors]
+        n = self.n_vectors
+        if self.which == "smallest_res":
+            order, from_top = numpy.argsort(ritz.resnorms), False
+        elif self.which in self._BY_VALUE:
+            key, from_top = self._BY_VALUE[self.which]
+            order = numpy.argsort(key(ritz.values))
         else:
-            raise utils.ArgumentError(
-                f"Invalid value '{which}' for 'which'. "
-                + "Valid are lm, sm, lr, sr, li, si and smallest_res.")
-        return ritz._get_vectors_dev(indices)
+            raise utils.ArgumentError("Invalid value '%s' for 'which'. Valid are %s and smallest_res."
+                                      % (self.which, ", ".join(sorted(self._BY_VALUE))))
+        # (order[-0:] would be everything: n_vectors == 0 selects nothing only from the small end,
+        # exactly like the reference's slices [-n:] and [:n])
+        chosen = order[-n:] if from_top else order[:n]
+        return ritz._get_vectors_dev(chosen)
 
 
 class UnionFactory(_DeflationVectorFactory):
