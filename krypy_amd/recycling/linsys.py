@@ -25,45 +25,38 @@ class _RecyclingSolver(object):
         """Solve the given linear system with recycling; remaining arguments go to the
         ``DeflatedSolver``.  Returns the solver instance (approximate solution in ``xk``).
         A ``ConvergenceError`` propagates and leaves ``last_solver`` untouched, as in the reference."""
-        if not isinstance(linear_system, linsys.TimedLinearSystem):
-            linear_system = linsys.ConvertedTimedLinearSystem(linear_system)
+        timed = linear_system if isinstance(linear_system, linsys.TimedLinearSystem) \
+            else linsys.ConvertedTimedLinearSystem(linear_system)
         with self.timings["vector_factory"]:
-            if vector_factory is None:
-                vector_factory = self._vector_factory
-            if isinstance(vector_factory, str):
+            factory = self._vector_factory if vector_factory is None else vector_factory
+            if isinstance(factory, str):
                 raise NotImplementedError(
                     "the string shortcuts select krypy's RitzFactory with convergence-bound "
                     "evaluators (out of scope, SURVEY.md section 2 rows 19-21); pass a "
                     "RitzFactorySimple instance")
-            if self.last_solver is None or vector_factory is None:
-                U = numpy.zeros((linear_system.N, 0))
-            else:
-                U = vector_factory.get(self.last_solver)
+            recycle = factory is not None and self.last_solver is not None
+            # first solve of a sequence / no factory: an empty basis, i.e. the plain solver
+            U = factory.get(self.last_solver) if recycle else numpy.zeros((timed.N, 0))
         with self.timings["solve"]:
-            self.last_solver = self._DeflatedSolver(linear_system, U=U, store_arnoldi=True,
-                                                    *args, **kwargs)
-        return self.last_solver
+            solver = self._DeflatedSolver(timed, *args, U=U, store_arnoldi=True, **kwargs)
+        self.last_solver = solver
+        return solver
 
 
-class RecyclingCg(_RecyclingSolver):
-    """Recycling preconditioned CG method."""
-
-    def __init__(self, *args, **kwargs):
-        super(RecyclingCg, self).__init__(deflation.DeflatedCg, *args, **kwargs)
-
-
-class RecyclingMinres(_RecyclingSolver):
-    """Recycling preconditioned MINRES method."""
+def _recycling(name, Deflated):
+    """``Recycling<Method>()``: a :class:`_RecyclingSolver` bound to one deflated solver class."""
 
     def __init__(self, *args, **kwargs):
-        super(RecyclingMinres, self).__init__(deflation.DeflatedMinres, *args, **kwargs)
+        _RecyclingSolver.__init__(self, Deflated, *args, **kwargs)
+
+    return type(name, (_RecyclingSolver,), {
+        "__init__": __init__, "__module__": __name__,
+        "__doc__": "Recycling preconditioned %s method." % name[len("Recycling"):].upper()})
 
 
-class RecyclingGmres(_RecyclingSolver):
-    """Recycling preconditioned GMRES method."""
-
-    def __init__(self, *args, **kwargs):
-        super(RecyclingGmres, self).__init__(deflation.DeflatedGmres, *args, **kwargs)
+RecyclingCg = _recycling("RecyclingCg", deflation.DeflatedCg)
+RecyclingMinres = _recycling("RecyclingMinres", deflation.DeflatedMinres)
+RecyclingGmres = _recycling("RecyclingGmres", deflation.DeflatedGmres)
 
 
 __all__ = ["RecyclingCg", "RecyclingMinres", "RecyclingGmres", "factories"]
