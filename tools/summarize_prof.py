@@ -52,6 +52,18 @@ def main(src, dst):
         lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
             short(name), calls, tot / 1e3, avg, pct, v[0], v[1], v[2]))
     lines.append("")
+    # the roofline kernel's identical micro-launches (bench.py / kh_bench_kernel) are the last launches of
+    # the run: their kernel-trace duration is what the live HIP-event average must agree with
+    try:
+        for pat, label in (("%k_mgs_chain%", "k_mgs_chain (64 links per launch)"),
+                           ("%k_cgs_dots%", "k_cgs_dots (16 columns)"), ("%k_cgs_update%", "k_cgs_update (16 columns)")):
+            d = q(tdb, "select end - start from kernels where name like '%s' order by start desc limit 20" % pat)
+            if d:
+                lines.append("Kernel-trace average of the last %d `%s` launches (bench.py's micro-launches): "
+                             "**%.1f us**." % (len(d), label, sum(x[0] for x in d) / len(d) / 1e3))
+        lines.append("")
+    except Exception as exc:  # pragma: no cover
+        lines += ["(micro-launch durations unavailable: %r)" % exc, ""]
     pm = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         db = os.path.join(src, "pmc_" + cname, "pmc_results.db")
