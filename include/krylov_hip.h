@@ -62,6 +62,10 @@ int kh_ctx_destroy(kh_ctx ctx);
 int kh_ctx_sync(kh_ctx ctx);
 /* info[0]=compute units, info[1]=total device memory (bytes), info[2]=free bytes, info[3]=reduction grid */
 int kh_ctx_info(kh_ctx ctx, int64_t info[4]);
+/* which Gram-Schmidt kernels ran so far on this context: [0] chain launches (k_mgs_chain*), [1] of
+ * those with the column head parked in LDS, [2] of those with the operator fused into the prologue,
+ * [3] register-resident panel sweeps (k_cgs_dots + k_cgs_update) */
+int kh_ctx_counters(kh_ctx ctx, int64_t out[4]);
 /* tuning knobs (0 keeps the default): reduction grid size, SpMV LDS tile (nnz) */
 int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
 /* event timing on the context's stream (for bench.py's per-kernel roofline numbers) */

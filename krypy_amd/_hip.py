@@ -44,6 +44,7 @@ _SIGNATURES = {
     "kh_ctx_destroy": [_H],
     "kh_ctx_sync": [_H],
     "kh_ctx_info": [_H, _c_int64_p],
+    "kh_ctx_counters": [_H, _c_int64_p],
     "kh_ctx_tune": [_H, _INT, _INT],
     "kh_timer_start": [_H],
     "kh_timer_stop": [_H, _c_double_p],
@@ -409,6 +410,12 @@ class Context(object):
         buf = (ctypes.c_int64 * 4)()
         _check(self._lib, self._lib.kh_ctx_info(self._h, buf), "kh_ctx_info")
         return dict(compute_units=buf[0], mem_total=buf[1], mem_free=buf[2], reduce_blocks=buf[3])
+
+    def counters(self):
+        """Launch counts of the Gram-Schmidt kernel families (``kh_ctx_counters``)."""
+        buf = (ctypes.c_int64 * 4)()
+        _check(self._lib, self._lib.kh_ctx_counters(self._h, buf), "kh_ctx_counters")
+        return dict(chain=buf[0], chain_lds=buf[1], chain_fused=buf[2], cgs_register=buf[3])
 
     def tune(self, reduce_blocks=0, spmv_tile=0):
         _check(self._lib, self._lib.kh_ctx_tune(self._h, reduce_blocks, spmv_tile), "kh_ctx_tune")

@@ -57,6 +57,8 @@ struct kh_ctx_s {
     int64_t hcap = 0;
     // register-resident MGS chain (chain.h)
     int chain_enabled = 1;
+    int64_t n_chain = 0, n_chain_lds = 0, n_chain_fused = 0, n_cgs_reg = 0;   // launch counters (kh_ctx_counters)
+    int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
     unsigned long long* chain_gran = nullptr;
     int* chain_err = nullptr;        // device error word
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};

@@ -276,21 +276,21 @@ static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
 }
 
 // the variant that parks the head of every column in LDS between its dot and its update (B == V)
-template <int R2, bool MASKED, bool CPLX = false>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
 static hipError_t launch_chain_lds(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
     constexpr size_t lds = ChainShapeLds<R2, CPLX>::LDS_BYTES;
     if (blocks_per_cu < 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_lds<R2, MASKED, CPLX>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_lds<R2, MASKED, CPLX, FND>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         int nb = 0;
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain_lds<R2, MASKED, CPLX>, CH_BS, lds);
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain_lds<R2, MASKED, CPLX, FND>, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_mgs_chain_lds<R2, MASKED, CPLX>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    hipLaunchKernelGGL((k_mgs_chain_lds<R2, MASKED, CPLX, FND>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -325,7 +325,10 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
                      const double* h_km1_dev, double* hdev, int slot, bool cplx = false, double* hpin = nullptr,
-                     int hcount = 0) {
+                     int hcount = 0, kh_mat Afuse = nullptr, const double* xk = nullptr) {
+    // Afuse: compute w = Afuse * xk in the kernel's prologue instead of reading w (banded operators;
+    // returns 0 without launching anything when that variant does not apply - the caller then runs the
+    // SpMV and calls again without Afuse)
     // cplx: V, B, w are (re, im) views of complex vectors (zpath.h); hdev holds (re, im) pairs
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     if (cplx && (dg != nullptr || P != nullptr)) return 0;
@@ -384,6 +387,26 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // masked LDS instantiations with 32 / 40 rows spill)
     bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
                    (padded || r2 <= 24);
+    // fused operator: only the padded real LDS kernel of the two long shapes has that prologue
+    bool fused = false;
+    if (Afuse != nullptr) {
+        fused = ctx->chain_spmv && use_lds && padded && !cplx && !presub && (r2 == 40 || r2 == 32) && xk != nullptr &&
+                Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
+                Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
+        if (!fused) return 0;
+        a.dia = Afuse->dia;
+        a.dia_ld = Afuse->dia_ld;
+        a.xk = xk;
+        a.n_last = n - 1;
+        a.offs.nd = Afuse->dia_nd;
+        for (int d = 0; d < KH_DIA_MAX; ++d) a.offs.off[d] = d < Afuse->dia_nd ? Afuse->dia_off[d] : 0;
+    } else {
+        a.dia = nullptr;
+        a.dia_ld = 0;
+        a.xk = nullptr;
+        a.n_last = n - 1;
+        a.offs.nd = 0;
+    }
 #define KH_CHAIN_PLAIN(R)                                                                             \
     (cplx ? (padded ? launch_chain<R, false, true>(ctx, G, a) : launch_chain<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain<R, false>(ctx, G, a) : launch_chain<R, true>(ctx, G, a)))
@@ -392,6 +415,17 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
           : (padded ? launch_chain_lds<R, false>(ctx, G, a) : launch_chain_lds<R, true>(ctx, G, a)))
 #define KH_CHAIN(R) (use_lds ? KH_CHAIN_LDS(R) : KH_CHAIN_PLAIN(R))
     for (int attempt = 0; attempt < 2; ++attempt) {
+        if (fused) {
+            if (r2 == 40) e = (a.offs.nd == 5) ? launch_chain_lds<40, false, false, 5>(ctx, G, a)
+                                               : launch_chain_lds<40, false, false, 7>(ctx, G, a);
+            else e = (a.offs.nd == 5) ? launch_chain_lds<32, false, false, 5>(ctx, G, a)
+                                      : launch_chain_lds<32, false, false, 7>(ctx, G, a);
+            if (e != hipSuccess) {       // the caller falls back to SpMV + the ordinary chain
+                (void)hipGetLastError();
+                return 0;
+            }
+            break;
+        }
         if (r2 == 4) e = KH_CHAIN(4);
         else if (r2 == 8) e = KH_CHAIN(8);
         else if (r2 == 16) e = KH_CHAIN(16);
@@ -412,6 +446,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         ctx->chain_enabled = 0;
         return 0;
     }
+    ctx->n_chain += 1;
+    ctx->n_chain_lds += use_lds ? 1 : 0;
+    ctx->n_chain_fused += fused ? 1 : 0;
     ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);   // one grid reduction per link (complex: both parts in it) + the norm
     if (hpin == nullptr)      // (otherwise workgroup 0 has written the error word to the pinned slot itself)
         KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
@@ -504,6 +541,7 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
 #undef KH_CGS_ANY
 #undef KH_CGS
     *nrm_count = nwave;
+    ctx->n_cgs_reg += 1;
     return 1;
 }
 
@@ -570,6 +608,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         const char* e = getenv("KRYPY_AMD_MGS_CHAIN");
         ctx->chain_enabled = (e == nullptr) ? 1 : atoi(e);
         if (ctx->ncu > CH_GMAX) ctx->chain_enabled = 0;
+        e = getenv("KRYPY_AMD_CHAIN_SPMV");
+        ctx->chain_spmv = (e == nullptr) ? 1 : atoi(e);
     }
     *out = ctx;
     return 0;
@@ -615,6 +655,15 @@ int kh_ctx_info(kh_ctx ctx, int64_t info[4]) {
     info[1] = (int64_t)tot;
     info[2] = (int64_t)fr;
     info[3] = ctx->nb;
+    return 0;
+}
+
+int kh_ctx_counters(kh_ctx ctx, int64_t out[4]) {
+    KH_ARG(ctx != nullptr && out != nullptr, "kh_ctx_counters: NULL");
+    out[0] = ctx->n_chain;
+    out[1] = ctx->n_chain_lds;
+    out[2] = ctx->n_chain_fused;
+    out[3] = ctx->n_cgs_reg;
     return 0;
 }
 
@@ -829,7 +878,10 @@ static int build_dia(kh_ctx ctx, kh_mat A, const std::vector<int>& offs, bool ha
     const int rpt = halo ? 4 : mode;                 // the ghost-row variant exists for 4 row pairs per lane
     const int64_t rows_per_wg = 2 * (int64_t)BS * rpt;
     const int64_t nblk = (A->n_rows + rows_per_wg - 1) / rows_per_wg;
-    const int64_t ld = nblk * rows_per_wg;
+    // leading dimension: whole workgroups, and at least the padded length of a device vector so that
+    // the chain kernel's fused prologue (chain.h) can read every diagonal without a predicate
+    const int64_t ld = ((std::max(nblk * rows_per_wg, padded_ld(ctx, A->n_rows)) + rows_per_wg - 1) / rows_per_wg) *
+                       rows_per_wg;
     const size_t bytes = sizeof(double) * (size_t)ld * offs.size();
     double* dia = nullptr;
     if (hipMalloc(&dia, bytes) != hipSuccess) {     // no room for the copy: the CSR kernel serves
@@ -1213,10 +1265,20 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     const bool want_cgs1 = (gs_mode == KH_GS_CGS && sweeps == 1 && ctx->chain_enabled);
     if (!want_chain && !want_cgs1) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
     // 1. operator
+    bool fused_chain = false;
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
                (long long)n);
-        if (fuse_dot0)
+        if (want_chain && proj == nullptr && A->kind == KH_MAT_CSR && A->dia != nullptr) {
+            // banded operator: the chain kernel computes w = A v_k in its prologue (no SpMV launch, w
+            // never touches HBM); returns 0 when that instantiation does not apply
+            const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev,
+                                     slot, false, ctx->hslot_pin[slot], (int)(k + 2 + pd), A, V->col(k));
+            if (rc < 0) return rc;
+            fused_chain = (rc == 1);
+        }
+        if (fused_chain) {
+        } else if (fuse_dot0)
             KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_DOT, V->col(start), tmp, 0));
         else
             KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_NONE, nullptr, nullptr, 0));
@@ -1226,8 +1288,8 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
 
     double* nrm_part = part_slot(ctx, SLOT_NRM);
     int nrm_count = grid;     // number of partial sums the norm arrives in
-    bool chained = false;
-    if (want_chain) {
+    bool chained = fused_chain;
+    if (want_chain && !fused_chain) {
         const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev, slot,
                                  false, ctx->hslot_pin[slot], (int)(k + 2 + pd));
         if (rc < 0) return rc;

@@ -114,6 +114,9 @@ class NumpyContext(object):
     def close(self):
         pass
 
+    def counters(self):
+        return dict(chain=0, chain_lds=0, chain_fused=0, cgs_register=0)
+
     def info(self):
         return dict(compute_units=0, mem_total=0, mem_free=0, reduce_blocks=0)
 

@@ -371,20 +371,55 @@ def test_rccl_single_rank_communicator(hip):
     ctx.close()
 
 
-def _second_context(chain):
-    """A private context with the register-resident MGS chain switched on/off (read at creation)."""
+def _second_context(chain, fused_spmv=True):
+    """A private context with the register-resident MGS chain (and the operator fused into its
+    prologue) switched on/off (both read at creation)."""
     import os
     from krypy_amd import _hip
 
-    old = os.environ.get("KRYPY_AMD_MGS_CHAIN")
-    os.environ["KRYPY_AMD_MGS_CHAIN"] = "1" if chain else "0"
+    want = {"KRYPY_AMD_MGS_CHAIN": "1" if chain else "0", "KRYPY_AMD_CHAIN_SPMV": "1" if fused_spmv else "0"}
+    old = {k: os.environ.get(k) for k in want}
+    os.environ.update(want)
     try:
         return _hip.Context(0)
     finally:
-        if old is None:
-            del os.environ["KRYPY_AMD_MGS_CHAIN"]
-        else:
-            os.environ["KRYPY_AMD_MGS_CHAIN"] = old
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("shape", [("lap2d", 3000, 2200), ("lap2d", 4000, 2500), ("lap3d", 190, 0),
+                                   ("lap3d", 215, 0)])
+def test_operator_fused_into_the_chain_prologue(hip, shape):
+    """Banded operator + long vector: the chain kernel computes w = A v_k in its prologue instead of
+    reading what a separate SpMV launch wrote.  Same arithmetic in the same order, so H and the basis
+    must come out bit for bit as with the SpMV launch (32 and 40 rows per lane, 5 and 7 diagonals,
+    single and double sweeps)."""
+    kind, a, b_ = shape
+    A = ref.laplace2d(a, b_) if kind == "lap2d" else ref.laplace3d(a).tocsr()
+    n = A.shape[0]
+    v = np.random.default_rng(3).standard_normal(n)
+    m = 6
+    out = []
+    for fused in (True, False):
+        ctx = _second_context(True, fused)
+        Ad = ctx.csr(A)
+        assert Ad.diagonals in (5, 7)
+        V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+        V.upload(0, v / np.linalg.norm(v))
+        H = np.zeros((m + 1, m))
+        for k in range(m):
+            H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 4 else 1, 0)
+        out.append((H, V.download()))
+        c = ctx.counters()
+        assert c["chain"] == m and c["chain_lds"] == m and c["chain_fused"] == (m if fused else 0), c
+        ctx.close()
+    (Hf, Vf), (Hs, Vs) = out
+    assert np.array_equal(Hf, Hs)
+    assert np.array_equal(Vf, Vs)
+    assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
 
 
 @pytest.mark.parametrize("shape", [(120, 120), (39, 41), (700, 300)])
