@@ -226,8 +226,51 @@ struct ChainShape {
 // (re, im interleaved), i.e. exactly one double2 row per element, so geometry, pipeline and padding
 // are unchanged; the dot is conj(v).w (two grid reductions per link: re, im), the update the complex
 // multiply of NumPy (separate roundings), H entries are (re, im) pairs in hdev.
-template <int R2, bool MASKED, bool CPLX = false>
+// Fused operator of the chain kernels (FND > 0 diagonals of a banded operator, krylov_hip.hip builds the
+// diagonal-major copy): this lane's rows of w = A x_k, computed straight into the registers that hold w.
+template <int R2, int FND>
+__device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, double2 (&w)[R2]) {
+    // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
+    // separate multiply and add, empty slots skipped): the 80 MB of w are never written nor read.
+    // The padding rows behind n hold zeros in every diagonal and come out as w = 0.
+    const double* __restrict__ xk = a.xk;
+    const int64_t last = a.n_last;
+    int64_t i2 = first;      // advanced through an opaque asm every two rows: that is what bounds the
+                             // loads in flight (and the live temporaries) of this fully unrolled loop
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const int64_t row = 2 * i2;
+        double2 av[FND];
+        double x0[FND], x1[FND];
+#pragma unroll
+        for (int d = 0; d < FND; ++d) {
+            const int64_t off = a.offs.off[d];
+            av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
+            // branch-free (clamped scalar loads of x: L2 hits): control flow in this fully
+            // unrolled prologue sends the register allocator into > 1000 spills
+            int64_t c0 = row + off, c1 = row + 1 + off;
+            c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+            c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+            x0[d] = xk[c0];
+            x1[d] = xk[c1];
+        }
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int d = 0; d < FND; ++d) {
+            const double p0 = av[d].x * x0[d], p1 = av[d].y * x1[d];
+            s0 = (av[d].x != 0.0) ? s0 + p0 : s0;
+            s1 = (av[d].y != 0.0) ? s1 + p1 : s1;
+        }
+        w[r].x = s0;
+        w[r].y = s1;
+        i2 += CH_BS;
+        if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight (one: 1023 it/s, two: 1028-1037, four: 1018-1030)
+    }
+}
+
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
+    static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
     __shared__ double smd[2 * (CH_BS / 64)];
@@ -241,7 +284,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
     double2 w[R2];
     double2 ring[2][PB];
-    {
+    if constexpr (FND > 0) {
+        chain_apply_banded<R2, FND>(a, first, w);
+    } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
@@ -449,42 +494,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     double2 w[R2];
     double2 ring[2][PB];
     if constexpr (FND > 0) {
-        // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
-        // separate multiply and add, empty slots skipped): the 80 MB of w are never written nor read.
-        // The padding rows behind n hold zeros in every diagonal and come out as w = 0.
-        const double* __restrict__ xk = a.xk;
-        const int64_t last = a.n_last;
-        int64_t i2 = first;      // advanced through an opaque asm: keeps the compiler from materialising the
-                                 // 12 addresses of all R2 rows up front (1366 spilled registers otherwise)
-#pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            const int64_t row = 2 * i2;
-            double2 av[FND];
-            double x0[FND], x1[FND];
-#pragma unroll
-            for (int d = 0; d < FND; ++d) {
-                const int64_t off = a.offs.off[d];
-                av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
-                // branch-free (clamped scalar loads of x: L2 hits): control flow in this fully
-                // unrolled prologue sends the register allocator into > 1000 spills
-                int64_t c0 = row + off, c1 = row + 1 + off;
-                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
-                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
-                x0[d] = xk[c0];
-                x1[d] = xk[c1];
-            }
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int d = 0; d < FND; ++d) {
-                const double p0 = av[d].x * x0[d], p1 = av[d].y * x1[d];
-                s0 = (av[d].x != 0.0) ? s0 + p0 : s0;
-                s1 = (av[d].y != 0.0) ? s1 + p1 : s1;
-            }
-            w[r].x = s0;
-            w[r].y = s1;
-            i2 += CH_BS;
-            if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight (one: 1023 it/s, two: 1028-1037, four: 1018-1030)
-        }
+        chain_apply_banded<R2, FND>(a, first, w);
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll

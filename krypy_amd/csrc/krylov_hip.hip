@@ -261,17 +261,17 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
 // is what matters for the in-kernel grid reduction, and it is identical for plain and cooperative
 // launches: it is checked here against the occupancy of this instantiation, and every spin in the
 // kernel is bounded.
-template <int R2, bool MASKED, bool CPLX = false>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
 static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
     if (blocks_per_cu < 0) {
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CPLX>, CH_BS, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CPLX, FND>, CH_BS, 0);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CPLX>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CPLX, FND>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -387,10 +387,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // masked LDS instantiations with 32 / 40 rows spill)
     bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
                    (padded || r2 <= 24);
-    // fused operator: only the padded real LDS kernel of the two long shapes has that prologue
+    // fused operator: the padded real kernels of the two long shapes have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && use_lds && padded && !cplx && !presub && (r2 == 40 || r2 == 32) && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && ctx->chain_debug == 0 && (r2 == 40 || r2 == 32) && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -416,10 +416,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 #define KH_CHAIN(R) (use_lds ? KH_CHAIN_LDS(R) : KH_CHAIN_PLAIN(R))
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fused) {
-            if (r2 == 40) e = (a.offs.nd == 5) ? launch_chain_lds<40, false, false, 5>(ctx, G, a)
-                                               : launch_chain_lds<40, false, false, 7>(ctx, G, a);
-            else e = (a.offs.nd == 5) ? launch_chain_lds<32, false, false, 5>(ctx, G, a)
-                                      : launch_chain_lds<32, false, false, 7>(ctx, G, a);
+#define KH_FUSED(R, D) (use_lds ? launch_chain_lds<R, false, false, D>(ctx, G, a) : launch_chain<R, false, false, D>(ctx, G, a))
+            if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
+            else e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
+#undef KH_FUSED
             if (e != hipSuccess) {       // the caller falls back to SpMV + the ordinary chain
                 (void)hipGetLastError();
                 return 0;

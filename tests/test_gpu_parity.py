@@ -401,24 +401,45 @@ def test_operator_fused_into_the_chain_prologue(hip, shape):
     A = ref.laplace2d(a, b_) if kind == "lap2d" else ref.laplace3d(a).tocsr()
     n = A.shape[0]
     v = np.random.default_rng(3).standard_normal(n)
+    dj = np.linspace(0.5, 1.5, n)
     m = 6
     out = []
     for fused in (True, False):
         ctx = _second_context(True, fused)
-        Ad = ctx.csr(A)
+        Ad, Md = ctx.csr(A), ctx.diag(dj)
         assert Ad.diagonals in (5, 7)
-        V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
-        V.upload(0, v / np.linalg.norm(v))
-        H = np.zeros((m + 1, m))
-        for k in range(m):
-            H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 4 else 1, 0)
-        out.append((H, V.download()))
-        c = ctx.counters()
-        assert c["chain"] == m and c["chain_lds"] == m and c["chain_fused"] == (m if fused else 0), c
+        res = {}
+        # plain / double-sweep MGS (LDS-parking kernel), Lanczos with its pre-subtraction, Jacobi (plain kernel)
+        for name, use_m, lanczos in (("mgs", False, False), ("lanczos", False, True), ("jacobi", True, False)):
+            before = ctx.counters()
+            V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+            P = ctx.alloc(n, m + 1) if use_m else None
+            if use_m:
+                nrm = np.sqrt(np.dot(v, dj * v))
+                P.upload(0, v / nrm)
+                V.upload(0, dj * v / nrm)
+            else:
+                V.upload(0, v / np.linalg.norm(v))
+            H = np.zeros((m + 1, m))
+            for k in range(m):
+                start = k if lanczos else 0
+                hk = float(H[k, k - 1]) if (lanczos and k > 0) else 0.0
+                hcol = ctx.arnoldi_step(Ad, Md if use_m else None, V, P, W, 0, k, start,
+                                        2 if (k == 4 and not lanczos) else 1, 0, hk)
+                H[start: k + 2, k] = hcol[start: k + 2]
+            res[name] = (H, V.download())
+            c = ctx.counters()
+            assert c["chain"] - before["chain"] == m, (name, c)
+            assert c["chain_lds"] - before["chain_lds"] == (0 if use_m else m), (name, c)
+            assert c["chain_fused"] - before["chain_fused"] == (m if fused else 0), (name, c)
+            del V, W, P
+        out.append(res)
         ctx.close()
-    (Hf, Vf), (Hs, Vs) = out
-    assert np.array_equal(Hf, Hs)
-    assert np.array_equal(Vf, Vs)
+    for name in out[0]:
+        (Hf, Vf), (Hs, Vs) = out[0][name], out[1][name]
+        assert np.array_equal(Hf, Hs), name
+        assert np.array_equal(Vf, Vs), name
+    Hf, Vf = out[0]["mgs"]
     assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
 
 
