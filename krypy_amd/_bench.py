@@ -74,6 +74,10 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         extra["spmv"] = {"kernel": "k_spmv_dia (%d diagonals)" % nd if nd else "k_spmv_stream", "avg_ms": ms,
                          "algorithmic_bytes": nb, "achieved_gbs": _gbs(nb, ms),
                          "frac_of_peak": _gbs(nb, ms) / peak_gbs}
+        if nd and getattr(ctx, "counters", None) is not None and ctx.counters().get("chain_fused", 0) > 0:
+            extra["spmv"]["in_solver"] = ("fused: the GMRES / Lanczos steps of this run computed A v_k in the prologue of "
+                                          "the chain kernel (no SpMV launch, w never written to HBM); the figures here "
+                                          "are the stand-alone kernel, as used for residuals and by the panel modes")
         if nd:
             # the banded copy holds 8 B per diagonal slot and no indices: what the kernel really moves
             moved = 8.0 * nd * Amat.shape[0] + 16.0 * Amat.shape[0]
