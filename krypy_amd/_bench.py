@@ -108,5 +108,8 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
         roof["note"] = ("algorithmic bytes = SURVEY 8(d): 16 N per basis column (the column is read for the "
                         "projection and again for the update).  The kernel serves half of that second read "
                         "from LDS / the register ring, so its HBM traffic (`traffic`, PMC) is below the "
-                        "algorithmic bytes and `frac` can exceed 1; traffic / avg_launch_ms is the HBM rate.")
+                        "algorithmic bytes and `frac` can exceed 1; traffic / avg_launch_ms is the HBM rate.  "
+                        "Measured on identical 64-link launches that load w (k_mgs_chain_lds<40,false,false,0>); the "
+                        "solver's own launches are the same kernel with w = A v_k computed in the prologue "
+                        "(<40,false,false,5>, k+1 links each).")
     return roof, extra
