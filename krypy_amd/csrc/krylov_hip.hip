@@ -387,10 +387,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // masked LDS instantiations with 32 / 40 rows spill)
     bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
                    (padded || r2 <= 24);
-    // fused operator: the padded real kernels of the two long shapes have that prologue
+    // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && padded && !cplx && ctx->chain_debug == 0 && (r2 == 40 || r2 == 32) && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && ctx->chain_debug == 0 && r2 >= 16 && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -418,7 +418,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         if (fused) {
 #define KH_FUSED(R, D) (use_lds ? launch_chain_lds<R, false, false, D>(ctx, G, a) : launch_chain<R, false, false, D>(ctx, G, a))
             if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
-            else e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
+            else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
+            else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);
+            else e = (a.offs.nd == 5) ? KH_FUSED(16, 5) : KH_FUSED(16, 7);
 #undef KH_FUSED
             if (e != hipSuccess) {       // the caller falls back to SpMV + the ordinary chain
                 (void)hipGetLastError();
