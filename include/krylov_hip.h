@@ -68,6 +68,11 @@ int kh_ctx_info(kh_ctx ctx, int64_t info[4]);
 int kh_ctx_counters(kh_ctx ctx, int64_t out[4]);
 /* tuning knobs (0 keeps the default): reduction grid size, SpMV LDS tile (nnz) */
 int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
+/* named switches of a context (1 = on, the default; the environment variables of INTEGRATION.md set the
+ * initial values): "spmv_dia" banded SpMV for stencil CSR operators, "chain" register-resident MGS chain,
+ * "chain_lds" column head parked in LDS, "chain_spmv" operator fused into the chain prologue.  bench.py
+ * uses it to time the CSR-stream and the banded SpMV kernel on the same operator. */
+int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value);
 /* event timing on the context's stream (for bench.py's per-kernel roofline numbers) */
 int kh_timer_start(kh_ctx ctx);
 int kh_timer_stop(kh_ctx ctx, double* elapsed_ms);

@@ -1,18 +1,66 @@
 """Live roofline measurements for bench.py: HIP-event timing of the hot kernels on the
-library's own stream (``kh_bench_kernel`` / ``kh_timer_*``), with the algorithmic byte counts of
-SURVEY.md section 8(d).  Not part of the solver path."""
+library's own stream (``kh_bench_kernel`` / ``kh_timer_*``).  Not part of the solver path.
+
+Every rate in here is bytes / time with the bytes named:
+
+  compulsory   the bytes a launch cannot avoid reading from / writing to HBM: every basis column
+               ONCE (8 N), w once in and v_{k+1} once out - the column's second use (the update after
+               the grid-wide reduction) is served on chip where the kernel manages to
+  moved        HBM traffic of the launch: the rocprofv3 FETCH_SIZE / WRITE_SIZE figure of
+               ``profiles/*_traffic.json`` when that file was collected from THIS source tree (stamp =
+               sha256 of the kernel sources), otherwise the kernel's own worst-case model (every byte it
+               requests from L2 and beyond)
+  survey_8d    the SURVEY.md 8(d) accounting (16 N per column: the column charged twice).  A kernel that
+               keeps half a column on chip beats that model, so it is a labelled side number only and
+               never a roofline fraction.
+
+``frac`` fields are always moved-or-compulsory bytes over the 8 TB/s spec peak and cannot exceed 1;
+``frac_of_attainable`` divides by the copy rate measured in the same run.
+"""
+import hashlib
+import os
+
 import numpy
 
 # kernel ids of kh_bench_kernel
 K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN, K_CGS = 0, 1, 2, 3, 4, 5, 8
+K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
+
+_SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h")
+
+
+def source_stamp():
+    """sha256 (first 16 hex digits) of the kernel sources: ties a PMC traffic file to the code it measured."""
+    h = hashlib.sha256()
+    base = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    for fn in _SOURCES:
+        with open(os.path.join(base, fn), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _gbs(nbytes, ms):
     return nbytes / (ms * 1e-3) / 1e9
 
 
-def roofline(ctx, ls, ortho, peak_gbs, reps=60):
+def chain_reread_fraction(n, ncu, lds=True):
+    """Share of a column the LDS chain kernel requests a second time from memory (the rest of the second
+    use comes from LDS and the register ring): NG*PB/R2 of chain.h's ChainShapeLds."""
+    n2 = (n + 1) // 2
+    for r2 in (4, 8, 16, 24, 32, 40):
+        g = -(-n2 // (r2 * 512))
+        if g <= ncu and g <= 512:
+            if not lds:
+                return r2, 1.0
+            pb = 5 if r2 == 40 else (2 if r2 == 4 else 4)
+            nb = r2 // pb
+            lb = 3 if nb >= 4 else 1
+            return r2, max(nb - lb - 1, 0) * pb / float(r2)
+    return 0, 1.0
+
+
+def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
     """Returns (roofline dict of the dominant kernel, extra dict with the other kernels)."""
     n = ls.N
     ncol = 18
@@ -24,92 +72,171 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60):
     W.upload(0, rng.standard_normal(n))
     kernels = {}
 
-    def run(which, nbytes, name, moved):
+    def run(which, name, compulsory, moved_model, survey=None):
         ctx.bench_kernel(which, V, W, 5)             # warm-up
         ms = ctx.bench_kernel(which, V, W, reps)
-        kernels[name] = {"avg_ms": ms, "algorithmic_bytes": nbytes, "achieved_gbs": _gbs(nbytes, ms),
-                         "moved_bytes_model": moved, "moved_gbs_model": _gbs(moved, ms)}
-        return ms
+        kernels[name] = {"avg_ms": ms, "compulsory_bytes": compulsory, "compulsory_gbs": _gbs(compulsory, ms),
+                         "moved_bytes_model": moved_model, "moved_gbs_model": _gbs(moved_model, ms),
+                         "frac": _gbs(moved_model, ms) / peak_gbs}
+        if survey is not None:
+            kernels[name]["survey_8d_bytes"] = survey
+        return kernels[name]
 
-    # algorithmic bytes per launch ("16 N (k+1)" per step = 16 N per basis column:
-    # the column is read once for the projection and once for the update; w is accounted once per
-    # step, not per column).  moved_bytes_model = what the launch really streams through L2.
-    run(K_GS_LINK, 16.0 * n, "k_gs_link<A_PART,T_DOT>", 32.0 * n)
-    run(K_MULTIDOT16, 8.0 * n * 16 + 8.0 * n, "k_multidot<16>", 8.0 * n * 17)
-    run(K_MULTIAXPY16, 8.0 * n * 16 + 16.0 * n, "k_multiaxpy<16>", 8.0 * n * 18)
-    run(K_AXPY_NRM, 8.0 * n + 16.0 * n, "k_gs_link<A_PART,T_NRM>", 24.0 * n)
-    run(K_SCALE_STORE, 16.0 * n, "k_scale_store", 16.0 * n)
+    # ---- attainable ceiling of this box, this run (SURVEY 8d / BASELINE.md section 3) ----
+    ld = V.ld
+    ceiling = {}
+    for which, name, nbytes in ((K_COPY, "copy, grid-stride (8 columns -> 8 columns)", 8.0 * ld * 16),
+                                (12, "copy, 1 x 16 B per lane", 8.0 * ld * 16),
+                                (13, "copy, 4 x 16 B per lane", 8.0 * ld * 16),
+                                (14, "copy, 8 x 16 B per lane", 8.0 * ld * 16),
+                                (15, "copy, 4 x 16 B per lane, non-temporal stores", 8.0 * ld * 16),
+                                (K_TRIAD, "triad a = b + s c (4-column chunks)", 8.0 * ld * 12),
+                                (K_READ, "read-only sum, grid-stride (16 columns)", 8.0 * ld * 16),
+                                (16, "read-only, 4 x 16 B per lane", 8.0 * ld * 16),
+                                (17, "read-only, 8 x 16 B per lane", 8.0 * ld * 16),
+                                (18, "read-only, 16 x 16 B per lane", 8.0 * ld * 16)):
+        try:
+            ctx.bench_kernel(which, V, W, 3)
+            ms = ctx.bench_kernel(which, V, W, 20)
+            ceiling[name] = {"avg_ms": ms, "bytes": nbytes, "gbs": _gbs(nbytes, ms), "frac_of_peak": _gbs(nbytes, ms) / peak_gbs}
+        except Exception as exc:
+            ceiling[name] = {"unavailable": repr(exc)}
+    rates = [v["gbs"] for v in ceiling.values() if "gbs" in v]
+    attainable = max(rates) if rates else None
+
+    run(K_GS_LINK, "k_gs_link<A_PART,T_DOT>", 32.0 * n, 32.0 * n, 16.0 * n)
+    run(K_MULTIDOT16, "k_multidot<16>", 8.0 * n * 17, 8.0 * n * 17)
+    run(K_MULTIAXPY16, "k_multiaxpy<16>", 8.0 * n * 18, 8.0 * n * 18)
+    run(K_AXPY_NRM, "k_gs_link<A_PART,T_NRM>", 24.0 * n, 24.0 * n)
+    run(K_SCALE_STORE, "k_scale_store", 16.0 * n, 16.0 * n)
+    info = ctx.info() if hasattr(ctx, "info") else {"compute_units": 256}
+    counters0 = ctx.counters() if hasattr(ctx, "counters") else {}
     chain = None
+    chain_name = None
     try:
-        # register-resident MGS chain: one launch = load w (8N) + 64 links x (v_j read for the dot +
-        # b_j read for the update = 16N, the SURVEY 8d per-column figure) + store v_{k+1} (8N)
-        nb = 16.0 * n * CHAIN_LINKS + 16.0 * n
-        run(K_CHAIN, nb, "k_mgs_chain (64 links/launch)", 8.0 * n * CHAIN_LINKS * 1.5 + 16.0 * n)
-        chain = kernels["k_mgs_chain (64 links/launch)"]
+        # register-resident MGS chain, 64 links per launch: w in (8N) + 64 columns (8N each) + v_{k+1} out (8N)
+        ms_probe = ctx.bench_kernel(K_CHAIN, V, W, 2)
+        c1 = ctx.counters() if hasattr(ctx, "counters") else {}
+        lds = c1.get("chain_lds", 0) > counters0.get("chain_lds", 0)
+        r2, rr = chain_reread_fraction(n, int(info.get("compute_units", 256)), lds)
+        chain_name = "%s<%d> (64 links per launch)" % ("k_mgs_chain_lds" if lds else "k_mgs_chain", r2)
+        comp = 8.0 * n * CHAIN_LINKS + 16.0 * n
+        chain = run(K_CHAIN, chain_name, comp, 8.0 * n * CHAIN_LINKS * (1.0 + rr) + 16.0 * n,
+                    16.0 * n * CHAIN_LINKS + 16.0 * n)
         chain["us_per_link"] = chain["avg_ms"] * 1e3 / CHAIN_LINKS
-    except Exception as exc:   # not eligible (odd n, w larger than the register file, multi-GPU)
+        chain["reread_fraction_model"] = rr
+        del ms_probe
+    except Exception as exc:   # not eligible (w larger than the register file, multi-GPU)
         kernels["k_mgs_chain"] = {"unavailable": repr(exc)}
     cgs = None
     try:
-        # register-resident panel GS: 16 columns read once for the dots, once for the update, w read
-        # twice and written once
+        # register-resident panel GS: 16 columns read for the dots, again for the update (the basis does not fit
+        # any cache), w read twice and written once: compulsory == moved
         nb = 16.0 * n * 16 + 32.0 * n
-        run(K_CGS, nb, "k_cgs_dots+k_cgs_update (16 columns)", nb)
-        cgs = kernels["k_cgs_dots+k_cgs_update (16 columns)"]
+        cgs = run(K_CGS, "k_cgs_dots+k_cgs_update (16 columns)", nb, nb)
     except Exception as exc:
         kernels["k_cgs_dots+k_cgs_update"] = {"unavailable": repr(exc)}
-    extra = {"kernels": kernels}
+    extra = {"kernels": kernels, "attainable": {"probes": ceiling, "best_gbs": attainable,
+                                                "note": "streaming probes timed in this run on 1.2-1.4 GB of the same device "
+                                                        "block (beyond the 256 MB Infinity Cache); MI355X_MICROARCH.md quotes "
+                                                        "6.29 TB/s for a float4 copy"}}
+
+    # ---- SpMV: both kernels of the library on the bytes each one moves ----
     Amat = ls.A._device_matrix()
     if Amat is not None and Amat.kind == "csr":
         X, Y = ctx.alloc(n, 1), ctx.alloc(Amat.shape[0], 1)
         X.upload(0, rng.standard_normal(n))
-        for _ in range(3):
-            ctx.apply(Amat, X, 0, Y, 0, 1)
-        ctx.timer_start()
-        for _ in range(reps):
-            ctx.apply(Amat, X, 0, Y, 0, 1)
-        ms = ctx.timer_stop() / reps
-        nb = 12.0 * Amat.nnz + 4.0 * (Amat.shape[0] + 1) + 16.0 * Amat.shape[0]
+
+        def time_spmv():
+            for _ in range(3):
+                ctx.apply(Amat, X, 0, Y, 0, 1)
+            ctx.timer_start()
+            for _ in range(reps):
+                ctx.apply(Amat, X, 0, Y, 0, 1)
+            return ctx.timer_stop() / reps
+
+        rows = Amat.shape[0]
+        csr_bytes = 12.0 * Amat.nnz + 4.0 * (rows + 1) + 16.0 * rows
         nd = Amat.diagonals
-        extra["spmv"] = {"kernel": "k_spmv_dia (%d diagonals)" % nd if nd else "k_spmv_stream", "avg_ms": ms,
-                         "algorithmic_bytes": nb, "achieved_gbs": _gbs(nb, ms),
-                         "frac_of_peak": _gbs(nb, ms) / peak_gbs}
-        if nd and getattr(ctx, "counters", None) is not None and ctx.counters().get("chain_fused", 0) > 0:
-            extra["spmv"]["in_solver"] = ("fused: the GMRES / Lanczos steps of this run computed A v_k in the prologue of "
-                                          "the chain kernel (no SpMV launch, w never written to HBM); the figures here "
-                                          "are the stand-alone kernel, as used for residuals and by the panel modes")
+        spmv = {}
         if nd:
-            # the banded copy holds 8 B per diagonal slot and no indices: what the kernel really moves
-            moved = 8.0 * nd * Amat.shape[0] + 16.0 * Amat.shape[0]
-            extra["spmv"].update({
-                "moved_bytes_model": moved, "moved_gbs_model": _gbs(moved, ms),
-                "note": "algorithmic bytes = SURVEY 8(d) CSR figure (12 nnz + 4 (N+1) + 16 N); the operator "
-                        "is banded, so the library multiplies with its diagonal-major copy (8 B per slot, no "
-                        "index stream): achieved_gbs is the CSR-equivalent rate, moved_gbs_model the rate on "
-                        "the bytes actually streamed"})
+            ms = time_spmv()
+            moved = 8.0 * nd * rows + 16.0 * rows
+            spmv["k_spmv_dia (%d diagonals)" % nd] = {
+                "avg_ms": ms, "moved_bytes": moved, "achieved_gbs": _gbs(moved, ms), "frac": _gbs(moved, ms) / peak_gbs,
+                "csr_equivalent_gbs_side_number": _gbs(csr_bytes, ms),
+                "note": "diagonal-major copy: 8 B per slot, no index stream; bytes = 8 nd N + 16 N (PMC: equal)"}
+        if hasattr(ctx, "set"):
+            ctx.set("spmv_dia", 0)
+            try:
+                ms = time_spmv()
+            finally:
+                ctx.set("spmv_dia", 1)
+            spmv["k_spmv_stream (CSR)"] = {
+                "avg_ms": ms, "moved_bytes": csr_bytes, "achieved_gbs": _gbs(csr_bytes, ms),
+                "frac": _gbs(csr_bytes, ms) / peak_gbs,
+                "note": "the CSR kernel north_star names: 12 nnz + 4 (N+1) + 16 N bytes (PMC: 804 MB vs 800 MB)"}
+        for v in spmv.values():
+            if attainable:
+                v["frac_of_attainable"] = v["achieved_gbs"] / attainable
+        extra["spmv"] = spmv
+        if nd and counters0.get("chain_fused", 0) > 0:
+            extra["spmv_in_solver"] = ("fused: the GMRES / Lanczos steps of this run computed A v_k in the prologue of the "
+                                       "chain kernel (no SpMV launch, w never written to HBM); the figures above are the "
+                                       "stand-alone kernels, as used for residuals and by the panel modes")
+
+    # ---- the roofline object of the dominant kernel ----
     if ortho in ("cgs", "cgs2") and cgs is not None:
-        nb, ms, name = cgs["algorithmic_bytes"], cgs["avg_ms"], "k_cgs_dots+k_cgs_update (16 columns per launch pair)"
+        k, name = cgs, "k_cgs_dots+k_cgs_update (16 columns per launch pair)"
+        traffic_keys = ("k_cgs_dots", "k_cgs_update")
     elif ortho in ("cgs", "cgs2"):
-        # the two panel kernels alternate; report the pair as one unit of 16 columns
         d, a = kernels["k_multidot<16>"], kernels["k_multiaxpy<16>"]
-        nb = d["algorithmic_bytes"] + a["algorithmic_bytes"]
-        ms = d["avg_ms"] + a["avg_ms"]
-        name = "k_multidot<16>+k_multiaxpy<16>"
+        k = {"avg_ms": d["avg_ms"] + a["avg_ms"], "compulsory_bytes": d["compulsory_bytes"] + a["compulsory_bytes"],
+             "moved_bytes_model": d["moved_bytes_model"] + a["moved_bytes_model"]}
+        name, traffic_keys = "k_multidot<16>+k_multiaxpy<16>", ()
     elif chain is not None:
-        nb, ms, name = chain["algorithmic_bytes"], chain["avg_ms"], "k_mgs_chain_lds (64 links per launch)"
+        k, name, traffic_keys = chain, chain_name, ("k_mgs_chain",)
     else:
-        d = kernels["k_gs_link<A_PART,T_DOT>"]
-        nb, ms, name = d["algorithmic_bytes"], d["avg_ms"], "k_gs_link<A_PART,T_DOT>"
-    ach = _gbs(nb, ms)
+        k, name, traffic_keys = kernels["k_gs_link<A_PART,T_DOT>"], "k_gs_link<A_PART,T_DOT>", ()
+    ms = k["avg_ms"]
+    comp = k["compulsory_bytes"]
+    moved, source = k["moved_bytes_model"], "model: every byte the kernel requests from L2 and beyond (upper bound)"
+    stamp = source_stamp()
+    traffic = None
+    for fn in sorted(traffic_files or [], reverse=True):
+        try:
+            import json
+            tj = json.load(open(fn))
+            if tj.get("source_stamp") != stamp or not traffic_keys:
+                continue
+            if int(tj.get("n", n)) != n:
+                continue
+            if not all(key in tj for key in traffic_keys):
+                continue
+            traffic = sum(tj[key]["hbm_read_bytes_per_launch"] + tj[key]["hbm_write_bytes_per_launch"]
+                          for key in traffic_keys)
+            moved, source = traffic, "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), " + os.path.basename(fn)
+            break
+        except Exception:
+            continue
+    ach = _gbs(moved, ms)
     roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": peak_gbs, "unit": "GB/s",
-            "frac": ach / peak_gbs, "traffic": None, "avg_launch_ms": ms,
-            "algorithmic_bytes_per_launch": nb}
-    if chain is not None and name.startswith("k_mgs_chain"):
-        roof["note"] = ("algorithmic bytes = SURVEY 8(d): 16 N per basis column (the column is read for the "
-                        "projection and again for the update).  The kernel serves half of that second read "
-                        "from LDS / the register ring, so its HBM traffic (`traffic`, PMC) is below the "
-                        "algorithmic bytes and `frac` can exceed 1; traffic / avg_launch_ms is the HBM rate.  "
-                        "Measured on identical 64-link launches that load w (k_mgs_chain_lds<40,false,false,0>); the "
-                        "solver's own launches are the same kernel with w = A v_k computed in the prologue "
-                        "(<40,false,false,5>, k+1 links each).")
+            "frac": ach / peak_gbs, "traffic": traffic, "avg_launch_ms": ms,
+            "bytes_per_launch": moved, "bytes_source": source,
+            "compulsory_bytes_per_launch": comp, "frac_compulsory": _gbs(comp, ms) / peak_gbs,
+            "source_stamp": stamp}
+    if attainable:
+        roof["attainable_gbs"] = attainable
+        roof["frac_of_attainable"] = ach / attainable
+        roof["frac_compulsory_of_attainable"] = _gbs(comp, ms) / attainable
+    if "survey_8d_bytes" in k:
+        roof["survey_8d_side_number"] = {
+            "bytes_per_launch": k["survey_8d_bytes"], "gbs": _gbs(k["survey_8d_bytes"], ms),
+            "note": "SURVEY 8(d) charges 16 N per basis column (read for the projection, read again for the "
+                    "update); the kernel serves part of the second use from LDS / registers / L2, so this rate "
+                    "is NOT an HBM rate and is not compared with the peak"}
+    if chain is not None and k is chain:
+        roof["note"] = ("64-link launches that load w (FND = 0 instantiation); the solver's own launches are the same "
+                        "kernel with w = A v_k computed in the prologue and k+1 links each.  frac = bytes_per_launch / "
+                        "avg_launch_ms / peak; frac_compulsory counts every column once.")
     return roof, extra

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "kh_ctx_info": [_H, _c_int64_p],
     "kh_ctx_counters": [_H, _c_int64_p],
     "kh_ctx_tune": [_H, _INT, _INT],
+    "kh_ctx_set": [_H, ctypes.c_char_p, _I64],
     "kh_timer_start": [_H],
     "kh_timer_stop": [_H, _c_double_p],
     "kh_comm_unique_id": [ctypes.c_char_p],
@@ -269,6 +270,14 @@ class DeviceVectors(object):
             pass
         self.handle = None
 
+    @property
+    def ld(self):
+        """Leading dimension (doubles) of the real ``kh_vec`` behind this block."""
+        a, b, c = _I64(0), _I64(0), _I64(0)
+        _check(self.ctx._lib, self.ctx._lib.kh_vec_shape(self.handle, ctypes.byref(a), ctypes.byref(b),
+                                                         ctypes.byref(c)), "kh_vec_shape")
+        return c.value
+
     def upload(self, col0, arr):
         """Copy a host ``(n, k)`` (or ``(n,)``) array into columns ``col0 ..``."""
         a = numpy.asarray(arr)
@@ -419,6 +428,10 @@ class Context(object):
 
     def tune(self, reduce_blocks=0, spmv_tile=0):
         _check(self._lib, self._lib.kh_ctx_tune(self._h, reduce_blocks, spmv_tile), "kh_ctx_tune")
+
+    def set(self, key, value):
+        """Named switch of the context (``kh_ctx_set``): spmv_dia, chain, chain_lds, chain_spmv."""
+        _check(self._lib, self._lib.kh_ctx_set(self._h, key.encode(), int(value)), "kh_ctx_set(%s)" % key)
 
     def timer_start(self):
         _check(self._lib, self._lib.kh_timer_start(self._h), "kh_timer_start")

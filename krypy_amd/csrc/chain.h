@@ -68,7 +68,23 @@ struct ChainArgs {
     const double* xk;
     int64_t n_last;    // n - 1
     DiaOffs offs;
+#ifdef KH_CHAIN_TRACE
+    unsigned long long* trace;   // diagnostic build only (make trace): [G][links][2 waves][8] 100 MHz stamps
+#endif
 };
+
+// Phase stamps of the diagnostic build (tools/chain_trace.py): wave 0 and wave 7 of every workgroup
+// note the constant 100 MHz clock at the phase boundaries of every link.  Compiled out of the product.
+#ifdef KH_CHAIN_TRACE
+#define CH_STAMP(a_, t_, total_, i_)                                                                   \
+    do {                                                                                               \
+        if ((a_).trace != nullptr && (threadIdx.x == 0 || threadIdx.x == CH_BS - 64))                  \
+            (a_).trace[((((size_t)blockIdx.x * (total_)) + (t_)) * 2 + (threadIdx.x ? 1 : 0)) * 8 + (i_)] = \
+                wall_clock64();                                                                        \
+    } while (0)
+#else
+#define CH_STAMP(a_, t_, total_, i_) do {} while (0)
+#endif
 
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -79,12 +95,16 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
 
 // Fixed-order sum of one double per workgroup over the whole grid; every thread gets the result.
 __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned long long* gran,
-                                           int G, int* err, double* smd, unsigned* smu) {
+                                           int G, int* err, double* smd, unsigned* smu,
+                                           unsigned long long* tr = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // 1. workgroup partial (8 waves, fixed order)
     part = wave_sum(part);
     if (lane == 0) smd[wid] = part;
     __syncthreads();
+#ifdef KH_CHAIN_TRACE
+    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 2] = wall_clock64();
+#endif
     unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
     if (tid == 0) {
         double s = smd[0];
@@ -95,6 +115,9 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
         st_agent(slot + 2 * blockIdx.x, tag | (bits & 0xffffffffull));
         st_agent(slot + 2 * blockIdx.x + 1, tag | (bits >> 32));
     }
+#ifdef KH_CHAIN_TRACE
+    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 3] = wall_clock64();
+#endif
     // 2. sweep all granules of this epoch (bounded spin)
     for (int g = tid; g < 2 * G; g += CH_BS) {
         unsigned long long x = ld_agent(slot + g);
@@ -112,6 +135,9 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
         }
         smu[g] = (unsigned)x;
     }
+#ifdef KH_CHAIN_TRACE
+    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 4] = wall_clock64();
+#endif
     __syncthreads();
     // 3. fixed-order sum of the G workgroup partials
     double v = 0.0;
@@ -533,6 +559,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
         // ---- dot phase: <v_j, w>; the first LB batches are parked in LDS on the way ----
         double acc0 = 0.0, acc1 = 0.0;
+        CH_STAMP(a, t, total, 0);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             // next: v_j batch b+1; after the last one the first update batch that is not in LDS
@@ -559,6 +586,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             }
         }
         double alpha, alpha_i = 0.0;
+        CH_STAMP(a, t, total, 1);
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
@@ -569,10 +597,16 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                 a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
+#ifdef KH_CHAIN_TRACE
+            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu,
+                             a.trace ? a.trace + (((size_t)blockIdx.x * total) + t) * 16 : nullptr);
+#else
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
                                    : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+#endif
             if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
+        CH_STAMP(a, t, total, 5);
         // ---- update phase: w -= alpha * v_j, batches in reverse order ----
 #define CH_UPD(r, p)                                              \
     do {                                                          \
@@ -600,6 +634,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) CH_UPD(b * PB + i, ring[g & 1][i]);
         }
+        CH_STAMP(a, t, total, 6);
         // (c) the head of the column from LDS (own entries: no barrier needed), one batch of reads at
         //     a time (hoisted all together they would spill)
 #pragma unroll
@@ -612,6 +647,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             }
         }
 #undef CH_UPD
+        CH_STAMP(a, t, total, 7);
     }
     // norm: <w,w> or <w, D w>
     double acc = 0.0;

@@ -765,6 +765,98 @@ __global__ __launch_bounds__(BS) void k_gemm_dense_mfma(int64_t n_rows, int64_t 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Attainable-bandwidth probes for bench.py ("measure the attainable ceiling on the box with
+// a device triad/copy kernel"): plain 16-byte grid-stride streams, non-temporal loads, no reuse.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BS) void k_stream_copy(int64_t n2, const double2* __restrict__ src,
+                                                    double2* __restrict__ dst) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        const double2 a = ld_nt2(src + i), b = ld_nt2(src + i + stride), c = ld_nt2(src + i + 2 * stride),
+                      d = ld_nt2(src + i + 3 * stride);
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
+    for (; i < n2; i += stride) dst[i] = ld_nt2(src + i);
+}
+
+__global__ __launch_bounds__(BS) void k_stream_triad(int64_t n2, const double2* __restrict__ b,
+                                                     const double2* __restrict__ c, double s,
+                                                     double2* __restrict__ a) {
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    for (; i + stride < n2; i += 2 * stride) {
+        const double2 b0 = ld_nt2(b + i), b1 = ld_nt2(b + i + stride), c0 = ld_nt2(c + i), c1 = ld_nt2(c + i + stride);
+        a[i] = make_double2(b0.x + s * c0.x, b0.y + s * c0.y);
+        a[i + stride] = make_double2(b1.x + s * c1.x, b1.y + s * c1.y);
+    }
+    for (; i < n2; i += stride) {
+        const double2 b0 = ld_nt2(b + i), c0 = ld_nt2(c + i);
+        a[i] = make_double2(b0.x + s * c0.x, b0.y + s * c0.y);
+    }
+}
+
+__global__ __launch_bounds__(BS) void k_stream_read(int64_t n2, const double2* __restrict__ src,
+                                                    double* __restrict__ part_out) {
+    __shared__ double sm[8];
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (; i + 3 * stride < n2; i += 4 * stride) {
+        const double2 a = ld_nt2(src + i), b = ld_nt2(src + i + stride), c = ld_nt2(src + i + 2 * stride),
+                      d = ld_nt2(src + i + 3 * stride);
+        s0 += a.x + a.y;
+        s1 += b.x + b.y;
+        s2 += c.x + c.y;
+        s3 += d.x + d.y;
+    }
+    for (; i < n2; i += stride) {
+        const double2 a = ld_nt2(src + i);
+        s0 += a.x + a.y;
+    }
+    const double r = block_sum((s0 + s1) + (s2 + s3), sm);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+}
+
+// tile-based probes (no grid-stride loop): a workgroup owns U*BS consecutive double2, every lane U of them
+template <int U, bool NTS>
+__global__ __launch_bounds__(BS) void k_probe_copy(int64_t n2, const double2* __restrict__ src,
+                                                   double2* __restrict__ dst) {
+    const int64_t base = (int64_t)blockIdx.x * (U * BS) + threadIdx.x;
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (base + u * BS < n2) ? ld_nt2(src + base + u * BS) : make_double2(0.0, 0.0);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (base + u * BS < n2) {
+            if (NTS) {
+                v2f64_t t;
+                t.x = v[u].x;
+                t.y = v[u].y;
+                __builtin_nontemporal_store(t, reinterpret_cast<v2f64_t*>(dst + base + u * BS));
+            } else {
+                dst[base + u * BS] = v[u];
+            }
+        }
+}
+
+template <int U>
+__global__ __launch_bounds__(BS) void k_probe_read(int64_t n2, const double2* __restrict__ src,
+                                                   double* __restrict__ sink) {
+    const int64_t base = (int64_t)blockIdx.x * (U * BS) + threadIdx.x;
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (base + u * BS < n2) ? ld_nt2(src + base + u * BS) : make_double2(0.0, 0.0);
+    double s = 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u].x + v[u].y;
+    if (s == 1.2345e300) sink[0] = s;       // never true: keeps the loads alive
+}
+
 // y = M x for a tiny dense row-major M (d x d, d <= 1024) held on the device: the projector's
 // R^{-1} Q^H and WR^H factors.  One workgroup, one row per thread, sequential sums (deterministic).
 __global__ __launch_bounds__(BS) void k_small_matvec(int d, const double* __restrict__ M,

@@ -59,11 +59,16 @@ struct kh_ctx_s {
     int chain_enabled = 1;
     int64_t n_chain = 0, n_chain_lds = 0, n_chain_fused = 0, n_cgs_reg = 0;   // launch counters (kh_ctx_counters)
     int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
+    int chain_lds = 1;      // park the head of every column in LDS (k_mgs_chain_lds; KRYPY_AMD_CHAIN_LDS)
+    int spmv_dia = 1;       // use the banded copy of a CSR operator when it has one (kh_ctx_set "spmv_dia")
     unsigned long long* chain_gran = nullptr;
     int* chain_err = nullptr;        // device error word
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     unsigned chain_epoch = 1;
     int chain_debug = 0;
+#ifdef KH_CHAIN_TRACE
+    unsigned long long* chain_trace = nullptr;   // diagnostic build: phase stamps of the next chain launch
+#endif
     double* cgs_part = nullptr;     // [CGS_MAXCOL][wave partials] of the register-resident panel GS
     // RCCL (resolved lazily with dlopen so that single-GPU runs never load librccl)
     void* comm = nullptr;

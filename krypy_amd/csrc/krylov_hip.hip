@@ -44,15 +44,30 @@ constexpr int SC_COEF = 6400;    // panel coefficients for axpy_panel / gemm_nn 
 // and completion event.
 static int ensure_hcap(kh_ctx ctx, int64_t need) {
     if (need <= ctx->hcap) return 0;
+    // a larger basis begins a step: the slots grow, and a column that is complete but not fetched yet
+    // (another basis' look-ahead step) moves into the new buffers - nothing in flight is dropped
     KH_HIP(hipStreamSynchronize(ctx->stream));
     const int64_t cap = std::max<int64_t>(need * 2, 1024);
     for (int s = 0; s < KH_NSLOT; ++s) {
-        if (ctx->hslot_dev[s]) (void)hipFree(ctx->hslot_dev[s]);
-        if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);
-        ctx->hslot_dev[s] = nullptr;
-        ctx->hslot_pin[s] = nullptr;
-        KH_HIP(hipMalloc(&ctx->hslot_dev[s], sizeof(double) * cap));
-        KH_HIP(hipHostMalloc(&ctx->hslot_pin[s], sizeof(double) * cap, hipHostMallocDefault));
+        double* dev = nullptr;
+        double* pin = nullptr;
+        KH_HIP(hipMalloc(&dev, sizeof(double) * cap));
+        hipError_t e = hipHostMalloc(&pin, sizeof(double) * cap, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            (void)hipFree(dev);
+            return fail(KH_ERR_NOMEM, "ensure_hcap: hipHostMalloc(%lld doubles): %s", (long long)cap,
+                        hipGetErrorString(e));
+        }
+        if (ctx->hslot_dev[s]) {
+            KH_HIP(hipMemcpy(dev, ctx->hslot_dev[s], sizeof(double) * ctx->hcap, hipMemcpyDeviceToDevice));
+            (void)hipFree(ctx->hslot_dev[s]);
+        }
+        if (ctx->hslot_pin[s]) {
+            memcpy(pin, ctx->hslot_pin[s], sizeof(double) * ctx->hcap);
+            (void)hipHostFree(ctx->hslot_pin[s]);
+        }
+        ctx->hslot_dev[s] = dev;
+        ctx->hslot_pin[s] = pin;
         if (!ctx->hev[s]) KH_HIP(hipEventCreateWithFlags(&ctx->hev[s], hipEventDisableTiming));
     }
     ctx->hcap = cap;
@@ -207,9 +222,14 @@ static void launch_dia(kh_ctx ctx, kh_mat A, const double* x, double* y, const d
 #undef KH_DIA_RPT
 }
 
+// the banded kernel serves when the operator has a diagonal-major copy (and nobody switched it off)
+static inline bool use_dia(kh_ctx ctx, kh_mat A, const double* y) {
+    return A->dia != nullptr && ctx->spmv_dia && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+}
+
 template <int EPI>
 static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
-    if (A->dia != nullptr && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
+    if (use_dia(ctx, A, y)) {
         launch_dia<EPI>(ctx, A, x, y, aux);
         return;
     }
@@ -233,7 +253,7 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
         if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux);
         KH_HIP(hipGetLastError());
         if (epi != EPI_NONE) {
-            const bool dia = A->dia != nullptr && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+            const bool dia = use_dia(ctx, A, y);
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, A->part,
                                dia ? A->dia_nblk : A->nblk, 0, scal_out, rmode);
             KH_HIP(hipGetLastError());
@@ -374,11 +394,11 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.hpin = hpin;
     a.hcount = hcount;
     a.errpin = ctx->chain_err_pin[slot];
+#ifdef KH_CHAIN_TRACE
+    a.trace = ctx->chain_trace;
+#endif
     hipError_t e;
-    static const int lds_env = [] {
-        const char* ev = getenv("KRYPY_AMD_CHAIN_LDS");
-        return ev ? atoi(ev) : 1;
-    }();
+    const int lds_env = ctx->chain_lds;
     // (the complex instantiation with 40 rows per lane spills 36 registers with the LDS traffic on top
     // and still beats the plain kernel, 769 vs 677 it/s at N = 5*10^6; 32 rows fit without spills since
     // both parts of the coefficient share one grid reduction)
@@ -612,6 +632,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         if (ctx->ncu > CH_GMAX) ctx->chain_enabled = 0;
         e = getenv("KRYPY_AMD_CHAIN_SPMV");
         ctx->chain_spmv = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_LDS");
+        ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
     }
     *out = ctx;
     return 0;
@@ -680,6 +702,16 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile) {
                "spmv_tile %d must be 1024, 2048 or 4096", spmv_tile);
         ctx->spmv_tile = spmv_tile;
     }
+    return 0;
+}
+
+int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
+    KH_ARG(ctx != nullptr && key != nullptr, "kh_ctx_set: NULL");
+    if (!strcmp(key, "spmv_dia")) ctx->spmv_dia = value != 0;
+    else if (!strcmp(key, "chain")) ctx->chain_enabled = (value != 0 && ctx->ncu <= CH_GMAX);
+    else if (!strcmp(key, "chain_lds")) ctx->chain_lds = value != 0;
+    else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
+    else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
 }
 
@@ -771,7 +803,19 @@ int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncol
     KH_TRY(check_vec(src, scol, ncols, "kh_vec_copy(src)"));
     KH_ARG(dst->n == src->n, "kh_vec_copy: length mismatch %lld vs %lld", (long long)dst->n,
            (long long)src->n);
-    if (ncols == 0) return 0;
+    if (ncols == 0 || (dst == src && dcol == scol)) return 0;
+    if (dst == src && dcol < scol + ncols && scol < dcol + ncols) {
+        // overlapping ranges of one block (a sliding window moving to the front): column by column, in
+        // the order that never overwrites a column before it has been read
+        const bool fwd = dcol < scol;
+        for (int64_t i = 0; i < ncols; ++i) {
+            const int64_t c = fwd ? i : ncols - 1 - i;
+            KH_HIP(hipMemcpyAsync(dst->col(dcol + c), src->col(scol + c), sizeof(double) * src->ld,
+                                  hipMemcpyDeviceToDevice, dst->ctx->stream));
+        }
+        return 0;
+    }
+    KH_ARG(dst->ld == src->ld || ncols == 1, "kh_vec_copy: blocks with different leading dimensions");
     KH_HIP(hipMemcpyAsync(dst->col(dcol), src->col(scol), sizeof(double) * src->ld * ncols,
                           hipMemcpyDeviceToDevice, dst->ctx->stream));
     return 0;
@@ -953,7 +997,9 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
                   const int32_t* indices, const double* data, kh_mat* out) {
     KH_ARG(ctx && out && indptr, "kh_csr_upload: NULL argument");
     KH_ARG(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "kh_csr_upload: negative size");
-    KH_ARG(n_rows < 2147483647LL && nnz < 2147483647LL, "kh_csr_upload: int32 CSR limits exceeded");
+    KH_ARG(n_rows < 2147483647LL && n_cols < 2147483647LL && nnz < 2147483647LL,
+           "kh_csr_upload: int32 CSR limits exceeded");
+    KH_ARG(nnz == 0 || (indices != nullptr && data != nullptr), "kh_csr_upload: NULL indices / data with nnz > 0");
     KH_ARG(indptr[0] == 0 && indptr[n_rows] == nnz, "kh_csr_upload: indptr[0]=%d indptr[n]=%d nnz=%lld",
            indptr[0], indptr[n_rows], (long long)nnz);
     for (int64_t r = 0; r < n_rows; ++r)
@@ -972,21 +1018,32 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     std::vector<int32_t> blk;
     build_rowblocks(indptr, n_rows, A->tile, blk);
     A->nblk = (int)blk.size() - 1;
-    KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
-    KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-    KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
-    KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
-    std::vector<int> offs;
-    const bool banded = detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs);
-    const int64_t npart = std::max<int64_t>(std::max(A->nblk, 1), banded ? (n_rows + 2 * BS - 1) / (2 * BS) : 1   /* RPT >= 1 */);
-    KH_HIP(hipMalloc(&A->part, sizeof(double) * npart));
-    KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
-    if (nnz > 0) {
-        KH_HIP(hipMemcpy(A->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
-        KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    // any failure from here on releases what has been allocated so far (kh_mat_free takes a partial handle)
+    auto body = [&]() -> int {
+        KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
+        KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+        KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
+        std::vector<int> offs;
+        const bool banded = detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs);
+        const int64_t npart = std::max<int64_t>(std::max(A->nblk, 1), banded ? (n_rows + 2 * BS - 1) / (2 * BS) : 1   /* RPT >= 1 */);
+        KH_HIP(hipMalloc(&A->part, sizeof(double) * npart));
+        KH_HIP(hipMemcpy(A->indptr, indptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyHostToDevice));
+        if (nnz > 0) {
+            KH_HIP(hipMemcpy(A->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+            KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        }
+        KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+        if (banded) KH_TRY(build_dia(ctx, A, offs));
+        return 0;
+    };
+    const int rc = body();
+    if (rc != 0) {
+        const std::string keep = g_err;
+        kh_mat_free(A);
+        g_err = keep;
+        return rc;
     }
-    KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
-    if (banded) KH_TRY(build_dia(ctx, A, offs));
     *out = A;
     return 0;
 }
@@ -1022,9 +1079,15 @@ int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
     A->kind = KH_MAT_DIAG;
     A->n_rows = A->n_cols = n;
     const size_t dbytes = sizeof(double) * (((n + 31) / 32) * 32 + CH_SLACK);
-    KH_HIP(hipMalloc(&A->diag, dbytes));
-    KH_HIP(hipMemset(A->diag, 0, dbytes));
-    if (n > 0) KH_HIP(hipMemcpy(A->diag, d, sizeof(double) * n, hipMemcpyHostToDevice));
+    hipError_t e = hipMalloc(&A->diag, dbytes);
+    if (e == hipSuccess) e = hipMemset(A->diag, 0, dbytes);
+    if (e == hipSuccess && n > 0) e = hipMemcpy(A->diag, d, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(A->diag);
+        delete A;
+        return fail(e == hipErrorOutOfMemory ? KH_ERR_NOMEM : KH_ERR_HIP, "kh_diag_upload(%lld): %s", (long long)n,
+                    hipGetErrorString(e));
+    }
     *out = A;
     return 0;
 }
@@ -1055,7 +1118,8 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
     const int64_t xneed = (A->kind == KH_MAT_CSR) ? A->n_cols - A->nrecv_prev - A->nrecv_next : A->n_cols;
     KH_ARG(X->n == xneed && Y->n == A->n_rows, "kh_apply: dimension mismatch (A %lldx%lld, x %lld, y %lld)",
            (long long)A->n_rows, (long long)A->n_cols, (long long)X->n, (long long)Y->n);
-    KH_ARG(!(X == Y && xcol == ycol), "kh_apply: in-place application is not supported");
+    KH_ARG(!(X == Y && xcol < ycol + ncols && ycol < xcol + ncols),
+           "kh_apply: input and output column ranges overlap (in-place application is not supported)");
     if (A->kind == KH_MAT_DENSE && ncols >= 2 && A->n_rows >= 1024 && X != Y) {
         // a panel: stream A once per 16 columns on the FP64 matrix cores (k_gemm_dense_mfma)
         constexpr int RT = 2;
@@ -1667,6 +1731,37 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
                 if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: cgs kernels not eligible");
                 break;
             }
+            case 9:     // attainable ceiling: copy of 8 columns (8 N doubles read + 8 N written per launch)
+                hipLaunchKernelGGL(k_stream_copy, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 8) >> 1,
+                                   reinterpret_cast<const double2*>(V->col(0)), reinterpret_cast<double2*>(V->col(8)));
+                break;
+            case 10:    // attainable ceiling: triad a = b + s c on 4-column chunks (2 reads + 1 write)
+                hipLaunchKernelGGL(k_stream_triad, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 4) >> 1,
+                                   reinterpret_cast<const double2*>(V->col(0)),
+                                   reinterpret_cast<const double2*>(V->col(4)), 0.5,
+                                   reinterpret_cast<double2*>(V->col(8)));
+                break;
+            case 11:    // attainable ceiling: read-only sum of 16 columns (what a dot phase does)
+                hipLaunchKernelGGL(k_stream_read, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 16) >> 1,
+                                   reinterpret_cast<const double2*>(V->col(0)), part_slot(ctx, SLOT_PING));
+                break;
+#define KH_PROBE_COPY(U, NTS)                                                                                  \
+    hipLaunchKernelGGL((k_probe_copy<U, NTS>), dim3((unsigned)((((V->ld * 8) >> 1) + U * BS - 1) / (U * BS))),  \
+                       dim3(BS), 0, ctx->stream, (V->ld * 8) >> 1, reinterpret_cast<const double2*>(V->col(0)), \
+                       reinterpret_cast<double2*>(V->col(8)))
+            case 12: KH_PROBE_COPY(1, false); break;
+            case 13: KH_PROBE_COPY(4, false); break;
+            case 14: KH_PROBE_COPY(8, false); break;
+            case 15: KH_PROBE_COPY(4, true); break;
+#undef KH_PROBE_COPY
+#define KH_PROBE_READ(U)                                                                                       \
+    hipLaunchKernelGGL((k_probe_read<U>), dim3((unsigned)((((V->ld * 16) >> 1) + U * BS - 1) / (U * BS))),       \
+                       dim3(BS), 0, ctx->stream, (V->ld * 16) >> 1, reinterpret_cast<const double2*>(V->col(0)), \
+                       part_slot(ctx, SLOT_PING))
+            case 16: KH_PROBE_READ(4); break;
+            case 17: KH_PROBE_READ(8); break;
+            case 18: KH_PROBE_READ(16); break;
+#undef KH_PROBE_READ
             default:
                 return fail(KH_ERR_ARG, "kh_bench_kernel: unknown kernel id %d", which);
         }
@@ -1679,6 +1774,39 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
     *avg_ms = (double)ms / reps;
     return 0;
 }
+
+#ifdef KH_CHAIN_TRACE
+// Diagnostic build only (make -C krypy_amd/csrc trace; tools/chain_trace.py): one traced 64-link launch of
+// the chain kernel (16 columns x 4 sweeps, like kh_bench_kernel); out gets [G][64][2 waves][8] stamps of
+// the constant 100 MHz clock.  Not part of the C ABI of the product.
+int kh_chain_trace(kh_ctx ctx, kh_vec V, kh_vec W, unsigned long long* out, int64_t cap, int* g_out) {
+    KH_ARG(ctx && V && W && out && g_out, "kh_chain_trace: NULL");
+    KH_ARG(V->ncols >= 17 && W->ncols >= 1 && V->n == W->n, "kh_chain_trace: need >= 17 basis columns");
+    int r2 = 0, G = 0;
+    KH_ARG(chain_geometry(ctx, V->n, &r2, &G), "kh_chain_trace: chain not eligible");
+    const size_t words = (size_t)G * 64 * 2 * 8;
+    KH_ARG((int64_t)words <= cap, "kh_chain_trace: buffer too small (%zu words)", words);
+    KH_TRY(ensure_hcap(ctx, 1024));
+    unsigned long long* dev = nullptr;
+    KH_HIP(hipMalloc(&dev, words * sizeof(unsigned long long)));
+    KH_HIP(hipMemset(dev, 0, words * sizeof(unsigned long long)));
+    for (int rep = 0; rep < 4; ++rep) {
+        ctx->chain_trace = (rep == 3) ? dev : nullptr;
+        const int rc = try_chain(ctx, V, V, W->col(0), W->ld, nullptr, nullptr, 15, 0, 4, false, 0.0, nullptr,
+                                 ctx->hslot_dev[0], 0);
+        ctx->chain_trace = nullptr;
+        if (rc != 1) {
+            (void)hipFree(dev);
+            return fail(KH_ERR_UNSUPPORTED, "kh_chain_trace: chain kernel not eligible");
+        }
+    }
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    KH_HIP(hipMemcpy(out, dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    (void)hipFree(dev);
+    *g_out = G;
+    return 0;
+}
+#endif
 
 }  // extern "C"
 

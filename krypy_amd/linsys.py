@@ -643,6 +643,8 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
 
     def _finalize(self):
         super(Minres, self)._finalize()
+        if hasattr(self, "lanczos"):
+            self.lanczos._settle()      # drop a speculative look-ahead step, if any (as Gmres does)
         if self.store_arnoldi and hasattr(self, "lanczos"):
             got = self.lanczos.get()
             self._V_trim, self.H = got[0], got[1]

@@ -13,6 +13,7 @@ Reference lines are cited as ``utils.py:<line>`` (= ``/root/reference/krypy/util
 """
 import time
 import warnings
+import weakref
 from collections import defaultdict
 
 import numpy
@@ -1167,9 +1168,28 @@ class Arnoldi(object):
         self._settle()
         return self._padded(self._P)
 
+    def _claim(self, slot):
+        """The H-column slots (device column, pinned copy, event) belong to the context, four of them,
+        keyed by step number mod 4.  Before this basis uses one, any OTHER basis that still has an
+        unfetched step parked there (two Arnoldi objects advanced alternately, a solver started while
+        another one has a look-ahead step in flight) settles first: its speculative steps are waited
+        for, discarded and re-enqueued at its next ``advance()`` - it never reads a foreign column."""
+        owners = self._ctx.__dict__.setdefault("_slot_owner", [None] * 4)
+        ref = owners[slot]
+        other = ref() if ref is not None else None
+        if other is not None and other is not self and other._enq > other.iter:
+            other._settle()
+        owners[slot] = weakref.ref(self)
+
+    def _release(self, slot):
+        owners = self._ctx.__dict__.get("_slot_owner")
+        if owners is not None and owners[slot] is not None and owners[slot]() is self:
+            owners[slot] = None
+
     def _begin(self):
         """Enqueue Arnoldi step ``self._enq`` on the device (no host synchronisation)."""
         k = self._enq
+        self._claim(k % 4)
         start, h_km1 = 0, 0.0
         if self.ortho == "lanczos":
             start = k
@@ -1190,6 +1210,7 @@ class Arnoldi(object):
             kp = k - self._base
             self._ctx.arnoldi_step_end(k % 4, kp + 2 + (self._proj.d if self._proj is not None else 0),
                                        cplx=self._cplx)
+            self._release(k % 4)
             self._V.zero(kp + 1, 1)
             if self._P is not None:
                 self._P.zero(kp + 1, 1)
@@ -1222,17 +1243,22 @@ class Arnoldi(object):
                 pd = self._proj.d if self._proj is not None else 0
                 kp = k - self._base
                 hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd, cplx=self._cplx)
+                self._release(k % 4)
                 if pd:
                     self._on_ya(hcol[kp + 2:].reshape(-1, 1).copy())
                     hcol = hcol[: kp + 2]
 
             elif self._Amat is not None:
+                self._claim(0)       # the one-call step runs through slot 0
                 hcol = ctx.arnoldi_step(self._Amat, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
+                self._release(0)
             else:
                 self.A._apply_dev(self._V, k, self._W, 0, 1)
+                self._claim(0)
                 hcol = ctx.arnoldi_step(None, self._Md, self._V, self._P, self._W, 0, k, start,
                                         self._sweeps, self._gs_mode, h_km1)
+                self._release(0)
             if self.ortho == "lanczos" and hcol.dtype.kind == "c":
                 hcol = hcol.real       # alpha = real(alpha), utils.py:1024-1027
             off = self._base          # (window: the column arrives in window coordinates)

@@ -239,6 +239,40 @@ def case_arnoldi_steps():
         assert rel(ar.V, g["arn_mgs_V"]) < RTOL, ortho
 
 
+def case_arnoldi_interleaved():
+    """Several Arnoldi objects advanced alternately on one context - the reference handles that
+    (every object owns its arrays); here the look-ahead H-column slots belong to the context, so each
+    basis has to reclaim them.  Also: a solver run between two advances, a Lanczos process whose
+    look-ahead coefficient sits in a slot another basis wants, and a larger basis starting while a
+    small one has an unfetched step (slot buffers are re-sized)."""
+    g = golden("kernels")
+    A, b = lap2d_system(40, rhs="rng1")
+    v = b.reshape(-1, 1)
+    a1 = utils.Arnoldi(A, v, maxiter=12, ortho="mgs")
+    a2 = utils.Arnoldi(A, v, maxiter=12, ortho="lanczos")
+    a3 = utils.Arnoldi(A, v, maxiter=12, ortho="dmgs")
+    for i in range(12):
+        a1.advance()
+        a2.advance()
+        if i % 3 == 0:       # uneven interleaving: a3 lags, then catches up
+            a3.advance()
+        if i == 5:           # a complete solve on the same context in between
+            A2, b2 = lap2d_system(64, rhs="ones")       # longer H columns: the slots are re-sized
+            try:
+                linsys.Gmres(linsys.LinearSystem(A2, b2), maxiter=2100, tol=1e-14)
+            except utils.ConvergenceError:
+                pass
+    while a3.iter < 12:
+        a3.advance()
+    for ar, ortho in ((a1, "mgs"), (a2, "lanczos"), (a3, "dmgs")):
+        assert rel(ar.H, g["arn_%s_H" % ortho]) < RTOL, ortho
+        assert rel(ar.V, g["arn_%s_V" % ortho]) < RTOL, ortho
+    # MINRES leaves no step in flight behind (Minres._finalize settles, like Gmres)
+    A3, b3, M3 = minres_jacobi_system(20)[:3]
+    sol = linsys.Minres(linsys.LinearSystem(A3, b3, M=M3, self_adjoint=True), tol=1e-8, maxiter=500)
+    assert sol.lanczos._enq == sol.lanczos.iter
+
+
 def case_arnoldi_invariant():
     """Invariant subspace detection (utils.py:1035-1039): 3 distinct eigenvalues -> 3 steps."""
     d = np.array([1.0] * 10 + [2.0] * 10 + [5.0] * 10)

@@ -107,6 +107,15 @@ def main(src, dst):
                                    "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
     except Exception as exc:  # pragma: no cover
         tj = {"error": repr(exc)}
+    if tj and "error" not in tj:
+        # tie the traffic numbers to the source tree they were measured on (bench.py attaches them to a
+        # roofline line only when the stamp matches the kernels it has just timed)
+        try:
+            b = json.loads(open(bj).read().strip().splitlines()[-1])
+            tj["source_stamp"] = b["roofline"]["source_stamp"]
+            tj["n"] = int(b["config"]["n"])
+        except Exception as exc:  # pragma: no cover
+            tj["stamp_error"] = repr(exc)
     if tj:
         lines += ["## Roofline-kernel traffic (bench.py micro-launches)", "", "```json", json.dumps(tj, indent=1), "```", ""]
         with open(os.path.splitext(dst)[0] + "_traffic.json", "w") as fh:
