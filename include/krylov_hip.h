@@ -73,6 +73,10 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
  * "chain_lds" column head parked in LDS, "chain_spmv" operator fused into the chain prologue.  bench.py
  * uses it to time the CSR-stream and the banded SpMV kernel on the same operator. */
 int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value);
+/* read a switch back, or a counter: "n_spmm" panel applications of a CSR operator that streamed the matrix
+ * once (k_spmm_stream / k_spmm_dia), "n_chain_recovered" Arnoldi steps re-run on the per-column kernels after
+ * a timeout of the chain kernel's grid-wide reduction */
+int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value);
 /* event timing on the context's stream (for bench.py's per-kernel roofline numbers) */
 int kh_timer_start(kh_ctx ctx);
 int kh_timer_stop(kh_ctx ctx, double* elapsed_ms);

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "kh_ctx_counters": [_H, _c_int64_p],
     "kh_ctx_tune": [_H, _INT, _INT],
     "kh_ctx_set": [_H, ctypes.c_char_p, _I64],
+    "kh_ctx_get": [_H, ctypes.c_char_p, _c_int64_p],
     "kh_timer_start": [_H],
     "kh_timer_stop": [_H, _c_double_p],
     "kh_comm_unique_id": [ctypes.c_char_p],
@@ -433,6 +434,12 @@ class Context(object):
         """Named switch of the context (``kh_ctx_set``): spmv_dia, chain, chain_lds, chain_spmv."""
         _check(self._lib, self._lib.kh_ctx_set(self._h, key.encode(), int(value)), "kh_ctx_set(%s)" % key)
 
+    def get(self, key):
+        """A switch or a counter of the context (``kh_ctx_get``), e.g. ``n_spmm``, ``n_chain_recovered``."""
+        v = _I64(0)
+        _check(self._lib, self._lib.kh_ctx_get(self._h, key.encode(), ctypes.byref(v)), "kh_ctx_get(%s)" % key)
+        return v.value
+
     def timer_start(self):
         _check(self._lib, self._lib.kh_timer_start(self._h), "kh_timer_start")
 
@@ -533,8 +540,10 @@ class Context(object):
                                                       _dptr(out)), "kh_zdot_panel")
             return out[:ncols]
         out = numpy.empty(max(ncols, 1), dtype=numpy.float64)
-        _check(self._lib, self._lib.kh_dot_panel(self._h, V.handle, j0, ncols, W.handle, wcol,
-                                                 _dptr(out)), "kh_dot_panel")
+        for c0 in range(0, max(ncols, 1), 1024):      # the C entry point takes at most 1024 columns per call
+            m = min(1024, ncols - c0)
+            _check(self._lib, self._lib.kh_dot_panel(self._h, V.handle, j0 + c0, m, W.handle, wcol,
+                                                     _dptr(out[c0:])), "kh_dot_panel")
         return out[:ncols]
 
     def gemm_tn(self, X, x0, nx, Y, y0, ny):
@@ -549,8 +558,12 @@ class Context(object):
             return out
         out = numpy.empty((nx, ny), dtype=numpy.float64)
         if nx and ny:
-            _check(self._lib, self._lib.kh_gemm_tn(self._h, X.handle, x0, nx, Y.handle, y0, ny,
-                                                   _dptr(out)), "kh_gemm_tn")
+            for r0 in range(0, nx, 1024):             # at most 1024 rows per call
+                m = min(1024, nx - r0)
+                blk = numpy.empty((m, ny), dtype=numpy.float64)
+                _check(self._lib, self._lib.kh_gemm_tn(self._h, X.handle, x0 + r0, m, Y.handle, y0, ny,
+                                                       _dptr(blk)), "kh_gemm_tn")
+                out[r0:r0 + m] = blk
         return out
 
     def axpy_panel(self, V, j0, ncols, h, W, wcol):
@@ -560,8 +573,10 @@ class Context(object):
                                                        wcol), "kh_zaxpy_panel")
             return
         h = _real_coeffs(h, "axpy_panel").reshape(-1)
-        _check(self._lib, self._lib.kh_axpy_panel(self._h, V.handle, j0, ncols, _dptr(h), W.handle,
-                                                  wcol), "kh_axpy_panel")
+        for c0 in range(0, max(ncols, 1), 1024):      # at most 1024 columns per call, left to right
+            m = min(1024, ncols - c0)
+            _check(self._lib, self._lib.kh_axpy_panel(self._h, V.handle, j0 + c0, m, _dptr(h[c0:]), W.handle,
+                                                      wcol), "kh_axpy_panel")
 
     def gemm_nn(self, X, x0, k, C, alpha, beta, Y, y0):
         if _same_dtype("gemm_nn", X, Y):

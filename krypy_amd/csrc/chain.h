@@ -20,10 +20,14 @@
 // the granules with relaxed agent-scope atomic loads until every tag matches - no flag, no fence,
 // placement independent.  Granule buffers alternate by epoch parity; a workgroup can only be one
 // epoch ahead of the slowest one, so two buffers suffice.  Every spin is bounded: on timeout an
-// error word is set, all workgroups fall through, and the host disables this path.
+// error word is set and all workgroups fall through; kh_arnoldi_step_end then switches this path off
+// for the context and runs the same step again on the per-column kernels (columns 0..k are intact).
 //
-// Residency: one 512-thread workgroup per CU (<= 256 VGPRs per lane); the launch is cooperative
-// so that a grid that cannot be co-resident is rejected instead of deadlocking.
+// Residency: one 512-thread workgroup per CU (<= 256 VGPRs per lane).  The launch is a plain one (a
+// cooperative launch costs ~1 ms of cross-queue synchronisation per step next to ordinary kernels and
+// checks nothing a plain launch does not have: residency is identical); the launcher checks the grid
+// against the occupancy of the instantiation itself, and the bounded spins cover what is left (a GPU
+// shared with another process).
 #pragma once
 #include <type_traits>
 #include "kernels.h"
@@ -49,9 +53,11 @@ struct ChainArgs {
     double* hdev;      // H column on the device (zeroed by the caller); hdev[j] += alpha
     int64_t hnext;     // index of H[k+1,k] in hdev
     unsigned long long* gran;  // [2][2*G] granules
+    unsigned* xcc_leader;      // [16] launch stamp of the last leader election per XCD
+    unsigned long long* xcc_res;   // [16][2 parities][2] the grid-wide sum, handed on inside an XCD through its L2
     unsigned epoch0;
     int* err;
-    int debug;         // measurement only: 1 = skip the grid reduction, 2 = skip the streaming phases
+    int debug;         // measurement only: 1 = skip the grid reduction, 2 = skip the streaming phases; tests: 4 = fake a timeout
     int presub;        // Lanczos: w -= h_km1 * bprev first
     double h_km1;
     const double* h_km1_dev;   // when non-null the coefficient is read from the device (look-ahead)
@@ -93,14 +99,87 @@ __device__ __forceinline__ void st_agent(unsigned long long* p, unsigned long lo
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// 64-lane sum with DPP moves (row_shr 1/2/4/8, row_bcast 15/31): the total ends up in lane 63.  About 100
+// cycles; __shfl_down compiles to ds_bpermute pairs and costs six LDS round trips.  Fixed tree, deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_take(double v) {
+    const long long b = __double_as_longlong(v);
+    int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {      // wave-uniform result
+    v += dpp_take<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_take<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_take<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_take<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row's sum
+    v += dpp_take<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_take<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// one granule of the current epoch (bounded spin; on timeout the error word is set and everybody falls through)
+__device__ __forceinline__ unsigned long long poll_granule(const unsigned long long* p, unsigned epoch, int* err) {
+    unsigned long long x = ld_agent(p);
+    unsigned spins = 0;
+    while ((unsigned)(x >> 32) != epoch) {
+        __builtin_amdgcn_s_sleep(1);
+        x = ld_agent(p);
+        if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (spins > (1u << 22)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    return x;
+}
+
+// Which XCD (accelerator die, private L2) this workgroup runs on, and whether it is that XCD's LEADER for this
+// launch: the first of the XCD's workgroups to raise the XCD's stamp to the launch's epoch.  Placement
+// independent: a workgroup only ever shares an L2 hand-off with workgroups that read the same XCC id.
+struct GridRole {
+    unsigned xcc;
+    bool leader;
+};
+
+__device__ __forceinline__ GridRole grid_role(unsigned* xcc_leader, unsigned stamp, int* sflag) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    GridRole r;
+    r.xcc = v & 0xfu;
+    if (threadIdx.x == 0)
+        *sflag = __hip_atomic_fetch_max(xcc_leader + r.xcc, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < stamp;
+    __syncthreads();
+    r.leader = *sflag != 0;
+    return r;
+}
+
 // Fixed-order sum of one double per workgroup over the whole grid; every thread gets the result.
+//   every workgroup   wave sums (DPP) -> LDS -> thread 0 publishes the workgroup's partial as two tagged granules
+//                     (write-through stores: visible on every XCD)
+//   XCD leaders (8)   every thread polls ONE granule of the sweep over the fabric (2 G <= 512 of them), neighbouring
+//                     lanes pair the halves of a partial with one DPP move, each wave adds its 32 partials (DPP tree),
+//                     the eight wave sums meet in LDS; thread 0 then stores the total as a tagged granule pair with
+//                     PLAIN stores - it stays in the XCD's L2
+//   everybody else    polls that pair with one 16-byte L1-bypassing load: an L2 hit on its own XCD, no fabric traffic
+// tools/probe/gsum_probe.hip, 245 workgroups: 2.2 us per sum against 3.6 us when all 245 workgroups sweep the
+// fabric themselves (and 30 times fewer polls on the fabric while stragglers still stream).  The order of the
+// additions is the same in every leader: all workgroups get the same bits.  (More than 256 workgroups: every
+// workgroup sweeps, through LDS.)
 __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned long long* gran,
-                                           int G, int* err, double* smd, unsigned* smu,
-                                           unsigned long long* tr = nullptr) {
+                                           int G, int* err, double* smd, unsigned* smu, const GridRole role,
+                                           unsigned long long* xcc_res, unsigned long long* tr = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = CH_BS / 64;
     // 1. workgroup partial (8 waves, fixed order)
-    part = wave_sum(part);
-    if (lane == 0) smd[wid] = part;
+    const double ws = wave_sum_dpp(part);
+    if (lane == 0) smd[wid] = ws;
     __syncthreads();
 #ifdef KH_CHAIN_TRACE
     if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 2] = wall_clock64();
@@ -109,7 +188,7 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     if (tid == 0) {
         double s = smd[0];
 #pragma unroll
-        for (int i = 1; i < CH_BS / 64; ++i) s += smd[i];
+        for (int i = 1; i < NW; ++i) s += smd[i];
         const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
         const unsigned long long tag = (unsigned long long)epoch << 32;
         st_agent(slot + 2 * blockIdx.x, tag | (bits & 0xffffffffull));
@@ -118,41 +197,80 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
 #ifdef KH_CHAIN_TRACE
     if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 3] = wall_clock64();
 #endif
-    // 2. sweep all granules of this epoch (bounded spin)
-    for (int g = tid; g < 2 * G; g += CH_BS) {
-        unsigned long long x = ld_agent(slot + g);
-        unsigned spins = 0;
-        while ((unsigned)(x >> 32) != epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            x = ld_agent(slot + g);
-            if ((++spins & 1023u) == 0) {
-                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1u << 22)) {
-                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+    if (2 * G <= CH_BS) {
+        unsigned long long* res = xcc_res + ((size_t)role.xcc * 2 + (epoch & 1u)) * 2;
+        if (!role.leader) {
+            // 2b. the leader of this XCD will put the total into `res`: one 16-byte load per poll, served by the L2
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            u64x2 ab;
+            unsigned spins = 0;
+            while (true) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ab) : "v"(res) : "memory");
+                if ((unsigned)(ab.x >> 32) == epoch && (unsigned)(ab.y >> 32) == epoch) break;
+                if ((++spins & 4095u) == 0) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1u << 24)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
+            return __longlong_as_double((long long)(((ab.y & 0xffffffffull) << 32) | (ab.x & 0xffffffffull)));
         }
-        smu[g] = (unsigned)x;
-    }
+        // 2a. leader: one granule per thread, lane 2b holds the low word of workgroup b's partial, lane 2b+1 the high one
+        unsigned mine = 0;
+        if (tid < 2 * G) {
+            unsigned long long x = ld_agent(slot + tid);
+            unsigned spins = 0;
+            while ((unsigned)(x >> 32) != epoch) {
+                x = ld_agent(slot + tid);
+                if ((++spins & 1023u) == 0) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1u << 22)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            mine = (unsigned)x;
+        }
 #ifdef KH_CHAIN_TRACE
-    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 4] = wall_clock64();
+        if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 4] = wall_clock64();
 #endif
+        const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);   // from lane - 1
+        const unsigned long long bits = ((unsigned long long)mine << 32) | low;
+        const double v = ((lane & 1) && tid < 2 * G) ? __longlong_as_double((long long)bits) : 0.0;
+        // 3. 32 partials per wave (DPP tree), eight wave sums through LDS
+        const double wv = wave_sum_dpp(v);
+        if (lane == 0) smd[NW + wid] = wv;
+        __syncthreads();
+        double s = smd[NW];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += smd[NW + i];
+        if (tid == 0) {      // 4. plain stores: the pair stays in this XCD's L2, where its other workgroups poll it
+            const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            res[0] = tag | (sb & 0xffffffffull);
+            res[1] = tag | (sb >> 32);
+        }
+        return s;
+    }
+    // 2'. sweep all granules of this epoch through LDS
+    for (int g = tid; g < 2 * G; g += CH_BS) smu[g] = (unsigned)poll_granule(slot + g, epoch, err);
     __syncthreads();
-    // 3. fixed-order sum of the G workgroup partials
+    // 3'. fixed-order sum of the G workgroup partials
     double v = 0.0;
     for (int b = tid; b < G; b += CH_BS) {
         const unsigned long long bits = ((unsigned long long)smu[2 * b + 1] << 32) | smu[2 * b];
         v += __longlong_as_double((long long)bits);
     }
-    v = wave_sum(v);
-    __syncthreads();          // smd reuse
-    if (lane == 0) smd[wid] = v;
+    v = wave_sum_dpp(v);
+    if (lane == 0) smd[NW + wid] = v;
     __syncthreads();
-    double s = smd[0];
+    double s = smd[NW];
 #pragma unroll
-    for (int i = 1; i < CH_BS / 64; ++i) s += smd[i];
-    __syncthreads();
+    for (int i = 1; i < NW; ++i) s += smd[NW + i];
+    __syncthreads();          // smu reuse by the next call
     return s;
 }
 
@@ -294,21 +412,36 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
     }
 }
 
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+// WL > 0: the vector is longer than the register file can hold (more than 40 rows per lane, N > 10.48 M on
+// 256 CUs): the last WL rows of w live in LDS (8 KB per row and workgroup, each lane touches only its own
+// entries: no barrier), the first R2 - WL in registers as ever.  R2 = 48 / 56 (WL = 8 / 16) take N to
+// 12.58 M / 14.68 M per GPU with the same single launch per Arnoldi step and the same arithmetic.
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
+    static_assert(WL == 0 || FND == 0, "the fused operator writes registers only");
+    constexpr int RW = R2 - WL;                   // rows of w in registers
+    extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
+#define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
+#define W_PUT(r, val)                                   \
+    do {                                                \
+        if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
+        else wl[((r) - RW) * CH_BS + tid] = (val);      \
+    } while (0)
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
     __shared__ double smd[2 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
+    __shared__ int slead;
     const int tid = threadIdx.x;
     const int G = gridDim.x;
+    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
     // chunk2 == R2 * CH_BS: thread `tid` owns elements first + r*CH_BS, r < R2
     const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
-    double2 w[R2];
+    double2 w[RW];
     double2 ring[2][PB];
     if constexpr (FND > 0) {
         chain_apply_banded<R2, FND>(a, first, w);
@@ -317,8 +450,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 v = win2[(int64_t)r * CH_BS];
-            w[r].x = CH_OK(r) ? v.x : 0.0;
-            w[r].y = CH_OK(r) ? v.y : 0.0;
+            double2 t;
+            t.x = CH_OK(r) ? v.x : 0.0;
+            t.y = CH_OK(r) ? v.y : 0.0;
+            W_PUT(r, t);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
@@ -328,12 +463,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 p = p2[(int64_t)r * CH_BS];
-            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
-            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
+            double2 t = W_GET(r);
+            t.x = CH_OK(r) ? t.x - hk * p.x : 0.0;
+            t.y = CH_OK(r) ? t.y - hk * p.y : 0.0;
+            W_PUT(r, t);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
     unsigned epoch = a.epoch0;
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
     const int total = a.ncol * a.sweeps;
     // prologue: first batch of the first column
     {
@@ -359,14 +497,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const double2 v = ring[b & 1][i];
+                const double2 wr = W_GET(b * PB + i);
                 if (CPLX) {               // conj(v) * w: acc0 = re, acc1 = im
-                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                    acc0 = fma(v.y, w[b * PB + i].y, acc0);
-                    acc1 = fma(v.x, w[b * PB + i].y, acc1);
-                    acc1 = fma(-v.y, w[b * PB + i].x, acc1);
+                    acc0 = fma(v.x, wr.x, acc0);
+                    acc0 = fma(v.y, wr.y, acc0);
+                    acc1 = fma(v.x, wr.y, acc1);
+                    acc1 = fma(-v.y, wr.x, acc1);
                 } else {
-                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                    acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                    acc0 = fma(v.x, wr.x, acc0);
+                    acc1 = fma(v.y, wr.y, acc1);
                 }
             }
         }
@@ -382,9 +521,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             }
         } else {
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
             if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
+        if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
         // ---- update phase: w -= alpha * b_j ----
         const int64_t jn = a.col0 + ((t + 1) % a.ncol);
         const double2* __restrict__ vn = (t + 1 < total)
@@ -401,15 +541,17 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             for (int i = 0; i < PB; ++i) {
                 const double2 p = ring[b & 1][i];
                 const int r = b * PB + i;
+                double2 wr = W_GET(r);
                 if (CPLX) {               // (alpha + i alpha_i) * (p.x + i p.y), NumPy's formula
                     const double tr = alpha * p.x - alpha_i * p.y;
                     const double ti = alpha * p.y + alpha_i * p.x;
-                    w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;
+                    wr.x = CH_OK(r) ? wr.x - tr : 0.0;
+                    wr.y = CH_OK(r) ? wr.y - ti : 0.0;
                 } else {
-                    w[r].x = CH_OK(r) ? w[r].x - alpha * p.x : 0.0;
-                    w[r].y = CH_OK(r) ? w[r].y - alpha * p.y : 0.0;
+                    wr.x = CH_OK(r) ? wr.x - alpha * p.x : 0.0;
+                    wr.y = CH_OK(r) ? wr.y - alpha * p.y : 0.0;
                 }
+                W_PUT(r, wr);
             }
         }
     }
@@ -420,18 +562,20 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 d = d2[(int64_t)r * CH_BS];
-            acc = fma(w[r].x, d.x * w[r].x, acc);
-            acc = fma(w[r].y, d.y * w[r].y, acc);
+            const double2 wr = W_GET(r);
+            acc = fma(wr.x, d.x * wr.x, acc);
+            acc = fma(wr.y, d.y * wr.y, acc);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            acc = fma(w[r].x, w[r].x, acc);
-            acc = fma(w[r].y, w[r].y, acc);
+            const double2 wr = W_GET(r);
+            acc = fma(wr.x, wr.x, acc);
+            acc = fma(wr.y, wr.y, acc);
         }
     }
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu);
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
     const double h = sqrt(fabs(h2));
     if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
@@ -442,11 +586,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
                 const double2 d = d2[(int64_t)r * CH_BS];
+                const double2 wr = W_GET(r);
                 double2 o, m;
-                o.x = w[r].x / h;
-                o.y = w[r].y / h;
-                m.x = (d.x * w[r].x) / h;
-                m.y = (d.y * w[r].y) / h;
+                o.x = wr.x / h;
+                o.y = wr.y / h;
+                m.x = (d.x * wr.x) / h;
+                m.y = (d.y * wr.y) / h;
                 pn2[(int64_t)r * CH_BS] = o;
                 vn2[(int64_t)r * CH_BS] = m;
             }
@@ -455,9 +600,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
+                const double2 wr = W_GET(r);
                 double2 o;
-                o.x = w[r].x / h;
-                o.y = w[r].y / h;
+                o.x = wr.x / h;
+                o.y = wr.y / h;
                 vn2[(int64_t)r * CH_BS] = o;
             }
         }
@@ -468,6 +614,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef W_PUT
+#undef W_GET
 #undef CH_OK
 }
 
@@ -507,8 +655,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB][CH_BS]
     __shared__ double smd[2 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
+    __shared__ int slead;
     const int tid = threadIdx.x;
     const int G = gridDim.x;
+    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
     const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
@@ -543,6 +693,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         }
     }
     unsigned epoch = a.epoch0;
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
     const int total = a.ncol * a.sweeps;
     {
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld) + first;
@@ -598,14 +749,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             }
         } else {
 #ifdef KH_CHAIN_TRACE
-            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu,
+            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res,
                              a.trace ? a.trace + (((size_t)blockIdx.x * total) + t) * 16 : nullptr);
 #else
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu);
+                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
 #endif
             if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
+        if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
         CH_STAMP(a, t, total, 5);
         // ---- update phase: w -= alpha * v_j, batches in reverse order ----
 #define CH_UPD(r, p)                                              \
@@ -667,7 +819,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             acc = fma(w[r].y, w[r].y, acc);
         }
     }
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu);
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
     const double h = sqrt(fabs(h2));
     if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
@@ -704,6 +856,275 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef CH_LD
+#undef CH_OK
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mgs_chain_pf: the LDS chain kernel with the memory system kept busy THROUGH the update phase.
+//
+// In k_mgs_chain_lds HBM idles from the end of a column's dot phase to the start of the next one: during
+// the grid-wide reduction (nothing to fetch into) and during the update, which is served by LDS, the ring
+// and L2 (phase stamps of the diagnostic build, tools/chain_trace.py: about 6 of 17.4 us per link at
+// N = 10^7).  Here
+//   * the dot phase issues batch b+2 into the ring slot batch b has just left, so it ends with the LAST TWO
+//     batches still in registers (nothing is re-fetched into the ring for the update);
+//   * the update starts with the LB batches parked in LDS, which empties those slots; the NG batches that
+//     are on chip nowhere are then fetched again (L2 hits for the most part: they were streamed just before
+//     the ring's two) straight INTO THE EMPTIED LDS SLOTS by LDS-DMA (global_load_lds_dwordx4, inline asm:
+//     no VGPR destination, and hipcc's own s_waitcnt bookkeeping for the ring stays exact because the DMAs
+//     are always the OLDEST vector-memory operations in flight);
+//   * the two ring slots are consumed next and each is refilled at once with the NEXT column's first two
+//     batches - 2*PB rows x 8 KB of HBM reads in flight while the DMA'd batches are waited for (one counted
+//     s_waitcnt vmcnt(2*PB)) and consumed, and while the next dot phase starts.
+// On chip at the reduction: LB batches in LDS + 2 in the ring (R2 = 40: 25 of 40 rows instead of 20), the
+// second read shrinks to NG = NB - 2 - LB batches (15 rows instead of 20).  Arithmetic and the order of
+// every floating-point operation are those of k_mgs_chain (each row is updated exactly once per link, the
+// dot sums the batches in ascending order): bit-identical results.  Only for B == V (no preconditioner).
+// ------------------------------------------------------------------------------------------
+template <int R2>
+struct ChainShapePf {
+    static constexpr int PB = ChainShape<R2>::PB;
+    static constexpr int NB = R2 / PB;
+    static constexpr int LB = (NB - 2 < 3) ? NB - 2 : 3;      // leading batches parked in LDS
+    static constexpr int NG = NB - 2 - LB;                    // batches fetched again (into the emptied LDS slots)
+    static_assert((NB % 2) == 0 && NB >= 2 && LB >= 0 && NG >= 0 && NG <= LB, "shape");
+    // what is left of the CU's 160 KB of LDS takes the first SP rows of the NEXT column while the grid-wide
+    // reduction is in flight (the only stretch of a link with nothing else to fetch into)
+    static constexpr int ROW_BYTES = CH_BS * (int)sizeof(double2);
+    static constexpr int STATIC_LDS = 2 * (CH_BS / 64) * 8 + 2 * CH_GMAX * 4 + 256;      // smd + smu + slack
+    static constexpr int SPARE = (160 * 1024 - STATIC_LDS - LB * PB * ROW_BYTES) / ROW_BYTES;
+    static constexpr int SP = SPARE < PB ? SPARE : PB;
+    static_assert(SP >= 1, "at least one spare row");
+    static constexpr size_t LDS_BYTES = (size_t)(LB * PB + SP) * ROW_BYTES;
+};
+
+typedef __attribute__((address_space(3))) double2 ch_lds_double2;
+
+// one wave-row (64 lanes x 16 B) global -> LDS at the wave-uniform byte address lds_dst (+ lane * 16)
+__device__ __forceinline__ void ch_dma16(const double2* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+__global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
+    static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
+    constexpr int PB = ChainShapePf<R2>::PB;
+    constexpr int NB = ChainShapePf<R2>::NB;
+    constexpr int LB = ChainShapePf<R2>::LB;
+    constexpr int NG = ChainShapePf<R2>::NG;
+    constexpr int SP = ChainShapePf<R2>::SP;
+    extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB parked rows + SP prefetched rows][CH_BS]
+    double2* const vsp = vlds + (size_t)LB * PB * CH_BS;
+    __shared__ double smd[2 * (CH_BS / 64)];
+    __shared__ unsigned smu[2 * CH_GMAX];
+    __shared__ int slead;
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+    // LDS byte address of this wave's 64 lanes in row 0 (the DMA destination is wave-uniform + lane * 16)
+    const unsigned lds_wave = (unsigned)(size_t)((ch_lds_double2*)vlds) +
+                              (unsigned)__builtin_amdgcn_readfirstlane((tid >> 6) * 64 * (int)sizeof(double2));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+#define CH_LD(ptr, reuse) ((reuse) ? *(ptr) : ld_nt2(ptr))
+    double2 w[R2];
+    double2 ring[2][PB];
+    if constexpr (FND > 0) {
+        chain_apply_banded<R2, FND>(a, first, w);
+    } else {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    }
+    if (a.presub) {
+        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 p = p2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
+            if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
+        }
+    }
+    unsigned epoch = a.epoch0;
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
+    const int total = a.ncol * a.sweeps;
+    // a batch that comes back from memory for the update is loaded normally (L2 keeps it), everything that is
+    // used once from memory - the batches that live on in LDS / the ring - non-temporally
+#define CH_REUSE(b) ((b) >= LB && (b) < LB + NG)
+    {   // the first column's first two batches (the first SP rows by LDS-DMA, as in every later link)
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld) + first;
+#pragma unroll
+        for (int i = 0; i < SP; ++i)
+            ch_dma16(v2 + (int64_t)i * CH_BS, lds_wave + (unsigned)(((LB * PB + i) * CH_BS) * sizeof(double2)));
+#pragma unroll
+        for (int i = SP; i < PB; ++i) ring[0][i] = CH_LD(v2 + (int64_t)i * CH_BS, CH_REUSE(0));
+        CH_ISSUE_FENCE();
+        if (NB > 1) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[1][i] = CH_LD(v2 + (int64_t)(PB + i) * CH_BS, CH_REUSE(1));
+            CH_ISSUE_FENCE();
+        }
+    }
+    for (int t = 0; t < total; ++t) {
+        const int64_t j = a.col0 + (t % a.ncol);
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + j * a.ld) + first;
+        const int64_t jn = a.col0 + ((t + 1) % a.ncol);
+        const double2* __restrict__ vn = (t + 1 < total)
+            ? reinterpret_cast<const double2*>(a.V + jn * a.ld) + first
+            : reinterpret_cast<const double2*>(a.w_in) + first;       // harmless: valid memory
+        // ---- dot phase: <v_j, w>; batch b sits in ring[b & 1], batch b+2 follows it into the same slot ----
+        double acc0 = 0.0, acc1 = 0.0;
+        // everything older than the two ring batches in flight has landed: the prefetched rows among it
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB - SP) : "memory");
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 v = (b == 0 && i < SP) ? vsp[i * CH_BS + tid] : ring[b & 1][i];
+                if (NB == 2 && b == 0 && i < SP) ring[0][i] = v;      // (two-batch shapes update from the ring)
+                if (b < LB) vlds[(b * PB + i) * CH_BS + tid] = v;
+                if (CPLX) {
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc0 = fma(v.y, w[b * PB + i].y, acc0);
+                    acc1 = fma(v.x, w[b * PB + i].y, acc1);
+                    acc1 = fma(-v.y, w[b * PB + i].x, acc1);
+                } else {
+                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
+                    acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                }
+            }
+            if (b + 2 < NB) {
+                CH_ISSUE_FENCE();
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    ring[b & 1][i] = CH_LD(v2 + (int64_t)((b + 2) * PB + i) * CH_BS, CH_REUSE(b + 2));
+                CH_ISSUE_FENCE();
+            }
+        }
+        // the next column's first SP rows: on their way while the coefficient is summed over the grid
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < SP; ++i)
+            ch_dma16(vn + (int64_t)i * CH_BS, lds_wave + (unsigned)(((LB * PB + i) * CH_BS) * sizeof(double2)));
+        double alpha, alpha_i = 0.0;
+        if (CPLX) {
+            alpha = acc0;
+            alpha_i = acc1;
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
+            if (blockIdx.x == 0 && tid == 0) {
+                a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
+                a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
+            }
+        } else {
+            alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+            if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
+        }
+        if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
+        // ---- update phase: w -= alpha * v_j ----
+#define CH_UPD(r, p)                                              \
+    do {                                                          \
+        if (CPLX) {                                               \
+            const double tr = alpha * (p).x - alpha_i * (p).y;    \
+            const double ti = alpha * (p).y + alpha_i * (p).x;    \
+            w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;                \
+            w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;                \
+        } else {                                                  \
+            w[r].x = CH_OK(r) ? w[r].x - alpha * (p).x : 0.0;     \
+            w[r].y = CH_OK(r) ? w[r].y - alpha * (p).y : 0.0;     \
+        }                                                         \
+    } while (0)
+        // (a) the head of the column from LDS (own entries: no barrier needed), one batch of reads at a time
+#pragma unroll
+        for (int b = 0; b < LB; ++b) {
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const double2 p = vlds[(b * PB + i) * CH_BS + tid];
+                CH_UPD(b * PB + i, p);
+            }
+        }
+        // (b) the batches that are nowhere on chip come back into the emptied slots by LDS-DMA
+        if constexpr (NG > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the slots have been read
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int i = 0; i < PB; ++i)
+                    ch_dma16(v2 + (int64_t)((LB + g) * PB + i) * CH_BS,
+                             lds_wave + (unsigned)(((g * PB + i) * CH_BS) * sizeof(double2)));
+        }
+        // (c) the two batches the ring still holds; each slot goes straight to the next column
+        if (NB > 1) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) CH_UPD((NB - 2) * PB + i, ring[0][i]);
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = SP; i < PB; ++i) ring[0][i] = CH_LD(vn + (int64_t)i * CH_BS, CH_REUSE(0));
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) CH_UPD((NB - 1) * PB + i, ring[1][i]);
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < PB; ++i) ring[1][i] = CH_LD(vn + (int64_t)(PB + i) * CH_BS, CH_REUSE(1));
+            CH_ISSUE_FENCE();
+        }
+        // (d) the DMA'd batches: everything older than the 2*PB ring loads just issued has landed
+        if constexpr (NG > 0) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PB - SP) : "memory");
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                CH_ISSUE_FENCE();
+#pragma unroll
+                for (int i = 0; i < PB; ++i) {
+                    const double2 p = vlds[(g * PB + i) * CH_BS + tid];
+                    CH_UPD((LB + g) * PB + i, p);
+                }
+            }
+        }
+#undef CH_UPD
+    }
+    // norm: <w,w> or <w, D w>
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        acc = fma(w[r].x, w[r].x, acc);
+        acc = fma(w[r].y, w[r].y, acc);
+    }
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    const double h = sqrt(fabs(h2));
+    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        if (r * CH_BS < rem) {
+            double2 o;
+            o.x = w[r].x / h;
+            o.y = w[r].y / h;
+            vn2[(int64_t)r * CH_BS] = o;
+        }
+    }
+    if (blockIdx.x == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by thread 0 of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#undef CH_REUSE
 #undef CH_LD
 #undef CH_OK
 }
@@ -752,8 +1173,18 @@ struct CgsArgs {
     int nt_cols;           // dots: non-temporal column loads (a panel far larger than the Infinity Cache)
 };
 
-template <int R2, bool MASKED, bool NTC>
+// WL > 0: as in k_mgs_chain, the last WL rows of w live in LDS (shards / vectors beyond 10.48 M rows per GPU)
+#define CGS_W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
+#define CGS_W_PUT(r, val)                               \
+    do {                                                \
+        if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
+        else wl[((r) - RW) * CH_BS + tid] = (val);      \
+    } while (0)
+
+template <int R2, bool MASKED, bool NTC, int WL = 0>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
+    constexpr int RW = R2 - WL;
+    extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
     constexpr int PB = CgsShape<R2>::PB;
     constexpr int NB = CgsShape<R2>::NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -761,15 +1192,17 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
-    double2 w[R2];
+    double2 w[RW];
     double2 ring[2][PB];
     {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);   // (the columns stay normal loads: the update pass re-reads them)
-            w[r].x = CH_OK(r) ? v.x : 0.0;
-            w[r].y = CH_OK(r) ? v.y : 0.0;
+            double2 t;
+            t.x = CH_OK(r) ? v.x : 0.0;
+            t.y = CH_OK(r) ? v.y : 0.0;
+            CGS_W_PUT(r, t);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
@@ -798,8 +1231,9 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
                 const double2 v = ring[(P0 + b) & 1][i];
-                acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                const double2 wr = CGS_W_GET(b * PB + i);
+                acc0 = fma(v.x, wr.x, acc0);
+                acc1 = fma(v.y, wr.y, acc1);
             }
         }
         const double s = wave_sum(acc0 + acc1);
@@ -818,8 +1252,10 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
 #undef CH_OK
 }
 
-template <int R2, bool MASKED>
+template <int R2, bool MASKED, int WL = 0>
 __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
+    constexpr int RW = R2 - WL;
+    extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
     constexpr int PB = CgsShape<R2>::PB;
     constexpr int NB = CgsShape<R2>::NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -827,14 +1263,16 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
-    double2 w[R2];
+    double2 w[RW];
     double2 ring[2][PB];
     double2* __restrict__ w2 = reinterpret_cast<double2*>(a.w) + first;
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
         const double2 v = ld_nt2(w2 + (int64_t)r * CH_BS);
-        w[r].x = CH_OK(r) ? v.x : 0.0;
-        w[r].y = CH_OK(r) ? v.y : 0.0;
+        double2 t;
+        t.x = CH_OK(r) ? v.x : 0.0;
+        t.y = CH_OK(r) ? v.y : 0.0;
+        CGS_W_PUT(r, t);
         if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
     }
     // reverse: the dots pass has just streamed the columns first to last, so the LAST ones are what
@@ -866,8 +1304,10 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
             for (int i = 0; i < PB; ++i) {
                 const double2 p = ring[(P0 + b) & 1][i];
                 const int r = b * PB + i;
-                w[r].x = CH_OK(r) ? w[r].x - h * p.x : 0.0;
-                w[r].y = CH_OK(r) ? w[r].y - h * p.y : 0.0;
+                double2 wr = CGS_W_GET(r);
+                wr.x = CH_OK(r) ? wr.x - h * p.x : 0.0;
+                wr.y = CH_OK(r) ? wr.y - h * p.y : 0.0;
+                CGS_W_PUT(r, wr);
             }
         }
     };
@@ -890,22 +1330,24 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
                 const double2 d = d2[(int64_t)r * CH_BS];
+                const double2 wr = CGS_W_GET(r);
                 double2 m;
-                m.x = d.x * w[r].x;
-                m.y = d.y * w[r].y;
-                acc = fma(w[r].x, m.x, acc);
-                acc = fma(w[r].y, m.y, acc);
+                m.x = d.x * wr.x;
+                m.y = d.y * wr.y;
+                acc = fma(wr.x, m.x, acc);
+                acc = fma(wr.y, m.y, acc);
                 m2[(int64_t)r * CH_BS] = m;
-                w2[(int64_t)r * CH_BS] = w[r];
+                w2[(int64_t)r * CH_BS] = wr;
             }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
-                acc = fma(w[r].x, w[r].x, acc);
-                acc = fma(w[r].y, w[r].y, acc);
-                w2[(int64_t)r * CH_BS] = w[r];
+                const double2 wr = CGS_W_GET(r);
+                acc = fma(wr.x, wr.x, acc);
+                acc = fma(wr.y, wr.y, acc);
+                w2[(int64_t)r * CH_BS] = wr;
             }
         }
     }
@@ -913,5 +1355,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
     if (lane == 0) a.part[blockIdx.x * (CH_BS / 64) + wid] = s;
 #undef CH_OK
 }
+#undef CGS_W_PUT
+#undef CGS_W_GET
 
 }  // namespace kh

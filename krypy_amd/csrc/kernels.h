@@ -511,6 +511,82 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// CSR SpMM, Y[:, 0:ncols] = A X[:, 0:ncols] (utils.py:1593-1594 with a block argument: A U of the deflation
+// set-up deflation.py:47, the explicit Ritz residuals deflation.py:849-855).  Same row blocks and the
+// same LDS staging as k_spmv_stream, but the matrix is read ONCE: a lane keeps its ITEMS (index, value)
+// pairs in registers and walks the columns of X in chunks of DC - gather, multiply, park DC product
+// tiles in LDS, one lane per row adds each column's products left to right.  Per column that is the
+// order of scipy's csr_matvecs (y[i, v] += a_ij * x[j, v], separate multiply and add): bit-identical
+// to A.dot(X).
+// ------------------------------------------------------------------------------------------
+template <int ITEMS, int DC>
+__global__ __launch_bounds__(BS) void k_spmm_stream(const int32_t* __restrict__ indptr,
+                                                    const int32_t* __restrict__ indices,
+                                                    const double* __restrict__ data,
+                                                    const int32_t* __restrict__ rowblk, int nblk, int tile,
+                                                    const double* __restrict__ X, int64_t ldx,
+                                                    double* __restrict__ Y, int64_t ldy, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) double prod[];   // [DC][tile]
+    __shared__ double sm[8];
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    const int nz0 = indptr[r0], nz1 = indptr[r1];
+    const int cnt = nz1 - nz0;
+    if (cnt <= tile) {
+        int c[ITEMS];
+        double a[ITEMS];
+        if (cnt > 0) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                const int tc = t < cnt ? t : cnt - 1;
+                c[i] = __builtin_nontemporal_load(indices + nz0 + tc);
+                a[i] = __builtin_nontemporal_load(data + nz0 + tc);
+            }
+        }
+        for (int j0 = 0; j0 < ncols; j0 += DC) {
+            const int nc = (ncols - j0 < DC) ? ncols - j0 : DC;
+            if (cnt > 0) {
+#pragma unroll
+                for (int dc = 0; dc < DC; ++dc) {
+                    if (dc < nc) {
+                        const double* __restrict__ x = X + (int64_t)(j0 + dc) * ldx;
+                        double pv[ITEMS];
+#pragma unroll
+                        for (int i = 0; i < ITEMS; ++i) pv[i] = a[i] * x[c[i]];
+#pragma unroll
+                        for (int i = 0; i < ITEMS; ++i) {
+                            const int t = threadIdx.x + i * BS;
+                            if (t < cnt) prod[dc * tile + t] = pv[i];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+                const int p0 = indptr[r] - nz0, p1 = indptr[r + 1] - nz0;
+                for (int dc = 0; dc < nc; ++dc) {
+                    const double* __restrict__ pr = prod + dc * tile;
+                    double s = 0.0;
+                    for (int p = p0; p < p1; ++p) s += pr[p];
+                    Y[(int64_t)(j0 + dc) * ldy + r] = s;
+                }
+            }
+            __syncthreads();
+        }
+    } else {  // one long row: tree reduction per column (not bit-ordered, like k_spmv_stream)
+        for (int j = 0; j < ncols; ++j) {
+            const double* __restrict__ x = X + (int64_t)j * ldx;
+            double s = 0.0;
+            for (int t = threadIdx.x; t < cnt; t += BS) s += data[nz0 + t] * x[indices[nz0 + t]];
+            s = block_sum(s, sm);
+            if (threadIdx.x == 0) Y[(int64_t)j * ldy + r0] = s;
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Banded ("DIA") SpMV for CSR operators whose entries sit on a few diagonals (finite-difference /
 // stencil matrices: configs 2, 3, 5).  kh_csr_upload detects the structure and k_dia_fill builds
 // the diagonal-major copy on the device: dia[d * ld + i] = A[i, i + off[d]] (0.0 where the row has
@@ -634,6 +710,49 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
     if (EPI != EPI_NONE) {
         const double r = block_sum(acc, sm);
         if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+    }
+}
+
+// Banded SpMM: the diagonal-major copy streamed once for DC columns of X (k_spmv_dia's order per column:
+// ascending offsets, separate multiply and add, empty slots skipped - the same bits).  A lane owns one pair
+// of neighbouring rows and DC accumulator pairs.
+template <int DC>
+__global__ __launch_bounds__(BS) void k_spmm_dia(DiaOffs o, const double* __restrict__ dia, int64_t ld,
+                                                 int64_t n, const double* __restrict__ X, int64_t ldx,
+                                                 double* __restrict__ Y, int64_t ldy, int nc) {
+    const int64_t r = ((int64_t)blockIdx.x * BS + threadIdx.x) * 2;
+    if (r >= n) return;
+    const int64_t last = n - 1;
+    double s0[DC], s1[DC];
+#pragma unroll
+    for (int j = 0; j < DC; ++j) s0[j] = s1[j] = 0.0;
+    for (int d = 0; d < o.nd; ++d) {
+        const int64_t off = o.off[d];
+        const double2 a = ld_nt2(reinterpret_cast<const double2*>(dia + (int64_t)d * ld + r));
+        int64_t c0 = r + off, c1 = r + 1 + off;
+        c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+        c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+        double x0[DC], x1[DC];
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            const double* __restrict__ x = X + (int64_t)(j < nc ? j : 0) * ldx;
+            x0[j] = x[c0];
+            x1[j] = x[c1];
+        }
+#pragma unroll
+        for (int j = 0; j < DC; ++j) {
+            const double p0 = a.x * x0[j], p1 = a.y * x1[j];
+            s0[j] = (a.x != 0.0) ? s0[j] + p0 : s0[j];
+            s1[j] = (a.y != 0.0) ? s1[j] + p1 : s1[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < DC; ++j) {
+        if (j < nc) {
+            double* __restrict__ y = Y + (int64_t)j * ldy;
+            if (r + 1 < n) *reinterpret_cast<double2*>(y + r) = make_double2(s0[j], s1[j]);
+            else y[r] = s0[j];
+        }
     }
 }
 

@@ -41,6 +41,18 @@ int fail(int code, const char* fmt, ...);
 
 }  // namespace kh
 
+// what kh_arnoldi_step_begin / kh_zarnoldi_step_begin enqueued in an H-column slot: enough to run the
+// step again on the per-column kernels when the chain kernel reports a timeout (kh_arnoldi_step_end)
+struct kh_step_s {
+    int kind = 0;            // 0 = nothing, 1 = real step, 2 = complex step
+    kh_mat A = nullptr, Md = nullptr;
+    kh_proj proj = nullptr;
+    kh_vec V = nullptr, P = nullptr, W = nullptr;
+    int64_t wcol = 0, k = 0, start = 0;
+    int sweeps = 1, gs_mode = 0;
+    double h_km1[2] = {0.0, 0.0};
+};
+
 struct kh_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -58,14 +70,21 @@ struct kh_ctx_s {
     // register-resident MGS chain (chain.h)
     int chain_enabled = 1;
     int64_t n_chain = 0, n_chain_lds = 0, n_chain_fused = 0, n_cgs_reg = 0;   // launch counters (kh_ctx_counters)
+    int64_t n_chain_recovered = 0;   // Arnoldi steps re-run on the link kernels after a chain timeout
+    int64_t n_spmm = 0;     // panel applications of a CSR operator that streamed the matrix once
     int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
+    int chain_pf = 1;       // ... and keep HBM busy through the update phase (k_mgs_chain_pf; KRYPY_AMD_CHAIN_PF)
+    int64_t n_chain_pf = 0;
     int chain_lds = 1;      // park the head of every column in LDS (k_mgs_chain_lds; KRYPY_AMD_CHAIN_LDS)
     int spmv_dia = 1;       // use the banded copy of a CSR operator when it has one (kh_ctx_set "spmv_dia")
     unsigned long long* chain_gran = nullptr;
+    unsigned long long* chain_xcc = nullptr;   // per-XCD result granules + leader stamps of the grid-wide sums
     int* chain_err = nullptr;        // device error word
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     unsigned chain_epoch = 1;
     int chain_debug = 0;
+    int chain_fault = 0;    // tests: the next chain launch reports a timeout and leaves garbage behind
+    kh_step_s step[KH_NSLOT];
 #ifdef KH_CHAIN_TRACE
     unsigned long long* chain_trace = nullptr;   // diagnostic build: phase stamps of the next chain launch
 #endif

@@ -281,17 +281,23 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
 // is what matters for the in-kernel grid reduction, and it is identical for plain and cooperative
 // launches: it is checked here against the occupancy of this instantiation, and every spin in the
 // kernel is bounded.
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0>
 static hipError_t launch_chain(kh_ctx ctx, int G, ChainArgs& a) {
     static int blocks_per_cu = -1;
+    constexpr size_t lds = (size_t)WL * CH_BS * sizeof(double2);      // rows of w that live in LDS (long vectors)
     if (blocks_per_cu < 0) {
+        if (lds > 0) {
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain<R2, MASKED, CPLX, FND, WL>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0 != hipSuccess) return e0;
+        }
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CPLX, FND>, CH_BS, 0);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain<R2, MASKED, CPLX, FND, WL>, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CPLX, FND>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+    hipLaunchKernelGGL((k_mgs_chain<R2, MASKED, CPLX, FND, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -314,12 +320,31 @@ static hipError_t launch_chain_lds(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// the variant that keeps HBM busy through the update phase (chain.h: k_mgs_chain_pf)
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+static hipError_t launch_chain_pf(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = ChainShapePf<R2>::LDS_BYTES;
+    if (blocks_per_cu < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_pf<R2, MASKED, CPLX, FND>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain_pf<R2, MASKED, CPLX, FND>, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((k_mgs_chain_pf<R2, MASKED, CPLX, FND>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
 static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
     if (n < 2) return false;
     // an odd n is handled as n+1: the extra element is the (always zero) padding behind the column
     const int64_t n2 = (n + 1) >> 1;
-    static const int kR2[] = {4, 8, 16, 24, 32, 40};
+    static const int kR2[] = {4, 8, 16, 24, 32, 40, 48, 56};   // 48 / 56: the last 8 / 16 rows of w live in LDS
     for (int c : kR2) {
         const int64_t g = (n2 + (int64_t)c * CH_BS - 1) / ((int64_t)c * CH_BS);
         if (g <= ctx->ncu && g <= CH_GMAX) {
@@ -328,7 +353,7 @@ static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
             return true;
         }
     }
-    return false;   // w does not fit the register file: stream it (k_gs_link)
+    return false;   // w fits neither registers nor registers + LDS (N > 14.68 M on 256 CUs): stream it (k_gs_link)
 }
 
 // leading dimension of a block of n-vectors: large vectors are padded to whole chain chunks so
@@ -366,6 +391,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     if (ctx->chain_epoch > 0xfff00000u) {
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
+        KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
         ctx->chain_epoch = 1;
     }
     ChainArgs a;
@@ -384,9 +410,12 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.hdev = hdev;
     a.hnext = cplx ? 2 * (k + 1) : k + 1;
     a.gran = ctx->chain_gran;
+    a.xcc_res = ctx->chain_xcc;
+    a.xcc_leader = reinterpret_cast<unsigned*>(ctx->chain_xcc + 64);
     a.epoch0 = ctx->chain_epoch;
     a.err = ctx->chain_err;
     a.debug = ctx->chain_debug;
+    if (ctx->chain_fault) a.debug = 4;     // kh_ctx_set("chain_fault", 1): the next launch behaves like a timed-out one
     a.presub = presub ? 1 : 0;
     a.h_km1 = h_km1;
     a.h_km1_dev = h_km1_dev;
@@ -405,12 +434,13 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     static thread_local bool lds_failed = false;   // the LDS variant could not be launched once: plain kernel from then on
     // (an unpadded block of a long vector - not what kh_vec_alloc produces - takes the plain kernel: the
     // masked LDS instantiations with 32 / 40 rows spill)
-    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && ctx->chain_debug == 0 &&
-                   (padded || r2 <= 24);
+    bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && (a.debug == 0 || a.debug == 4) &&
+                   (padded || r2 <= 24) && r2 <= 40;     // (48 / 56 rows: LDS holds a part of w itself)
+    if (r2 > 40 && cplx) return 0;
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && padded && !cplx && ctx->chain_debug == 0 && r2 >= 16 && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && (a.debug == 0 || a.debug == 4) && r2 >= 16 && r2 <= 40 && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -433,10 +463,19 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 #define KH_CHAIN_LDS(R)                                                                                       \
     (cplx ? (padded ? launch_chain_lds<R, false, true>(ctx, G, a) : launch_chain_lds<R, true, true>(ctx, G, a)) \
           : (padded ? launch_chain_lds<R, false>(ctx, G, a) : launch_chain_lds<R, true>(ctx, G, a)))
-#define KH_CHAIN(R) (use_lds ? KH_CHAIN_LDS(R) : KH_CHAIN_PLAIN(R))
+#define KH_CHAIN_PF(R)                                                                                      \
+    (cplx ? (padded ? launch_chain_pf<R, false, true>(ctx, G, a) : launch_chain_pf<R, true, true>(ctx, G, a)) \
+          : (padded ? launch_chain_pf<R, false>(ctx, G, a) : launch_chain_pf<R, true>(ctx, G, a)))
+    // k_mgs_chain_pf wins where the whole column stays on chip (<= 24 rows per lane: 6.9 vs 7.2 us per link at
+    // N = 4*10^6); with 32 / 40 rows its prefetches sit in the CU's memory queue in front of the reduction's polls
+    // and cost what they save (17.4 vs 16.3 us per link at N = 10^7)
+    const bool use_pf = use_lds && ctx->chain_pf && r2 <= 24;
+#define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fused) {
-#define KH_FUSED(R, D) (use_lds ? launch_chain_lds<R, false, false, D>(ctx, G, a) : launch_chain<R, false, false, D>(ctx, G, a))
+#define KH_FUSED(R, D)                                                                                   \
+    (use_lds ? (use_pf ? launch_chain_pf<R, false, false, D>(ctx, G, a) : launch_chain_lds<R, false, false, D>(ctx, G, a)) \
+             : launch_chain<R, false, false, D>(ctx, G, a))
             if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
             else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
             else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);
@@ -453,13 +492,16 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         else if (r2 == 16) e = KH_CHAIN(16);
         else if (r2 == 24) e = KH_CHAIN(24);
         else if (r2 == 32) e = KH_CHAIN(32);
-        else e = KH_CHAIN(40);
+        else if (r2 == 40) e = KH_CHAIN(40);
+        else if (r2 == 48) e = padded ? launch_chain<48, false, false, 0, 8>(ctx, G, a) : launch_chain<48, true, false, 0, 8>(ctx, G, a);
+        else e = padded ? launch_chain<56, false, false, 0, 16>(ctx, G, a) : launch_chain<56, true, false, 0, 16>(ctx, G, a);
         if (e == hipSuccess || !use_lds) break;
         (void)hipGetLastError();     // e.g. the 120 KB of dynamic LDS were refused: fall back to the plain kernel
         lds_failed = true;
         use_lds = false;
     }
 #undef KH_CHAIN
+#undef KH_CHAIN_PF
 #undef KH_CHAIN_LDS
 #undef KH_CHAIN_PLAIN
     if (e != hipSuccess) {
@@ -468,8 +510,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         ctx->chain_enabled = 0;
         return 0;
     }
+    if (a.debug == 4) ctx->chain_fault = 0;
     ctx->n_chain += 1;
     ctx->n_chain_lds += use_lds ? 1 : 0;
+    ctx->n_chain_pf += use_pf ? 1 : 0;
     ctx->n_chain_fused += fused ? 1 : 0;
     ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);   // one grid reduction per link (complex: both parts in it) + the norm
     if (hpin == nullptr)      // (otherwise workgroup 0 has written the error word to the pinned slot itself)
@@ -482,14 +526,30 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 constexpr int CGS_MAXCOL = 256;
 constexpr int CGS_PSTRIDE = CH_GMAX * (CH_BS / 64);   // wave partials per column
 
-template <int R2, bool MASKED>
+template <int R2, bool MASKED, int WL = 0>
 static hipError_t launch_cgs(kh_ctx ctx, int G, CgsArgs& a, bool update) {
+    constexpr size_t lds = (size_t)WL * CH_BS * sizeof(double2);
+    if (lds > 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_update<R2, MASKED, WL>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, true, WL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, false, WL>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_done = true;
+        }
+    }
     if (update)
-        hipLaunchKernelGGL((k_cgs_update<R2, MASKED>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_update<R2, MASKED, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     else if (a.nt_cols)
-        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, true>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, true, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false>), dim3(G), dim3(CH_BS), 0, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -533,9 +593,11 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
     }();
     a.nt_cols = ((double)ncol * (double)n * 8.0 > nt_gb * 1e9) ? 1 : 0;
 #define KH_CGS(R, UPD) (padded ? launch_cgs<R, false>(ctx, G, a, UPD) : launch_cgs<R, true>(ctx, G, a, UPD))
+#define KH_CGS_L(R, WL, UPD) (padded ? launch_cgs<R, false, WL>(ctx, G, a, UPD) : launch_cgs<R, true, WL>(ctx, G, a, UPD))
 #define KH_CGS_ANY(UPD)                                                                        \
     (r2 == 4 ? KH_CGS(4, UPD) : r2 == 8 ? KH_CGS(8, UPD) : r2 == 16 ? KH_CGS(16, UPD)            \
-     : r2 == 24 ? KH_CGS(24, UPD) : r2 == 32 ? KH_CGS(32, UPD) : KH_CGS(40, UPD))
+     : r2 == 24 ? KH_CGS(24, UPD) : r2 == 32 ? KH_CGS(32, UPD) : r2 == 40 ? KH_CGS(40, UPD)     \
+     : r2 == 48 ? KH_CGS_L(48, 8, UPD) : KH_CGS_L(56, 16, UPD))
     for (int s = 0; s < sweeps; ++s) {
         a.Vb = V->d;
         a.coef = nullptr;
@@ -561,6 +623,7 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         a.ld = V->ld;
     }
 #undef KH_CGS_ANY
+#undef KH_CGS_L
 #undef KH_CGS
     *nrm_count = nwave;
     ctx->n_cgs_reg += 1;
@@ -620,6 +683,9 @@ int kh_ctx_create(int device, kh_ctx* out) {
     KH_HIP(hipEventCreate(&ctx->ev1));
     KH_HIP(hipMalloc(&ctx->chain_gran, sizeof(unsigned long long) * 4 * CH_GMAX));
     KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
+    // XCD-leader hand-off of the chain kernel's grid-wide sums: [16][2][2] result granules + [16] election stamps
+    KH_HIP(hipMalloc(&ctx->chain_xcc, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
+    KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
     KH_HIP(hipMalloc(&ctx->chain_err, sizeof(int)));
     KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
     for (int s = 0; s < KH_NSLOT; ++s) {
@@ -634,6 +700,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_spmv = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_LDS");
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_PF");
+        ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
     }
     *out = ctx;
     return 0;
@@ -651,6 +719,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
     }
     (void)hipFree(ctx->cgs_part);
     (void)hipFree(ctx->chain_gran);
+    (void)hipFree(ctx->chain_xcc);
     (void)hipFree(ctx->chain_err);
     for (int s = 0; s < KH_NSLOT; ++s)
         if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
@@ -710,8 +779,24 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     if (!strcmp(key, "spmv_dia")) ctx->spmv_dia = value != 0;
     else if (!strcmp(key, "chain")) ctx->chain_enabled = (value != 0 && ctx->ncu <= CH_GMAX);
     else if (!strcmp(key, "chain_lds")) ctx->chain_lds = value != 0;
+    else if (!strcmp(key, "chain_pf")) ctx->chain_pf = value != 0;
     else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
+    else if (!strcmp(key, "chain_fault")) ctx->chain_fault = value != 0;
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
+    return 0;
+}
+
+int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
+    KH_ARG(ctx != nullptr && key != nullptr && value != nullptr, "kh_ctx_get: NULL");
+    if (!strcmp(key, "spmv_dia")) *value = ctx->spmv_dia;
+    else if (!strcmp(key, "chain")) *value = ctx->chain_enabled;
+    else if (!strcmp(key, "chain_lds")) *value = ctx->chain_lds;
+    else if (!strcmp(key, "chain_pf")) *value = ctx->chain_pf;
+    else if (!strcmp(key, "n_chain_pf")) *value = ctx->n_chain_pf;
+    else if (!strcmp(key, "chain_spmv")) *value = ctx->chain_spmv;
+    else if (!strcmp(key, "n_spmm")) *value = ctx->n_spmm;
+    else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
+    else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
     return 0;
 }
 
@@ -1132,6 +1217,51 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
         KH_HIP(hipGetLastError());
         return 0;
     }
+    if (A->kind == KH_MAT_CSR && ncols >= 2 && A->nblk > 0 &&
+        (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) == 0) {
+        // a panel: the matrix is streamed once for all columns (a sharded operator exchanges one halo per
+        // column and stays on the loop below)
+        if (use_dia(ctx, A, Y->col(ycol)) && (Y->ld & 1) == 0) {
+            constexpr int DC = 8;
+            DiaOffs o;
+            o.nd = A->dia_nd;
+            for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < A->dia_nd ? A->dia_off[d] : 0;
+            const unsigned grid = (unsigned)((A->n_rows + 2 * BS - 1) / (2 * BS));
+            for (int64_t c = 0; c < ncols; c += DC) {
+                const int nc = (int)std::min<int64_t>(DC, ncols - c);
+                hipLaunchKernelGGL((k_spmm_dia<DC>), dim3(grid), dim3(BS), 0, ctx->stream, o, A->dia, A->dia_ld,
+                                   A->n_rows, X->col(xcol + c), X->ld, Y->col(ycol + c), Y->ld, nc);
+            }
+            KH_HIP(hipGetLastError());
+            ctx->n_spmm += 1;
+            return 0;
+        }
+        constexpr int DC = 4;
+        const size_t lds = (size_t)A->tile * sizeof(double) * DC;
+        static bool attr_done = false;
+        if (!attr_done) {
+            // 32-64 KB of dynamic LDS: above the 48 KB a kernel gets without asking
+            KH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_stream<4, DC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * BS * 8 * DC));
+            KH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_stream<8, DC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * BS * 8 * DC));
+            KH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmm_stream<16, DC>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 16 * BS * 8 * DC));
+            attr_done = true;
+        }
+#define KH_SPMM(I)                                                                                             \
+    hipLaunchKernelGGL((k_spmm_stream<I, DC>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, \
+                       A->data, A->rowblk, A->nblk, A->tile, X->col(xcol), X->ld, Y->col(ycol), Y->ld, (int)ncols)
+        switch (A->tile / BS) {
+            case 4: KH_SPMM(4); break;
+            case 16: KH_SPMM(16); break;
+            default: KH_SPMM(8); break;
+        }
+#undef KH_SPMM
+        KH_HIP(hipGetLastError());
+        ctx->n_spmm += 1;
+        return 0;
+    }
     for (int64_t c = 0; c < ncols; ++c)
         KH_TRY(apply_one(ctx, A, X->col(xcol + c), Y->col(ycol + c), EPI_NONE, nullptr, nullptr, 0));
     return 0;
@@ -1218,9 +1348,9 @@ int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int
     KH_TRY(check_vec(X, x0, k, "kh_gemm_nn(X)"));
     KH_TRY(check_vec(Y, y0, nc, "kh_gemm_nn(Y)"));
     KH_ARG(X->n == Y->n, "kh_gemm_nn: length mismatch");
-    KH_ARG(k <= 1024, "kh_gemm_nn: inner dimension at most 1024");
     KH_ARG(X != Y, "kh_gemm_nn: X and Y must be different blocks");
-    std::vector<double> coef((size_t)std::max<int64_t>(k, 1));
+    constexpr int64_t KMAX = 1024;      // coefficients staged per pass (SC_COEF region of the device scalars)
+    std::vector<double> coef((size_t)std::max<int64_t>(std::min(k, KMAX), 1));
     double* dev = ctx->scal + SC_COEF;
     for (int64_t c = 0; c < nc; ++c) {
         if (k == 0) {
@@ -1228,10 +1358,15 @@ int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int
             else if (beta != 1.0) KH_TRY(kh_waxpby(ctx, Y, y0 + c, beta, Y, y0 + c, 0.0, Y, y0 + c));
             continue;
         }
-        for (int64_t i = 0; i < k; ++i) coef[i] = alpha * C[i * nc + c];
-        KH_TRY(push_scalars(ctx, coef.data(), k, dev));
-        // y = beta*y - (-1) * sum coef_i x_i  : exact sign flip, additions left to right
-        KH_TRY(multiaxpy_cols(ctx, X, x0, k, dev, -1.0, beta, Y->col(y0 + c), T_NONE, nullptr, nullptr));
+        // a basis longer than KMAX columns (GMRES with maxiter > 1024): passes of KMAX columns, left to right
+        for (int64_t i0 = 0; i0 < k; i0 += KMAX) {
+            const int64_t kk = std::min(KMAX, k - i0);
+            for (int64_t i = 0; i < kk; ++i) coef[i] = alpha * C[(i0 + i) * nc + c];
+            KH_TRY(push_scalars(ctx, coef.data(), kk, dev));
+            // y = beta*y - (-1) * sum coef_i x_i  : exact sign flip, additions left to right
+            KH_TRY(multiaxpy_cols(ctx, X, x0 + i0, kk, dev, -1.0, i0 == 0 ? beta : 1.0, Y->col(y0 + c), T_NONE,
+                                  nullptr, nullptr));
+        }
     }
     return 0;
 }
@@ -1281,6 +1416,21 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
     return 0;
 }
 
+// A step begun while its predecessor (same basis, step k-1) is marked "timed out, to be re-run" would
+// read a garbage column: it is not launched at all, only marked the same way, and kh_arnoldi_step_end runs
+// it when its turn comes (the predecessor has been recovered by then: the host fetches the steps in order).
+static bool step_poisoned(kh_ctx ctx, int slot) {
+    const kh_step_s& st = ctx->step[slot];
+    for (int s2 = 0; s2 < KH_NSLOT; ++s2) {
+        const kh_step_s& o = ctx->step[s2];
+        if (s2 != slot && o.kind != 0 && o.V == st.V && o.k == st.k - 1 && *ctx->chain_err_pin[s2] != 0) {
+            *ctx->chain_err_pin[slot] = 1;
+            return true;
+        }
+    }
+    return false;
+}
+
 // ---- fused hot path -----------------------------------------------------------------------------
 #define KH_LINK(ASRC, TAIL, P, VN, DG, MW, PIN, SIN, AARG, POUT, HS)                                  \
     hipLaunchKernelGGL((k_gs_link<ASRC, TAIL>), dim3(grid), dim3(BS), 0, ctx->stream, n, P, VN, w, DG, \
@@ -1299,16 +1449,34 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     const int64_t pd = proj ? proj->d : 0;
     KH_ARG(proj == nullptr || (proj->W->n == V->n && A != nullptr), "kh_arnoldi_step: projector needs A and length N");
     KH_TRY(ensure_hcap(ctx, std::max<int64_t>(k + 2, V->ncols + 1) + pd));
-    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_arnoldi_step: Md must be a diagonal operator");
+    // Md: the Jacobi preconditioner (diagonal; V = Md P), or - same recurrence with the roles of the blocks swapped,
+    // utils.py:184-193 - the SPD matrix B of a non-Euclidean inner product (diagonal, CSR or dense; V = B P holds
+    // B times the basis, P the basis itself): dots against V, updates with P, norm sqrt(<w, Md w>)
+    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG || Md->kind == KH_MAT_CSR || Md->kind == KH_MAT_DENSE,
+           "kh_arnoldi_step: Md must be a real diagonal, CSR or dense operator");
+    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG || (Md->n_rows == V->n && Md->n_cols == V->n && proj == nullptr),
+           "kh_arnoldi_step: a matrix Md must be N x N (and takes no projector)");
     KH_ARG((Md == nullptr) == (P == nullptr), "kh_arnoldi_step: P and Md go together");
     KH_ARG(P == nullptr || (P->n == V->n && P->ncols >= V->ncols), "kh_arnoldi_step: P shape");
     KH_TRY(check_vec(W, wcol, Md ? 2 : 1, "kh_arnoldi_step(W)"));
     KH_ARG(W->n == V->n, "kh_arnoldi_step: W length");
     const int64_t n = V->n;
+    {
+        kh_step_s& st = ctx->step[slot];
+        st.kind = 1;
+        st.A = A; st.proj = proj; st.Md = Md; st.V = V; st.P = P; st.W = W;
+        st.wcol = wcol; st.k = k; st.start = start; st.sweeps = sweeps; st.gs_mode = gs_mode;
+        st.h_km1[0] = h_km1;
+        if (step_poisoned(ctx, slot)) {     // its predecessor waits to be re-run: so will this one (kh_arnoldi_step_end)
+            KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+            return 0;
+        }
+    }
     kh_vec B = P ? P : V;
     double* w = W->col(wcol);
     double* mw = Md ? W->col(wcol + 1) : nullptr;
-    const double* dg = Md ? Md->diag : nullptr;
+    const bool md_mat = Md != nullptr && Md->kind != KH_MAT_DIAG;      // Md w needs an operator application
+    const double* dg = (Md && !md_mat) ? Md->diag : nullptr;
     const int grid = grid_for(ctx, n);
     const bool multi = kh_multi(ctx);
     double* hdev = ctx->hslot_dev[slot];
@@ -1321,7 +1489,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     if (presub && h_km1 != h_km1) hk_dev = ctx->hslot_dev[(slot + KH_NSLOT - 1) % KH_NSLOT] + k;
     // reference-order MGS: keep w in registers for the whole chain when it fits (chain.h)
     int cr2 = 0, cg = 0;
-    const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) &&
+    const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) && !md_mat &&
                              chain_geometry(ctx, n, &cr2, &cg));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
                             A->nblk > 0 && !want_chain && proj == nullptr);
@@ -1410,6 +1578,9 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                 const double* vn = V->col(colof(t));
                 if (src == A_PART) KH_LINK(A_PART, T_DOT, pcol, vn, nullptr, nullptr, pin, nullptr, 0.0, pout, hs);
                 else KH_LINK(A_SCAL, T_DOT, pcol, vn, nullptr, nullptr, nullptr, tmp, 0.0, pout, hs);
+            } else if (md_mat) {      // last update only; Md w and <w, Md w> follow below
+                if (src == A_PART) KH_LINK(A_PART, T_NONE, pcol, nullptr, nullptr, nullptr, pin, nullptr, 0.0, nullptr, hs);
+                else KH_LINK(A_SCAL, T_NONE, pcol, nullptr, nullptr, nullptr, nullptr, tmp, 0.0, nullptr, hs);
             } else if (Md) {
                 if (src == A_PART) KH_LINK(A_PART, T_NRM_DIAG, pcol, nullptr, dg, mw, pin, nullptr, 0.0, pout, hs);
                 else KH_LINK(A_SCAL, T_NRM_DIAG, pcol, nullptr, dg, mw, nullptr, tmp, 0.0, pout, hs);
@@ -1453,9 +1624,18 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
             // needed: one tiny axpy on scalars)
             hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0,
                                hdev + start, 1.0, coef);
-            const int tail = (s == sweeps - 1) ? (Md ? T_NRM_DIAG : T_NRM) : T_NONE;
+            const int tail = (s == sweeps - 1 && !md_mat) ? (Md ? T_NRM_DIAG : T_NRM) : T_NONE;
             KH_TRY(multiaxpy_cols(ctx, B, start, ncol, coef, 1.0, 1.0, w, tail, dg, mw));
         }
+    }
+    if (md_mat) {
+        // non-Euclidean inner product with a matrix B: mw = B w, then the partial sums of <w, B w>
+        KH_TRY(apply_one(ctx, Md, w, mw, EPI_NONE, nullptr, nullptr, 0));
+        ColPtrs cp;
+        cp.c[0] = mw;
+        launch_multidot<1>(ctx, n, cp, w, nrm_part);
+        KH_HIP(hipGetLastError());
+        nrm_count = grid;
     }
     // 3. norm and normalise
     if (!chained) {
@@ -1485,14 +1665,34 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
            "kh_arnoldi_step_end: slot %d / count %lld", slot, (long long)count);
     KH_ARG(ctx->hev[slot] != nullptr, "kh_arnoldi_step_end: no step was begun");
     KH_HIP(hipEventSynchronize(ctx->hev[slot]));
-    memcpy(hcol_out, ctx->hslot_pin[slot], sizeof(double) * count);
     if (*ctx->chain_err_pin[slot] != 0) {
+        // The grid-wide reduction of the chain kernel timed out (its workgroups were not co-resident: a shared
+        // or partially masked GPU).  Column k+1 of the basis and this H column are garbage, columns 0..k are
+        // intact: switch the chain off for this context and run the SAME step again on the per-column kernels.
+        // Steps begun after it (look-ahead) consumed the garbage; each of them reports the error in its own
+        // slot and is recovered in turn when the host asks for it, in order.
         *ctx->chain_err_pin[slot] = 0;
         ctx->chain_enabled = 0;
-        (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
-        return fail(KH_ERR_HIP, "grid-wide reduction of the MGS chain kernel timed out (workgroups not "
-                                "co-resident?); the chain path is now disabled for this context");
+        ctx->n_chain_recovered += 1;
+        KH_HIP(hipStreamSynchronize(ctx->stream));
+        KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
+        for (int s2 = 0; s2 < KH_NSLOT; ++s2)      // later steps in flight saw the same error word
+            if (s2 != slot && *ctx->chain_err_pin[s2] == 0 && ctx->step[s2].kind != 0 &&
+                ctx->step[s2].V == ctx->step[slot].V && ctx->step[s2].k > ctx->step[slot].k)
+                *ctx->chain_err_pin[s2] = 1;
+        const kh_step_s st = ctx->step[slot];
+        if (st.kind == 1)
+            KH_TRY(kh_arnoldi_step_begin(ctx, st.A, st.proj, st.Md, st.V, st.P, st.W, st.wcol, st.k, st.start, st.sweeps,
+                                         st.gs_mode, st.h_km1[0], slot));
+        else if (st.kind == 2)
+            KH_TRY(kh_zarnoldi_step_begin(ctx, st.A, st.V, st.W, st.wcol, st.k, st.start, st.sweeps, st.gs_mode,
+                                          st.h_km1, slot));
+        else
+            return fail(KH_ERR_HIP, "grid-wide reduction of the MGS chain kernel timed out and the step cannot be "
+                                    "re-run (no record of it)");
+        KH_HIP(hipEventSynchronize(ctx->hev[slot]));
     }
+    memcpy(hcol_out, ctx->hslot_pin[slot], sizeof(double) * count);
     return 0;
 }
 

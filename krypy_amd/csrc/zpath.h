@@ -621,6 +621,17 @@ int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wco
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_zarnoldi_step_begin: k=%lld needs %lld basis columns, have %lld",
            (long long)k, (long long)(k + 2), (long long)V->ncols);
     KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1))));
+    {
+        kh_step_s& st = ctx->step[slot];
+        st.kind = 2;
+        st.A = A; st.proj = nullptr; st.Md = nullptr; st.V = V; st.P = nullptr; st.W = W;
+        st.wcol = wcol; st.k = k; st.start = start; st.sweeps = sweeps; st.gs_mode = gs_mode;
+        st.h_km1[0] = h_km1[0]; st.h_km1[1] = h_km1[1];
+        if (step_poisoned(ctx, slot)) {
+            KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+            return 0;
+        }
+    }
     double* hdev = ctx->hslot_dev[slot];
     const double* hk_dev = nullptr;
     if (start > 0 && start == k && h_km1[0] != h_km1[0])

@@ -1027,6 +1027,7 @@ class Arnoldi(object):
         self._V = ctx.alloc(N, self._cols, dtype=bdt, zero=False)
         self._P = ctx.alloc(N, self._cols, dtype=bdt, zero=False) if self.M is not None else None
         self._W = ctx.alloc(N, 2, dtype=bdt)
+        self._BV = None
         self.H = numpy.zeros((self.maxiter + 1, self.maxiter), dtype=self.dtype)
         self._h2 = 0.0   # running sum of squares of H (Frobenius), for the invariance pre-test
         # fused device path: Euclidean inner product, M a plain diagonal (or absent)
@@ -1038,6 +1039,19 @@ class Arnoldi(object):
                 self._Md = md
         # (the complex step kernel takes no preconditioner: complex + M runs the general loop)
         self._fused = self._euclid and (self.M is None or self._Md is not None)
+        # Non-Euclidean inner product <x, y> = x^T B y with B a real matrix on the device (utils.py:184-193) and no
+        # preconditioner: the step kernel's preconditioned recurrence with the roles of its two blocks swapped -
+        # a second block BV = B V travels with the basis, the coefficients are <B v_j, w>, the updates w -= alpha v_j,
+        # the norm sqrt(<w, B w>) - one C call and one host synchronisation per step instead of one per coefficient.
+        self._ipB = None
+        if (not self._euclid and self.M is None and not cplx and ortho in _GS_OF_ORTHO):
+            try:
+                Bop = get_linearoperator((N, N), ip_B)
+            except TypeError:
+                Bop = None          # a user callable: the general loop hands it host arrays
+            bm = Bop._device_matrix() if Bop is not None else None
+            if bm is not None and bm.dtype == _hip._F64 and bm.kind in ("diag", "csr", "dense"):
+                self._ipB = bm
         self._Amat = self.A._device_matrix(ctx, bdt) if self._fused else None
         # deflated solvers hand in  P * MlAMr  with P the complement of a device projector: the
         # projection then runs inside the fused step and <U, A v_k> comes back with the H column
@@ -1080,6 +1094,9 @@ class Arnoldi(object):
             ctx.vdiv(self._V, 0, v.block, v.col, float(self.vnorm))
         else:
             self.invariant = True
+        if self._ipB is not None and ortho != "house":
+            self._BV = ctx.alloc(N, self._cols, dtype=bdt, zero=False)
+            ctx.apply(self._ipB, self._V, 0, self._BV, 0, 1)
 
     _WINDOW_COLS = 66        # columns of the sliding Lanczos window (re-based every 64 steps)
     _BASIS_SHARE = 0.30      # share of device memory the first allocation of V (and P) may take
@@ -1131,7 +1148,7 @@ class Arnoldi(object):
             return
         cols = min(self.maxiter + 1, max(need, 2 * self._cols))
         done = self.iter + 1
-        for name in ("_V", "_P"):
+        for name in ("_V", "_P", "_BV"):
             old = getattr(self, name)
             if old is None:
                 continue
@@ -1266,6 +1283,15 @@ class Arnoldi(object):
             hn = float(numpy.real(hcol[k + 1 - off]))
         elif self.ortho == "house":
             hn = self._advance_house(k)
+        elif self._BV is not None:
+            # inner product matrix on the device: dots against BV, updates with V, norm sqrt(<w, B w>)
+            self.A._apply_dev(self._V, k, self._W, 0, 1)
+            self._claim(0)
+            hcol = ctx.arnoldi_step(None, self._ipB, self._BV, self._V, self._W, 0, k, start, self._sweeps,
+                                    self._gs_mode, h_km1)
+            self._release(0)
+            H[start: k + 1, k] += hcol[start: k + 1]
+            hn = float(hcol[k + 1])
         else:
             hn = self._advance_general(k, start, h_km1)
         H[k + 1, k] = hn

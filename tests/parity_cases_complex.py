@@ -27,7 +27,15 @@ def check_run(sol, g, tag, tol=RTOL, explicit_tol=1e-6, xtol=1e-9):
     got, want = np.asarray(sol.resnorms), g[tag + "_resnorms"]
     assert len(got) == len(want), (tag, len(got), len(want))
     assert np.max(np.abs(got[:-1] - want[:-1]) / want[:-1]) < tol, tag
-    assert abs(got[-1] - want[-1]) / want[-1] < explicit_tol, tag
+    # The last entry is the EXPLICIT residual ||b - A x_k|| / ||b|| at the 1e-10 level: b - A x_k cancels
+    # ten digits, so two correct evaluations (different summation orders of the dot products, of the SpMV
+    # rows, of x_k = x_0 + V y) differ by about eps * (||A|| ||x_k|| + ||b||) / ||b|| in absolute terms.  The bound
+    # is computed from the run itself (||A||_1 <= 9 for these stencil matrices with their complex shifts).
+    ls = sol.linear_system
+    xn = float(np.linalg.norm(sol.xk))
+    bn = float(np.linalg.norm(np.asarray(ls.b)))
+    cancel = 64 * np.finfo(float).eps * (9.0 * xn + bn) / bn / want[-1]
+    assert abs(got[-1] - want[-1]) / want[-1] < max(explicit_tol, cancel), (tag, got[-1], want[-1], cancel)
     assert crel(sol.xk[:, 0], g[tag + "_xk"]) < xtol, tag
 
 

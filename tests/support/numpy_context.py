@@ -262,7 +262,7 @@ class NumpyContext(object):
                     w = w - h[j - start] * B.a[:, j]
         W.a[:, wcol] = w        # (before the store of v_{k+1}: W may alias the basis block, in-place QR)
         if Md is not None:
-            mw = Md.mat * w
+            mw = self._matvec(Md, w)      # Jacobi diagonal, or the SPD matrix of a non-Euclidean inner product
             W.a[:, wcol + 1] = mw
             hn = float(np.sqrt(abs(self._allreduce(np.array([np.dot(w, mw)]))[0])))
             with np.errstate(divide="ignore", invalid="ignore"):

@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+from krypy_amd import linsys, utils
 from oracle import krylov_ref as ref
 from oracle.inputs import lap2d_system
 from tests import parity_cases as pc
@@ -120,6 +121,89 @@ def test_csr_spmv_bit_identical_to_scipy(hip, kind):
         mask[7] = False
         assert np.array_equal(got[mask], want[mask])
         assert np.allclose(got[7], want[7], rtol=1e-12)    # tree-reduced row: not bit-ordered
+    else:
+        assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("solver", ["gmres", "minres", "gmres_complex"])
+def test_chain_timeout_is_recovered(hip, solver):
+    """A timeout of the chain kernel's grid-wide reduction (workgroups not co-resident on a shared GPU) must
+    not fail the solve: kh_arnoldi_step_end switches the chain off and runs the step again on the per-column
+    kernels from the intact columns 0..k - also when look-ahead steps were already in flight on the garbage.
+    kh_ctx_set("chain_fault", 1) makes the next chain launch set the error word and halve every coefficient."""
+    A = ref.laplace2d(300, 220)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(A.shape[0])
+    kw = dict(maxiter=40, tol=1e-30)
+    if solver == "gmres_complex":
+        A = (A + 0.3j * sp.diags(rng.standard_normal(A.shape[0]))).tocsr()
+        b = b + 1j * rng.standard_normal(A.shape[0])
+
+    def run(fault_at):
+        hip.set("chain", 1)
+        ls = linsys.LinearSystem(A, b, self_adjoint=(solver == "minres"))
+        cls = linsys.Minres if solver == "minres" else linsys.Gmres
+
+        class Faulty(cls):
+            def _finalize_iteration(self, yk, resnorm):
+                if self.iter == fault_at:
+                    hip.set("chain_fault", 1)
+                return super(Faulty, self)._finalize_iteration(yk, resnorm)
+
+        before = hip.get("n_chain_recovered")
+        try:
+            sol = Faulty(ls, **kw)
+        except utils.ConvergenceError as e:
+            sol = e.solver
+        return sol, hip.get("n_chain_recovered") - before
+
+    try:
+        good, n0 = run(-1)
+        bad, n1 = run(7)
+    finally:
+        hip.set("chain", 1)
+    assert n0 == 0 and n1 >= 1, (n0, n1)
+    assert hip.get("chain") == 1
+    assert len(bad.resnorms) == len(good.resnorms) == 41
+    # the per-column kernels and the chain kernel differ in the order of their partial sums only
+    # (test_mgs_chain_every_register_shape): the recovered solve is the undisturbed one to rounding
+    assert np.max(np.abs(np.asarray(bad.resnorms) - np.asarray(good.resnorms)) / np.asarray(good.resnorms)) < 1e-9
+    assert np.linalg.norm(bad.xk - good.xk) < 1e-9 * np.linalg.norm(good.xk)
+
+
+@pytest.mark.parametrize("kind", ["lap2d_banded", "lap2d_csr", "random", "long_row"])
+@pytest.mark.parametrize("d", [1, 2, 5, 16, 32])
+def test_csr_panel_apply_streams_the_matrix_once(hip, kind, d):
+    """kh_apply of a CSR operator to a block of d vectors (A U of the deflation set-up, deflation.py:47; Ritz
+    residuals, deflation.py:849-855): ONE pass over the matrix (k_spmm_stream / k_spmm_dia), every column
+    bit-identical to scipy's A.dot(X) (csr_matvecs adds a row's products left to right, per column)."""
+    rng = np.random.default_rng(17)
+    if kind.startswith("lap2d"):
+        A = ref.laplace2d(301, 97)
+    elif kind == "random":
+        A = sp.random(30011, 30011, density=1e-3, random_state=8, format="csr")
+    else:
+        A = sp.random(300, 40000, density=1e-3, random_state=5, format="lil")
+        A[11, :] = rng.standard_normal(40000)
+        A = A.tocsr()
+    A.sort_indices()
+    hip.set("spmv_dia", 0 if kind == "lap2d_csr" else 1)
+    try:
+        Ad = hip.csr(A)
+        assert (Ad.diagonals > 0) == kind.startswith("lap2d")
+        x = rng.standard_normal((A.shape[1], d))
+        X, Y = hip.upload(x), hip.alloc(A.shape[0], d + 1)
+        before = hip.get("n_spmm")
+        hip.apply(Ad, X, 0, Y, 1, d)                       # (an offset in the output block, too)
+        got, want = Y.download(1, d), A.dot(x)
+        assert hip.get("n_spmm") - before == (1 if d >= 2 else 0)
+    finally:
+        hip.set("spmv_dia", 1)
+    if kind == "long_row":
+        mask = np.ones(A.shape[0], bool)
+        mask[11] = False
+        assert np.array_equal(got[mask], want[mask])
+        assert np.allclose(got[11], want[11], rtol=1e-12)   # tree-reduced row: not bit-ordered
     else:
         assert np.array_equal(got, want)
 
@@ -498,14 +582,18 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
-@pytest.mark.parametrize("rows", [8, 16, 24, 32, 40])
+@pytest.mark.parametrize("rows", [8, 16, 24, 32, 40, 48, 56])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_mgs_chain_every_register_shape(hip, rows, cplx):
     """The chain kernel is instantiated for 4 ... 40 `double2` rows of w per lane; the vector length
     picks the instantiation.  One size per shape (real and complex, i.e. the LDS-parking kernel in both
     flavours): chain == per-column link kernels up to the order of the partial sums, and the
     Arnoldi relation A V_m = V_{m+1} H holds."""
-    n2 = {8: 700_000, 16: 1_500_000, 24: 2_800_000, 32: 3_900_000, 40: 5_000_000}[rows]   # double2 per vector
+    if cplx and rows > 40:
+        pytest.skip("48 / 56 rows per lane (part of w in LDS) exist for real vectors")
+    # 48 / 56: vectors beyond what the register file holds (N = 12 M / 14 M: config 5's 12.5 M-row shards)
+    n2 = {8: 700_000, 16: 1_500_000, 24: 2_800_000, 32: 3_900_000, 40: 5_000_000, 48: 6_000_000,
+          56: 7_000_000}[rows]   # double2 per vector
     n = n2 if cplx else 2 * n2                     # complex entries are one double2 each
     rng = np.random.default_rng(rows)
     A = sp.diags([np.full(n - 1, -1.0), np.linspace(2.0, 3.0, n), np.full(n - 1, -1.0)], [-1, 0, 1]).tocsr()
@@ -523,6 +611,7 @@ def test_mgs_chain_every_register_shape(hip, rows, cplx):
         H = np.zeros((m + 1, m), dtype=dt)
         for k in range(m):
             H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 0)
+        assert ctx.counters()["chain"] == (m if chain else 0)      # the one-launch kernel really ran
         res.append((H, V.download()))
         ctx.close()
     (Hc, Vc), (Hl, Vl) = res
@@ -544,6 +633,7 @@ def test_mgs_chain_every_register_shape(hip, rows, cplx):
         H = np.zeros((m + 1, m))
         for k in range(m):
             H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 1)
+        assert (ctx.counters()["cgs_register"] > 0) == chain
         res.append((H, V.download()))
         ctx.close()
     (Hc, Vc), (Hl, Vl) = res
