@@ -372,8 +372,8 @@ struct ChainShape {
 // multiply of NumPy (separate roundings), H entries are (re, im) pairs in hdev.
 // Fused operator of the chain kernels (FND > 0 diagonals of a banded operator, krylov_hip.hip builds the
 // diagonal-major copy): this lane's rows of w = A x_k, computed straight into the registers that hold w.
-template <int R2, int FND>
-__device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, double2 (&w)[R2]) {
+template <int R2, int FND, class Put>
+__device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, Put&& put) {
     // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
     // separate multiply and add, empty slots skipped): the 80 MB of w are never written nor read.
     // The padding rows behind n hold zeros in every diagonal and come out as w = 0.
@@ -405,8 +405,7 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
             s0 = (av[d].x != 0.0) ? s0 + p0 : s0;
             s1 = (av[d].y != 0.0) ? s1 + p1 : s1;
         }
-        w[r].x = s0;
-        w[r].y = s1;
+        put(r, s0, s1);         // (row r of w: a register, or - long shapes - this lane's LDS entry)
         i2 += CH_BS;
         if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight (one: 1023 it/s, two: 1028-1037, four: 1018-1030)
     }
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     double2 w[RW];
     double2 ring[2][PB];
     if constexpr (FND > 0) {
-        chain_apply_banded<R2, FND>(a, first, w);
+        chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
@@ -642,7 +641,11 @@ struct ChainShapeLds {
     static constexpr int LB = NB >= 4 ? 3 : 1;                // leading batches kept in LDS
     static constexpr int NG = NB - LB - 1;                    // update batches that still come from memory
     static_assert((NB % 2) == 0 && NG >= 0 && (NG % 2) == 0, "ring parity must reset every phase");
-    static constexpr size_t LDS_BYTES = (size_t)LB * PB * CH_BS * sizeof(double2);
+    // R2 = 40 fills the register file to the last VGPR (w alone takes 160 of the 256); the 36 KB of LDS the parked
+    // batches leave free take the last WL = 4 rows of w instead (k_mgs_chain's W_GET / W_PUT): 16 registers back,
+    // no scratch traffic in the link loop (18 spilled registers with the operator in the prologue otherwise)
+    static constexpr int WL = (R2 == 40 && !CPLX) ? 4 : 0;
+    static constexpr size_t LDS_BYTES = (size_t)(LB * PB + WL) * CH_BS * sizeof(double2);
 };
 
 template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
@@ -652,7 +655,16 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     constexpr int NB = ChainShapeLds<R2, CPLX>::NB;
     constexpr int LB = ChainShapeLds<R2, CPLX>::LB;
     constexpr int NG = ChainShapeLds<R2, CPLX>::NG;
-    extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB][CH_BS]
+    constexpr int WL = ChainShapeLds<R2, CPLX>::WL;
+    constexpr int RW = R2 - WL;                   // rows of w in registers
+    extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB parked rows + WL rows of w][CH_BS]
+    double2* const wl = vlds + (size_t)LB * PB * CH_BS;
+#define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
+#define W_PUT(r, val)                                   \
+    do {                                                \
+        if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
+        else wl[((r) - RW) * CH_BS + tid] = (val);      \
+    } while (0)
     __shared__ double smd[2 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
@@ -667,17 +679,19 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     // keeps it; everything that is used once (the batches that live on in LDS / the ring, the second
     // read itself, w) is loaded non-temporally and does not evict it
 #define CH_LD(ptr, reuse) ((reuse) ? *(ptr) : ld_nt2(ptr))
-    double2 w[R2];
+    double2 w[RW];
     double2 ring[2][PB];
     if constexpr (FND > 0) {
-        chain_apply_banded<R2, FND>(a, first, w);
+        chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
-            w[r].x = CH_OK(r) ? v.x : 0.0;
-            w[r].y = CH_OK(r) ? v.y : 0.0;
+            double2 t;
+            t.x = CH_OK(r) ? v.x : 0.0;
+            t.y = CH_OK(r) ? v.y : 0.0;
+            W_PUT(r, t);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
@@ -687,8 +701,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 p = p2[(int64_t)r * CH_BS];
-            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
-            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
+            double2 t = W_GET(r);
+            t.x = CH_OK(r) ? t.x - hk * p.x : 0.0;
+            t.y = CH_OK(r) ? t.y - hk * p.y : 0.0;
+            W_PUT(r, t);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
@@ -725,14 +741,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             for (int i = 0; i < PB; ++i) {
                 const double2 v = ring[b & 1][i];
                 if (b < LB) vlds[(b * PB + i) * CH_BS + tid] = v;
+                const double2 wr = W_GET(b * PB + i);
                 if (CPLX) {
-                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                    acc0 = fma(v.y, w[b * PB + i].y, acc0);
-                    acc1 = fma(v.x, w[b * PB + i].y, acc1);
-                    acc1 = fma(-v.y, w[b * PB + i].x, acc1);
+                    acc0 = fma(v.x, wr.x, acc0);
+                    acc0 = fma(v.y, wr.y, acc0);
+                    acc1 = fma(v.x, wr.y, acc1);
+                    acc1 = fma(-v.y, wr.x, acc1);
                 } else {
-                    acc0 = fma(v.x, w[b * PB + i].x, acc0);
-                    acc1 = fma(v.y, w[b * PB + i].y, acc1);
+                    acc0 = fma(v.x, wr.x, acc0);
+                    acc1 = fma(v.y, wr.y, acc1);
                 }
             }
         }
@@ -762,15 +779,17 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         // ---- update phase: w -= alpha * v_j, batches in reverse order ----
 #define CH_UPD(r, p)                                              \
     do {                                                          \
+        double2 wr_ = W_GET(r);                                   \
         if (CPLX) {                                               \
             const double tr = alpha * (p).x - alpha_i * (p).y;    \
             const double ti = alpha * (p).y + alpha_i * (p).x;    \
-            w[r].x = CH_OK(r) ? w[r].x - tr : 0.0;                \
-            w[r].y = CH_OK(r) ? w[r].y - ti : 0.0;                \
+            wr_.x = CH_OK(r) ? wr_.x - tr : 0.0;                  \
+            wr_.y = CH_OK(r) ? wr_.y - ti : 0.0;                  \
         } else {                                                  \
-            w[r].x = CH_OK(r) ? w[r].x - alpha * (p).x : 0.0;     \
-            w[r].y = CH_OK(r) ? w[r].y - alpha * (p).y : 0.0;     \
+            wr_.x = CH_OK(r) ? wr_.x - alpha * (p).x : 0.0;       \
+            wr_.y = CH_OK(r) ? wr_.y - alpha * (p).y : 0.0;       \
         }                                                         \
+        W_PUT(r, wr_);                                            \
     } while (0)
         // (a) the last batch of the dot phase is still in ring[1]
 #pragma unroll
@@ -808,15 +827,17 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             const double2 d = d2[(int64_t)r * CH_BS];
-            acc = fma(w[r].x, d.x * w[r].x, acc);
-            acc = fma(w[r].y, d.y * w[r].y, acc);
+            const double2 wr = W_GET(r);
+            acc = fma(wr.x, d.x * wr.x, acc);
+            acc = fma(wr.y, d.y * wr.y, acc);
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            acc = fma(w[r].x, w[r].x, acc);
-            acc = fma(w[r].y, w[r].y, acc);
+            const double2 wr = W_GET(r);
+            acc = fma(wr.x, wr.x, acc);
+            acc = fma(wr.y, wr.y, acc);
         }
     }
     const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
@@ -830,11 +851,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
                 const double2 d = d2[(int64_t)r * CH_BS];
+                const double2 wr = W_GET(r);
                 double2 o, m;
-                o.x = w[r].x / h;
-                o.y = w[r].y / h;
-                m.x = (d.x * w[r].x) / h;
-                m.y = (d.y * w[r].y) / h;
+                o.x = wr.x / h;
+                o.y = wr.y / h;
+                m.x = (d.x * wr.x) / h;
+                m.y = (d.y * wr.y) / h;
                 pn2[(int64_t)r * CH_BS] = o;
                 vn2[(int64_t)r * CH_BS] = m;
             }
@@ -843,9 +865,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
             if (r * CH_BS < rem) {
+                const double2 wr = W_GET(r);
                 double2 o;
-                o.x = w[r].x / h;
-                o.y = w[r].y / h;
+                o.x = wr.x / h;
+                o.y = wr.y / h;
                 vn2[(int64_t)r * CH_BS] = o;
             }
         }
@@ -856,6 +879,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+#undef W_PUT
+#undef W_GET
 #undef CH_LD
 #undef CH_OK
 }
@@ -937,7 +962,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
     double2 w[R2];
     double2 ring[2][PB];
     if constexpr (FND > 0) {
-        chain_apply_banded<R2, FND>(a, first, w);
+        chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { w[r] = make_double2(s0, s1); });
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll

@@ -75,20 +75,20 @@ int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
     return 0;
 }
 
-int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x) {
+int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream) {
     if (ctx->comm == nullptr) return 0;
     const int64_t nloc = A->n_rows;
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     KH_NCCL(g_rccl.GroupStart());
     if (ctx->rank > 0) {
-        if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, A->nsend_prev, ncclDouble, ctx->rank - 1, comm, ctx->stream));
-        if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(A->ghost, A->nrecv_prev, ncclDouble, ctx->rank - 1, comm, ctx->stream));
+        if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, A->nsend_prev, ncclDouble, ctx->rank - 1, comm, stream));
+        if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(A->ghost, A->nrecv_prev, ncclDouble, ctx->rank - 1, comm, stream));
     }
     if (ctx->rank + 1 < ctx->nranks) {
         if (A->nsend_next)
-            KH_NCCL(g_rccl.Send(x + (nloc - A->nsend_next), A->nsend_next, ncclDouble, ctx->rank + 1, comm, ctx->stream));
+            KH_NCCL(g_rccl.Send(x + (nloc - A->nsend_next), A->nsend_next, ncclDouble, ctx->rank + 1, comm, stream));
         if (A->nrecv_next)
-            KH_NCCL(g_rccl.Recv(A->ghost + A->nrecv_prev, A->nrecv_next, ncclDouble, ctx->rank + 1, comm, ctx->stream));
+            KH_NCCL(g_rccl.Recv(A->ghost + A->nrecv_prev, A->nrecv_next, ncclDouble, ctx->rank + 1, comm, stream));
     }
     KH_NCCL(g_rccl.GroupEnd());
     return 0;
@@ -126,6 +126,13 @@ int kh_comm_init(kh_ctx ctx, int rank, int nranks, const unsigned char id[128]) 
         ctx->force_multi = (e != nullptr && atoi(e) != 0) ? 1 : 0;
     }
     KH_HIP(hipMalloc(&ctx->commbuf, sizeof(double) * kh::SCAL_CAP));
+    KH_HIP(hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking));
+    KH_HIP(hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming));
+    KH_HIP(hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+    {
+        const char* e = getenv("KRYPY_AMD_SPMV_SPLIT");
+        ctx->spmv_split = (e == nullptr) ? 1 : atoi(e);
+    }
     return 0;
 }
 
@@ -139,6 +146,14 @@ int kh_comm_destroy(kh_ctx ctx) {
     ctx->rank = 0;
     (void)hipFree(ctx->commbuf);
     ctx->commbuf = nullptr;
+    if (ctx->comm_stream) {
+        (void)hipStreamSynchronize(ctx->comm_stream);
+        (void)hipStreamDestroy(ctx->comm_stream);
+        (void)hipEventDestroy(ctx->ev_x);
+        (void)hipEventDestroy(ctx->ev_halo);
+        ctx->comm_stream = nullptr;
+        ctx->ev_x = ctx->ev_halo = nullptr;
+    }
     return 0;
 }
 

@@ -440,10 +440,14 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                                                     const double* __restrict__ ghost,
                                                     double* __restrict__ y,
                                                     const double* __restrict__ aux,
-                                                    double* __restrict__ part_out) {
+                                                    double* __restrict__ part_out,
+                                                    int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0) {
     extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products
     __shared__ double sm[8];
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    // a launch over a subset of the row blocks (interior / boundary rows of a shard, krylov_hip.hip): the
+    // launch's blocks 0 .. blk_lo-1 are themselves, the others lie blk_skip further on
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    bid = bid < blk_lo ? bid : bid + blk_skip;
     const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
     const int nz0 = indptr[r0], nz1 = indptr[r1];
     const int cnt = nz1 - nz0;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
     }
     if (EPI != EPI_NONE) {
         const double r = block_sum(acc, sm);
-        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+        if (threadIdx.x == 0) part_out[part_off + blockIdx.x] = r;
     }
 }
 
@@ -632,9 +636,12 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                                                  const double* __restrict__ ghost, int nprev,
                                                  int nnext, double* __restrict__ y,
                                                  const double* __restrict__ aux,
-                                                 double* __restrict__ part_out) {
+                                                 double* __restrict__ part_out,
+                                                 int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0) {
     __shared__ double sm[8];
-    const int64_t base = (int64_t)xcd_remap(blockIdx.x, nblk) * (2 * BS * RPT);
+    int lb = xcd_remap(blockIdx.x, gridDim.x);       // (subset launches: see k_spmv_stream)
+    lb = lb < blk_lo ? lb : lb + blk_skip;
+    const int64_t base = (int64_t)lb * (2 * BS * RPT);
     const int64_t last = n - 1;
     const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     double s0[RPT], s1[RPT];
@@ -709,7 +716,7 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
     }
     if (EPI != EPI_NONE) {
         const double r = block_sum(acc, sm);
-        if (threadIdx.x == 0) part_out[blockIdx.x] = r;
+        if (threadIdx.x == 0) part_out[part_off + blockIdx.x] = r;
     }
 }
 

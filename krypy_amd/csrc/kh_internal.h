@@ -93,6 +93,11 @@ struct kh_ctx_s {
     void* comm = nullptr;
     int rank = 0, nranks = 1;
     int force_multi = 0;   // tests: run the multi-rank code path on a 1-rank communicator
+    // sharded SpMV: the halo exchange runs on its own stream while the interior rows are multiplied
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_x = nullptr, ev_halo = nullptr;
+    int spmv_split = 1;
+    int64_t n_spmv_split = 0;
     double* commbuf = nullptr;  // device staging for host all-reduces
 };
 
@@ -131,6 +136,8 @@ struct kh_mat_s {
     // halo of a block-row shard
     int64_t nsend_prev = 0, nsend_next = 0, nrecv_prev = 0, nrecv_next = 0;
     double* ghost = nullptr;    // nrecv_prev + nrecv_next doubles
+    // row blocks [b0, b1) of the banded / the CSR-stream kernel touch no ghost column (interior of the slab)
+    int dia_b0 = 0, dia_b1 = 0, csr_b0 = 0, csr_b1 = 0;
 };
 
 // true when reductions must be all-reduced / halos exchanged (several ranks, or a 1-rank
@@ -152,7 +159,7 @@ struct kh_proj_s {
 namespace kh {
 // comm.hip
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
-int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x);
+int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream);
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
 }  // namespace kh

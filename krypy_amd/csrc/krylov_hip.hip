@@ -186,34 +186,51 @@ static int multiaxpy_cols(kh_ctx ctx, kh_vec X, int64_t j0, int64_t nc, const do
 }
 
 // ---- operator application -------------------------------------------------------------------
+// which row blocks of the operator a launch covers: all of them, or - for a shard whose halo is still on its
+// way - the blocks [lo, hi) of interior rows / the blocks outside (boundary rows); `off` = first partial-sum slot
+struct SpmvRange {
+    int grid = -1;                 // -1: every block
+    int blk_lo = 0x7fffffff, blk_skip = 0, part_off = 0;
+    static SpmvRange interior(int lo, int hi) { SpmvRange r; r.grid = hi - lo; r.blk_lo = 0; r.blk_skip = lo; r.part_off = 0; return r; }
+    static SpmvRange boundary(int lo, int hi, int nblk) {
+        SpmvRange r; r.grid = lo + (nblk - hi); r.blk_lo = lo; r.blk_skip = hi - lo; r.part_off = hi - lo; return r;
+    }
+};
+
 template <int EPI, int ITEMS>
-static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux, const SpmvRange& rg) {
     const size_t lds = (size_t)A->tile * sizeof(double);
-    hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr,
+    const int grid = rg.grid < 0 ? A->nblk : rg.grid;
+    if (grid == 0) return;
+    hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(grid), dim3(BS), lds, ctx->stream, A->indptr,
                        A->indices, A->data, A->rowblk, A->nblk, A->tile,
-                       A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part);
+                       A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part, rg.blk_lo, rg.blk_skip,
+                       rg.part_off);
 }
 
 template <int EPI, int ND, int RPT, bool HALO>
-static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* x, double* y, const double* aux) {
-    hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT, HALO>), dim3(A->dia_nblk), dim3(BS), 0, ctx->stream, o, A->dia,
+static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* x, double* y, const double* aux,
+                          const SpmvRange& rg) {
+    const int grid = rg.grid < 0 ? A->dia_nblk : rg.grid;
+    if (grid == 0) return;
+    hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT, HALO>), dim3(grid), dim3(BS), 0, ctx->stream, o, A->dia,
                        A->dia_ld, A->n_rows, A->dia_nblk, x, A->ghost, (int)A->nrecv_prev, (int)A->nrecv_next, y,
-                       aux, A->part);
+                       aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off);
 }
 
 template <int EPI>
-static void launch_dia(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+static void launch_dia(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux, const SpmvRange& rg) {
     DiaOffs o;
     o.nd = A->dia_nd;
     for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < A->dia_nd ? A->dia_off[d] : 0;
     // rows per workgroup = 2 * BS * RPT (fixed at upload: dia_ld covers whole workgroups)
 #define KH_DIA_RPT(R, H)                                                            \
     switch (A->dia_nd) {                                                            \
-        case 3: launch_dia_nd<EPI, 3, R, H>(ctx, A, o, x, y, aux); break;           \
-        case 5: launch_dia_nd<EPI, 5, R, H>(ctx, A, o, x, y, aux); break;           \
-        case 7: launch_dia_nd<EPI, 7, R, H>(ctx, A, o, x, y, aux); break;           \
-        case 9: launch_dia_nd<EPI, 9, R, H>(ctx, A, o, x, y, aux); break;           \
-        default: launch_dia_nd<EPI, 0, R, H>(ctx, A, o, x, y, aux); break;          \
+        case 3: launch_dia_nd<EPI, 3, R, H>(ctx, A, o, x, y, aux, rg); break;           \
+        case 5: launch_dia_nd<EPI, 5, R, H>(ctx, A, o, x, y, aux, rg); break;           \
+        case 7: launch_dia_nd<EPI, 7, R, H>(ctx, A, o, x, y, aux, rg); break;           \
+        case 9: launch_dia_nd<EPI, 9, R, H>(ctx, A, o, x, y, aux, rg); break;           \
+        default: launch_dia_nd<EPI, 0, R, H>(ctx, A, o, x, y, aux, rg); break;          \
     }
     if (A->nrecv_prev + A->nrecv_next > 0) { KH_DIA_RPT(4, true) }      // shard with ghost rows: dia_rpt == 4
     else if (A->dia_rpt == 4) { KH_DIA_RPT(4, false) }
@@ -228,15 +245,16 @@ static inline bool use_dia(kh_ctx ctx, kh_mat A, const double* y) {
 }
 
 template <int EPI>
-static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux) {
+static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux,
+                        const SpmvRange& rg = SpmvRange()) {
     if (use_dia(ctx, A, y)) {
-        launch_dia<EPI>(ctx, A, x, y, aux);
+        launch_dia<EPI>(ctx, A, x, y, aux, rg);
         return;
     }
     switch (A->tile / BS) {      // tile is one of 1024 / 2048 / 4096 (kh_ctx_tune)
-        case 4: launch_spmv_items<EPI, 4>(ctx, A, x, y, aux); break;
-        case 16: launch_spmv_items<EPI, 16>(ctx, A, x, y, aux); break;
-        default: launch_spmv_items<EPI, 8>(ctx, A, x, y, aux); break;
+        case 4: launch_spmv_items<EPI, 4>(ctx, A, x, y, aux, rg); break;
+        case 16: launch_spmv_items<EPI, 16>(ctx, A, x, y, aux, rg); break;
+        default: launch_spmv_items<EPI, 8>(ctx, A, x, y, aux, rg); break;
     }
 }
 
@@ -245,15 +263,40 @@ static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const 
 static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
                      double* scal_out, int rmode) {
     if (A->kind == KH_MAT_CSR) {
-        if (kh_multi(ctx) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0)
-            KH_TRY(comm_halo_exchange(ctx, A, x));
-        if (A->nblk == 0) return 0;
-        if (epi == EPI_NONE) launch_spmv<EPI_NONE>(ctx, A, x, y, nullptr);
-        if (epi == EPI_DOT) launch_spmv<EPI_DOT>(ctx, A, x, y, aux);
-        if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux);
+        const bool halo = kh_multi(ctx) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0;
+        if (A->nblk == 0) {
+            if (halo) KH_TRY(comm_halo_exchange(ctx, A, x, ctx->stream));
+            return 0;
+        }
+        const bool dia = use_dia(ctx, A, y);
+        // a shard's rows that touch no ghost column (the bulk of a slab) do not wait for the halo: the exchange
+        // runs on the communication stream while they are multiplied, the boundary rows follow it
+        const int lo = dia ? A->dia_b0 : A->csr_b0, hi = dia ? A->dia_b1 : A->csr_b1;
+        const int nblk = dia ? A->dia_nblk : A->nblk;
+        const bool split = kh_multi(ctx) && ctx->spmv_split && ctx->comm_stream != nullptr && lo < hi &&
+                           (halo || ctx->force_multi) && (lo > 0 || hi < nblk);
+#define KH_SPMV(RG)                                                            \
+    do {                                                                       \
+        if (epi == EPI_NONE) launch_spmv<EPI_NONE>(ctx, A, x, y, nullptr, RG); \
+        if (epi == EPI_DOT) launch_spmv<EPI_DOT>(ctx, A, x, y, aux, RG);       \
+        if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux, RG);       \
+    } while (0)
+        if (split) {
+            KH_HIP(hipEventRecord(ctx->ev_x, ctx->stream));                   // x is complete
+            KH_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_x, 0));
+            if (halo) KH_TRY(comm_halo_exchange(ctx, A, x, ctx->comm_stream));
+            KH_HIP(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
+            KH_SPMV(SpmvRange::interior(lo, hi));
+            KH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
+            KH_SPMV(SpmvRange::boundary(lo, hi, nblk));
+            ctx->n_spmv_split += 1;
+        } else {
+            if (halo) KH_TRY(comm_halo_exchange(ctx, A, x, ctx->stream));
+            KH_SPMV(SpmvRange());
+        }
+#undef KH_SPMV
         KH_HIP(hipGetLastError());
         if (epi != EPI_NONE) {
-            const bool dia = use_dia(ctx, A, y);
             hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, A->part,
                                dia ? A->dia_nblk : A->nblk, 0, scal_out, rmode);
             KH_HIP(hipGetLastError());
@@ -782,6 +825,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_pf")) ctx->chain_pf = value != 0;
     else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
     else if (!strcmp(key, "chain_fault")) ctx->chain_fault = value != 0;
+    else if (!strcmp(key, "spmv_split")) ctx->spmv_split = value != 0;
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
 }
@@ -795,6 +839,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_pf")) *value = ctx->n_chain_pf;
     else if (!strcmp(key, "chain_spmv")) *value = ctx->chain_spmv;
     else if (!strcmp(key, "n_spmm")) *value = ctx->n_spmm;
+    else if (!strcmp(key, "spmv_split")) *value = ctx->spmv_split;
+    else if (!strcmp(key, "n_spmv_split")) *value = ctx->n_spmv_split;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
     return 0;
@@ -1041,17 +1087,48 @@ namespace kh {
 // kh_mat_set_halo: the ghost columns are known now - look for the banded structure of the shard
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A) {
     const int64_t ng = A->nrecv_prev + A->nrecv_next;
-    if (ng == 0) return 0;                       // square operator: what kh_csr_upload found stands
+    // interior / boundary row blocks of both SpMV kernels (apply_one overlaps the halo exchange with the interior)
+    A->dia_b0 = A->csr_b0 = 0;
+    A->dia_b1 = A->dia_nblk;
+    A->csr_b1 = A->nblk;
+    if (ng == 0) {                               // square operator: what kh_csr_upload found stands
+        if (ctx->force_multi && ctx->nranks == 1) {      // tests / bench --force-sharded: a one-block "boundary" at
+            A->dia_b0 = std::min(1, A->dia_nblk);         // both ends exercises the split launches on one GPU
+            A->dia_b1 = std::max(A->dia_nblk - 1, A->dia_b0);
+            A->csr_b0 = std::min(1, A->nblk);
+            A->csr_b1 = std::max(A->nblk - 1, A->csr_b0);
+        }
+        return 0;
+    }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(A->dia);
     A->dia = nullptr;
     A->dia_nd = 0;
+    A->dia_nblk = 0;
     if (A->nnz == 0) return 0;
     std::vector<int32_t> indptr(A->n_rows + 1), indices(A->nnz);
     std::vector<double> data(A->nnz);
     KH_HIP(hipMemcpy(indptr.data(), A->indptr, sizeof(int32_t) * indptr.size(), hipMemcpyDeviceToHost));
     KH_HIP(hipMemcpy(indices.data(), A->indices, sizeof(int32_t) * indices.size(), hipMemcpyDeviceToHost));
     KH_HIP(hipMemcpy(data.data(), A->data, sizeof(double) * data.size(), hipMemcpyDeviceToHost));
+    // rows [0, bnd_lo) read ghosts of the previous slab, rows [bnd_hi, n) ghosts of the next one
+    int64_t bnd_lo = 0, bnd_hi = A->n_rows;
+    const int64_t nloc = A->n_rows, gprev = nloc + A->nrecv_prev;
+    for (int64_t r = 0; r < nloc; ++r)
+        for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+            const int64_t c = indices[p];
+            if (c >= gprev) bnd_hi = std::min(bnd_hi, r);
+            else if (c >= nloc) bnd_lo = std::max(bnd_lo, r + 1);
+        }
+    {
+        std::vector<int32_t> blk;
+        build_rowblocks(indptr.data(), A->n_rows, A->tile, blk);       // (the table kh_csr_upload built)
+        int b0 = 0, b1 = (int)blk.size() - 1;
+        while (b0 < b1 && blk[b0] < bnd_lo) ++b0;                       // first block that starts at / behind bnd_lo
+        while (b1 > b0 && blk[b1] > bnd_hi) --b1;                       // blocks [b0, b1) end at / before bnd_hi
+        A->csr_b0 = b0;
+        A->csr_b1 = std::max(b1, b0);
+    }
     std::vector<int> offs;
     if (!detect_dia(A->n_rows, A->n_cols, A->nnz, indptr.data(), indices.data(), data.data(), offs,
                     A->nrecv_prev, A->nrecv_next))
@@ -1062,7 +1139,13 @@ int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A) {
         A->part = nullptr;
         KH_HIP(hipMalloc(&A->part, sizeof(double) * need));
     }
-    return build_dia(ctx, A, offs, true);
+    KH_TRY(build_dia(ctx, A, offs, true));
+    if (A->dia != nullptr) {
+        const int64_t rows_per_wg = 2 * (int64_t)BS * A->dia_rpt;
+        A->dia_b0 = (int)std::min<int64_t>((bnd_lo + rows_per_wg - 1) / rows_per_wg, A->dia_nblk);
+        A->dia_b1 = (int)std::max<int64_t>(bnd_hi / rows_per_wg, A->dia_b0);
+    }
+    return 0;
 }
 }  // namespace kh
 }  // extern "C++"

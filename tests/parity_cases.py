@@ -528,14 +528,22 @@ def case_recycling_factories_toy():
             fac = recycling.factories.RitzFactorySimple(n_vectors=3, which=which)
             rs = Solver()
             sols = [rs.solve(ls, vector_factory=fac, maxiter=50, tol=1e-5, x0=None) for _ in range(3)]
-            for s in sols:
+            for isol, s in enumerate(sols):
                 assert s.resnorms[-1] <= 1e-5 and s.projection.U.shape[0] == N
-                # the reference's run of the same sequence (tests/golden/recycling_toy.npz)
-                assert len(s.resnorms) == int(g["iters"][row]), (Solver.__name__, which, row)
+                # the reference's run of the same sequence (tests/golden/recycling_toy.npz).  One selection rule is
+                # not defined by the data from the third solve on: 'smallest_res' ranks the Ritz pairs by residual
+                # norm, and the pairs deflated in the solve before are exact eigenvectors whose residuals (2e-12,
+                # 2e-12, 3e-11, 1.5e-10, 2.6e-10 here) are rounding noise - which three of these five are "smallest"
+                # depends on the summation order of the dot products (0.01 or 0.02 as third: 14 or 15 iterations,
+                # observed with the chain kernel on / off on the same GPU).  One iteration of slack there.
+                slack = 1 if (which == "smallest_res" and isol == 2) else 0
+                assert abs(len(s.resnorms) - int(g["iters"][row])) <= slack, (Solver.__name__, which, row,
+                                                                              len(s.resnorms), int(g["iters"][row]))
                 assert s.projection.U.shape[1] == int(g["ncols"][row])
                 # last entry = explicit residual b - A x_k at 7e-6 |b| with cond(A) = 2e8: it carries
                 # eps * cond * |b| / |r| ~ 3e-3 of cancellation noise in the reference itself
-                assert abs(s.resnorms[-1] - float(g["last"][row])) < 1e-2 * float(g["last"][row])
+                if len(s.resnorms) == int(g["iters"][row]):
+                    assert abs(s.resnorms[-1] - float(g["last"][row])) < 1e-2 * float(g["last"][row])
                 row += 1
             for s in sols[1:]:
                 assert len(s.resnorms) <= len(sols[0].resnorms)

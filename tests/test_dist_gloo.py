@@ -1,4 +1,4 @@
-"""world_size-2 CPU tests (gloo) of the block-row-sharded path: slab partition, column
+"""world_size-2 ... 8 CPU tests (gloo) of the block-row-sharded path: slab partition, column
 localisation, halo exchange plan and all-reduced reductions, driven through the SAME host layer
 (krypy_amd.dist.ShardedCSROperator + LinearSystem + RestartedGmres / DeflatedGmres / Minres).
 
@@ -68,6 +68,8 @@ def _case_gmres(rank, world, ctx):
     op = kdist.ShardedCSROperator(A[r0:r1], r0, A.shape[0], ctx)
     assert op.halo == ((nx if rank > 0 else 0), (nx if rank + 1 < world else 0),
                        (nx if rank > 0 else 0), (nx if rank + 1 < world else 0))
+    if world == 5:
+        assert [c // nx for c in cuts] == [0, 9, 19, 28, 38, 48]       # uneven slabs
     ls = linsys.LinearSystem(op, b[r0:r1])
     res = {}
     for ortho in ("mgs", "cgs2"):
@@ -76,9 +78,10 @@ def _case_gmres(rank, world, ctx):
     return r0, r1, res
 
 
-def test_sharded_restarted_gmres_matches_single_process():
+@pytest.mark.parametrize("world", [2, 5])
+def test_sharded_restarted_gmres_matches_single_process(world):
     from oracle import krylov_ref as ref
-    out = _run(_case_gmres)
+    out = _run(_case_gmres, world)
     A, b = lap2d_system(48, rhs="rng1")
     o = ref.restarted_gmres(A, b, tol=1e-8, maxiter=40, max_restarts=30)
     for ortho in ("mgs", "cgs2"):
@@ -90,7 +93,8 @@ def test_sharded_restarted_gmres_matches_single_process():
             first = slice(0, 40)                                     # first cycle: 1e-10
             assert np.max(np.abs(resn[first] - np.array(o.resnorms)[first])
                           / np.array(o.resnorms)[first]) < 1e-10
-        assert np.array_equal(out[0][2][ortho][0], out[1][2][ortho][0])   # replicated scalars agree
+        for r in range(1, world):
+            assert np.array_equal(out[0][2][ortho][0], out[r][2][ortho][0])   # replicated scalars agree
         assert np.linalg.norm(A.dot(x) - b) <= 1.0001e-8 * np.linalg.norm(b)
         assert np.linalg.norm(x - o.xk) < 1e-7 * np.linalg.norm(o.xk)
 
@@ -113,9 +117,12 @@ def _case_deflated_and_minres(rank, world, ctx):
         m.xk[:, 0].copy(), np.array(c.resnorms)
 
 
-def test_sharded_deflated_gmres_minres_cg():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_deflated_gmres_minres_cg(world):
+    """world 8: twelve planes of 144 rows over eight ranks - slabs of one and two planes (uneven), the one-plane
+    slabs send their whole slab to both neighbours."""
     from oracle import krylov_ref as ref
-    out = _run(_case_deflated_and_minres)
+    out = _run(_case_deflated_and_minres, world)
     A, b = lap3d_system(12, rhs="ones")
     U = np.random.default_rng(4).standard_normal((A.shape[0], 5))
     o = ref.deflated_gmres(A, b, U, tol=1e-9, maxiter=200)

@@ -681,6 +681,24 @@ def test_multi_rank_code_path_on_one_gpu(hip):
     rho = ctx.cg_update(0.5, X, 0, B, 0, YK, 0, R, 0, None, None, 0)
     r2 = want - 0.5 * b
     assert abs(rho - np.dot(r2, r2)) < 1e-12 * rho
+    # the sharded SpMV runs as two launches - interior row blocks while the halo exchange is on the
+    # communication stream, boundary blocks after it (forced mode on one rank: a one-block boundary at both ends)
+    # - for the banded and for the CSR-stream kernel: the same bits as one launch
+    assert ctx.get("n_spmv_split") > 0
+    A2 = ref.laplace2d(300, 211)
+    op2 = kdist.ShardedCSROperator(A2, 0, A2.shape[0], ctx)
+    x2 = np.random.default_rng(8).standard_normal((A2.shape[0], 1))
+    X2, Y2 = ctx.upload(x2), ctx.alloc(A2.shape[0], 1)
+    for dia in (1, 0):
+        ctx.set("spmv_dia", dia)
+        for split in (1, 0):
+            ctx.set("spmv_split", split)
+            before = ctx.get("n_spmv_split")
+            ctx.apply(op2._device_matrix(), X2, 0, Y2, 0, 1)
+            assert (ctx.get("n_spmv_split") - before) == split
+            assert np.array_equal(Y2.download(), A2.dot(x2)), (dia, split)
+    ctx.set("spmv_dia", 1)
+    ctx.set("spmv_split", 1)
     ctx.close()
 
 
