@@ -207,6 +207,26 @@ class _DeflationMixin(object):
             return self._basis_source()._V
         return self._Vb  # Cg with store_arnoldi
 
+    def estimate_time(self, nsteps, ndefl, deflweight=1.0):
+        """Predicted run time of ``nsteps`` iterations with ``ndefl`` deflation vectors, from the measured
+        timings of a :class:`~krypy_amd.linsys.TimedLinearSystem` (deflation.py:191-233).
+
+        The solver's own operation counts come from ``operations(nsteps)``; on top of them the deflation costs
+        ``ndefl`` applications of ``A``, ``M``, ``Ml``, ``Mr`` (building ``A U``), the inner products of the QR of
+        ``U`` (``d(d+1)/2``), of ``E = <U, A U>`` (``d^2``) and of the two projection sweeps per application
+        (``2 d`` per ``Ml`` application), and the matching vector updates.  ``deflweight`` scales the deflation
+        part.  Raises :class:`utils.RuntimeError` without a timed linear system, like the reference."""
+        ops = self.operations(nsteps)
+        d, napp = ndefl, ops["Ml"]
+        tri = d * (d + 1) / 2
+        deflation_ops = {"A": d, "M": d, "Ml": d, "Mr": d,
+                         "ip_B": tri + d * d + 2 * d * napp,
+                         "axpy": tri + d * d + (2 * d + 2) * napp}
+        if not isinstance(self.linear_system, linsys.TimedLinearSystem):
+            raise utils.RuntimeError("A `TimedLinearSystem` has to be used in order to obtain timings.")
+        t = self.linear_system.timings
+        return t.get_ops(ops) + deflweight * t.get_ops(deflation_ops)
+
 
 class DeflatedCg(_DeflationMixin, linsys.Cg):
     """Deflated preconditioned CG method (deflation.py:236-263)."""
@@ -356,3 +376,16 @@ class Ritz(object):
         for i in range(resnorms.shape[0]):
             resnorms[i] = utils.norm(res[:, [i]], Mres[:, [i]], ip_B=ls.ip_B)
         return resnorms
+
+
+# ---- out of scope: perturbation bounds on pseudospectra of small dense matrices
+def __getattr__(name):
+    if name in ("Arnoldifyer", "bound_pseudo"):
+        def _stub(*args, **kwargs):
+            raise NotImplementedError(
+                "krypy_amd.deflation.%s: the a-priori bound machinery (Arnoldifyer / bound_pseudo, optional pseudopy) "
+                "is host-side analysis outside the accelerated Krylov path and is not provided (SURVEY.md section "
+                "2)" % name)
+        _stub.__name__ = name
+        return _stub
+    raise AttributeError("module 'krypy_amd.deflation' has no attribute %r" % name)

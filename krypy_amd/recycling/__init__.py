@@ -9,3 +9,12 @@ from . import factories
 from .linsys import RecyclingCg, RecyclingGmres, RecyclingMinres
 
 __all__ = ["RecyclingCg", "RecyclingMinres", "RecyclingGmres", "factories"]
+
+
+def __getattr__(name):
+    if name in ("evaluators", "generators"):
+        raise NotImplementedError(
+            "krypy_amd.recycling.%s: the greedy RitzFactory with its a-priori / approximate-Krylov evaluators and "
+            "subset generators (convergence-bound cost models) is outside the accelerated path and not provided "
+            "(SURVEY.md section 2 rows 19-21); RitzFactorySimple and UnionFactory are" % name)
+    raise AttributeError("module 'krypy_amd.recycling' has no attribute %r" % name)

@@ -55,3 +55,12 @@ class UnionFactory(_DeflationVectorFactory):
             v = factory.get(solver)
             vectors.append(v.download() if hasattr(v, "download") else v)
         return numpy.asarray(numpy.block(vectors))
+
+
+class RitzFactory(_DeflationVectorFactory):
+    def __init__(self, *args, **kwargs):
+        """The reference's greedy selection driven by convergence-bound evaluators (factories.py:20-139): host-side
+        cost models on small dense matrices, out of scope."""
+        raise NotImplementedError(
+            "RitzFactory (greedy subset selection with RitzApriori / RitzApproxKrylov evaluators) is not provided; "
+            "use RitzFactorySimple(n_vectors=..., which=...) or UnionFactory")

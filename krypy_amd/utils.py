@@ -1805,3 +1805,22 @@ class Projection(object):
     def matrix(self):
         """Dense matrix of the projection - testing only (utils.py:667-677)."""
         return self.apply(numpy.eye(self._N))
+
+
+# ---- names of the reference that are outside the hot path (SURVEY.md section 2: spectral bounds, intervals,
+# pseudospectrum helpers - scalar analysis on small dense data) are not rebuilt here.  Code written against krypy
+# gets a clear message instead of an AttributeError.
+_OUT_OF_SCOPE = ("BoundCG", "BoundMinres", "Interval", "Intervals", "NormalizedRootsPolynomial", "arnoldi_projected",
+                 "bound_perturbed_gmres", "gap", "get_residual_norms", "norm_MMlr", "strakos")
+
+
+def __getattr__(name):
+    if name in _OUT_OF_SCOPE:
+        def _stub(*args, **kwargs):
+            raise NotImplementedError(
+                "krypy_amd.utils.%s: krypy's convergence-bound / spectral helpers are host-side scalar analysis "
+                "outside the accelerated Krylov path and are not provided (SURVEY.md section 2); use krypy.utils.%s "
+                "on host arrays" % (name, name))
+        _stub.__name__ = name
+        return _stub
+    raise AttributeError("module 'krypy_amd.utils' has no attribute %r" % name)

@@ -472,6 +472,25 @@ def gen_recycling_toy(krypy):
     save("recycling_toy", iters=np.array(iters), last=np.array(last), ncols=np.array(ncols))
 
 
+def gen_estimate_time(krypy):
+    """_DeflationMixin.estimate_time (deflation.py:191-233) of the three deflated solvers with a synthetic timing
+    table (one distinct prime per operation, so every term of the operation-count model shows up in the number)."""
+    A = np.diag(np.linspace(1.0, 2.0, 30))
+    b = np.ones((30, 1))
+    U = np.eye(30)[:, :3]
+    prices = dict(A=2.0, M=3.0, Ml=5.0, Mr=7.0, ip_B=11.0, axpy=13.0)
+    out = []
+    for Solver in (krypy.deflation.DeflatedCg, krypy.deflation.DeflatedMinres, krypy.deflation.DeflatedGmres):
+        tls = krypy.linsys.TimedLinearSystem(A, b, self_adjoint=True, positive_definite=True)
+        s = Solver(tls, U=U, tol=1e-8)
+        tls.timings.clear()
+        for k, v in prices.items():
+            tls.timings[k] = [v, 10.0 * v]          # Timings.get reports the minimum
+        for nsteps, ndefl, w in ((7, 3, 1.0), (12, 0, 1.0), (5, 4, 2.5)):
+            out.append(s.estimate_time(nsteps, ndefl, deflweight=w))
+    save("estimate_time", values=np.array(out))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -491,6 +510,7 @@ def main():
     gen_deflation_matrix(krypy)
     gen_api_surface(krypy)
     gen_recycling_toy(krypy)
+    gen_estimate_time(krypy)
 
 
 if __name__ == "__main__":

@@ -15,6 +15,29 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
 
 
+def _gpu_visible():
+    try:
+        import ctypes
+        from krypy_amd import _hip
+        lib = ctypes.CDLL(_hip.library_path())
+        n = ctypes.c_int(0)
+        return lib.kh_device_count(ctypes.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    """A plain ``pytest tests`` on a machine without a GPU runs the CPU suite and SKIPS the gpu-marked tests.
+    With an explicit ``-m`` expression nothing is skipped: ``-m gpu`` on a box without a working device or without
+    the HIP library fails loudly (the `hip` fixture raises), it never passes on a fallback."""
+    if config.getoption("-m") or _gpu_visible():
+        return
+    skip = pytest.mark.skip(reason="no MI355X visible (run with -m gpu on a GPU box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

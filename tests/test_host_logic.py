@@ -20,7 +20,7 @@ SIMPLE = [
     pc.case_minres_cg_sparse, pc.case_cg_dense, pc.case_deflated_gmres_recycling,
     pc.case_recycling_gmres_lap3d, pc.case_recycling_factories_toy, pc.case_inner_product_matrix_B,
     pc.case_solver_zoo, pc.case_ritz, pc.case_arnoldi_house, pc.case_basis_growth,
-    pc.case_lanczos_window, pc.case_api_surface, pc.case_arnoldi_interleaved,
+    pc.case_lanczos_window, pc.case_api_surface, pc.case_arnoldi_interleaved, pc.case_estimate_time,
 ] + pcc.CASES
 
 
