@@ -296,6 +296,26 @@ def _run():
     assert n_iters == args.steps * m, (n_iters, args.steps, m)
     its = n_iters / dt
 
+    # ---- loss of orthogonality of one cycle's basis, ||V^T V - I||_F over all 101 columns (outside the timed
+    # region): the evidence that the panel form the sharded runs default to is as good a basis as the
+    # reference-order MGS at this size (all-reduced over the ranks like every other inner product) ----
+    def basis_orthogonality(mode):
+        try:
+            s1 = linsys.Gmres(ls, x0=x0, maxiter=m, tol=1e-8, ortho=mode, store_arnoldi=True)
+        except utils.ConvergenceError as e:
+            s1 = e.solver
+        Vb = s1.arnoldi._V
+        G = ctx.gemm_tn(Vb, 0, m + 1, Vb, 0, m + 1)
+        return float(np.linalg.norm(G - np.eye(m + 1)))
+
+    orth = {}
+    try:
+        orth[ortho] = basis_orthogonality(ortho)
+        if ortho != "mgs" and not sharded:
+            orth["mgs"] = basis_orthogonality("mgs")
+    except Exception as exc:
+        orth["error"] = repr(exc)
+
     # ---- the other Gram-Schmidt variants on the same inputs (outside the timed region) ----
     others = {}
     if not sharded and args.other_modes:
@@ -336,7 +356,8 @@ def _run():
                                % (m, nx, ny, N, nnz_global),
                    "n": N, "ortho": ortho, "restart": m, "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "row-sharded x%d (RCCL)" % world,
-                   "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms},
+                   "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
+                   "basis_orthogonality_fro": orth},
         "roofline": roof,
     }
     out.update(extra)

@@ -261,6 +261,15 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
  * the previous slot's device-side column. */
 int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
                            int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot);
+/* the complex twins of kh_proj_create / kh_proj_apply_complement (utils.py:604-627 with complex data) and the
+ * complex step with the deflation projector inside it (deflation.py:127-143): T = R^{-1} Q^H and WRH = WR^H are
+ * d x d row-major arrays of (re, im) pairs (NULL: identity); the step returns <U, A v_k> (d complex numbers) behind
+ * the H column, like the real one */
+int kh_zproj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH, int iterations,
+                    kh_proj* out);
+int kh_zproj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_vec Z, int64_t zcol, double* ya_out);
+int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
+                                int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 /* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot

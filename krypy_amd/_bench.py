@@ -200,7 +200,11 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
         k, name, traffic_keys = kernels["k_gs_link<A_PART,T_DOT>"], "k_gs_link<A_PART,T_DOT>", ()
     ms = k["avg_ms"]
     comp = k["compulsory_bytes"]
-    moved, source = k["moved_bytes_model"], "model: every byte the kernel requests from L2 and beyond (upper bound)"
+    # without PMC numbers for exactly this source tree the only bytes known to cross the HBM interface are the
+    # compulsory ones: a lower bound on the traffic, so no fraction below can exceed 1 (the kernel's own
+    # request model - every byte it asks L2 for - stays in `kernels` as moved_bytes_model, an upper bound)
+    moved, source = comp, ("compulsory bytes (lower bound on the HBM traffic: no profiles/*_traffic.json carries the "
+                           "stamp of these kernel sources)")
     stamp = source_stamp()
     traffic = None
     for fn in sorted(traffic_files or [], reverse=True):

@@ -104,6 +104,9 @@ _SIGNATURES = {
     "kh_zwaxpby": [_H, _H, _I64, _c_double_p, _H, _I64, _c_double_p, _H, _I64],
     "kh_zarnoldi_step": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _c_double_p],
     "kh_zarnoldi_step_begin": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
+    "kh_zarnoldi_step_begin_proj": [_H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
+    "kh_zproj_create": [_H, _H, _H, _I64, _c_double_p, _c_double_p, _INT, ctypes.POINTER(_H)],
+    "kh_zproj_apply_complement": [_H, _H, _H, _I64, _H, _I64, _c_double_p],
 }
 
 _lib = None
@@ -257,9 +260,7 @@ class DeviceVectors(object):
         h = ctx._pool_take(self._rn, self.ncols, zero)
         if h is None:
             h = _H()
-            rc = ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h))
-            if rc != 0 and ctx._pool_flush():
-                rc = ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h))
+            rc = ctx._with_memory(lambda: ctx._lib.kh_vec_alloc(ctx._h, self._rn, self.ncols, ctypes.byref(h)))
             _check(ctx._lib, rc, "kh_vec_alloc(%d x %d)" % (self._rn, self.ncols))
         self.handle = h
 
@@ -396,6 +397,18 @@ class Context(object):
         else:
             self._lib.kh_vec_free(h)
 
+    def _with_memory(self, call):
+        """Run an allocating C call; on failure release what the process is merely holding on to - blocks of
+        solvers that are garbage but sit in reference cycles (a solver and the operators it built refer to each
+        other), then the block pool - and try once more."""
+        rc = call()
+        if rc == -3:           # KH_ERR_NOMEM
+            import gc
+            gc.collect()
+            self._pool_flush()
+            rc = call()
+        return rc
+
     def _pool_flush(self):
         pool = self.__dict__.get("_pool") or {}
         n = 0
@@ -502,9 +515,9 @@ class Context(object):
         n_cols = A.shape[1] if n_cols is None else n_cols
         h = _H()
         fn = self._lib.kh_zcsr_upload if dt == _C128 else self._lib.kh_csr_upload
-        _check(self._lib, fn(
+        _check(self._lib, self._with_memory(lambda: fn(
             self._h, n_rows, n_cols, data.size, indptr.ctypes.data_as(_c_int32_p),
-            indices.ctypes.data_as(_c_int32_p), _dptr(data), ctypes.byref(h)), "kh_csr_upload")
+            indices.ctypes.data_as(_c_int32_p), _dptr(data), ctypes.byref(h))), "kh_csr_upload")
         return DeviceMatrix(self, h, "csr", (n_rows, n_cols), data.size, dt)
 
     def dense(self, A, dtype=None):
@@ -513,8 +526,8 @@ class Context(object):
         a = numpy.ascontiguousarray(A, dtype=dt)
         h = _H()
         fn = self._lib.kh_zdense_upload if dt == _C128 else self._lib.kh_dense_upload
-        _check(self._lib, fn(self._h, a.shape[0], a.shape[1], _dptr(a), a.shape[1], ctypes.byref(h)),
-               "kh_dense_upload")
+        _check(self._lib, self._with_memory(lambda: fn(self._h, a.shape[0], a.shape[1], _dptr(a), a.shape[1],
+                                                       ctypes.byref(h))), "kh_dense_upload")
         return DeviceMatrix(self, h, "dense", a.shape, a.size, dt)
 
     def diag(self, d, dtype=None):
@@ -647,12 +660,12 @@ class Context(object):
     def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
                            proj=None):
         if _same_dtype("arnoldi_step_begin", V, W):
-            if Md is not None or P is not None or proj is not None:
-                raise BackendError("arnoldi_step_begin: the complex step takes no preconditioner / projector")
+            if Md is not None or P is not None:
+                raise BackendError("arnoldi_step_begin: the complex step takes no preconditioner")
             hk = numpy.array([h_km1, 0.0], dtype=numpy.float64)
-            _check(self._lib, self._lib.kh_zarnoldi_step_begin(
-                self._h, A.handle if A is not None else None, V.handle, W.handle, wcol, k, start, sweeps,
-                gs_mode, _dptr(hk), slot), "kh_zarnoldi_step_begin")
+            _check(self._lib, self._lib.kh_zarnoldi_step_begin_proj(
+                self._h, A.handle if A is not None else None, proj.handle if proj is not None else None,
+                V.handle, W.handle, wcol, k, start, sweeps, gs_mode, _dptr(hk), slot), "kh_zarnoldi_step_begin")
             return
         _check(self._lib, self._lib.kh_arnoldi_step_begin(
             self._h, A.handle if A is not None else None,
@@ -662,23 +675,28 @@ class Context(object):
 
     def proj_create(self, W, V, d, T, WRH, iterations):
         """Device image of a Projection (``kh_proj``): T = R^{-1} Q^H, WRH = WR^H (d x d) or None."""
+        cplx = _same_dtype("proj_create", W, V)
+
         def mat(M):
             if M is None:
                 return None, None
-            M = numpy.ascontiguousarray(M, dtype=numpy.float64)
-            return M, _dptr(M)
+            M = numpy.ascontiguousarray(M, dtype=numpy.complex128 if cplx else numpy.float64)
+            return M, M.ctypes.data_as(_c_double_p)
         Tm, Tp = mat(T)
         Wm, Wp = mat(WRH)
         h = _H()
-        _check(self._lib, self._lib.kh_proj_create(self._h, W.handle, V.handle, d, Tp, Wp, iterations,
-                                                   ctypes.byref(h)), "kh_proj_create")
-        return DeviceProjector(self, h, d, (W, V))
+        fn = self._lib.kh_zproj_create if cplx else self._lib.kh_proj_create
+        _check(self._lib, fn(self._h, W.handle, V.handle, d, Tp, Wp, iterations, ctypes.byref(h)), "kh_proj_create")
+        p = DeviceProjector(self, h, d, (W, V))
+        p.cplx = cplx
+        return p
 
     def proj_apply_complement(self, proj, A, acol, Z, zcol, want_ya=False):
-        ya = numpy.empty(proj.d, dtype=numpy.float64) if want_ya else None
-        _check(self._lib, self._lib.kh_proj_apply_complement(
-            self._h, proj.handle, A.handle, acol, Z.handle, zcol,
-            _dptr(ya) if want_ya else None), "kh_proj_apply_complement")
+        cplx = getattr(proj, "cplx", False)
+        ya = numpy.empty(proj.d, dtype=numpy.complex128 if cplx else numpy.float64) if want_ya else None
+        fn = self._lib.kh_zproj_apply_complement if cplx else self._lib.kh_proj_apply_complement
+        _check(self._lib, fn(self._h, proj.handle, A.handle, acol, Z.handle, zcol,
+                             ya.ctypes.data_as(_c_double_p) if want_ya else None), "kh_proj_apply_complement")
         return ya
 
     def arnoldi_step_end(self, slot, count, cplx=False):

@@ -54,7 +54,7 @@ struct ChainArgs {
     int64_t hnext;     // index of H[k+1,k] in hdev
     unsigned long long* gran;  // [2][2*G] granules
     unsigned* xcc_leader;      // [16] launch stamp of the last leader election per XCD
-    unsigned long long* xcc_res;   // [16][2 parities][2] the grid-wide sum, handed on inside an XCD through its L2
+    unsigned long long* xcc_res;   // [16][2 parities][4] the grid-wide sum(s), handed on inside an XCD through its L2
     unsigned epoch0;
     int* err;
     int debug;         // measurement only: 1 = skip the grid reduction, 2 = skip the streaming phases; tests: 4 = fake a timeout
@@ -198,7 +198,7 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 3] = wall_clock64();
 #endif
     if (2 * G <= CH_BS) {
-        unsigned long long* res = xcc_res + ((size_t)role.xcc * 2 + (epoch & 1u)) * 2;
+        unsigned long long* res = xcc_res + ((size_t)role.xcc * 2 + (epoch & 1u)) * 4;
         if (!role.leader) {
             // 2b. the leader of this XCD will put the total into `res`: one 16-byte load per poll, served by the L2
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
@@ -274,14 +274,16 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     return s;
 }
 
-// Two sums in one round (the real and imaginary part of a complex coefficient): four granules per
-// workgroup, one publish, one sweep.  Needs 4*G <= 2*CH_GMAX words per parity (checked by the
-// launcher); same protocol, same fixed summation order as grid_sum.
+// Two sums in one round (the real and imaginary part of a complex coefficient): four granules per workgroup, one
+// publish; the XCD leaders sweep 4 G <= 1024 granules (two per thread: workgroups b and b + 128 of the same kind
+// and half land in the same lane), everybody else reads the leader's two result pairs from the L2.  Same protocol
+// and the same fixed summation order in every leader as grid_sum.  smd holds 4 * 8 doubles.
 __device__ __forceinline__ void grid_sum2(double& p0, double& p1, unsigned epoch, unsigned long long* gran,
-                                          int G, int* err, double* smd, unsigned* smu) {
+                                          int G, int* err, double* smd, unsigned* smu, const GridRole role,
+                                          unsigned long long* xcc_res) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = CH_BS / 64;
-    const double a0 = wave_sum(p0), a1 = wave_sum(p1);
+    const double a0 = wave_sum_dpp(p0), a1 = wave_sum_dpp(p1);
     if (lane == 0) {
         smd[wid] = a0;
         smd[NW + wid] = a1;
@@ -297,45 +299,79 @@ __device__ __forceinline__ void grid_sum2(double& p0, double& p1, unsigned epoch
         st_agent(slot + 4 * blockIdx.x + 2 * tid, tag | (bits & 0xffffffffull));
         st_agent(slot + 4 * blockIdx.x + 2 * tid + 1, tag | (bits >> 32));
     }
-    for (int g = tid; g < 4 * G; g += CH_BS) {
-        unsigned long long x = ld_agent(slot + g);
+    unsigned long long* res = xcc_res + ((size_t)role.xcc * 2 + (epoch & 1u)) * 4;
+    if (!role.leader) {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 ab, cd;
         unsigned spins = 0;
-        while ((unsigned)(x >> 32) != epoch) {
-            __builtin_amdgcn_s_sleep(1);
-            x = ld_agent(slot + g);
-            if ((++spins & 1023u) == 0) {
+        while (true) {
+            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(ab), "=&v"(cd)
+                         : "v"(res)
+                         : "memory");
+            if ((unsigned)(ab.x >> 32) == epoch && (unsigned)(ab.y >> 32) == epoch && (unsigned)(cd.x >> 32) == epoch &&
+                (unsigned)(cd.y >> 32) == epoch)
+                break;
+            if ((++spins & 4095u) == 0) {
                 if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                if (spins > (1u << 22)) {
+                if (spins > (1u << 24)) {
                     __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
         }
-        smu[g] = (unsigned)x;
+        p0 = __longlong_as_double((long long)(((ab.y & 0xffffffffull) << 32) | (ab.x & 0xffffffffull)));
+        p1 = __longlong_as_double((long long)(((cd.y & 0xffffffffull) << 32) | (cd.x & 0xffffffffull)));
+        return;
     }
-    __syncthreads();
-    double v0 = 0.0, v1 = 0.0;
-    for (int b = tid; b < G; b += CH_BS) {
-        const unsigned long long b0 = ((unsigned long long)smu[4 * b + 1] << 32) | smu[4 * b];
-        const unsigned long long b1 = ((unsigned long long)smu[4 * b + 3] << 32) | smu[4 * b + 2];
-        v0 += __longlong_as_double((long long)b0);
-        v1 += __longlong_as_double((long long)b1);
+    // leader: granule g = 4 b + 2 kind + half; this thread takes g = tid and g = tid + 512
+    double d = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int g = tid + rr * CH_BS;
+        unsigned mine = 0;
+        if (g < 4 * G) {
+            unsigned long long x = ld_agent(slot + g);
+            unsigned spins = 0;
+            while ((unsigned)(x >> 32) != epoch) {
+                x = ld_agent(slot + g);
+                if ((++spins & 1023u) == 0) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1u << 22)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            mine = (unsigned)x;
+        }
+        const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);   // from lane - 1
+        const unsigned long long bits = ((unsigned long long)mine << 32) | low;
+        d += ((lane & 1) && g < 4 * G) ? __longlong_as_double((long long)bits) : 0.0;
     }
-    v0 = wave_sum(v0);
-    v1 = wave_sum(v1);
-    __syncthreads();          // smd reuse
+    const bool kind1 = ((lane >> 1) & 1) != 0;
+    const double w0 = wave_sum_dpp(kind1 ? 0.0 : d), w1 = wave_sum_dpp(kind1 ? d : 0.0);
     if (lane == 0) {
-        smd[wid] = v0;
-        smd[NW + wid] = v1;
+        smd[2 * NW + wid] = w0;
+        smd[3 * NW + wid] = w1;
     }
     __syncthreads();
-    double s0 = smd[0], s1 = smd[NW];
+    double s0 = smd[2 * NW], s1 = smd[3 * NW];
 #pragma unroll
     for (int i = 1; i < NW; ++i) {
-        s0 += smd[i];
-        s1 += smd[NW + i];
+        s0 += smd[2 * NW + i];
+        s1 += smd[3 * NW + i];
     }
-    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        const unsigned long long b0 = (unsigned long long)__double_as_longlong(s0);
+        const unsigned long long b1 = (unsigned long long)__double_as_longlong(s1);
+        res[0] = tag | (b0 & 0xffffffffull);
+        res[1] = tag | (b0 >> 32);
+        res[2] = tag | (b1 & 0xffffffffull);
+        res[3] = tag | (b1 >> 32);
+    }
     p0 = s0;
     p1 = s1;
 }
@@ -429,7 +465,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     } while (0)
     constexpr int PB = ChainShape<R2>::PB;
     constexpr int NB = ChainShape<R2>::NB;
-    __shared__ double smd[2 * (CH_BS / 64)];
+    __shared__ double smd[4 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
     const int tid = threadIdx.x;
@@ -495,7 +531,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 v = ring[b & 1][i];
+                double2 v = ring[b & 1][i];
+                if (MASKED && !CH_OK(b * PB + i)) v = make_double2(0.0, 0.0);   // beyond the vector: whatever the block holds there (0 * NaN)
                 const double2 wr = W_GET(b * PB + i);
                 if (CPLX) {               // conj(v) * w: acc0 = re, acc1 = im
                     acc0 = fma(v.x, wr.x, acc0);
@@ -512,7 +549,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
-            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
             if (blockIdx.x == 0 && tid == 0) {
                 // first sweep assigns (the caller does not clear the H column for a chain launch)
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
@@ -665,7 +702,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
         else wl[((r) - RW) * CH_BS + tid] = (val);      \
     } while (0)
-    __shared__ double smd[2 * (CH_BS / 64)];
+    __shared__ double smd[4 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
     const int tid = threadIdx.x;
@@ -739,7 +776,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 v = ring[b & 1][i];
+                double2 v = ring[b & 1][i];
+                if (MASKED && !CH_OK(b * PB + i)) v = make_double2(0.0, 0.0);   // beyond the vector: whatever the block holds there
                 if (b < LB) vlds[(b * PB + i) * CH_BS + tid] = v;
                 const double2 wr = W_GET(b * PB + i);
                 if (CPLX) {
@@ -758,7 +796,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
-            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
             if (blockIdx.x == 0 && tid == 0) {
                 // first sweep assigns (the caller does not clear the H column for a chain launch)
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
@@ -945,7 +983,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
     constexpr int SP = ChainShapePf<R2>::SP;
     extern __shared__ __attribute__((aligned(16))) double2 vlds[];   // [LB*PB parked rows + SP prefetched rows][CH_BS]
     double2* const vsp = vlds + (size_t)LB * PB * CH_BS;
-    __shared__ double smd[2 * (CH_BS / 64)];
+    __shared__ double smd[4 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
     const int tid = threadIdx.x;
@@ -1019,7 +1057,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 v = (b == 0 && i < SP) ? vsp[i * CH_BS + tid] : ring[b & 1][i];
+                double2 v = (b == 0 && i < SP) ? vsp[i * CH_BS + tid] : ring[b & 1][i];
+                if (MASKED && !CH_OK(b * PB + i)) v = make_double2(0.0, 0.0);   // beyond the vector: whatever the block holds there
                 if (NB == 2 && b == 0 && i < SP) ring[0][i] = v;      // (two-batch shapes update from the ring)
                 if (b < LB) vlds[(b * PB + i) * CH_BS + tid] = v;
                 if (CPLX) {
@@ -1049,7 +1088,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
-            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu);
+            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
             if (blockIdx.x == 0 && tid == 0) {
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
                 a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
@@ -1255,7 +1294,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                const double2 v = ring[(P0 + b) & 1][i];
+                double2 v = ring[(P0 + b) & 1][i];
+                if (MASKED && !CH_OK(b * PB + i)) v = make_double2(0.0, 0.0);   // beyond the vector: whatever the block holds there
                 const double2 wr = CGS_W_GET(b * PB + i);
                 acc0 = fma(v.x, wr.x, acc0);
                 acc1 = fma(v.y, wr.y, acc1);

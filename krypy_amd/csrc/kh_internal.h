@@ -149,6 +149,7 @@ struct kh_proj_s {
     kh_vec W, V;
     int64_t d;
     int iterations;
+    int cplx = 0;            // W, V, T, WRH and the coefficient buffers hold complex numbers (kh_zproj_create)
     double* T = nullptr;     // d x d row-major, device (nullptr: identity)
     double* WRH = nullptr;   // d x d row-major, device (nullptr: identity)
     double* c0 = nullptr;    // d

@@ -434,7 +434,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     if (ctx->chain_epoch > 0xfff00000u) {
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
-        KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
+        KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
         ctx->chain_epoch = 1;
     }
     ChainArgs a;
@@ -454,7 +454,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.hnext = cplx ? 2 * (k + 1) : k + 1;
     a.gran = ctx->chain_gran;
     a.xcc_res = ctx->chain_xcc;
-    a.xcc_leader = reinterpret_cast<unsigned*>(ctx->chain_xcc + 64);
+    a.xcc_leader = reinterpret_cast<unsigned*>(ctx->chain_xcc + 128);
     a.epoch0 = ctx->chain_epoch;
     a.err = ctx->chain_err;
     a.debug = ctx->chain_debug;
@@ -726,9 +726,9 @@ int kh_ctx_create(int device, kh_ctx* out) {
     KH_HIP(hipEventCreate(&ctx->ev1));
     KH_HIP(hipMalloc(&ctx->chain_gran, sizeof(unsigned long long) * 4 * CH_GMAX));
     KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
-    // XCD-leader hand-off of the chain kernel's grid-wide sums: [16][2][2] result granules + [16] election stamps
-    KH_HIP(hipMalloc(&ctx->chain_xcc, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
-    KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 64 + sizeof(unsigned) * 16));
+    // XCD-leader hand-off of the chain kernel's grid-wide sums: [16][2][4] result granules + [16] election stamps
+    KH_HIP(hipMalloc(&ctx->chain_xcc, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
+    KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
     KH_HIP(hipMalloc(&ctx->chain_err, sizeof(int)));
     KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
     for (int s = 0; s < KH_NSLOT; ++s) {

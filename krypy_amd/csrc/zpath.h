@@ -14,6 +14,7 @@
 namespace kh {
 
 constexpr int ZMAXC = 8;   // complex columns per panel launch (2 partial-sum slots each)
+constexpr int ZMAXD = 512; // widest complex projector (kh_zproj_create)
 
 struct ZColPtrs {
     const double2* c[ZMAXC];
@@ -534,9 +535,48 @@ int kh_zwaxpby(kh_ctx ctx, kh_vec Z, int64_t zcol_, const double alpha[2], kh_ve
 // One complex Arnoldi.advance() (utils.py:954-1048, mgs/dmgs/lanczos/cgs; no preconditioner), enqueued
 // on the context's stream: the H column (k+2 complex numbers, the last one (H[k+1,k], 0)) lands in
 // `hdev`.  h_km1_dev: Lanczos coefficient still on the device (look-ahead), else h_km1 from the host.
+// y = M x for a tiny dense complex row-major M (d x d) on the device: the projector's R^{-1} Q^H and WR^H.
+// One workgroup, one row per thread, NumPy's complex multiply, sums left to right (deterministic).
+__global__ __launch_bounds__(BS) void k_zsmall_matvec(int d, const double2* __restrict__ M, const double2* __restrict__ x,
+                                                      double2* __restrict__ y) {
+    for (int i = threadIdx.x; i < d; i += BS) {
+        double2 s = make_double2(0.0, 0.0);
+        if (M == nullptr) {
+            s = x[i];
+        } else {
+            for (int j = 0; j < d; ++j) {
+                const double2 m = M[(int64_t)i * d + j], v = x[j];
+                s.x += m.x * v.x - m.y * v.y;
+                s.y += m.x * v.y + m.y * v.x;
+            }
+        }
+        y[i] = s;
+    }
+}
+
+// complex deflation projector on the device (the c128 twin of proj_apply_dev): z <- complement projection of z,
+// ya_dev (d complex numbers) gets <Y, z_in>
+static int zproj_apply_dev(kh_ctx ctx, kh_proj p, double2* z, double* ya_dev) {
+    const int d = (int)p->d;
+    for (int it = 0; it < p->iterations; ++it) {
+        KH_TRY(zdot_dev(ctx, p->W, 0, d, z, p->c0));
+        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, 2 * d));
+        if (it == 0 && ya_dev != nullptr)
+            hipLaunchKernelGGL(k_zsmall_matvec, dim3(1), dim3(BS), 0, ctx->stream, d,
+                               reinterpret_cast<const double2*>(p->WRH), reinterpret_cast<const double2*>(p->c0),
+                               reinterpret_cast<double2*>(ya_dev));
+        hipLaunchKernelGGL(k_zsmall_matvec, dim3(1), dim3(BS), 0, ctx->stream, d,
+                           reinterpret_cast<const double2*>(p->T), reinterpret_cast<const double2*>(p->c0),
+                           reinterpret_cast<double2*>(p->c1));
+        KH_HIP(hipGetLastError());
+        KH_TRY(zaxpy_dev(ctx, p->V, 0, d, p->c1, 1.0, 1.0, z, false, nullptr));
+    }
+    return 0;
+}
+
 static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
                          int sweeps, int gs_mode, const double h_km1[2], const double* h_km1_dev, double* hdev,
-                         int slot) {
+                         int slot, kh_proj proj = nullptr) {
     KH_TRY(zcheck(V, k, 2, "kh_zarnoldi_step(V)"));
     KH_TRY(zcheck(W, wcol, 1, "kh_zarnoldi_step(W)"));
     KH_ARG(V->n == W->n && start >= 0 && start <= k && sweeps >= 1 && sweeps <= 4, "kh_zarnoldi_step: arguments");
@@ -548,6 +588,8 @@ static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol,
     if (A != nullptr) {
         KH_ARG(A->kind >= KH_MAT_ZCSR && A->n_rows == n, "kh_zarnoldi_step: complex operator of matching size needed");
         KH_TRY(zapply_one(ctx, A, V->col(k), W->col(wcol)));
+        // deflated solvers: w <- (I - P) w, and <U, A v_k> behind the H column (deflation.py:135-143)
+        if (proj != nullptr) KH_TRY(zproj_apply_dev(ctx, proj, w, hdev + 2 * (k + 2)));
     }
     double* nrm_part = ctx->part + (int64_t)(2 * ZMAXC + 2) * NB_MAX;
     const int grid = zgrid(ctx, n);
@@ -614,17 +656,20 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
 // The same step split like kh_arnoldi_step_begin / _end (look-ahead): results are collected with
 // kh_arnoldi_step_end(ctx, slot, 2*(k+2), out).  h_km1[0] = NaN: Lanczos coefficient H[k,k-1] of the
 // step begun just before this one, still in the previous H-column slot on the device.
-int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
-                           int sweeps, int gs_mode, const double h_km1[2], int slot) {
+int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
+                                int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot) {
     KH_ARG(ctx && V && W && h_km1, "kh_zarnoldi_step_begin: NULL argument");
     KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_zarnoldi_step_begin: slot %d not in [0,%d)", slot, KH_NSLOT);
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_zarnoldi_step_begin: k=%lld needs %lld basis columns, have %lld",
            (long long)k, (long long)(k + 2), (long long)V->ncols);
-    KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1))));
+    const int64_t pd = proj ? proj->d : 0;
+    KH_ARG(proj == nullptr || (proj->cplx && proj->W->n == V->n && A != nullptr),
+           "kh_zarnoldi_step_begin: a complex projector of length N and the operator are needed");
+    KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1) + pd)));
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 2;
-        st.A = A; st.proj = nullptr; st.Md = nullptr; st.V = V; st.P = nullptr; st.W = W;
+        st.A = A; st.proj = proj; st.Md = nullptr; st.V = V; st.P = nullptr; st.W = W;
         st.wcol = wcol; st.k = k; st.start = start; st.sweeps = sweeps; st.gs_mode = gs_mode;
         st.h_km1[0] = h_km1[0]; st.h_km1[1] = h_km1[1];
         if (step_poisoned(ctx, slot)) {
@@ -636,10 +681,58 @@ int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wco
     const double* hk_dev = nullptr;
     if (start > 0 && start == k && h_km1[0] != h_km1[0])
         hk_dev = ctx->hslot_dev[(slot + KH_NSLOT - 1) % KH_NSLOT] + 2 * k;
-    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, hk_dev, hdev, slot));
-    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * 2 * (k + 2), hipMemcpyDeviceToHost,
+    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, hk_dev, hdev, slot, proj));
+    KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * 2 * (k + 2 + pd), hipMemcpyDeviceToHost,
                           ctx->stream));
     KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+    return 0;
+}
+
+int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
+                           int sweeps, int gs_mode, const double h_km1[2], int slot) {
+    return kh_zarnoldi_step_begin_proj(ctx, A, nullptr, V, W, wcol, k, start, sweeps, gs_mode, h_km1, slot);
+}
+
+// complex projector: W, V complex blocks (real kh_vec of length 2N), T = R^{-1} Q^H and WRH = WR^H as d x d
+// row-major (re, im) pairs (NULL: identity)
+int kh_zproj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH, int iterations,
+                    kh_proj* out) {
+    KH_ARG(ctx && W && V && out, "kh_zproj_create: NULL");
+    KH_ARG(d >= 1 && d <= ZMAXD && W->ncols >= d && V->ncols >= d && W->n == V->n && (W->n & 1) == 0,
+           "kh_zproj_create: shapes");
+    KH_ARG(iterations >= 1, "kh_zproj_create: iterations < 1");
+    kh_proj p = new kh_proj_s();
+    p->ctx = ctx;
+    p->W = W;
+    p->V = V;
+    p->d = d;
+    p->iterations = iterations;
+    p->cplx = 1;
+    KH_HIP(hipMalloc(&p->c0, sizeof(double) * 6 * d));
+    p->c1 = p->c0 + 2 * d;
+    p->ya = p->c0 + 4 * d;
+    if (T) {
+        KH_HIP(hipMalloc(&p->T, sizeof(double) * 2 * d * d));
+        KH_HIP(hipMemcpy(p->T, T, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
+    }
+    if (WRH) {
+        KH_HIP(hipMalloc(&p->WRH, sizeof(double) * 2 * d * d));
+        KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
+    }
+    *out = p;
+    return 0;
+}
+
+int kh_zproj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_vec Z, int64_t zcol_, double* ya_out) {
+    KH_ARG(ctx && p && p->cplx, "kh_zproj_apply_complement: complex projector needed");
+    KH_TRY(zcheck(A, acol, 1, "kh_zproj_apply_complement(a)"));
+    KH_TRY(zcheck(Z, zcol_, 1, "kh_zproj_apply_complement(z)"));
+    KH_ARG(A->n == p->W->n && Z->n == A->n, "kh_zproj_apply_complement: length mismatch");
+    if (!(A == Z && acol == zcol_))
+        KH_HIP(hipMemcpyAsync(Z->col(zcol_), A->col(acol), sizeof(double) * A->n, hipMemcpyDeviceToDevice,
+                              ctx->stream));
+    KH_TRY(zproj_apply_dev(ctx, p, zcolw(Z, zcol_), ya_out ? p->ya : nullptr));
+    if (ya_out) return zfetch(ctx, p->ya, 2 * p->d, ya_out);
     return 0;
 }
 

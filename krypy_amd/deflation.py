@@ -11,6 +11,8 @@ matrices) are outside the hot path and not provided.
 
 Reference lines are cited as ``deflation.py:<line>`` (= ``/root/reference/krypy/deflation.py``).
 """
+import weakref
+
 import numpy
 import scipy.linalg
 
@@ -139,7 +141,7 @@ class _DeflationMixin(object):
             # (I - P) A runs inside the fused Arnoldi step; DeflatedCg keeps the Python path: its
             # C recurrence needs self.iter / self.rhos at application time
             P._kh_proj = self.projection._device_projector()
-            P._on_ya = self._store_UAv
+            P._on_ya = weakref.WeakMethod(self._store_UAv)     # (no solver <-> operator reference cycle)
         self.MlAMr = P * self.linear_system.MlAMr
         super(_DeflationMixin, self)._solve()
 

@@ -1060,8 +1060,9 @@ class Arnoldi(object):
         if self._fused and self._Amat is None and isinstance(self.A, _ProductLinearOperator):
             Pop, inner = self.A.args
             kp = getattr(Pop, "_kh_proj", None)
-            if kp is not None and not cplx and inner._device_matrix() is not None:
-                self._Amat, self._proj, self._on_ya = inner._device_matrix(), kp, Pop._on_ya
+            im = inner._device_matrix(ctx, bdt) if kp is not None else None
+            if kp is not None and im is not None and bool(getattr(kp, "cplx", False)) == cplx:
+                self._Amat, self._proj, self._on_ya = im, kp, Pop._on_ya
         # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
         # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU
         # never idles while the host does its O(k) work.  A speculative step past the end of the
@@ -1262,7 +1263,7 @@ class Arnoldi(object):
                 hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd, cplx=self._cplx)
                 self._release(k % 4)
                 if pd:
-                    self._on_ya(hcol[kp + 2:].reshape(-1, 1).copy())
+                    self._on_ya()(hcol[kp + 2:].reshape(-1, 1).copy())
                     hcol = hcol[: kp + 2]
 
             elif self._Amat is not None:
@@ -1314,6 +1315,8 @@ class Arnoldi(object):
             self._V.zero(k + 1 - self._base, 1)
             if self._P is not None:
                 self._P.zero(k + 1 - self._base, 1)
+            if self._BV is not None:
+                self._BV.zero(k + 1 - self._base, 1)      # (0 / 0: nothing non-finite goes back to the block pool)
 
     def _advance_house(self, k):
         """One Householder Arnoldi step (utils.py:970-994) on the device."""
@@ -1647,8 +1650,10 @@ class Projection(object):
         trip; ``WR^H`` maps the first sweep's coefficients to ``<Y, a>``."""
         if self._k == 0 or not (self.ip_B is None or isinstance(self.ip_B, IdentityLinearOperator)):
             return None
-        if _is_c(self._Vd.dtype) or _is_c(self._Wd.dtype):
-            return None     # kh_proj is real; complex projections run sweep by sweep (zdot/zaxpy)
+        if _is_c(self._Vd.dtype) != _is_c(self._Wd.dtype):
+            return None     # one real and one complex block: the sweep-by-sweep path promotes what it needs
+        if _is_c(self._Vd.dtype) and self._k > 512:
+            return None     # (kh_zproj_create takes at most 512 vectors)
         if "_kh_proj" not in self.__dict__:
             T = None
             if self.Q is not None and self.R is not None:
@@ -1668,9 +1673,9 @@ class Projection(object):
             z = a.copy()
             return (z, numpy.zeros((0, 1))) if return_Ya else z
         a = a.astype(self._Vd.dtype)
-        proj = self._device_projector() if not _is_c(a.dtype) else None
-        if proj is not None:
-            z = DVec(ctx.alloc(self._N, 1))
+        proj = self._device_projector()
+        if proj is not None and _is_c(a.dtype) == bool(getattr(proj, "cplx", False)):
+            z = DVec(ctx.alloc(self._N, 1, dtype=a.dtype))
             Ya = ctx.proj_apply_complement(proj, a.block, a.col, z.block, z.col, want_ya=return_Ya)
             return (z, Ya.reshape(-1, 1)) if return_Ya else z
         z = a.copy()

@@ -291,14 +291,16 @@ class NumpyContext(object):
         self._slots[slot] = np.concatenate([hcol, ya])
 
     def proj_create(self, W, V, d, T, WRH, iterations):
-        if _same("proj_create", W, V):
-            raise BackendError("kh_proj is real only")
+        cplx = _same("proj_create", W, V)     # (kh_zproj_create for complex blocks)
+        if cplx and d > 512:
+            raise BackendError("kh_zproj_create: at most 512 vectors")
         class _P(object):
             pass
         p = _P()
-        p.W, p.V, p.d, p.iterations, p.handle = W, V, d, iterations, None
-        p.T = None if T is None else np.array(T, dtype=float)
-        p.WRH = None if WRH is None else np.array(WRH, dtype=float)
+        p.W, p.V, p.d, p.iterations, p.handle, p.cplx = W, V, d, iterations, None, cplx
+        dt = complex if cplx else float
+        p.T = None if T is None else np.array(T, dtype=dt)
+        p.WRH = None if WRH is None else np.array(WRH, dtype=dt)
         return p
 
     def proj_apply_complement(self, proj, A, acol, Z, zcol, want_ya=False):
@@ -307,7 +309,7 @@ class NumpyContext(object):
         z = A.a[:, acol].copy()
         ya = None
         for it in range(proj.iterations):
-            c = self._allreduce(proj.W.a[:, :d].T.dot(z))
+            c = self._allreduce(proj.W.a[:, :d].T.conj().dot(z))
             if it == 0 and want_ya:
                 ya = c.copy() if proj.WRH is None else proj.WRH.dot(c)
             c = c if proj.T is None else proj.T.dot(c)

@@ -56,6 +56,27 @@ def test_gmres_issues_one_device_call_per_iteration(cpu_double):
     assert cpu_double.calls.get("dot_panel", 0) == 0 and cpu_double.calls.get("axpy_panel", 0) == 0
 
 
+def test_complex_deflated_gmres_projects_inside_the_step(cpu_double):
+    """Complex deflated solves used to apply the projector sweep by sweep from Python (two panel products and two
+    panel updates per iteration, each a C call with a host synchronisation); with kh_zproj_create the projector runs
+    inside the fused complex step like the real one: one begin / end pair per iteration."""
+    import numpy as np
+    from krypy_amd import deflation, linsys
+    from oracle.inputs import complex_systems
+
+    c = complex_systems(24)
+    U = np.linalg.qr(np.random.default_rng(2).standard_normal((576, 4)) + 1j * np.random.default_rng(3).standard_normal((576, 4)))[0]
+    ls = linsys.LinearSystem(c["nonh"], c["b"])
+    cpu_double.calls.clear()
+    s = deflation.DeflatedGmres(ls, U=U, tol=1e-9, maxiter=300)
+    n = len(s.resnorms) - 1
+    assert s.xk.dtype.kind == "c" and n > 20
+    assert cpu_double.calls.get("arnoldi_step") >= n          # (the look-ahead may run one step past the end)
+    assert cpu_double.calls.get("dot_panel", 0) + cpu_double.calls.get("axpy_panel", 0) < 40, dict(cpu_double.calls)
+    r = c["b"] - c["nonh"].dot(s.xk[:, 0])
+    assert np.linalg.norm(r) <= 1.01e-9 * np.linalg.norm(c["b"])
+
+
 def test_reference_solver_matrix(cpu_double):
     """All 13,216 solves of the reference's solver test matrix (6 matrices, 3 of them complex, x inner
     products x right-hand sides x preconditioners x solvers x parameters) against the reference's own

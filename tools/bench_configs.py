@@ -44,11 +44,8 @@ def config3(ctx, steps=400):
 
 
 def config4(ctx, n=32768):
-    rng = np.random.default_rng(0)
-    A = rng.standard_normal((n, n))
-    A = (A + A.T) * (0.5 / np.sqrt(n))
-    A[np.diag_indices(n)] += 3.0
-    b = rng.standard_normal(n)
+    from oracle.inputs import dense_spd_system      # G = rng(0) normal, A = G G^T / n + I
+    A, b = dense_spd_system(n)
     ls = linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
     for it in range(2):
         ctx.sync()
@@ -64,14 +61,14 @@ def config4(ctx, n=32768):
                 final_relres=float(s.resnorms[-1]))
 
 
-def config5(ctx, nx=200, m=100, d=16):
+def config5(ctx, nx=200, m=100, d=16, nz=None, ortho="mgs"):
     import oracle.krylov_ref as ref
-    A = ref.laplace3d(nx)
+    A = ref.laplace3d(nx) if nz is None else ref.laplace3d(nx, nx, nz)
     N = A.shape[0]
     b = np.random.default_rng(0).standard_normal(N)
     ls = linsys.LinearSystem(A, b, self_adjoint=True)
     try:
-        s0 = deflation.DeflatedGmres(ls, tol=1e-12, maxiter=m, store_arnoldi=True)
+        s0 = deflation.DeflatedGmres(ls, tol=1e-12, maxiter=m, store_arnoldi=True, ortho=ortho)
     except utils.ConvergenceError as e:
         s0 = e.solver
     ritz = deflation.Ritz(s0)
@@ -81,15 +78,15 @@ def config5(ctx, nx=200, m=100, d=16):
         ctx.sync()
         t0 = time.perf_counter()
         try:
-            s1 = deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m)
+            s1 = deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, ortho=ortho)
         except utils.ConvergenceError as e:
             s1 = e.solver
         ctx.sync()
         dts.append(time.perf_counter() - t0)
     dt = min(dts[1:])
     n_it = len(s1.resnorms) - 1
-    return dict(config="5 (one-GPU shape): 3-D 7-pt %d^3 (N=%d), DeflatedGmres(%d) with %d Ritz vectors"
-                       % (nx, N, m, d), iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+    return dict(config="5 (one-GPU shape): 3-D 7-pt %dx%dx%d (N=%d), DeflatedGmres(%d) with %d Ritz vectors, ortho=%s"
+                       % (nx, nx, nx if nz is None else nz, N, m, d, ortho), iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
                 solve_ms=[round(x * 1e3, 1) for x in dts],
                 plain_relres=float(s0.resnorms[-1]), deflated_relres=float(s1.resnorms[-1]))
 
@@ -98,4 +95,8 @@ if __name__ == "__main__":
     ctx = _hip.get_context()
     which = sys.argv[1:] or ["3", "4", "5"]
     for w in which:
-        print(json.dumps({"3": config3, "4": config4, "5": config5}[w](ctx)), flush=True)
+        fn = {"3": config3, "4": config4, "5": config5,
+              # the per-GPU share of config 5 at its stated size: a 500 x 500 x 50 slab, 12.5 M rows (beyond the
+              # register file: 48 rows per lane, eight of them in LDS), reference-order MGS and the panel form
+              "5s": lambda c: config5(c, nx=500, nz=50), "5sc": lambda c: config5(c, nx=500, nz=50, ortho="cgs")}[w]
+        print(json.dumps(fn(ctx)), flush=True)

@@ -81,14 +81,14 @@ __device__ __forceinline__ double gsum(double part, unsigned epoch, unsigned lon
         if (V >= 2 && V != 3 && tid == 0) {       // the XCD's leader hands the total to its neighbours through the shared L2
             const unsigned long long bits2 = (unsigned long long)__double_as_longlong(s);
             const unsigned long long tag = (unsigned long long)epoch << 32;
-            unsigned long long* r = xs.res + ((size_t)xcc * 2 + (epoch & 1u)) * 2;
+            unsigned long long* r = xs.res + ((size_t)xcc * 2 + (epoch & 1u)) * 4;
             r[0] = tag | (bits2 & 0xffffffffull);
             r[1] = tag | (bits2 >> 32);
         }
         return s;
     }
     // V == 2, not the leader: poll the XCD's result pair (L2-served)
-    const unsigned long long* r = xs.res + ((size_t)xcc * 2 + (epoch & 1u)) * 2;
+    const unsigned long long* r = xs.res + ((size_t)xcc * 2 + (epoch & 1u)) * 4;
     if (V >= 5) {
         typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
         const u64x2* r2 = reinterpret_cast<const u64x2*>(r);
@@ -122,7 +122,7 @@ __device__ __forceinline__ double gsum(double part, unsigned epoch, unsigned lon
 template <int V>
 __global__ __launch_bounds__(CH_BS) void k(unsigned long long* gran, int* err, double* out, int iters, unsigned epoch0,
                                            XcdState xs, unsigned launch_id, const double2* bg, int bg_rows, unsigned* xcc_out) {
-    __shared__ double smd[2 * (CH_BS / 64)];
+    __shared__ double smd[4 * (CH_BS / 64)];
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int lead;
     const int tid = threadIdx.x;
@@ -196,7 +196,7 @@ int main() {
     CK(hipMalloc(&err, sizeof(int))); CK(hipMemset(err, 0, sizeof(int)));
     CK(hipMalloc(&out, sizeof(double) * 512));
     CK(hipMalloc(&xs.leader, sizeof(unsigned) * 16)); CK(hipMemset(xs.leader, 0, sizeof(unsigned) * 16));
-    CK(hipMalloc(&xs.res, sizeof(unsigned long long) * 16 * 4)); CK(hipMemset(xs.res, 0, sizeof(unsigned long long) * 16 * 4));
+    CK(hipMalloc(&xs.res, sizeof(unsigned long long) * 16 * 8)); CK(hipMemset(xs.res, 0, sizeof(unsigned long long) * 16 * 8));
     CK(hipMalloc(&xcc_out, sizeof(unsigned) * 512));
     const size_t bgbytes = (size_t)256 * 64 * 8 * CH_BS * sizeof(double2);      // 1 GB
     CK(hipMalloc(&bg, bgbytes)); CK(hipMemset(bg, 0, bgbytes));
