@@ -75,20 +75,21 @@ int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
     return 0;
 }
 
-int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream) {
+int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream, int width) {
+    // width: doubles per vector entry (1 real, 2 complex); counts and offsets below are in entries
     if (ctx->comm == nullptr) return 0;
     const int64_t nloc = A->n_rows;
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     KH_NCCL(g_rccl.GroupStart());
     if (ctx->rank > 0) {
-        if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, A->nsend_prev, ncclDouble, ctx->rank - 1, comm, stream));
-        if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(A->ghost, A->nrecv_prev, ncclDouble, ctx->rank - 1, comm, stream));
+        if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, width * A->nsend_prev, ncclDouble, ctx->rank - 1, comm, stream));
+        if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(A->ghost, width * A->nrecv_prev, ncclDouble, ctx->rank - 1, comm, stream));
     }
     if (ctx->rank + 1 < ctx->nranks) {
         if (A->nsend_next)
-            KH_NCCL(g_rccl.Send(x + (nloc - A->nsend_next), A->nsend_next, ncclDouble, ctx->rank + 1, comm, stream));
+            KH_NCCL(g_rccl.Send(x + width * (nloc - A->nsend_next), width * A->nsend_next, ncclDouble, ctx->rank + 1, comm, stream));
         if (A->nrecv_next)
-            KH_NCCL(g_rccl.Recv(A->ghost + A->nrecv_prev, A->nrecv_next, ncclDouble, ctx->rank + 1, comm, stream));
+            KH_NCCL(g_rccl.Recv(A->ghost + width * A->nrecv_prev, width * A->nrecv_next, ncclDouble, ctx->rank + 1, comm, stream));
     }
     KH_NCCL(g_rccl.GroupEnd());
     return 0;
@@ -171,7 +172,8 @@ int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count) {
 int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next, int64_t nrecv_prev,
                     int64_t nrecv_next) {
     KH_ARG(ctx && A, "kh_mat_set_halo: NULL");
-    KH_ARG(A->kind == KH_MAT_CSR, "kh_mat_set_halo: CSR operators only");
+    KH_ARG(A->kind == KH_MAT_CSR || A->kind == KH_MAT_ZCSR, "kh_mat_set_halo: CSR operators only");
+    const int width = A->kind == KH_MAT_ZCSR ? 2 : 1;
     KH_ARG(nsend_prev >= 0 && nsend_next >= 0 && nrecv_prev >= 0 && nrecv_next >= 0, "negative halo");
     KH_ARG(nsend_prev <= A->n_rows && nsend_next <= A->n_rows, "halo wider than the local slab");
     KH_ARG(A->n_cols == A->n_rows + nrecv_prev + nrecv_next,
@@ -185,9 +187,10 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
     A->ghost = nullptr;
     const int64_t ng = nrecv_prev + nrecv_next;
     if (ng > 0) {
-        KH_HIP(hipMalloc(&A->ghost, sizeof(double) * ng));
-        KH_HIP(hipMemset(A->ghost, 0, sizeof(double) * ng));
+        KH_HIP(hipMalloc(&A->ghost, sizeof(double) * width * ng));
+        KH_HIP(hipMemset(A->ghost, 0, sizeof(double) * width * ng));
     }
+    if (A->kind == KH_MAT_ZCSR) return 0;       // (no banded copy / split launches for complex operators)
     return kh::dia_rebuild_for_halo(ctx, A);
 }
 

@@ -160,7 +160,7 @@ struct kh_proj_s {
 namespace kh {
 // comm.hip
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
-int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream);
+int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream, int width = 1);
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
 }  // namespace kh

@@ -1152,8 +1152,9 @@ int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A) {
 
 int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count) {
     KH_ARG(A && (values || count == 0), "kh_mat_set_ghost: NULL");
-    KH_ARG(A->kind == KH_MAT_CSR && count == A->nrecv_prev + A->nrecv_next,
-           "kh_mat_set_ghost: %lld values for %lld ghost columns", (long long)count,
+    KH_ARG((A->kind == KH_MAT_CSR && count == A->nrecv_prev + A->nrecv_next) ||
+               (A->kind == KH_MAT_ZCSR && count == 2 * (A->nrecv_prev + A->nrecv_next)),
+           "kh_mat_set_ghost: %lld doubles for %lld ghost columns", (long long)count,
            (long long)(A->nrecv_prev + A->nrecv_next));
     if (count == 0) return 0;
     KH_HIP(hipMemcpyAsync(A->ghost, values, sizeof(double) * count, hipMemcpyHostToDevice, A->ctx->stream));

@@ -133,7 +133,10 @@ __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__
                                                      const int32_t* __restrict__ indices,
                                                      const double2* __restrict__ data,
                                                      const int32_t* __restrict__ rowblk, int nblk, int tile,
-                                                     const double2* __restrict__ x, double2* __restrict__ y) {
+                                                     const double2* __restrict__ x, double2* __restrict__ y,
+                                                     int64_t nloc, const double2* __restrict__ ghost) {
+    // columns >= nloc of a block-row shard are ghost entries (rows of the neighbouring slabs, filled by the halo
+    // exchange): the same layout as the real kernels
     extern __shared__ __attribute__((aligned(16))) double2 zprod[];
     __shared__ double sm[8];
     const int bid = xcd_remap(blockIdx.x, nblk);
@@ -153,7 +156,7 @@ __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__
             }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {
-                const double2 xv = x[c[i]];
+                const double2 xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
                 double2 p;
                 p.x = a[i].x * xv.x - a[i].y * xv.y;
                 p.y = a[i].x * xv.y + a[i].y * xv.x;
@@ -181,7 +184,8 @@ __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__
         double sr = 0.0, si = 0.0;
         for (int t = threadIdx.x; t < cnt; t += BS) {
             const double2 a = data[nz0 + t];
-            const double2 xv = x[indices[nz0 + t]];
+            const int cc = indices[nz0 + t];
+            const double2 xv = (cc < nloc) ? x[cc] : ghost[cc - nloc];
             sr += a.x * xv.x - a.y * xv.y;
             si += a.x * xv.y + a.y * xv.x;
         }
@@ -342,13 +346,18 @@ static int zapply_one(kh_ctx ctx, kh_mat A, const double* x, double* y) {
     const double2* x2 = reinterpret_cast<const double2*>(x);
     double2* y2 = reinterpret_cast<double2*>(y);
     if (A->kind == KH_MAT_ZCSR) {
+        // a block-row shard: the neighbours' boundary entries first ((re, im) pairs: twice the doubles)
+        if (kh_multi(ctx) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0)
+            KH_TRY(comm_halo_exchange(ctx, A, x, ctx->stream, 2));
         if (A->nblk == 0) return 0;
         const size_t lds = (size_t)A->tile * sizeof(double2);
         const double2* d2 = reinterpret_cast<const double2*>(A->data);
+        const int64_t nloc = A->n_cols - A->nrecv_prev - A->nrecv_next;
+        const double2* gh = reinterpret_cast<const double2*>(A->ghost);
         switch (A->tile / BS) {
-            case 4: hipLaunchKernelGGL((k_zspmv_stream<4>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
-            case 16: hipLaunchKernelGGL((k_zspmv_stream<16>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
-            default: hipLaunchKernelGGL((k_zspmv_stream<8>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2); break;
+            case 4: hipLaunchKernelGGL((k_zspmv_stream<4>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2, nloc, gh); break;
+            case 16: hipLaunchKernelGGL((k_zspmv_stream<16>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2, nloc, gh); break;
+            default: hipLaunchKernelGGL((k_zspmv_stream<8>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, d2, A->rowblk, A->nblk, A->tile, x2, y2, nloc, gh); break;
         }
     } else if (A->kind == KH_MAT_ZDENSE) {
         const int grid = (int)((A->n_rows + BS / 64 - 1) / (BS / 64));
@@ -369,7 +378,7 @@ using namespace kh;
 static int zapply_cols(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols) {
     KH_TRY(zcheck(X, xcol, ncols, "kh_apply(X, complex)"));
     KH_TRY(zcheck(Y, ycol, ncols, "kh_apply(Y, complex)"));
-    KH_ARG(X->n == 2 * A->n_cols && Y->n == 2 * A->n_rows,
+    KH_ARG(X->n == 2 * (A->n_cols - A->nrecv_prev - A->nrecv_next) && Y->n == 2 * A->n_rows,
            "kh_apply: dimension mismatch (complex A %lldx%lld, x %lld, y %lld reals)", (long long)A->n_rows,
            (long long)A->n_cols, (long long)X->n, (long long)Y->n);
     KH_ARG(!(X == Y && xcol == ycol), "kh_apply: in-place application is not supported");
@@ -559,8 +568,7 @@ __global__ __launch_bounds__(BS) void k_zsmall_matvec(int d, const double2* __re
 static int zproj_apply_dev(kh_ctx ctx, kh_proj p, double2* z, double* ya_dev) {
     const int d = (int)p->d;
     for (int it = 0; it < p->iterations; ++it) {
-        KH_TRY(zdot_dev(ctx, p->W, 0, d, z, p->c0));
-        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, 2 * d));
+        KH_TRY(zdot_dev(ctx, p->W, 0, d, z, p->c0));          // (all-reduced over the ranks inside)
         if (it == 0 && ya_dev != nullptr)
             hipLaunchKernelGGL(k_zsmall_matvec, dim3(1), dim3(BS), 0, ctx->stream, d,
                                reinterpret_cast<const double2*>(p->WRH), reinterpret_cast<const double2*>(p->c0),

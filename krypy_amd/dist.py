@@ -6,7 +6,8 @@ rotations and all small factors stay replicated on every rank's host.  Two excha
 both run inside ``libkrylov_hip.so`` over RCCL/xGMI:
 
 * all-reduce(sum, fp64) of dot-product panels (inside ``kh_dot_panel``, ``kh_nrm2``,
-  ``kh_arnoldi_step``, ``kh_residual``, ``kh_cg_update``) - the host layer is unchanged, it just
+  ``kh_arnoldi_step``, ``kh_residual``, ``kh_cg_update``; complex data: ``kh_zdot_panel`` and the complex step) -
+  the host layer is unchanged, it just
   sees the local slab length as ``N``;
 * a nearest-neighbour halo exchange before each sharded SpMV (``kh_mat_set_halo``): for a banded
   matrix (stencils) a rank needs the last ``h`` entries of the previous slab and the first ``h``
@@ -69,7 +70,6 @@ class ShardedCSROperator(utils.LinearOperator):
     def __init__(self, A_rows, row0, n_global, ctx=None):
         ctx = _hip.get_context() if ctx is None else ctx
         self._ctx = ctx
-        utils._require_real(A_rows.dtype, "sharded matrix")
         A_local, nrp, nrn = localize_columns(A_rows, row0, n_global)
         nloc = A_local.shape[0]
         # every rank learns its neighbours' halo widths: what rank p receives from p-1 is what
@@ -82,23 +82,37 @@ class ShardedCSROperator(utils.LinearOperator):
         nsend_next = int(table[2 * (ctx.rank + 1)]) if ctx.rank + 1 < ctx.nranks else 0
         if nsend_prev > nloc or nsend_next > nloc:
             raise utils.ArgumentError("halo wider than the local slab: use fewer ranks")
-        self._dmat = ctx.csr(A_local, n_cols=A_local.shape[1])
-        ctx.set_halo(self._dmat, nsend_prev, nsend_next, nrp, nrn)
+        self._A_local = A_local
         self.halo = (nsend_prev, nsend_next, nrp, nrn)
         self.row0, self.n_global = row0, n_global
-        super(ShardedCSROperator, self).__init__((nloc, nloc), numpy.dtype(float), self._dot_host)
+        # device images by block dtype: the matrix' own, and - like MatrixLinearOperator - a c128 copy of a real
+        # matrix the first time it meets complex vectors (complex halo entries travel as (re, im) pairs)
+        self._dmats = {}
+        dt = numpy.dtype(complex if numpy.dtype(A_local.dtype).kind == "c" else float)
+        self._dmat = self._image(dt)
+        super(ShardedCSROperator, self).__init__((nloc, nloc), dt, self._dot_host)
+
+    def _image(self, dt):
+        kind = numpy.dtype(dt).kind
+        dm = self._dmats.get(kind)
+        if dm is None:
+            dm = self._ctx.csr(self._A_local, n_cols=self._A_local.shape[1], dtype=dt)
+            self._ctx.set_halo(dm, *self.halo)
+            self._dmats[kind] = dm
+        return dm
 
     def _device_matrix(self, ctx=None, dtype=None):
         if dtype is not None and numpy.dtype(dtype).kind == "c":
-            return None   # real halo exchange only: complex operands take the generic path and fail loudly
+            return self._image(numpy.dtype(complex))
         return self._dmat
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
-        self._ctx.apply(self._dmat, X, xcol, Y, ycol, ncols)
+        self._ctx.apply(self._device_matrix(dtype=X.dtype), X, xcol, Y, ycol, ncols)
 
     def _dot_host(self, X):
-        X = numpy.asarray(X, dtype=float)
-        Xd = self._ctx.upload(X)
-        Yd = self._ctx.alloc(self.shape[0], X.shape[1])
+        X = numpy.asarray(X)
+        dt = utils._bdt(self.dtype, X.dtype)
+        Xd = self._ctx.upload(X, dtype=dt)
+        Yd = self._ctx.alloc(self.shape[0], X.shape[1], dtype=dt)
         self._apply_dev(Xd, 0, Yd, 0, X.shape[1])
         return numpy.ascontiguousarray(Yd.download())

@@ -105,6 +105,9 @@ class NumpyContext(object):
     def _allreduce(self, x):
         if self._comm is None:
             return x
+        x = np.asarray(x)
+        if np.iscomplexobj(x):       # (re, im) pairs, like the RCCL all-reduce of complex panels
+            return self._comm.allreduce(x.real.copy()) + 1j * self._comm.allreduce(x.imag.copy())
         return self._comm.allreduce(np.asarray(x, dtype=float))
 
     # bookkeeping
@@ -396,6 +399,10 @@ class GlooComm(object):
         import torch
         import torch.distributed as dist
 
+        if np.iscomplexobj(x):            # (re, im) pairs, like the RCCL exchange of a complex block
+            xr = np.ascontiguousarray(x, dtype=complex).view(float)
+            gp, gn = self.exchange(xr, 2 * nsend_prev, 2 * nsend_next, 2 * nrecv_prev, 2 * nrecv_next)
+            return gp.view(complex), gn.view(complex)
         reqs = []
         gp = torch.zeros(nrecv_prev, dtype=torch.float64)
         gn = torch.zeros(nrecv_next, dtype=torch.float64)

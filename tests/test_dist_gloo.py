@@ -140,6 +140,54 @@ def test_sharded_deflated_gmres_minres_cg(world):
     assert np.linalg.norm(xm - om.xk) < 1e-7 * np.linalg.norm(om.xk)
 
 
+def _case_complex(rank, world, ctx):
+    from krypy_amd import deflation, dist as kdist, linsys
+    from oracle.inputs import complex_systems
+    c = complex_systems(24)
+    A, b = c["nonh"], c["b"]
+    N = A.shape[0]
+    cuts = kdist.slab_cuts(N, world, align=24)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    op = kdist.ShardedCSROperator(A[r0:r1], r0, N, ctx)
+    assert op.dtype.kind == "c" and op.halo[2] == (24 if rank > 0 else 0)
+    ls = linsys.LinearSystem(op, b[r0:r1])
+    s = linsys.Gmres(ls, tol=1e-10, maxiter=300)
+    U = np.linalg.qr(np.random.default_rng(2).standard_normal((N, 4)) + 1j * np.random.default_rng(3).standard_normal((N, 4)))[0]
+    sd = deflation.DeflatedGmres(ls, U=U[r0:r1], tol=1e-9, maxiter=300)
+    # a REAL sharded matrix meeting a complex right-hand side: the c128 image of the slab and its halo
+    opr = kdist.ShardedCSROperator(c["L"][r0:r1], r0, N, ctx)
+    sr = linsys.Gmres(linsys.LinearSystem(opr, b[r0:r1]), tol=1e-10, maxiter=300)
+    return r0, r1, np.array(s.resnorms), s.xk[:, 0].copy(), np.array(sd.resnorms), sd.xk[:, 0].copy(), \
+        np.array(sr.resnorms), sr.xk[:, 0].copy()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_complex_gmres(world):
+    """Complex (c128) block-row sharding: the halo carries (re, im) pairs, the inner products are all-reduced as
+    pairs, the deflation projector runs inside the complex step - against the single-process complex oracle and the
+    reference's golden run."""
+    from oracle import krylov_ref_c as refc
+    from oracle.inputs import complex_systems
+    from tests.conftest import load_golden
+    out = _run(_case_complex, world)
+    c = complex_systems(24)
+    A, b = c["nonh"], c["b"]
+    g = load_golden("complex_nx24")
+    xo, reso, _, _ = refc.gmres(A, b, tol=1e-10, maxiter=300)
+    x = np.zeros(A.shape[0], dtype=complex)
+    xd = np.zeros(A.shape[0], dtype=complex)
+    xr = np.zeros(A.shape[0], dtype=complex)
+    for rank, (r0, r1, resn, xk, dres, dx, rres, rx) in out.items():
+        x[r0:r1], xd[r0:r1], xr[r0:r1] = xk, dx, rx
+        assert len(resn) == len(reso) == len(g["gmres_resnorms"])
+        assert np.max(np.abs(resn[:-1] - reso[:-1]) / reso[:-1]) < 1e-9
+        assert len(rres) == len(g["gmres_realA_resnorms"])
+    assert np.linalg.norm(x - xo) < 1e-8 * np.linalg.norm(xo)
+    assert np.linalg.norm(x - g["gmres_xk"]) < 1e-8 * np.linalg.norm(xo)
+    assert np.linalg.norm(A.dot(xd) - b) <= 1.01e-9 * np.linalg.norm(b)
+    assert np.linalg.norm(xr - g["gmres_realA_xk"]) < 1e-8 * np.linalg.norm(xr)
+
+
 def test_slab_cuts_and_localize():
     from krypy_amd import dist as kdist
     assert kdist.slab_cuts(100, 4) == [0, 25, 50, 75, 100]
