@@ -357,6 +357,10 @@ def _run():
                    "n": N, "ortho": ortho, "restart": m, "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "row-sharded x%d (RCCL)" % world,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
+                   # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
+                   # total time (the contract); the median cycle says what a typical one took
+                   "median_cycle_ms": float(np.median(cycle_ms)) if cycle_ms else None,
+                   "iterations_per_s_at_median_cycle": (m / float(np.median(cycle_ms)) * 1e3) if cycle_ms else None,
                    "basis_orthogonality_fro": orth},
         "roofline": roof,
     }

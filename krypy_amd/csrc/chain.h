@@ -669,6 +669,11 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 // Ring parity: batch NB-1 sits in ring[1]; the NG = NB - LB - 1 batches that still come from memory
 // start in ring[0] and NG is even, so the next column's first batch lands in ring[0] again.
 // ------------------------------------------------------------------------------------------
+// (experiment knob: the first KH_CH_REUSE_SKIP of the batches that come back from memory for the update are
+// streamed non-temporally as well, i.e. given up to HBM so that the others fit the 4 MB of L2 per XCD)
+#ifndef KH_CH_REUSE_SKIP
+#define KH_CH_REUSE_SKIP 0
+#endif
 template <int R2, bool CPLX = false>
 struct ChainShapeLds {
     // 5 rows per batch for R2 = 40, like the plain kernel (the complex instantiation spills 36 registers
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                                                             : (NG > 0 ? v2 + (int64_t)(NB - 2) * PB * CH_BS : vn);
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                ring[(b + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, (b + 1 < NB) && (b + 1 >= LB) && (b + 1 <= NB - 2));
+                ring[(b + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, (b + 1 < NB) && (b + 1 >= LB + KH_CH_REUSE_SKIP) && (b + 1 <= NB - 2));
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {

@@ -83,6 +83,7 @@ struct kh_ctx_s {
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     unsigned chain_epoch = 1;
     int chain_debug = 0;
+    int roctx = 0;          // KRYPY_AMD_ROCTX=1: roctx ranges around the entry points of the hot loop
     int chain_fault = 0;    // tests: the next chain launch reports a timeout and leaves garbage behind
     kh_step_s step[KH_NSLOT];
 #ifdef KH_CHAIN_TRACE

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -23,6 +25,39 @@ int fail(int code, const char* fmt, ...) {
     g_err = buf;
     return code;
 }
+
+// ---- optional roctx ranges (rocprofv3 --marker-trace): KRYPY_AMD_ROCTX=1 ----------------------
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    bool tried = false;
+};
+static Roctx g_roctx;
+static inline void roctx_push(kh_ctx ctx, const char* fmt, long long a, long long b) {
+    if (!ctx->roctx) return;
+    if (!g_roctx.tried) {
+        g_roctx.tried = true;
+        void* lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("/opt/rocm/lib/libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) {
+            g_roctx.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+            g_roctx.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+        }
+    }
+    if (g_roctx.push) {
+        char buf[96];
+        snprintf(buf, sizeof(buf), fmt, a, b);
+        g_roctx.push(buf);
+    }
+}
+static inline void roctx_pop(kh_ctx ctx) {
+    if (ctx->roctx && g_roctx.pop) g_roctx.pop();
+}
+struct RoctxScope {        // one range per C entry point of the hot loop
+    kh_ctx ctx;
+    RoctxScope(kh_ctx c, const char* fmt, long long a = 0, long long b = 0) : ctx(c) { roctx_push(c, fmt, a, b); }
+    ~RoctxScope() { roctx_pop(ctx); }
+};
 
 static inline int grid_for(kh_ctx ctx, int64_t n) {
     // enough workgroups to cover n/2 double2 elements, capped at the fixed reduction grid
@@ -745,6 +780,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_PF");
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_ROCTX");
+        ctx->roctx = (e == nullptr) ? 0 : atoi(e);
     }
     *out = ctx;
     return 0;
@@ -1429,6 +1466,7 @@ int kh_axpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double*
 int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc,
                double alpha, double beta, kh_vec Y, int64_t y0) {
     KH_ARG(ctx && (C || k == 0 || nc == 0), "kh_gemm_nn: NULL");
+    RoctxScope range_(ctx, "kh_gemm_nn k=%lld nc=%lld", (long long)k, (long long)nc);
     KH_TRY(check_vec(X, x0, k, "kh_gemm_nn(X)"));
     KH_TRY(check_vec(Y, y0, nc, "kh_gemm_nn(Y)"));
     KH_ARG(X->n == Y->n, "kh_gemm_nn: length mismatch");
@@ -1525,6 +1563,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                           int slot) {
     KH_ARG(ctx && V && W, "kh_arnoldi_step: NULL argument");
     KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_arnoldi_step: slot %d not in [0,%d)", slot, KH_NSLOT);
+    RoctxScope range_(ctx, "kh_arnoldi_step_begin k=%lld start=%lld", (long long)k, (long long)start);
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_arnoldi_step: k=%lld needs %lld basis columns, have %lld",
            (long long)k, (long long)(k + 2), (long long)V->ncols);
     KH_ARG(start >= 0 && start <= k, "kh_arnoldi_step: start=%lld not in [0,k]", (long long)start);
@@ -1745,6 +1784,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
 
 int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
     KH_ARG(ctx && hcol_out, "kh_arnoldi_step_end: NULL");
+    RoctxScope range_(ctx, "kh_arnoldi_step_end slot=%lld count=%lld", (long long)slot, (long long)count);
     KH_ARG(slot >= 0 && slot < KH_NSLOT && count >= 0 && count <= ctx->hcap,
            "kh_arnoldi_step_end: slot %d / count %lld", slot, (long long)count);
     KH_ARG(ctx->hev[slot] != nullptr, "kh_arnoldi_step_end: no step was begun");
@@ -1791,6 +1831,7 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
 int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,
                 int64_t rcol, double* nrm) {
     KH_ARG(ctx && A && nrm, "kh_residual: NULL");
+    RoctxScope range_(ctx, "kh_residual");
     KH_TRY(check_vec(Bv, bcol, 1, "kh_residual(B)"));
     KH_TRY(check_vec(X, xcol, 1, "kh_residual(X)"));
     KH_TRY(check_vec(R, rcol, 1, "kh_residual(R)"));
@@ -1860,6 +1901,7 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
                int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega,
                double rho, double* out) {
     KH_ARG(ctx && A && out, "kh_cg_step: NULL");
+    RoctxScope range_(ctx, "kh_cg_step");
     KH_TRY(check_vec(Pd, pcol, 1, "kh_cg_step(p)"));
     KH_TRY(check_vec(AP, apcol, 1, "kh_cg_step(Ap)"));
     KH_TRY(check_vec(YK, ycol, 1, "kh_cg_step(yk)"));

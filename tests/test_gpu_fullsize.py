@@ -145,3 +145,52 @@ def test_config5_shape_deflated_gmres_single_gpu(hip):
     # the Krylov basis of the projected operator is orthogonal to U^* A (range of P = ker <U, .>)
     G = ctx.gemm_tn(U, 0, 16, s1.arnoldi._V, 0, n)
     assert np.linalg.norm(G) < 1e-9
+
+
+def test_config5_slab_at_its_stated_size_through_the_sharded_path(hip):
+    """Config 5 puts 12.5 M rows (a 500 x 500 x 50 slab of the 500 x 500 x 400 grid) on every GPU.  That is beyond
+    what the register file holds (10.48 M): the 48-rows-per-lane kernels keep eight rows of w in LDS.  One such
+    slab through the code path a rank takes on 8 GPUs (1-rank RCCL communicator in forced mode, ShardedCSROperator,
+    panel Gram-Schmidt with all-reduced coefficients, split SpMV) - DeflatedGmres with 16 Ritz vectors harvested
+    from a plain cycle: deflation identities, orthogonality of the basis, and the register-resident kernels ran."""
+    import os
+    from krypy_amd import _hip, deflation, dist as kdist, linsys, utils
+
+    A = ref.laplace3d(500, 500, 50)
+    N = A.shape[0]
+    assert N == 12_500_000
+    b = np.random.default_rng(0).standard_normal(N)
+    os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
+    try:
+        ctx = _hip.Context(0)
+        ctx.comm_init(0, 1, ctx.comm_unique_id())
+    finally:
+        del os.environ["KRYPY_AMD_FORCE_MULTI"]
+    old = _hip._install_context_for_testing(ctx)
+    try:
+        op = kdist.ShardedCSROperator(A, 0, N, ctx)
+        ls = linsys.LinearSystem(op, b, self_adjoint=True)
+        try:
+            s0 = deflation.DeflatedGmres(ls, tol=1e-12, maxiter=40, store_arnoldi=True, ortho="cgs")
+        except utils.ConvergenceError as e:
+            s0 = e.solver
+        ritz = deflation.Ritz(s0)
+        Ud = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:16])
+        before = ctx.counters()["cgs_register"]
+        try:
+            s1 = deflation.DeflatedGmres(ls, U=Ud, tol=1e-12, maxiter=40, store_arnoldi=True, ortho="cgs")
+        except utils.ConvergenceError as e:
+            s1 = e.solver
+        assert ctx.counters()["cgs_register"] - before >= 40          # k_cgs_dots / k_cgs_update<48, ., 8>
+        assert ctx.get("n_spmv_split") > 0
+        assert s1.resnorms[-1] < s0.resnorms[-1]
+        U, AU = s1.projection._Ud, s1.projection._AUd
+        E = ctx.gemm_tn(U, 0, 16, AU, 0, 16)
+        assert np.linalg.norm(E - s1.E) < 1e-10 * np.linalg.norm(E)
+        n = s1.H.shape[1]
+        G = ctx.gemm_tn(s1.arnoldi._V, 0, n + 1, s1.arnoldi._V, 0, n + 1)
+        assert np.linalg.norm(G - np.eye(n + 1)) < 1e-11
+        assert np.linalg.norm(ctx.gemm_tn(U, 0, 16, s1.arnoldi._V, 0, n)) < 1e-9
+    finally:
+        _hip._install_context_for_testing(old)
+        ctx.close()
