@@ -238,19 +238,27 @@ class DeflatedCg(_DeflationMixin, linsys.Cg):
         super(DeflatedCg, self).__init__(*args, **kwargs)
 
     def _store_UAv(self, UAp):
-        r""":math:`\langle U, M_lAM_rV_n\rangle` by the three-term recurrence of
-        deflation.py:247-263 (CG applies the operator to ``p``, not to the Lanczos vector)."""
-        self._UAps.append(UAp)
-        c = UAp.copy()
-        rhos = self.rhos
-        if self.iter > 0:
-            c -= (1 + rhos[-1] / rhos[-2]) * self._UAps[-2]
-        if self.iter > 1:
-            c += rhos[-2] / rhos[-3] * self._UAps[-3]
-        c *= ((-1) ** self.iter) / numpy.sqrt(rhos[-1])
-        if self.iter > 0:
-            c -= numpy.sqrt(rhos[-2] / rhos[-1]) * self.C[:, [-1]]
-        self.C = numpy.column_stack([self.C, c])
+        r"""Next column of :math:`C=\langle U, M_lAM_rV_n\rangle` (deflation.py:247-263).
+
+        CG applies the operator to its search direction :math:`p_k`, not to the Lanczos vector :math:`v_k`.  With
+        :math:`r_k = p_k - \omega_{k-1} p_{k-1}`, :math:`\omega_j=\rho_{j+1}/\rho_j`, and
+        :math:`v_k = (-1)^k r_k/\sqrt{\rho_k}`, the column is a combination of the last three
+        :math:`\langle U, A p_j\rangle` and of the previous column: weights first, then one pass."""
+        hist = self._UAps
+        hist.append(UAp)
+        k, rho = self.iter, self.rhos
+        weights = [1.0]
+        if k >= 1:
+            weights.append(-(1 + rho[-1] / rho[-2]))
+        if k >= 2:
+            weights.append(rho[-2] / rho[-3])
+        col = numpy.array(hist[-1], copy=True)
+        for back, wgt in enumerate(weights[1:], start=2):
+            col += wgt * hist[-back]
+        col *= (-1.0 if k % 2 else 1.0) / numpy.sqrt(rho[-1])
+        if k >= 1:
+            col -= numpy.sqrt(rho[-2] / rho[-1]) * self.C[:, -1:]
+        self.C = numpy.column_stack([self.C, col])
 
 
 class DeflatedMinres(_DeflationMixin, linsys.Minres):

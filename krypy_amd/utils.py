@@ -511,27 +511,21 @@ class LinearOperator(object):
         self._tmp = {}
 
     # -- host API ---------------------------------------------------------------------
-    def dot(self, X):
+    def _host_apply(self, fn, X, rows_needed, what):
+        """Shared body of :meth:`dot` / :meth:`dot_adj`: the reference's contract (utils.py:1381-1405) - shape
+        check against the operator, ``LinearOperatorError`` for a missing callable, an empty block passes through."""
         X = numpy.asanyarray(X)
-        m, n = self.shape
-        if X.shape[0] != n:
+        if X.shape[0] != rows_needed:
             raise LinearOperatorError("dimension mismatch")
-        if self._dot is None:
-            raise LinearOperatorError("dot undefined")
-        if X.shape[1] == 0:
-            return numpy.zeros(X.shape)
-        return self._dot(X)
+        if fn is None:
+            raise LinearOperatorError(what + " undefined")
+        return fn(X) if X.shape[1] else numpy.zeros(X.shape)
+
+    def dot(self, X):
+        return self._host_apply(self._dot, X, self.shape[1], "dot")
 
     def dot_adj(self, X):
-        X = numpy.asanyarray(X)
-        m, n = self.shape
-        if X.shape[0] != m:
-            raise LinearOperatorError("dimension mismatch")
-        if self._dot_adj is None:
-            raise LinearOperatorError("dot_adj undefined")
-        if X.shape[1] == 0:
-            return numpy.zeros(X.shape)
-        return self._dot_adj(X)
+        return self._host_apply(self._dot_adj, X, self.shape[0], "dot_adj")
 
     @property
     def adj(self):

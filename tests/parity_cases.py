@@ -223,13 +223,12 @@ def case_api_errors():
         raise AssertionError
     except utils.ArgumentError:
         pass
-    # complex data is supported (tests/parity_cases_complex.py); what stays real fails loudly
+    # complex data is supported everywhere (tests/parity_cases_complex.py), block-row shards included since round 2
     from krypy_amd import dist
-    try:
-        dist.ShardedCSROperator(sp.csr_matrix(A.astype(complex)), 0, 100)
-        raise AssertionError("complex sharded matrix must fail loudly")
-    except NotImplementedError:
-        pass
+    Ac = sp.csr_matrix(A.astype(complex) * (1.0 + 0.5j))
+    opc = dist.ShardedCSROperator(Ac, 0, 100)
+    xc = (np.arange(100.0) + 1j).reshape(-1, 1)
+    assert opc.dtype.kind == "c" and np.allclose(opc.dot(xc), Ac.dot(xc), rtol=1e-15, atol=0)
     G = utils.Givens(np.array([[-3.0], [4.0]]))
     assert abs(G.c + 0.6) < 1e-15 and abs(G.s - 0.8) < 1e-15 and abs(G.r - 5) < 1e-15
 
