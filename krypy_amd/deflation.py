@@ -135,8 +135,18 @@ class _DeflationMixin(object):
 
     def _solve(self):
         N = self.linear_system.N
-        P = utils.LinearOperator((N, N), self.projection._bdt, self._apply_projection)
-        P._apply_dev = self._apply_projection_dev
+        # the projected operator refers to its solver weakly: self.MlAMr -> P -> self would be a cycle, and the
+        # solver's basis (10 GB at N = 10^7) would wait for the garbage collector instead of going back to the pool
+        me = weakref.ref(self)
+
+        def solver():
+            s = me()
+            if s is None:
+                raise utils.RuntimeError("the deflated solver behind this projected operator is gone")
+            return s
+
+        P = utils.LinearOperator((N, N), self.projection._bdt, lambda Av: solver()._apply_projection(Av))
+        P._apply_dev = lambda X, xcol, Y, ycol, ncols=1: solver()._apply_projection_dev(X, xcol, Y, ycol, ncols)
         if type(self)._store_UAv is _DeflationMixin._store_UAv:
             # (I - P) A runs inside the fused Arnoldi step; DeflatedCg keeps the Python path: its
             # C recurrence needs self.iter / self.rhos at application time
