@@ -270,6 +270,20 @@ int kh_zproj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, 
 int kh_zproj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_vec Z, int64_t zcol, double* ya_out);
 int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
                                 int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot);
+/* The general complex step: Md = the Jacobi preconditioner as a complex diagonal (kh_zdiag_upload) with its second
+ * block P (V = Md P, krypy/utils.py:1026-1045), W with two columns then; Md = P = NULL: as above. */
+int kh_zarnoldi_step_begin_md(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                              int64_t k, int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot);
+/* Complex kh_minres_update (krypy/linsys.py:844-846): z = (v_k - r0 W0 - r1 W1)/r2; W <- [W1, z]; yk += y0 z with
+ * complex coefficients ((re, im) pairs), one pass. */
+int kh_zminres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, const double r0[2], const double r1[2],
+                      const double r2[2], const double y0[2], kh_vec YK, int64_t ycol);
+/* Complex kh_cg_step (krypy/linsys.py:622-665), one host synchronisation per iteration.  A complex; the vectors are
+ * complex blocks (real kh_vec of length 2N); Md NULL or a REAL diagonal of length 2N (each Jacobi entry twice).
+ * out[0] = d with step length alpha = rho / d = Re(rho / <p, Ap>), out[1] = <r, z>, out[2..3] = <p, Ap>. */
+int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
+                int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega, double rho,
+                double* out);
 
 /* ---- measurement ----------------------------------------------------------------------- */
 /* bench.py's roofline numbers: average duration (ms) of `reps` back-to-back launches of one hot

@@ -105,6 +105,9 @@ _SIGNATURES = {
     "kh_zarnoldi_step": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _c_double_p],
     "kh_zarnoldi_step_begin": [_H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
     "kh_zarnoldi_step_begin_proj": [_H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
+    "kh_zarnoldi_step_begin_md": [_H, _H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_double_p, _INT],
+    "kh_zminres_update": [_H, _H, _I64, _H, _INT, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _H, _I64],
+    "kh_zcg_step": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _INT, _D, _D, _c_double_p],
     "kh_zproj_create": [_H, _H, _H, _I64, _c_double_p, _c_double_p, _INT, ctypes.POINTER(_H)],
     "kh_zproj_apply_complement": [_H, _H, _H, _I64, _H, _I64, _c_double_p],
 }
@@ -642,8 +645,9 @@ class Context(object):
 
     def arnoldi_step(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
         if _same_dtype("arnoldi_step", V, W):
-            if Md is not None or P is not None:
-                raise BackendError("arnoldi_step: the complex step takes no preconditioner")
+            if Md is not None or P is not None:       # (complex diagonal Md with its block P: the general entry)
+                self.arnoldi_step_begin(A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, 0)
+                return self.arnoldi_step_end(0, k + 2, cplx=True)
             out = numpy.empty(k + 2, dtype=numpy.complex128)
             hk, hkp = _zarr([h_km1])
             _check(self._lib, self._lib.kh_zarnoldi_step(
@@ -660,12 +664,13 @@ class Context(object):
     def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
                            proj=None):
         if _same_dtype("arnoldi_step_begin", V, W):
-            if Md is not None or P is not None:
-                raise BackendError("arnoldi_step_begin: the complex step takes no preconditioner")
-            hk = numpy.array([h_km1, 0.0], dtype=numpy.float64)
-            _check(self._lib, self._lib.kh_zarnoldi_step_begin_proj(
+            if (Md is None) != (P is None) or (Md is not None and (Md.dtype != _C128 or Md.kind != "diag")):
+                raise BackendError("arnoldi_step_begin: the complex step takes a complex diagonal Md with its block P")
+            hk = numpy.array([numpy.real(h_km1), numpy.imag(h_km1)], dtype=numpy.float64)
+            _check(self._lib, self._lib.kh_zarnoldi_step_begin_md(
                 self._h, A.handle if A is not None else None, proj.handle if proj is not None else None,
-                V.handle, W.handle, wcol, k, start, sweeps, gs_mode, _dptr(hk), slot), "kh_zarnoldi_step_begin")
+                Md.handle if Md is not None else None, V.handle, P.handle if P is not None else None,
+                W.handle, wcol, k, start, sweeps, gs_mode, _dptr(hk), slot), "kh_zarnoldi_step_begin")
             return
         _check(self._lib, self._lib.kh_arnoldi_step_begin(
             self._h, A.handle if A is not None else None,
@@ -718,18 +723,20 @@ class Context(object):
 
     def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
         if _same_dtype("minres_update", V, Wk, YK):
-            # z = (V_k - r0 W0 - r1 W1)/r2 written over W0 (= column `slot`);  yk += y0 z
-            self.waxpby(Wk, slot, -complex(r0), Wk, slot, 1.0 + 0.0j, V, k)
-            self.axpy_panel(Wk, 1 - slot, 1, [r1], Wk, slot)
-            self.vdiv(Wk, slot, Wk, slot, r2)
-            self.waxpby(YK, ycol, complex(y0), Wk, slot, 1.0 + 0.0j, YK, ycol)
+            # z = (V_k - r0 W0 - r1 W1)/r2 written over W0 (= column `slot`);  yk += y0 z: one pass, complex scalars
+            c = [_zarr([x]) for x in (r0, r1, r2, y0)]
+            _check(self._lib, self._lib.kh_zminres_update(self._h, V.handle, k, Wk.handle, slot, c[0][1], c[1][1],
+                                                          c[2][1], c[3][1], YK.handle, ycol), "kh_zminres_update")
             return
         _check(self._lib, self._lib.kh_minres_update(self._h, V.handle, k, Wk.handle, slot, r0, r1,
                                                      r2, y0, YK.handle, ycol), "kh_minres_update")
 
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
-        if _same_dtype("cg_update", Pd, AP, YK, R):
-            raise BackendError("cg_update is real only (complex CG runs the step by step path)")
+        """``yk += alpha p; r -= alpha Ap; z = Md r; return <r, z>`` in one pass.  The recurrences have real
+        coefficients, so complex blocks run as their real views of length 2N; ``Md`` is then a REAL diagonal of
+        length 2N (every Jacobi entry twice) and the result the real part of ``<r, z>``."""
+        if _same_dtype("cg_update", Pd, AP, YK, R) and Md is not None and (Md.dtype != _F64 or Md.shape[0] != 2 * R.n):
+            raise BackendError("cg_update on complex blocks: Md must be the real diagonal of length 2N")
         out = _D(0.0)
         _check(self._lib, self._lib.kh_cg_update(
             self._h, alpha, Pd.handle, pcol, AP.handle, apcol, YK.handle, ycol, R.handle, rcol,
@@ -739,15 +746,24 @@ class Context(object):
 
 
     def cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
-        """One CG iteration in one call; returns ``(<p, Ap>, rho_new)``."""
+        """One CG iteration in one call; returns ``(d, rho_new, <p, Ap>)`` where ``alpha = rho / d`` is the step
+        the device took: ``d = <p, Ap>`` for real data, ``rho / d = Re(rho / <p, Ap>)`` for complex data (then ``A``
+        is a complex operator and ``Md`` a REAL diagonal of length 2N, every Jacobi entry twice)."""
         if _same_dtype("cg_step", Pd, AP, YK, R):
-            raise BackendError("cg_step is real only (complex CG runs the step by step path)")
+            if A.dtype != _C128 or (Md is not None and (Md.dtype != _F64 or Md.shape[0] != 2 * R.n)):
+                raise BackendError("cg_step on complex blocks: complex operator and real diagonal of length 2N needed")
+            out = numpy.empty(4, dtype=numpy.float64)
+            _check(self._lib, self._lib.kh_zcg_step(
+                self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle,
+                apcol, YK.handle, ycol, R.handle, rcol, Z.handle if Z is not None else None, zcol,
+                1 if first else 0, omega, rho, _dptr(out)), "kh_zcg_step")
+            return float(out[0]), float(out[1]), complex(out[2], out[3])
         out = numpy.empty(2, dtype=numpy.float64)
         _check(self._lib, self._lib.kh_cg_step(
             self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle,
             apcol, YK.handle, ycol, R.handle, rcol, Z.handle if Z is not None else None, zcol,
             1 if first else 0, omega, rho, _dptr(out)), "kh_cg_step")
-        return float(out[0]), float(out[1])
+        return float(out[0]), float(out[1]), float(out[0])
 
     def bench_kernel(self, which, V, W, reps):
         ms = _D(0.0)

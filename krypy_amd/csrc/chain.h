@@ -1250,7 +1250,10 @@ struct CgsArgs {
         else wl[((r) - RW) * CH_BS + tid] = (val);      \
     } while (0)
 
-template <int R2, bool MASKED, bool NTC, int WL = 0>
+// CPLX: every double2 is one complex number: <v, w> = conj(v) w as two sums per column (partials of column t in
+// rows 2t (re) and 2t+1 (im) of `part`, so the reduction leaves (re, im) pairs), the update multiplies by a complex
+// coefficient (NumPy's product: (ac - bd, ad + bc)); the norm is that of the real view either way.
+template <int R2, bool MASKED, bool NTC, int WL = 0, bool CPLX = false>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
     constexpr int RW = R2 - WL;
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
@@ -1289,7 +1292,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
         const double2* __restrict__ vn =
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + (t + 1 < a.ncol ? t + 1 : t)) * a.ld) + first;
-        double acc0 = 0.0, acc1 = 0.0;
+        double acc0 = 0.0, acc1 = 0.0, aci0 = 0.0, aci1 = 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
@@ -1304,10 +1307,22 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
                 const double2 wr = CGS_W_GET(b * PB + i);
                 acc0 = fma(v.x, wr.x, acc0);
                 acc1 = fma(v.y, wr.y, acc1);
+                if (CPLX) {
+                    aci0 = fma(v.x, wr.y, aci0);
+                    aci1 = fma(v.y, wr.x, aci1);
+                }
             }
         }
         const double s = wave_sum(acc0 + acc1);
-        if (lane == 0) a.part[(int64_t)t * a.pstride + slot] = s;
+        if (CPLX) {
+            const double si = wave_sum(aci0 - aci1);
+            if (lane == 0) {
+                a.part[(int64_t)(2 * t) * a.pstride + slot] = s;
+                a.part[(int64_t)(2 * t + 1) * a.pstride + slot] = si;
+            }
+        } else if (lane == 0) {
+            a.part[(int64_t)t * a.pstride + slot] = s;
+        }
     };
     if constexpr ((NB & 1) == 0) {
         for (int t = 0; t < a.ncol; ++t) column(std::integral_constant<int, 0>{}, t);
@@ -1322,7 +1337,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
 #undef CH_OK
 }
 
-template <int R2, bool MASKED, int WL = 0>
+template <int R2, bool MASKED, int WL = 0, bool CPLX = false>
 __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
     constexpr int RW = R2 - WL;
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
@@ -1359,7 +1374,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
         constexpr int P0 = decltype(par)::value;
         const int t = tfirst + it * tstep;
         const int tn = (it + 1 < a.ncol) ? t + tstep : t;
-        const double h = a.coef[t];
+        const double h = CPLX ? a.coef[2 * t] : a.coef[t];
+        const double hi = CPLX ? a.coef[2 * t + 1] : 0.0;
         const double2* __restrict__ b2 =
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + t) * a.ld) + first;
         const double2* __restrict__ bn =
@@ -1375,8 +1391,15 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
                 const double2 p = ring[(P0 + b) & 1][i];
                 const int r = b * PB + i;
                 double2 wr = CGS_W_GET(r);
-                wr.x = CH_OK(r) ? wr.x - h * p.x : 0.0;
-                wr.y = CH_OK(r) ? wr.y - h * p.y : 0.0;
+                if (CPLX) {
+                    const double tr = h * p.x - hi * p.y;
+                    const double ti = h * p.y + hi * p.x;
+                    wr.x = CH_OK(r) ? wr.x - tr : 0.0;
+                    wr.y = CH_OK(r) ? wr.y - ti : 0.0;
+                } else {
+                    wr.x = CH_OK(r) ? wr.x - h * p.x : 0.0;
+                    wr.y = CH_OK(r) ? wr.y - h * p.y : 0.0;
+                }
                 CGS_W_PUT(r, wr);
             }
         }

@@ -604,39 +604,43 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 constexpr int CGS_MAXCOL = 256;
 constexpr int CGS_PSTRIDE = CH_GMAX * (CH_BS / 64);   // wave partials per column
 
-template <int R2, bool MASKED, int WL = 0>
+template <int R2, bool MASKED, int WL = 0, bool CPLX = false>
 static hipError_t launch_cgs(kh_ctx ctx, int G, CgsArgs& a, bool update) {
     constexpr size_t lds = (size_t)WL * CH_BS * sizeof(double2);
     if (lds > 0) {
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_update<R2, MASKED, WL>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_update<R2, MASKED, WL, CPLX>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, true, WL>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, true, WL, CPLX>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, false, WL>),
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, false, WL, CPLX>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
             attr_done = true;
         }
     }
     if (update)
-        hipLaunchKernelGGL((k_cgs_update<R2, MASKED, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_update<R2, MASKED, WL, CPLX>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     else if (a.nt_cols)
-        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, true, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, true, WL, CPLX>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false, WL>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false, WL, CPLX>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
 // One Arnoldi step's panel sweeps with w register-resident.  Returns 1 when done (the norm's wave
 // partials are in SLOT_NRM.., *nrm_count of them), 0 when not eligible, negative on error.
+// cplx: V, B, w are complex blocks (real views of even length), hdev / coef hold (re, im) pairs and `start` counts
+// complex entries of the H column; no Jacobi tail then (dg must be NULL).
 static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, const double* dg, double* mw,
                        int64_t start, int64_t ncol, int sweeps, bool multi, double* hdev, double* coef,
-                       int* nrm_count) {
+                       int* nrm_count, bool cplx = false) {
     if (!ctx->chain_enabled || ncol > CGS_MAXCOL) return 0;
+    if (cplx && (dg != nullptr || (V->n & 1))) return 0;
+    const int cw = cplx ? 2 : 1;           // doubles per coefficient
     const int64_t n = V->n;
     int r2 = 0, G = 0;
     if (!chain_geometry(ctx, n, &r2, &G)) return 0;
@@ -646,7 +650,7 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
     const int64_t need_ld = (int64_t)G * chunk2 * 2;
     const bool padded = V->ld >= need_ld && B->ld >= need_ld && wld >= need_ld;
     if (ctx->cgs_part == nullptr)
-        KH_HIP(hipMalloc(&ctx->cgs_part, sizeof(double) * (size_t)CGS_MAXCOL * CGS_PSTRIDE));
+        KH_HIP(hipMalloc(&ctx->cgs_part, sizeof(double) * (size_t)2 * CGS_MAXCOL * CGS_PSTRIDE));   // (re, im rows when complex)
     const int nwave = G * (CH_BS / 64);
     CgsArgs a;
     a.n2 = n2;
@@ -670,8 +674,10 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         return e ? atof(e) : 0.75;       // GB; measured: N = 10^7 668 -> 703 it/s, N/2 1315 -> 1441, N/4 2504 -> 2576, N/8 equal
     }();
     a.nt_cols = ((double)ncol * (double)n * 8.0 > nt_gb * 1e9) ? 1 : 0;
-#define KH_CGS(R, UPD) (padded ? launch_cgs<R, false>(ctx, G, a, UPD) : launch_cgs<R, true>(ctx, G, a, UPD))
-#define KH_CGS_L(R, WL, UPD) (padded ? launch_cgs<R, false, WL>(ctx, G, a, UPD) : launch_cgs<R, true, WL>(ctx, G, a, UPD))
+#define KH_CGS_L(R, WL, UPD)                                                                                      \
+    (cplx ? (padded ? launch_cgs<R, false, WL, true>(ctx, G, a, UPD) : launch_cgs<R, true, WL, true>(ctx, G, a, UPD)) \
+          : (padded ? launch_cgs<R, false, WL>(ctx, G, a, UPD) : launch_cgs<R, true, WL>(ctx, G, a, UPD)))
+#define KH_CGS(R, UPD) KH_CGS_L(R, 0, UPD)
 #define KH_CGS_ANY(UPD)                                                                        \
     (r2 == 4 ? KH_CGS(4, UPD) : r2 == 8 ? KH_CGS(8, UPD) : r2 == 16 ? KH_CGS(16, UPD)            \
      : r2 == 24 ? KH_CGS(24, UPD) : r2 == 32 ? KH_CGS(32, UPD) : r2 == 40 ? KH_CGS(40, UPD)     \
@@ -683,14 +689,14 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         KH_HIP(KH_CGS_ANY(false));
         // one sweep: the coefficients ARE the H entries - reduce (and all-reduce) straight into the H
         // column, which the caller then need not clear, and skip the accumulate launch
-        if (sweeps == 1) coef = hdev + start;
-        hipLaunchKernelGGL(k_reduce_partials, dim3((int)ncol), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
+        if (sweeps == 1) coef = hdev + cw * start;
+        hipLaunchKernelGGL(k_reduce_partials, dim3((int)(cw * ncol)), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
                            CGS_PSTRIDE, coef, 0);
         KH_HIP(hipGetLastError());
-        if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, ncol));
+        if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, cw * ncol));
         if (sweeps > 1)
-            hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, ncol, hdev + start, 1.0, hdev + start,
-                               1.0, coef);
+            hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, cw * ncol, hdev + cw * start, 1.0,
+                               hdev + cw * start, 1.0, coef);
         a.Vb = B->d;
         a.ld = B->ld;
         a.coef = coef;
@@ -1809,8 +1815,8 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
             KH_TRY(kh_arnoldi_step_begin(ctx, st.A, st.proj, st.Md, st.V, st.P, st.W, st.wcol, st.k, st.start, st.sweeps,
                                          st.gs_mode, st.h_km1[0], slot));
         else if (st.kind == 2)
-            KH_TRY(kh_zarnoldi_step_begin(ctx, st.A, st.V, st.W, st.wcol, st.k, st.start, st.sweeps, st.gs_mode,
-                                          st.h_km1, slot));
+            KH_TRY(kh_zarnoldi_step_begin_md(ctx, st.A, st.proj, st.Md, st.V, st.P, st.W, st.wcol, st.k, st.start,
+                                             st.sweeps, st.gs_mode, st.h_km1, slot));
         else
             return fail(KH_ERR_HIP, "grid-wide reduction of the MGS chain kernel timed out and the step cannot be "
                                     "re-run (no record of it)");
@@ -1878,7 +1884,8 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_update: Md must be diagonal");
     if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_update(z)"));
     const int64_t n = R->n;
-    KH_ARG(Pd->n == n && AP->n == n && YK->n == n, "kh_cg_update: length mismatch");
+    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && (!Md || (Md->n_rows == n && Z->n == n)),
+           "kh_cg_update: length mismatch");
     double* part = part_slot(ctx, SLOT_NRM);
     const int grid = grid_lin(ctx, n);
     if (Md)
@@ -1910,7 +1917,8 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
     KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_step: Md must be diagonal");
     if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_step(z)"));
     const int64_t n = R->n;
-    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && A->n_rows == n, "kh_cg_step: length mismatch");
+    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && A->n_rows == n && (!Md || (Md->n_rows == n && Z->n == n)),
+           "kh_cg_step: length mismatch");
     KH_ARG(!(Pd == AP && pcol == apcol), "kh_cg_step: p and Ap must be different columns");
     double* p = Pd->col(pcol);
     double* ap = AP->col(apcol);

@@ -115,6 +115,52 @@ __global__ __launch_bounds__(BS) void k_zwaxpby(int64_t n, double2* z, double2 a
     }
 }
 
+// Complex twin of k_minres_update (linsys.py:844-846), one pass:
+//   z = ((v - r0 w0) - r1 w1) / r2 ;  w0 <- z ;  yk += y0 z
+// NumPy's complex arithmetic: products as (ac - bd, ad + bc), the quotient by Smith's formula (ratio and scale once).
+__global__ __launch_bounds__(BS) void k_zminres_update(int64_t n, const double2* __restrict__ v,
+                                                       double2* __restrict__ w0, const double2* __restrict__ w1,
+                                                       double2 r0, double2 r1, double2 r2, double2 y0,
+                                                       double2* __restrict__ yk) {
+    const bool big_re = fabs(r2.x) >= fabs(r2.y);
+    const double rat = big_re ? r2.y / r2.x : r2.x / r2.y;
+    const double scl = 1.0 / (big_re ? (r2.x + r2.y * rat) : (r2.y + r2.x * rat));
+    const int64_t stride = (int64_t)gridDim.x * BS;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
+        const double2 a = w0[i], b = w1[i];
+        double2 t = v[i];
+        t.x = t.x - (r0.x * a.x - r0.y * a.y);
+        t.y = t.y - (r0.x * a.y + r0.y * a.x);
+        t.x = t.x - (r1.x * b.x - r1.y * b.y);
+        t.y = t.y - (r1.x * b.y + r1.y * b.x);
+        double2 z;
+        if (big_re) {
+            z.x = (t.x + t.y * rat) * scl;
+            z.y = (t.y - t.x * rat) * scl;
+        } else {
+            z.x = (t.x * rat + t.y) * scl;
+            z.y = (t.y * rat - t.x) * scl;
+        }
+        w0[i] = z;
+        double2 o = yk[i];
+        o.x = o.x + (y0.x * z.x - y0.y * z.y);
+        o.y = o.y + (y0.x * z.y + y0.y * z.x);
+        yk[i] = o;
+    }
+}
+
+// Complex CG: t[2], t[3] = <p, Ap>; t[0] <- the real number d with rho / d = Re(rho / <p, Ap>), the step length the
+// reference takes (linsys.py:640-648: complex quotient, then the real part) - Smith's formula with a real numerator.
+__global__ void k_zcg_den(double* __restrict__ t) {
+    const double re = t[2], im = t[3];
+    if (fabs(re) >= fabs(im)) {
+        t[0] = re + im * (im / re);
+    } else {
+        const double ratio = re / im;
+        t[0] = (re * ratio + im) / ratio;
+    }
+}
+
 __global__ __launch_bounds__(BS) void k_zdiag_apply(int64_t n, const double2* __restrict__ d,
                                                     const double2* __restrict__ x, double2* __restrict__ y) {
     const int64_t stride = (int64_t)gridDim.x * BS;
@@ -584,9 +630,15 @@ static int zproj_apply_dev(kh_ctx ctx, kh_proj p, double2* z, double* ya_dev) {
 
 static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
                          int sweeps, int gs_mode, const double h_km1[2], const double* h_km1_dev, double* hdev,
-                         int slot, kh_proj proj = nullptr) {
+                         int slot, kh_proj proj = nullptr, kh_mat Md = nullptr, kh_vec P = nullptr) {
     KH_TRY(zcheck(V, k, 2, "kh_zarnoldi_step(V)"));
-    KH_TRY(zcheck(W, wcol, 1, "kh_zarnoldi_step(W)"));
+    KH_TRY(zcheck(W, wcol, Md ? 2 : 1, "kh_zarnoldi_step(W)"));
+    // Md: the Jacobi preconditioner as a complex diagonal, V = Md P (utils.py:1026-1045): dots against V, updates
+    // with P, norm sqrt(Re <w, Md w>), both blocks get their next column
+    KH_ARG((Md == nullptr) == (P == nullptr), "kh_zarnoldi_step: P and Md go together");
+    KH_ARG(Md == nullptr || (Md->kind == KH_MAT_ZDIAG && 2 * Md->n_rows == V->n && P->n == V->n && P->ncols >= V->ncols),
+           "kh_zarnoldi_step: Md must be a complex diagonal of the vectors' length, P a block like V");
+    kh_vec Bk = P ? P : V;
     KH_ARG(V->n == W->n && start >= 0 && start <= k && sweeps >= 1 && sweeps <= 4, "kh_zarnoldi_step: arguments");
     const int64_t n = V->n / 2;
     double* tmp = ctx->scal + ZSC_TMP;
@@ -607,35 +659,60 @@ static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol,
             KH_TRY(zpush(ctx, h_km1, 2, coef));
             cf = coef;
         }
-        KH_TRY(zaxpy_dev(ctx, V, k - 1, 1, cf, 1.0, 1.0, w, false, nullptr));
+        KH_TRY(zaxpy_dev(ctx, Bk, k - 1, 1, cf, 1.0, 1.0, w, false, nullptr));
     }
     const int64_t ncol = k - start + 1;
     // reference-order MGS with w in registers for the whole chain (chain.h, CPLX instantiation):
     // one launch instead of 4 per column
-    if (gs_mode == KH_GS_MGS) {
+    if (gs_mode == KH_GS_MGS && Md == nullptr) {
         const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, false, 0.0,
                                  nullptr, hdev, slot, true);
         if (rc != 0) return rc < 0 ? rc : 0;
     }
-    for (int s = 0; s < sweeps; ++s) {
+    // panel (classical) Gram-Schmidt with w register-resident: two launches per sweep (chain.h, CPLX instantiations)
+    const double* nrm_src = nrm_part;
+    int nrm_n = grid;
+    bool panel_done = false;
+    if (gs_mode != KH_GS_MGS && Md == nullptr) {
+        int cnt = 0;
+        const int rc = try_cgs_reg(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, start, ncol, sweeps, kh_multi(ctx),
+                                   hdev, coef, &cnt, true);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            panel_done = true;
+            nrm_src = part_slot(ctx, SLOT_NRM);
+            nrm_n = cnt;
+        }
+    }
+    for (int s = 0; s < sweeps && !panel_done; ++s) {
         const bool last_sweep = (s == sweeps - 1);
         if (gs_mode == KH_GS_MGS) {
             for (int64_t j = start; j <= k; ++j) {
                 KH_TRY(zdot_dev(ctx, V, j, 1, w, coef));
                 hipLaunchKernelGGL(k_zacc, dim3(1), dim3(64), 0, ctx->stream, 2, hdev + 2 * j, coef);
-                KH_TRY(zaxpy_dev(ctx, V, j, 1, coef, 1.0, 1.0, w, last_sweep && j == k, nrm_part));
+                KH_TRY(zaxpy_dev(ctx, Bk, j, 1, coef, 1.0, 1.0, w, !Md && last_sweep && j == k, nrm_part));
             }
         } else {
             KH_ARG(ncol <= 512, "kh_zarnoldi_step: panel mode handles at most 512 columns");
             KH_TRY(zdot_dev(ctx, V, start, ncol, w, coef));
             hipLaunchKernelGGL(k_zacc, dim3(1), dim3(256), 0, ctx->stream, (int)(2 * ncol), hdev + 2 * start, coef);
-            KH_TRY(zaxpy_dev(ctx, V, start, ncol, coef, 1.0, 1.0, w, last_sweep, nrm_part));
+            KH_TRY(zaxpy_dev(ctx, Bk, start, ncol, coef, 1.0, 1.0, w, !Md && last_sweep, nrm_part));
         }
     }
     // norm (real) and normalise through the real kernels on the 2n view
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, grid, 0, tmp, 0);
-    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
     const int rgrid = (int)std::min<int64_t>(std::max<int64_t>(((V->n >> 1) + BS - 1) / BS, 1), ctx->nb);
+    if (Md != nullptr) {
+        // mw = Md w; H[k+1,k] = sqrt(Re <w, mw>) (the real dot of the two 2n views); p_{k+1} = w / h, v_{k+1} = mw / h
+        KH_TRY(zapply_one(ctx, Md, W->col(wcol), W->col(wcol + 1)));
+        KH_TRY(dot_panel_dev(ctx, W, wcol, 1, W->col(wcol + 1), tmp, 0));
+        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
+        hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(rgrid), dim3(BS), 0, ctx->stream, V->n, W->col(wcol),
+                           W->col(wcol + 1), V->col(k + 1), P->col(k + 1), nullptr, 0, tmp, hdev + 2 * (k + 1));
+        KH_HIP(hipGetLastError());
+        return 0;
+    }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_src, nrm_n, 0, tmp, 0);
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
     hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(rgrid), dim3(BS), 0, ctx->stream, V->n, W->col(wcol), nullptr,
                        V->col(k + 1), nullptr, nullptr, 0, tmp, hdev + 2 * (k + 1));
     KH_HIP(hipGetLastError());
@@ -664,8 +741,8 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
 // The same step split like kh_arnoldi_step_begin / _end (look-ahead): results are collected with
 // kh_arnoldi_step_end(ctx, slot, 2*(k+2), out).  h_km1[0] = NaN: Lanczos coefficient H[k,k-1] of the
 // step begun just before this one, still in the previous H-column slot on the device.
-int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
-                                int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot) {
+int kh_zarnoldi_step_begin_md(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t wcol,
+                              int64_t k, int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot) {
     KH_ARG(ctx && V && W && h_km1, "kh_zarnoldi_step_begin: NULL argument");
     KH_ARG(slot >= 0 && slot < KH_NSLOT, "kh_zarnoldi_step_begin: slot %d not in [0,%d)", slot, KH_NSLOT);
     KH_ARG(k >= 0 && k + 1 < V->ncols, "kh_zarnoldi_step_begin: k=%lld needs %lld basis columns, have %lld",
@@ -677,7 +754,7 @@ int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 2;
-        st.A = A; st.proj = proj; st.Md = nullptr; st.V = V; st.P = nullptr; st.W = W;
+        st.A = A; st.proj = proj; st.Md = Md; st.V = V; st.P = P; st.W = W;
         st.wcol = wcol; st.k = k; st.start = start; st.sweeps = sweeps; st.gs_mode = gs_mode;
         st.h_km1[0] = h_km1[0]; st.h_km1[1] = h_km1[1];
         if (step_poisoned(ctx, slot)) {
@@ -689,16 +766,85 @@ int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh
     const double* hk_dev = nullptr;
     if (start > 0 && start == k && h_km1[0] != h_km1[0])
         hk_dev = ctx->hslot_dev[(slot + KH_NSLOT - 1) % KH_NSLOT] + 2 * k;
-    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, hk_dev, hdev, slot, proj));
+    KH_TRY(zstep_enqueue(ctx, A, V, W, wcol, k, start, sweeps, gs_mode, h_km1, hk_dev, hdev, slot, proj, Md, P));
     KH_HIP(hipMemcpyAsync(ctx->hslot_pin[slot], hdev, sizeof(double) * 2 * (k + 2 + pd), hipMemcpyDeviceToHost,
                           ctx->stream));
     KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
     return 0;
 }
 
+int kh_zarnoldi_step_begin_proj(kh_ctx ctx, kh_mat A, kh_proj proj, kh_vec V, kh_vec W, int64_t wcol, int64_t k,
+                                int64_t start, int sweeps, int gs_mode, const double h_km1[2], int slot) {
+    return kh_zarnoldi_step_begin_md(ctx, A, proj, nullptr, V, nullptr, W, wcol, k, start, sweeps, gs_mode, h_km1, slot);
+}
+
 int kh_zarnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int64_t k, int64_t start,
                            int sweeps, int gs_mode, const double h_km1[2], int slot) {
-    return kh_zarnoldi_step_begin_proj(ctx, A, nullptr, V, W, wcol, k, start, sweeps, gs_mode, h_km1, slot);
+    return kh_zarnoldi_step_begin_md(ctx, A, nullptr, nullptr, V, nullptr, W, wcol, k, start, sweeps, gs_mode, h_km1, slot);
+}
+
+// Complex MINRES update in one pass (linsys.py:844-846); coefficients as (re, im) pairs.
+int kh_zminres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, const double r0[2], const double r1[2],
+                      const double r2[2], const double y0[2], kh_vec YK, int64_t ycol) {
+    KH_ARG(ctx && r0 && r1 && r2 && y0, "kh_zminres_update: NULL");
+    KH_TRY(zcheck(V, k, 1, "kh_zminres_update(V)"));
+    KH_TRY(zcheck(Wk, 0, 2, "kh_zminres_update(W)"));
+    KH_TRY(zcheck(YK, ycol, 1, "kh_zminres_update(yk)"));
+    KH_ARG(slot == 0 || slot == 1, "kh_zminres_update: slot");
+    KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_zminres_update: length mismatch");
+    KH_ARG(!(YK == Wk) && !(YK == V && ycol == k) && !(V == Wk), "kh_zminres_update: yk, v_k and W must not overlap");
+    const int64_t n = V->n / 2;
+    auto c2 = [](const double* q) { double2 r; r.x = q[0]; r.y = q[1]; return r; };
+    hipLaunchKernelGGL(k_zminres_update, dim3(zgrid(ctx, n)), dim3(BS), 0, ctx->stream, n, zcol(V, k), zcolw(Wk, slot),
+                       zcol(Wk, 1 - slot), c2(r0), c2(r1), c2(r2), c2(y0), zcolw(YK, ycol));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+// One whole pass of the CG loop (linsys.py:622-665) for complex data with a single host synchronisation: the
+// complex twin of kh_cg_step.  A: complex operator; the vectors are real blocks of length 2N (interleaved re, im);
+// Md: NULL or a REAL diagonal of length 2N (every entry of the real Jacobi scaling twice) - the recurrences have real
+// coefficients, so they run on the real views.  out[0] = d with alpha = rho / d = Re(rho / <p, Ap>) (what the device
+// used), out[1] = <r, z> (real part), out[2], out[3] = <p, Ap>.
+int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
+                int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol_, int first, double omega, double rho,
+                double* out) {
+    KH_ARG(ctx && A && out, "kh_zcg_step: NULL");
+    RoctxScope range_(ctx, "kh_zcg_step");
+    KH_TRY(zcheck(Pd, pcol, 1, "kh_zcg_step(p)"));
+    KH_TRY(zcheck(AP, apcol, 1, "kh_zcg_step(Ap)"));
+    KH_TRY(zcheck(YK, ycol, 1, "kh_zcg_step(yk)"));
+    KH_TRY(zcheck(R, rcol, 1, "kh_zcg_step(r)"));
+    KH_ARG(A->kind >= KH_MAT_ZCSR, "kh_zcg_step: complex operator expected");
+    const int64_t n = R->n;              // reals
+    KH_ARG(Md == nullptr || (Md->kind == KH_MAT_DIAG && Md->n_rows == n),
+           "kh_zcg_step: Md must be a real diagonal of length 2N (entries duplicated)");
+    if (Md) KH_TRY(zcheck(Z, zcol_, 1, "kh_zcg_step(z)"));
+    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && 2 * A->n_rows == n && (!Md || Z->n == n),
+           "kh_zcg_step: length mismatch");
+    KH_ARG(!(Pd == AP && pcol == apcol), "kh_zcg_step: p and Ap must be different columns");
+    double* p = Pd->col(pcol);
+    double* ap = AP->col(apcol);
+    double* r = R->col(rcol);
+    double* z = Md ? Z->col(zcol_) : r;
+    const int grid = grid_lin(ctx, n);
+    double* tmp = ctx->scal + SC_TMP;       // tmp[0] = d, tmp[1] = rho_new, tmp[2..3] = <p, Ap>
+    if (!first)                             // p = z + omega p   (linsys.py:627)
+        hipLaunchKernelGGL(k_waxpby, dim3(grid), dim3(BS), 0, ctx->stream, n, p, 1.0, z, omega, p);
+    KH_TRY(zapply_one(ctx, A, p, ap));
+    KH_TRY(zdot_dev(ctx, Pd, pcol, 1, reinterpret_cast<const double2*>(ap), tmp + 2));
+    hipLaunchKernelGGL(k_zcg_den, dim3(1), dim3(1), 0, ctx->stream, tmp);
+    double* part = part_slot(ctx, SLOT_NRM);
+    if (Md)
+        hipLaunchKernelGGL((k_cg_update<true>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
+                           YK->col(ycol), r, Md->diag, z, part, tmp);
+    else
+        hipLaunchKernelGGL((k_cg_update<false>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
+                           YK->col(ycol), r, nullptr, nullptr, part, tmp);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp + 1, 0);
+    KH_HIP(hipGetLastError());
+    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
+    return fetch_scalars(ctx, tmp, 4, out);
 }
 
 // complex projector: W, V complex blocks (real kh_vec of length 2N), T = R^{-1} Q^H and WRH = WR^H as d x d

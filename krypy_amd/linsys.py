@@ -433,9 +433,10 @@ class Cg(_KrylovSolver):
         M_id = isinstance(ls.M, utils.IdentityLinearOperator)
         bdt = self._bdt
         cplx = utils._is_c(bdt)
-        Md = None if (M_id or cplx) else ls.M._device_matrix()
-        # (kh_cg_update is real: complex CG takes the step by step branch below)
-        fused = not cplx and euclid and (M_id or (Md is not None and Md.kind == "diag"))
+        # the CG recurrences have real coefficients: on complex data they run on the real views of length 2N, with
+        # the (real) Jacobi scaling as a diagonal of that length
+        Md = None if M_id else (ls.M._real_diag_image(ctx) if cplx else ls.M._device_matrix())
+        fused = euclid and (M_id or (Md is not None and Md.kind == "diag"))
 
         yk = DVec(ctx.alloc(N, 1, dtype=bdt))
         self.rhos = rhos = [self.MMlr0_norm ** 2]
@@ -469,7 +470,7 @@ class Cg(_KrylovSolver):
                 # p = MMlrk + rhos[-1]/rhos[-2] * p   (linsys.py:627)
                 omega = rhos[-1] / rhos[-2]
             if one_call:
-                pAp, rho_new = ctx.cg_step(
+                den, rho_new, pAp = ctx.cg_step(
                     Amat, None if M_id else Md, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
                     self._Mlrk.block, self._Mlrk.col, None if M_id else self._MMlrk.block,
                     0 if M_id else self._MMlrk.col, k == 0, float(omega) if k > 0 else 0.0,
@@ -485,7 +486,8 @@ class Cg(_KrylovSolver):
                 warnings.warn(
                     f"Iter {k}: abs(alpha.imag) = {abs(alpha.imag)} > 1e-12. "
                     "Is your operator self-adjoint in the provided inner product?")
-            alpha = float(numpy.real(alpha))
+            # (one_call: the step length the device took, real part of the same quotient)
+            alpha = float(rhos[-1]) / den if one_call else float(numpy.real(alpha))
 
             if self.store_arnoldi:
                 if k > 0:

@@ -543,6 +543,10 @@ class LinearOperator(object):
         """The DeviceMatrix this operator *is* (plain matrices only), else None."""
         return None
 
+    def _real_diag_image(self, ctx=None):
+        """Real diagonal of length 2N acting on the real view of a complex block (real diagonal matrices only)."""
+        return None
+
     def _scratch(self, ctx, n, ncols, key=0, dtype=None):
         dtype = _bdt(dtype)
         k = (id(ctx), n, ncols, key, dtype.kind)
@@ -811,6 +815,18 @@ class MatrixLinearOperator(LinearOperator):
             self._dmats[dt.kind] = dm
         return dm
 
+    def _real_diag_image(self, ctx=None):
+        """A diagonal matrix with real entries as a REAL device diagonal of length 2N, every entry twice: how a
+        Jacobi scaling acts on the real view (re, im interleaved) of a complex block.  None for anything else."""
+        if "d2" not in self._dmats:
+            d = _diagonal_of(self._A) if _is_sparse(self._A) else None
+            dm = None
+            if d is not None and not numpy.any(numpy.imag(d)):
+                ctx = _hip.get_context() if ctx is None else ctx
+                dm = ctx.diag(numpy.repeat(numpy.real(d).astype(float), 2))
+            self._dmats["d2"] = dm
+        return self._dmats["d2"]
+
     @property
     def _dmat(self):
         return self._dmats.get(_bdt(self.dtype).kind)
@@ -913,6 +929,9 @@ class TimedLinearOperator(LinearOperator):
 
     def _device_matrix(self, ctx=None, dtype=None):
         return self._linear_operator._device_matrix(ctx, dtype)
+
+    def _real_diag_image(self, ctx=None):
+        return self._linear_operator._real_diag_image(ctx)
 
     def _apply_dev(self, X, xcol, Y, ycol, ncols=1):
         if ncols == 0:
@@ -1038,7 +1057,9 @@ class Arnoldi(object):
             md = self.M._device_matrix()
             if md is not None and md.kind == "diag":
                 self._Md = md
-        # (the complex step kernel takes no preconditioner: complex + M runs the general loop)
+        elif self.M is not None and self.M._real_diag_image(ctx) is not None:
+            # complex data, real Jacobi scaling: the complex step takes it as a c128 diagonal
+            self._Md = self.M._device_matrix(ctx, numpy.dtype(complex))
         self._fused = self._euclid and (self.M is None or self._Md is not None)
         # Non-Euclidean inner product <x, y> = x^T B y with B a real matrix on the device (utils.py:184-193) and no
         # preconditioner: the step kernel's preconditioned recurrence with the roles of its two blocks swapped -

@@ -62,6 +62,24 @@ def cpu_double():
 _real_ctx = []
 
 
+def _cap_host_memory():
+    """Fail-safe for the GPU box: a test that asks for absurd host memory (scipy.sparse.random at n = 3e5 wants
+    n^2 integers, 671 GiB) must die with a MemoryError, not take the box down with it.  RLIMIT_DATA counts private
+    writable mappings (NumPy's buffers), not the device / pinned mappings of the HIP runtime; applied after the HIP
+    context exists.  KRYPY_AMD_TEST_RLIMIT_GB=0 switches it off (default 96 GB; the largest test holds ~30 GB)."""
+    try:
+        import resource
+        gb = float(os.environ.get("KRYPY_AMD_TEST_RLIMIT_GB", "96"))
+        if gb > 0:
+            soft, hard = resource.getrlimit(resource.RLIMIT_DATA)
+            want = int(gb * (1 << 30))
+            if hard != resource.RLIM_INFINITY:
+                want = min(want, hard)
+            resource.setrlimit(resource.RLIMIT_DATA, (want, hard))
+    except Exception:
+        pass
+
+
 @pytest.fixture
 def hip():
     """The real HIP context (GPU tests).  Fails - never skips - when the library or GPU is absent."""
@@ -73,5 +91,6 @@ def hip():
             __graft_entry__.build()
         _hip._install_context_for_testing(None)
         _real_ctx.append(_hip.get_context())
+        _cap_host_memory()
     _hip._install_context_for_testing(_real_ctx[0])
     return _real_ctx[0]

@@ -242,8 +242,8 @@ class NumpyContext(object):
         self._count("arnoldi_step")
         B = P if P is not None else V
         cplx = _same("arnoldi_step", V, W)
-        if cplx and (Md is not None or P is not None):
-            raise BackendError("arnoldi_step: the complex step takes no preconditioner")
+        if cplx and ((Md is None) != (P is None) or (Md is not None and (Md.kind != "diag" or Md.dtype.kind != "c"))):
+            raise BackendError("arnoldi_step: the complex step takes a complex diagonal Md with its block P")
         hcol = np.zeros(k + 2, dtype=V.dtype)
         if A is not None:
             if (A.dtype.kind == "c") != cplx:
@@ -267,7 +267,7 @@ class NumpyContext(object):
         if Md is not None:
             mw = self._matvec(Md, w)      # Jacobi diagonal, or the SPD matrix of a non-Euclidean inner product
             W.a[:, wcol + 1] = mw
-            hn = float(np.sqrt(abs(self._allreduce(np.array([np.dot(w, mw)]))[0])))
+            hn = float(np.sqrt(abs(self._allreduce(np.array([np.vdot(w, mw).real]))[0])))
             with np.errstate(divide="ignore", invalid="ignore"):
                 P.a[:, k + 1] = w / hn
                 V.a[:, k + 1] = mw / hn
@@ -342,39 +342,56 @@ class NumpyContext(object):
 
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
         self._count("cg_update")
-        if _same("cg_update", Pd, AP, YK, R):
-            raise BackendError("cg_update is real only")
+        cplx = _same("cg_update", Pd, AP, YK, R)
         YK.a[:, ycol] = YK.a[:, ycol] + alpha * Pd.a[:, pcol]
         r = R.a[:, rcol] - alpha * AP.a[:, apcol]
         R.a[:, rcol] = r
         z = r
         if Md is not None:
-            z = Md.mat * r
+            z = _jacobi(Md, r, cplx, "cg_update") * r
             Z.a[:, zcol] = z
-        return float(self._allreduce(np.array([np.dot(r, z)]))[0])
+        return float(self._allreduce(np.array([np.vdot(r, z).real]))[0])
+
+
+def _jacobi(Md, r, cplx, what):
+    """The diagonal kh_cg_update / kh_cg_step scale with: real of length N for real blocks, and for complex blocks
+    the REAL diagonal of length 2N (every entry twice) that acts on the interleaved real view."""
+    if Md.kind != "diag" or Md.dtype.kind == "c" or Md.mat.size != (2 if cplx else 1) * r.size:
+        raise BackendError("%s: Md must be a real diagonal of the real view's length" % what)
+    if cplx:
+        assert np.array_equal(Md.mat[0::2], Md.mat[1::2])
+        return Md.mat[0::2]
+    return Md.mat
 
 
 def _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
     """Semantics of kh_cg_step (include/krylov_hip.h)."""
     self._count("cg_step")
-    if _same("cg_step", Pd, AP, YK, R):
-        raise BackendError("cg_step is real only")
+    cplx = _same("cg_step", Pd, AP, YK, R)
+    if cplx != (A.dtype.kind == "c"):
+        raise BackendError("cg_step: operator / block dtype mismatch")
     z = Z.a[:, zcol] if Md is not None else R.a[:, rcol]
     if not first:
         Pd.a[:, pcol] = z + omega * Pd.a[:, pcol]
     p = Pd.a[:, pcol]
     ap = self._matvec(A, p)
     AP.a[:, apcol] = ap
-    pap = float(self._allreduce(np.array([np.dot(p, ap)]))[0])
-    alpha = rho / pap
+    pap = self._allreduce(np.array([np.vdot(p, ap)]))[0]
+    if cplx:                      # rho / den = Re(rho / <p, Ap>)  (kh_zcg_step)
+        re, im = float(pap.real), float(pap.imag)
+        den = re + im * (im / re) if abs(re) >= abs(im) else (re * (re / im) + im) / (re / im)
+        pap = complex(pap)
+    else:
+        den = pap = float(pap)
+    alpha = rho / den
     YK.a[:, ycol] = YK.a[:, ycol] + alpha * p
     r = R.a[:, rcol] - alpha * ap
     R.a[:, rcol] = r
     zz = r
     if Md is not None:
-        zz = Md.mat * r
+        zz = _jacobi(Md, r, cplx, "cg_step") * r
         Z.a[:, zcol] = zz
-    return pap, float(self._allreduce(np.array([np.dot(r, zz)]))[0])
+    return den, float(self._allreduce(np.array([np.vdot(r, zz).real]))[0]), pap
 
 
 NumpyContext.cg_step = _cg_step

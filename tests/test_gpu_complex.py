@@ -172,6 +172,113 @@ def test_complex_arnoldi_step_against_numpy(hip, mode):
     assert np.linalg.norm(Vd.download() - V) < 1e-10
 
 
+@pytest.mark.parametrize("mode", ["mgs", "dmgs", "cgs", "lanczos"])
+def test_complex_arnoldi_step_with_jacobi_against_numpy(hip, mode):
+    """kh_zarnoldi_step_begin_md: the complex step with a diagonal preconditioner (V = M P, utils.py:1026-1045) -
+    coefficients against V, updates with P, norm sqrt(Re <w, M w>) - step by step against NumPy."""
+    from krypy_amd import _hip
+    from oracle.inputs import complex_systems
+
+    c = complex_systems(40)
+    A = c["hind"] if mode == "lanczos" else c["nonh"]
+    N, m = A.shape[0], 20
+    rng = np.random.default_rng(4)
+    d = 0.5 + rng.random(N)
+    p0 = _crand(rng, N)
+    nrm0 = np.sqrt(np.vdot(p0, d * p0).real)
+    P = np.zeros((N, m + 1), dtype=complex, order="F")
+    V = np.zeros((N, m + 1), dtype=complex, order="F")
+    P[:, 0], V[:, 0] = p0 / nrm0, d * p0 / nrm0
+    Vd, Pd = hip.alloc(N, m + 1, dtype=complex), hip.alloc(N, m + 1, dtype=complex)
+    Vd.upload(0, V[:, [0]])
+    Pd.upload(0, P[:, [0]])
+    Wd = hip.alloc(N, 2, dtype=complex)
+    Ad, Md = hip.csr(A), hip.diag(d, dtype=complex)
+    sweeps = 2 if mode == "dmgs" else 1
+    gs = _hip.GS_CGS if mode == "cgs" else _hip.GS_MGS
+    H = np.zeros((m + 1, m), dtype=complex)
+    for k in range(m):
+        start = k if mode == "lanczos" else 0
+        hk = H[k, k - 1] if (mode == "lanczos" and k > 0) else 0.0
+        if k % 2:       # both entry styles: synchronous, and begin / end in a slot
+            hcol = hip.arnoldi_step(Ad, Md, Vd, Pd, Wd, 0, k, start, sweeps, gs, hk)
+        else:
+            hip.arnoldi_step_begin(Ad, Md, Vd, Pd, Wd, 0, k, start, sweeps, gs, hk, k % 4)
+            hcol = hip.arnoldi_step_end(k % 4, k + 2, cplx=True)
+        w = A.dot(V[:, k])
+        if mode == "lanczos" and k > 0:
+            w = w - hk * P[:, k - 1]
+            H[k - 1, k] = hk
+        for _ in range(sweeps):
+            if mode == "cgs":
+                h = V[:, : k + 1].conj().T.dot(w)
+                H[: k + 1, k] += h
+                for j in range(k + 1):
+                    w = w - h[j] * P[:, j]
+            else:
+                for j in range(start, k + 1):
+                    a = np.vdot(V[:, j], w)
+                    H[j, k] += a
+                    w = w - a * P[:, j]
+        H[k + 1, k] = np.sqrt(np.vdot(w, d * w).real)
+        P[:, k + 1], V[:, k + 1] = w / H[k + 1, k], d * w / H[k + 1, k]
+        assert hcol.shape == (k + 2,) and hcol[k + 1].imag == 0.0
+        assert np.allclose(hcol[start:], H[start: k + 2, k], rtol=1e-11, atol=1e-12), (mode, k)
+    assert np.linalg.norm(Vd.download() - V) < 1e-10 and np.linalg.norm(Pd.download() - P) < 1e-10
+    # P^H V = P^H M P = I: the basis is orthonormal in the M inner product
+    if mode != "lanczos":
+        assert np.linalg.norm(Pd.download().conj().T.dot(Vd.download()) - np.eye(m + 1)) < 1e-10
+
+
+@pytest.mark.parametrize("n", [1, 63, 4097, 300001])
+def test_complex_minres_update_and_cg_step_kernels(hip, n):
+    """kh_zminres_update and kh_zcg_step against the same formulas in NumPy (complex scalars; the CG step on the
+    real views with a duplicated real Jacobi diagonal), edge sizes included."""
+    rng = np.random.default_rng(n)
+    # --- MINRES: z = (v - r0 W0 - r1 W1)/r2; W <- [W1, z]; yk += y0 z
+    V, W, yk = _crand(rng, n, 3), _crand(rng, n, 2), _crand(rng, n, 1)
+    r0, r1, r2, y0 = (complex(*rng.standard_normal(2)) for _ in range(4))
+    for slot, rr2 in ((0, r2), (1, complex(r2.imag, 5 * r2.real)), (0, complex(2.5, 0.0))):    # |re| >= |im|, <, real
+        Vd, Wd, Yd = hip.upload(V), hip.upload(W), hip.upload(yk)
+        hip.minres_update(Vd, 1, Wd, slot, r0, r1, rr2, y0, Yd, 0)
+        z = ((V[:, 1] - r0 * W[:, slot]) - r1 * W[:, 1 - slot]) / rr2
+        got = Wd.download()
+        assert np.allclose(got[:, slot], z, rtol=1e-14, atol=1e-14)
+        assert np.array_equal(got[:, 1 - slot], W[:, 1 - slot])
+        assert np.allclose(Yd.download()[:, 0], yk[:, 0] + y0 * z, rtol=1e-14, atol=1e-14)
+    # --- CG: p = z + omega p; Ap = A p; alpha = Re(rho / <p, Ap>); yk += alpha p; r -= alpha Ap; z = D r; <r, z>
+    # Hermitian, diagonally dominant, banded (NOT sp.random: its sampling allocates n^2 integers)
+    offs = [o for o in (1, 7, 64) if o < n]
+    B = sp.diags([_crand(rng, n - o) for o in offs], offs, shape=(n, n)) if offs else sp.csr_matrix((n, n), dtype=complex)
+    A = (B + B.conj().T + sp.identity(n) * 12.0).tocsr()
+    Ad = hip.csr(A)
+    d = 0.5 + rng.random(n)
+    Dd = hip.diag(np.repeat(d, 2))
+    for jac in (False, True):
+        for first in (True, False):
+            p, r, zv, y = _crand(rng, n, 1), _crand(rng, n, 1), _crand(rng, n, 1), _crand(rng, n, 1)
+            pd_, rd, zd, yd, apd = hip.upload(p), hip.upload(r), hip.upload(zv), hip.upload(y), hip.alloc(n, 1, dtype=complex)
+            omega, rho = 0.37, 1.9
+            den, rho_new, pap = hip.cg_step(Ad, Dd if jac else None, pd_, 0, apd, 0, yd, 0, rd, 0, zd if jac else None, 0,
+                                            first, omega, rho)
+            pp = p[:, 0] if first else (zv[:, 0] if jac else r[:, 0]) + omega * p[:, 0]
+            ap = A.dot(pp)
+            want = np.vdot(pp, ap)
+            assert abs(pap - want) <= 1e-13 * abs(want) * max(1.0, np.sqrt(n) / 30)
+            alpha = (rho / pap).real
+            assert abs(rho / den - alpha) <= 4e-16 * abs(alpha)
+            alpha = rho / den
+            rn = r[:, 0] - alpha * ap
+            zn = d * rn if jac else rn
+            tol = dict(rtol=1e-13, atol=1e-13)
+            assert np.allclose(pd_.download()[:, 0], pp, **tol) and np.allclose(apd.download()[:, 0], ap, **tol)
+            assert np.allclose(yd.download()[:, 0], y[:, 0] + alpha * pp, **tol)
+            assert np.allclose(rd.download()[:, 0], rn, **tol)
+            if jac:
+                assert np.allclose(zd.download()[:, 0], zn, **tol)
+            assert abs(rho_new - np.vdot(rn, zn).real) <= 1e-12 * abs(np.vdot(rn, zn).real)
+
+
 def test_complex_shard_with_ghost_columns_and_rccl_path(hip):
     """Complex block-row sharding on the device: (i) every slab of a 3-way split multiplied with its ghost entries
     written by hand (kh_mat_set_ghost) equals the global complex SpMV bit for bit; (ii) a complex solve and a

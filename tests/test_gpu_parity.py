@@ -620,17 +620,15 @@ def test_mgs_chain_every_register_shape(hip, rows, cplx):
     assert np.linalg.norm(A.dot(Vc[:, :m]) - Vc.dot(Hc)) < 1e-12 * np.linalg.norm(Hc)
     G = Vc.conj().T.dot(Vc)
     assert np.linalg.norm(G - np.eye(m + 1)) < 1e-12
-    if cplx:
-        return
-    # the register-resident panel kernels (k_cgs_dots / k_cgs_update) have their own batch shape per
-    # instantiation: same check against the chunked panel kernels, odd and even column counts
+    # the register-resident panel kernels (k_cgs_dots / k_cgs_update, real and - since round 2 - complex) have their
+    # own batch shape per instantiation: same check against the chunked panel kernels, odd and even column counts
     res = []
     for chain in (True, False):
         ctx = _second_context(chain)
         Ad = ctx.csr(A)
-        V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+        V, W = ctx.alloc(n, m + 1, dtype=dt), ctx.alloc(n, 2, dtype=dt)
         V.upload(0, b / np.linalg.norm(b))
-        H = np.zeros((m + 1, m))
+        H = np.zeros((m + 1, m), dtype=dt)
         for k in range(m):
             H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 1)
         assert (ctx.counters()["cgs_register"] > 0) == chain

@@ -77,6 +77,52 @@ def test_complex_deflated_gmres_projects_inside_the_step(cpu_double):
     assert np.linalg.norm(r) <= 1.01e-9 * np.linalg.norm(c["b"])
 
 
+def test_complex_cg_minres_gmres_with_jacobi_stay_on_the_fused_entries(cpu_double):
+    """Complex CG runs one ``kh_zcg_step`` per iteration (real recurrences on the real views, the Jacobi scaling as a
+    real diagonal of length 2N); complex MINRES / GMRES with a Jacobi preconditioner run the complex step with its
+    complex diagonal and second block instead of a host loop over the Gram-Schmidt links, and the MINRES update is
+    one ``kh_zminres_update``.  Same iterates as the CPU oracle."""
+    import numpy as np
+    import scipy.sparse as sp
+    from krypy_amd import linsys
+    from oracle import krylov_ref_c as refc
+    from oracle.inputs import complex_systems
+
+    c = complex_systems(16)
+    b = c["b"]
+    d = np.asarray(c["hpd"].diagonal()).real
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    hpd = dict(self_adjoint=True, positive_definite=True)
+
+    def counted(make):
+        cpu_double.calls.clear()
+        s = make()
+        return s, dict(cpu_double.calls)
+
+    for kw in ({}, dict(M=M, Minv=Minv)):
+        s, calls = counted(lambda: linsys.Cg(linsys.LinearSystem(c["hpd"], b, **hpd, **kw), tol=1e-10, maxiter=300))
+        n = len(s.resnorms) - 1
+        assert s.xk.dtype.kind == "c" and calls.get("cg_step") == n, calls
+        assert calls.get("dot_panel", 0) + calls.get("waxpby", 0) + calls.get("nrm2", 0) <= 6, calls
+        xo, reso = refc.cg(c["hpd"], b, tol=1e-10, maxiter=300, M=kw.get("M"))
+        assert len(reso) == len(s.resnorms)
+        # (the last entry is the explicitly computed residual b - A x at 1e-10 ||b||: cancellation leaves it ~1e-6 relative)
+        assert np.allclose(s.resnorms[:-1], reso[:-1], rtol=1e-8, atol=0) and abs(s.resnorms[-1] / reso[-1] - 1) < 1e-5
+        assert np.linalg.norm(s.xk[:, 0] - xo) <= 1e-10 * np.linalg.norm(xo)
+    s, calls = counted(lambda: linsys.Minres(linsys.LinearSystem(c["hind"], b, M=M, Minv=Minv, self_adjoint=True),
+                                             tol=1e-10, maxiter=600))
+    n = len(s.resnorms) - 1
+    assert calls.get("arnoldi_step") >= n and calls.get("minres_update") == n, calls
+    assert calls.get("dot_panel", 0) + calls.get("axpy_panel", 0) == 0, calls
+    xo, reso = refc.minres(c["hind"], b, tol=1e-10, maxiter=600, M=M)
+    assert len(reso) == len(s.resnorms) and np.allclose(s.resnorms[:-1], reso[:-1], rtol=1e-7, atol=0)
+    s, calls = counted(lambda: linsys.Gmres(linsys.LinearSystem(c["nonh"], b, M=M, Minv=Minv), tol=1e-10, maxiter=300))
+    n = len(s.resnorms) - 1
+    assert calls.get("arnoldi_step") >= n and calls.get("dot_panel", 0) + calls.get("axpy_panel", 0) == 0, calls
+    xo, reso, _, _ = refc.gmres(c["nonh"], b, tol=1e-10, maxiter=300, M=M)
+    assert len(reso) == len(s.resnorms) and np.allclose(s.resnorms[:-1], reso[:-1], rtol=1e-7, atol=0)
+
+
 def test_solvers_leave_no_reference_cycles(cpu_double):
     """A finished solver must die with its last reference: its basis is an (N, m+1) device block (8-10 GB at the
     benchmark sizes) that goes back to the block pool in ``DeviceVectors.__del__``.  A solver <-> operator cycle
