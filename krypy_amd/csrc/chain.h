@@ -81,7 +81,17 @@ struct ChainArgs {
 
 // Phase stamps of the diagnostic build (tools/chain_trace.py): wave 0 and wave 7 of every workgroup
 // note the constant 100 MHz clock at the phase boundaries of every link.  Compiled out of the product.
-#ifdef KH_CHAIN_TRACE
+#if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
+// (mode 2: every wave keeps the SUM of each phase's duration over the links of a launch in scalar registers and
+// wave 0 / wave 7 write the eight sums once at the end - no vector registers, no stores inside the link loop: the
+// per-link stamps of mode 1 cost the kernel its register allocation and stretch a link from 16 to 40 us)
+#define CH_STAMP(a_, t_, total_, i_)                          \
+    do {                                                      \
+        const unsigned long long n_ = wall_clock64();         \
+        if ((i_) != 0) tr_acc[i_] += n_ - tr_prev;            \
+        tr_prev = n_;                                         \
+    } while (0)
+#elif defined(KH_CHAIN_TRACE)
 #define CH_STAMP(a_, t_, total_, i_)                                                                   \
     do {                                                                                               \
         if ((a_).trace != nullptr && (threadIdx.x == 0 || threadIdx.x == CH_BS - 64))                  \
@@ -674,6 +684,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #ifndef KH_CH_REUSE_SKIP
 #define KH_CH_REUSE_SKIP 0
 #endif
+// (experiment knobs, round 2: KH_CH_SKIP_LAST = 1 streams batch NB-2 non-temporally too - its second read is issued
+// BEFORE the grid-wide reduction and hidden by it, so it may come from further away and leave the L2 to the other
+// NG-1 batches; KH_CH_LDS_EARLY = 1 runs the LDS-parked part of the update while the first re-read batches fly)
+#ifndef KH_CH_SKIP_LAST
+#define KH_CH_SKIP_LAST 0
+#endif
+#ifndef KH_CH_LDS_EARLY
+#define KH_CH_LDS_EARLY 0
+#endif
 template <int R2, bool CPLX = false>
 struct ChainShapeLds {
     // 5 rows per batch for R2 = 40, like the plain kernel (the complex instantiation spills 36 registers
@@ -759,6 +778,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         for (int i = 0; i < PB; ++i) ring[0][i] = CH_LD(v2 + (int64_t)i * CH_BS, false);
         CH_ISSUE_FENCE();
     }
+#if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
+    unsigned long long tr_prev = 0, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < total; ++t) {
         const int64_t j = a.col0 + (t % a.ncol);
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + j * a.ld) + first;
@@ -777,7 +799,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                                                             : (NG > 0 ? v2 + (int64_t)(NB - 2) * PB * CH_BS : vn);
 #pragma unroll
             for (int i = 0; i < PB; ++i)
-                ring[(b + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, (b + 1 < NB) && (b + 1 >= LB + KH_CH_REUSE_SKIP) && (b + 1 <= NB - 2));
+                ring[(b + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, (b + 1 < NB) && (b + 1 >= LB + KH_CH_REUSE_SKIP) && (b + 1 <= NB - 2 - KH_CH_SKIP_LAST));
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
@@ -808,7 +830,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                 a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
-#ifdef KH_CHAIN_TRACE
+#if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
+            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr);
+#elif defined(KH_CHAIN_TRACE)
             alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res,
                              a.trace ? a.trace + (((size_t)blockIdx.x * total) + t) * 16 : nullptr);
 #else
@@ -838,6 +862,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) CH_UPD((NB - 1) * PB + i, ring[1][i]);
         // (b) batches NB-2 ... LB from memory through the ring
+        constexpr bool EARLY = (KH_CH_LDS_EARLY != 0) && NG >= 2;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const int b = NB - 2 - g;
@@ -845,24 +870,45 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #pragma unroll
             for (int i = 0; i < PB; ++i) ring[(g + 1) & 1][i] = CH_LD(nx + (int64_t)i * CH_BS, false);
             CH_ISSUE_FENCE();
+            if (EARLY && g == 1) {
+                // two re-read batches are in flight (this iteration's load and the previous one's): walk the
+                // LDS-parked head of the column while they are on their way
+#pragma unroll
+                for (int bb = LB - 1; bb >= 0; --bb) {
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) {
+                        const double2 p = vlds[(bb * PB + i) * CH_BS + tid];
+                        CH_UPD(bb * PB + i, p);
+                    }
+                    CH_ISSUE_FENCE();
+                }
+            }
 #pragma unroll
             for (int i = 0; i < PB; ++i) CH_UPD(b * PB + i, ring[g & 1][i]);
         }
         CH_STAMP(a, t, total, 6);
         // (c) the head of the column from LDS (own entries: no barrier needed), one batch of reads at
         //     a time (hoisted all together they would spill)
+        if (!EARLY) {
 #pragma unroll
-        for (int b = LB - 1; b >= 0; --b) {
-            CH_ISSUE_FENCE();
+            for (int b = LB - 1; b >= 0; --b) {
+                CH_ISSUE_FENCE();
 #pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const double2 p = vlds[(b * PB + i) * CH_BS + tid];
-                CH_UPD(b * PB + i, p);
+                for (int i = 0; i < PB; ++i) {
+                    const double2 p = vlds[(b * PB + i) * CH_BS + tid];
+                    CH_UPD(b * PB + i, p);
+                }
             }
         }
 #undef CH_UPD
         CH_STAMP(a, t, total, 7);
     }
+#if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
+    if (a.trace != nullptr && (tid == 0 || tid == CH_BS - 64)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * 2 + (tid ? 1 : 0)) * 8 + i] = tr_acc[i];
+    }
+#endif
     // norm: <w,w> or <w, D w>
     double acc = 0.0;
     if (a.dg != nullptr) {
