@@ -88,8 +88,8 @@ struct ChainArgs {
 #define CH_STAMP(a_, t_, total_, i_)                          \
     do {                                                      \
         const unsigned long long n_ = wall_clock64();         \
-        if ((i_) != 0) tr_acc[i_] += n_ - tr_prev;            \
-        tr_prev = n_;                                         \
+        if ((i_) != 0) tr_acc[i_] += n_ - tr_acc[8];          \
+        tr_acc[8] = n_;                                       \
     } while (0)
 #elif defined(KH_CHAIN_TRACE)
 #define CH_STAMP(a_, t_, total_, i_)                                                                   \
@@ -191,9 +191,24 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     const double ws = wave_sum_dpp(part);
     if (lane == 0) smd[wid] = ws;
     __syncthreads();
-#ifdef KH_CHAIN_TRACE
-    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 2] = wall_clock64();
+#if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
+#define GS_STAMP(i_)                                          \
+    do {                                                      \
+        if (tr != nullptr) {                                  \
+            const unsigned long long n_ = wall_clock64();     \
+            tr[i_] += n_ - tr[8];                             \
+            tr[8] = n_;                                       \
+        }                                                     \
+    } while (0)
+#elif defined(KH_CHAIN_TRACE)
+#define GS_STAMP(i_)                                                                                      \
+    do {                                                                                                  \
+        if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + (i_)] = wall_clock64();  \
+    } while (0)
+#else
+#define GS_STAMP(i_) do {} while (0)
 #endif
+    GS_STAMP(2);
     unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
     if (tid == 0) {
         double s = smd[0];
@@ -204,9 +219,7 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
         st_agent(slot + 2 * blockIdx.x, tag | (bits & 0xffffffffull));
         st_agent(slot + 2 * blockIdx.x + 1, tag | (bits >> 32));
     }
-#ifdef KH_CHAIN_TRACE
-    if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 3] = wall_clock64();
-#endif
+    GS_STAMP(3);
     if (2 * G <= CH_BS) {
         unsigned long long* res = xcc_res + ((size_t)role.xcc * 2 + (epoch & 1u)) * 4;
         if (!role.leader) {
@@ -244,9 +257,7 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
             }
             mine = (unsigned)x;
         }
-#ifdef KH_CHAIN_TRACE
-        if (tr != nullptr && (tid == 0 || tid == CH_BS - 64)) tr[(tid ? 8 : 0) + 4] = wall_clock64();
-#endif
+        GS_STAMP(4);
         const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);   // from lane - 1
         const unsigned long long bits = ((unsigned long long)mine << 32) | low;
         const double v = ((lane & 1) && tid < 2 * G) ? __longlong_as_double((long long)bits) : 0.0;
@@ -283,6 +294,8 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
     __syncthreads();          // smu reuse by the next call
     return s;
 }
+
+#undef GS_STAMP
 
 // Two sums in one round (the real and imaginary part of a complex coefficient): four granules per workgroup, one
 // publish; the XCD leaders sweep 4 G <= 1024 granules (two per thread: workgroups b and b + 128 of the same kind
@@ -779,7 +792,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         CH_ISSUE_FENCE();
     }
 #if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
-    unsigned long long tr_prev = 0, tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tr_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // [8]: the previous stamp
 #endif
     for (int t = 0; t < total; ++t) {
         const int64_t j = a.col0 + (t % a.ncol);
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             }
         } else {
 #if defined(KH_CHAIN_TRACE) && KH_CHAIN_TRACE == 2
-            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr);
+            alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res, tr_acc);
 #elif defined(KH_CHAIN_TRACE)
             alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res,
                              a.trace ? a.trace + (((size_t)blockIdx.x * total) + t) * 16 : nullptr);

@@ -39,13 +39,18 @@ T = buf[:G * 16].reshape(G, 2, 8).astype(np.float64) * 0.01 / links     # micros
 ms = ctx.bench_kernel(5, V, W, 20)
 print("n = %d, G = %d workgroups; %.3f ms per 64-link launch = %.2f us per link (events, this build)"
       % (n, G, ms, ms * 1e3 / links))
-names = {1: "dot phase (stream the column)", 5: "grid-wide sum (incl. waiting for the slowest workgroup)",
+names = {1: "dot phase (stream the column)", 2: "sum: waiting for the other waves of the workgroup",
+         3: "sum: workgroup partial published", 4: "sum: leaders - sweep of the fabric granules",
+         5: "sum: result (leaders: add + store; others: poll the L2)",
          6: "update: ring batch + batches read again", 7: "update: LDS-parked batches"}
-for w in (0, 1):
-    print("wave %d: mean over workgroups (p10 .. p90), us per link" % (0 if w == 0 else 7))
-    tot = 0.0
-    for i in (1, 5, 6, 7):
-        d = T[:, w, i]
-        tot += d.mean()
-        print("  %-58s %6.2f  (%5.2f .. %5.2f)" % (names[i], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
-    print("  %-58s %6.2f" % ("sum of the phases", tot))
+lead = T[:, 0, 4] > 0
+print("%d leader workgroups" % lead.sum())
+for label, sel in (("the %d other workgroups" % (~lead).sum(), ~lead), ("the leaders", lead)):
+    for w in (0, 1):
+        print("%s, wave %d: mean (p10 .. p90), us per link" % (label, 0 if w == 0 else 7))
+        tot = 0.0
+        for i in (1, 2, 3, 4, 5, 6, 7):
+            d = T[sel, w, i]
+            tot += d.mean()
+            print("  %-58s %6.2f  (%5.2f .. %5.2f)" % (names[i], d.mean(), np.percentile(d, 10), np.percentile(d, 90)))
+        print("  %-58s %6.2f" % ("sum of the phases", tot))
