@@ -1021,8 +1021,13 @@ struct ChainShapePf {
     static constexpr int ROW_BYTES = CH_BS * (int)sizeof(double2);
     static constexpr int STATIC_LDS = 2 * (CH_BS / 64) * 8 + 2 * CH_GMAX * 4 + 256;      // smd + smu + slack
     static constexpr int SPARE = (160 * 1024 - STATIC_LDS - LB * PB * ROW_BYTES) / ROW_BYTES;
-    static constexpr int SP = SPARE < PB ? SPARE : PB;
-    static_assert(SP >= 1, "at least one spare row");
+    // (KH_PF_SP_CAP, experiment: cap the rows prefetched in front of the reduction's polls; 0 = none)
+#ifndef KH_PF_SP_CAP
+#define KH_PF_SP_CAP 64
+#endif
+    static constexpr int SP0 = SPARE < PB ? SPARE : PB;
+    static constexpr int SP = SP0 < KH_PF_SP_CAP ? SP0 : KH_PF_SP_CAP;
+    static_assert(SP0 >= 1, "at least one spare row");
     static constexpr size_t LDS_BYTES = (size_t)(LB * PB + SP) * ROW_BYTES;
 };
 

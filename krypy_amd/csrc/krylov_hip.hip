@@ -547,7 +547,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // k_mgs_chain_pf wins where the whole column stays on chip (<= 24 rows per lane: 6.9 vs 7.2 us per link at
     // N = 4*10^6); with 32 / 40 rows its prefetches sit in the CU's memory queue in front of the reduction's polls
     // and cost what they save (17.4 vs 16.3 us per link at N = 10^7)
-    const bool use_pf = use_lds && ctx->chain_pf && r2 <= 24;
+    const bool use_pf = use_lds && ctx->chain_pf && (r2 <= 24 || (ctx->chain_pf == 2 && r2 <= 40));   // (2: measurement)
 #define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fused) {
@@ -865,7 +865,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     if (!strcmp(key, "spmv_dia")) ctx->spmv_dia = value != 0;
     else if (!strcmp(key, "chain")) ctx->chain_enabled = (value != 0 && ctx->ncu <= CH_GMAX);
     else if (!strcmp(key, "chain_lds")) ctx->chain_lds = value != 0;
-    else if (!strcmp(key, "chain_pf")) ctx->chain_pf = value != 0;
+    else if (!strcmp(key, "chain_pf")) ctx->chain_pf = (int)value;
     else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
     else if (!strcmp(key, "chain_fault")) ctx->chain_fault = value != 0;
     else if (!strcmp(key, "spmv_split")) ctx->spmv_split = value != 0;
