@@ -188,6 +188,55 @@ def test_sharded_complex_gmres(world):
     assert np.linalg.norm(xr - g["gmres_realA_xk"]) < 1e-8 * np.linalg.norm(xr)
 
 
+def _case_complex_jacobi(rank, world, ctx):
+    """Sharded complex CG / MINRES with a Jacobi preconditioner: the fused complex CG step (real recurrences on the
+    real views, all-reduced <p, Ap> pair and <r, z>) and the complex step with its diagonal, on row slabs."""
+    import scipy.sparse as sp
+    from krypy_amd import dist as kdist, linsys
+    from oracle.inputs import complex_systems
+    nx = 24
+    c = complex_systems(nx)
+    b = c["b"]
+    N = b.shape[0]
+    cuts = kdist.slab_cuts(N, world, align=nx)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    d = np.asarray(c["hpd"].diagonal()).real[r0:r1]
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    out = {}
+    ctx.calls.clear()
+    A = kdist.ShardedCSROperator(c["hpd"][r0:r1], r0, N, ctx)
+    s = linsys.Cg(linsys.LinearSystem(A, b[r0:r1], M=M, Minv=Minv, self_adjoint=True, positive_definite=True),
+                  tol=1e-10, maxiter=300)
+    assert ctx.calls.get("cg_step") == len(s.resnorms) - 1, dict(ctx.calls)
+    out["cg"] = (np.array(s.resnorms), s.xk[:, 0].copy())
+    A = kdist.ShardedCSROperator(c["hind"][r0:r1], r0, N, ctx)
+    ctx.calls.clear()
+    s = linsys.Minres(linsys.LinearSystem(A, b[r0:r1], M=M, Minv=Minv, self_adjoint=True), tol=1e-10, maxiter=600)
+    assert ctx.calls.get("dot_panel", 0) + ctx.calls.get("axpy_panel", 0) == 0, dict(ctx.calls)
+    out["minres"] = (np.array(s.resnorms), s.xk[:, 0].copy())
+    return r0, r1, out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_complex_cg_minres_with_jacobi(world):
+    import scipy.sparse as sp
+    from oracle import krylov_ref_c as refc
+    from oracle.inputs import complex_systems
+    out = _run(_case_complex_jacobi, world)
+    c = complex_systems(24)
+    b = c["b"]
+    M = sp.diags(1.0 / np.asarray(c["hpd"].diagonal()).real).tocsr()
+    for name, A, fn, maxiter in (("cg", c["hpd"], refc.cg, 300), ("minres", c["hind"], refc.minres, 600)):
+        xo, reso = fn(A, b, tol=1e-10, maxiter=maxiter, M=M)
+        x = np.zeros(b.shape[0], dtype=complex)
+        for rank, (r0, r1, res) in out.items():
+            resn, xk = res[name]
+            x[r0:r1] = xk
+            assert len(resn) == len(reso), (name, len(resn), len(reso))
+            assert np.max(np.abs(resn[:-1] - reso[:-1]) / reso[:-1]) < 1e-7, name
+        assert np.linalg.norm(x - xo) < 1e-8 * np.linalg.norm(xo), name
+
+
 def test_slab_cuts_and_localize():
     from krypy_amd import dist as kdist
     assert kdist.slab_cuts(100, 4) == [0, 25, 50, 75, 100]
