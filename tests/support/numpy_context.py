@@ -137,6 +137,16 @@ class NumpyContext(object):
     def allreduce_host(self, vals):
         return self._allreduce(np.asarray(vals, dtype=float))
 
+    # launcher-side protocol of the real context (kh_comm_unique_id / kh_comm_init): rank 0 makes an id, every rank
+    # joins with it.  Here the communicator is torch.distributed's default (gloo) group, created by the launcher.
+    def comm_unique_id(self):
+        return b"gloo-test-double".ljust(128, b"\0")
+
+    def comm_init(self, rank, nranks, unique_id):
+        assert len(unique_id) == 128 and unique_id.startswith(b"gloo-test-double"), "every rank must get rank 0's id"
+        self.rank, self.nranks = rank, nranks
+        self._comm = GlooComm(rank, nranks) if nranks > 1 else None
+
     # allocation
     def alloc(self, n, ncols=1, dtype=float, zero=True):
         v = NumpyVectors(self, n, ncols, dtype)

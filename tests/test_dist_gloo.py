@@ -237,6 +237,77 @@ def test_sharded_complex_cg_minres_with_jacobi(world):
         assert np.linalg.norm(x - xo) < 1e-8 * np.linalg.norm(xo), name
 
 
+def _bench_worker(rank, world, port, q):
+    """bench.py exactly as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` starts it (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), with the NumPy double standing in for the device."""
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        from krypy_amd import _hip
+        from tests.support.numpy_context import NumpyContext
+        ctx = NumpyContext()
+        _hip._install_context_for_testing(ctx)
+        import sys
+        import bench
+        sys.argv = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--nx", "40", "--ny", "36",
+                    "--restart", "12", "--no-roofline", "--no-cpu-baseline"]
+        out, r, dist = bench._run()
+        assert r == rank and ctx.nranks == world and ctx.rank == rank
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", out))
+    except BaseException:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_sharded_path_runs_on_n_ranks(world):
+    """The N > 1 leg of bench.py (row slabs of the grid, unique-id broadcast, comm_init, the panel form as default,
+    max-over-ranks timing, the JSON contract) has never run on more than one GPU: at least its host logic runs
+    here on gloo ranks, at a toy size, and must do the same iterations as one process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        rank, status, payload = q.get(timeout=600)
+        assert status == "ok", payload
+        outs[rank] = payload
+    for p in procs:
+        p.join(timeout=60)
+    o = outs[0]
+    assert o["n_gpus"] == world and o["steps"] == 2 and o["warmup"] == 1 and o["unit"] == "iterations/s"
+    assert o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24
+    assert o["config"]["parallelism"] == "row-sharded x%d (RCCL)" % world
+    assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 24) < 1e-6
+    # every rank reports the same (max-over-ranks) time and the same residual
+    assert len({round(outs[r]["value"], 6) for r in outs}) == 1
+    assert len({outs[r]["config"]["final_relres"] for r in outs}) == 1
+    # ... and that residual is the single-process one
+    from krypy_amd import _hip, linsys, utils
+    from tests.support.numpy_context import NumpyContext
+    import bench
+    old = _hip._install_context_for_testing(NumpyContext())
+    try:
+        A = bench.laplace2d(40, 36)
+        b = np.random.default_rng(0).standard_normal(A.shape[0])
+        ls = linsys.LinearSystem(A, b)
+        x0 = None
+        for ncyc in (1, 2):          # warm-up cycle, then the two timed ones from its iterate
+            try:
+                s = linsys.RestartedGmres(ls, x0=x0, maxiter=12, max_restarts=ncyc - 1, tol=1e-8, ortho="cgs")
+            except utils.ConvergenceError as e:
+                s = e.solver
+            x0 = s.xk
+        assert abs(s.resnorms[-1] - o["config"]["final_relres"]) <= 1e-9 * s.resnorms[-1]
+        assert o["config"]["basis_orthogonality_fro"]["cgs"] < 1e-10
+    finally:
+        _hip._install_context_for_testing(old)
+
+
 def test_slab_cuts_and_localize():
     from krypy_amd import dist as kdist
     assert kdist.slab_cuts(100, 4) == [0, 25, 50, 75, 100]
