@@ -306,6 +306,34 @@ def case_estimate_time():
         pass
 
 
+def case_input_kinds():
+    """Everything `get_linearoperator` / `LinearSystem` accept in the reference (utils.py:241-259, linsys.py:74-99):
+    any SciPy sparse format and the newer sparse arrays, numpy.matrix, Fortran-ordered and integer / float32 data,
+    non-contiguous and integer right-hand sides - same solution as a dense solve, in fp64 on the device."""
+    import warnings
+    import krypy_amd
+    A = ref.laplace2d(12).tocsr()
+    N = A.shape[0]
+    b = np.arange(1.0, N + 1.0)
+    xref = np.linalg.solve(A.toarray(), b)
+    kinds = {
+        "float32": (A.astype(np.float32), b.astype(np.float32)), "int64 A": (A.astype(np.int64), b),
+        "int b": (A, np.arange(1, N + 1)), "F-ordered dense": (np.asfortranarray(A.toarray()), b),
+        "strided b": (A, np.repeat(b, 2)[::2]), "csc": (A.tocsc(), b), "coo": (A.tocoo(), b), "lil": (A.tolil(), b),
+        "bsr": (A.tobsr(), b), "dia": (A.todia(), b), "csr_array": (sp.csr_array(A), b),
+        "matrix": (np.matrix(A.toarray()), b), "column b": (A, b.reshape(-1, 1)),
+    }
+    for name, (AA, bb) in kinds.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            x, sol = krypy_amd.gmres(AA, bb, tol=1e-11, maxiter=200)
+        x = np.asarray(x)
+        assert x.dtype == np.float64 and x.shape == np.asarray(bb).shape, (name, x.dtype, x.shape)
+        assert np.linalg.norm(x.ravel() - xref) <= 1e-9 * np.linalg.norm(xref), name
+    # the inputs are never modified (SURVEY 8b: solvers copy)
+    assert np.array_equal(b, np.arange(1.0, N + 1.0)) and abs(A - ref.laplace2d(12)).sum() == 0
+
+
 def case_arnoldi_interleaved():
     """Several Arnoldi objects advanced alternately on one context - the reference handles that
     (every object owns its arrays); here the look-ahead H-column slots belong to the context, so each
