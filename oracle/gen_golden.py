@@ -491,6 +491,16 @@ def gen_estimate_time(krypy):
     save("estimate_time", values=np.array(out))
 
 
+def gen_edge_cases(krypy):
+    """Degenerate input through the solver API (oracle.inputs.edge_scenarios): status / message / length of
+    resnorms / last residual / ||xk|| / last error norm as the unmodified reference produces them."""
+    from oracle.inputs import run_edge_scenarios
+    rows = run_edge_scenarios(krypy)
+    save("edge_cases", names=np.array([r[0] for r in rows]), status=np.array([r[1] for r in rows]),
+         message=np.array([r[2] for r in rows]), n_res=np.array([r[3] for r in rows], dtype=np.int64),
+         last=np.array([r[4] for r in rows]), xnorm=np.array([r[5] for r in rows]), err=np.array([r[6] for r in rows]))
+
+
 def main():
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
@@ -511,6 +521,7 @@ def main():
     gen_api_surface(krypy)
     gen_recycling_toy(krypy)
     gen_estimate_time(krypy)
+    gen_edge_cases(krypy)
 
 
 if __name__ == "__main__":

@@ -204,3 +204,64 @@ def run_deflation_matrix(linsys, deflation, ConvergenceError, visit):
                     visit(idx, name, Solver, ls, sol, failed, A, B)
                     idx += 1
     return idx
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases of the solver API: what the reference does with degenerate input (zero right-hand side, exact initial
+# guess, maxiter 0, tol 0, wrong shapes, a rank-deficient deflation basis ...).  Each scenario takes the package
+# (`krypy` for the fixture, `krypy_amd` in the tests) and returns a solver; run_edge_scenarios reduces the outcome
+# to (status, message, len(resnorms), resnorms[-1], ||xk||).
+# ---------------------------------------------------------------------------------------------
+def edge_scenarios():
+    A = laplace2d(8).tocsr()
+    N = A.shape[0]
+    b = np.arange(1.0, N + 1.0)
+    xex = np.linalg.solve(A.toarray(), b)
+    sing = sp.diags(np.r_[0.0, np.ones(N - 1)]).tocsr()
+    spd = dict(self_adjoint=True, positive_definite=True)
+    return [
+        ("zero rhs gmres", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, np.zeros(N)))),
+        ("zero rhs minres", lambda m: m.linsys.Minres(m.linsys.LinearSystem(A, np.zeros(N), self_adjoint=True))),
+        ("zero rhs cg", lambda m: m.linsys.Cg(m.linsys.LinearSystem(A, np.zeros(N), **spd))),
+        ("x0 exact", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, b), x0=xex.reshape(-1, 1), tol=1e-8)),
+        ("maxiter 0", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, b), maxiter=0)),
+        ("maxiter 0 cg", lambda m: m.linsys.Cg(m.linsys.LinearSystem(A, b, **spd), maxiter=0)),
+        ("maxiter beyond N", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, b), maxiter=5 * N, tol=1e-12)),
+        ("tol 0", lambda m: m.linsys.Minres(m.linsys.LinearSystem(A, b, self_adjoint=True), maxiter=10, tol=0.0)),
+        ("negative tol", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, b), tol=-1.0, maxiter=5)),
+        ("singular consistent", lambda m: m.linsys.Minres(
+            m.linsys.LinearSystem(sing, np.r_[0.0, np.ones(N - 1)], self_adjoint=True), tol=1e-10)),
+        ("b wrong length", lambda m: m.linsys.Gmres(m.linsys.LinearSystem(A, np.ones(N + 1)))),
+        ("restart fails", lambda m: m.linsys.RestartedGmres(m.linsys.LinearSystem(A, b), maxiter=3, max_restarts=0,
+                                                            tol=1e-12)),
+        ("restart succeeds", lambda m: m.linsys.RestartedGmres(m.linsys.LinearSystem(A, b), maxiter=5, max_restarts=40,
+                                                               tol=1e-8)),
+        ("U rank deficient", lambda m: m.deflation.DeflatedGmres(m.linsys.LinearSystem(A, b), U=np.ones((N, 2)),
+                                                                 tol=1e-8)),
+        ("U spans the solution", lambda m: m.deflation.DeflatedMinres(
+            m.linsys.LinearSystem(A, b, self_adjoint=True), U=xex.reshape(-1, 1), tol=1e-8)),
+        ("U empty", lambda m: m.deflation.DeflatedCg(m.linsys.LinearSystem(A, b, **spd), U=np.zeros((N, 0)), tol=1e-8)),
+        ("explicit residual", lambda m: m.linsys.Cg(m.linsys.LinearSystem(A, b, **spd), tol=1e-8,
+                                                    explicit_residual=True)),
+        ("exact_solution errnorms", lambda m: m.linsys.Gmres(
+            m.linsys.LinearSystem(A, b, exact_solution=xex.reshape(-1, 1)), tol=1e-8)),
+    ]
+
+
+def run_edge_scenarios(pkg):
+    import warnings
+    out = []
+    for name, fn in edge_scenarios():
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sol = fn(pkg)
+            extra = float(sol.errnorms[-1]) if getattr(sol, "errnorms", None) is not None and len(sol.errnorms) else -1.0
+            out.append((name, "ok", "", len(sol.resnorms), float(sol.resnorms[-1]), float(np.linalg.norm(sol.xk)), extra))
+        except Exception as e:      # noqa: BLE001  (the point is to record what is raised)
+            sol = getattr(e, "solver", None)
+            n = len(sol.resnorms) if sol is not None else -1
+            out.append((name, type(e).__name__, str(e), n, float(sol.resnorms[-1]) if n > 0 else -1.0,
+                        float(np.linalg.norm(sol.xk)) if sol is not None and getattr(sol, "xk", None) is not None else -1.0,
+                        -1.0))
+    return out

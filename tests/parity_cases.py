@@ -334,6 +334,33 @@ def case_input_kinds():
     assert np.array_equal(b, np.arange(1.0, N + 1.0)) and abs(A - ref.laplace2d(12)).sum() == 0
 
 
+def case_edge_cases():
+    """Degenerate input: same outcome as the unmodified reference (tests/golden/edge_cases.npz from
+    oracle/gen_golden.py:gen_edge_cases) - exception class and message, iteration count, last residual, ||xk||."""
+    import krypy_amd
+    from oracle.inputs import run_edge_scenarios
+    g = golden("edge_cases")
+    rows = run_edge_scenarios(krypy_amd)
+    assert [r[0] for r in rows] == [str(x) for x in g["names"]]
+    for i, (name, status, msg, n, last, xnorm, err) in enumerate(rows):
+        assert status == str(g["status"][i]), (name, status, str(g["status"][i]), msg)
+        assert n == int(g["n_res"][i]), (name, n, int(g["n_res"][i]))
+        if status == "ConvergenceError":       # "... residual: 0.01367..." - the digits beyond 1e-10 are rounding
+            a, b_ = msg.split("residual: "), str(g["message"][i]).split("residual: ")
+            assert a[0] == b_[0], (name, msg)
+            if len(a) > 1:
+                assert abs(float(a[1].rstrip(").")) - float(b_[1].rstrip(")."))) <= 1e-10 * float(b_[1].rstrip(").")), name
+        elif status != "ok":
+            assert msg == str(g["message"][i]), (name, msg)
+        if n > 0:
+            gl = float(g["last"][i])
+            # residuals at rounding level (an exact initial guess, a solution inside the deflation space) are noise
+            assert abs(last - gl) <= 1e-7 * gl + 5e-15, (name, last, gl)
+            assert abs(xnorm - float(g["xnorm"][i])) <= 1e-9 * max(1.0, float(g["xnorm"][i])), name
+        if float(g["err"][i]) >= 0:
+            assert abs(err - float(g["err"][i])) <= 1e-6 * float(g["err"][i]), (name, err)
+
+
 def case_arnoldi_interleaved():
     """Several Arnoldi objects advanced alternately on one context - the reference handles that
     (every object owns its arrays); here the look-ahead H-column slots belong to the context, so each
