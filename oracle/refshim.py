@@ -3,7 +3,7 @@
 BUILD-CONTAINER ONLY: ``/root/reference`` does not exist on the GPU box, and
 nothing in ``tests -m gpu``, ``smoke()`` or ``bench.py`` imports this module.
 It is used by ``oracle/gen_golden.py`` (to emit the committed fixtures under
-``tests/golden/``) and by ``tests/test_oracle_vs_reference.py`` (skipped when the
+``tests/golden/``) and by ``tests/test_differential_vs_reference.py`` (skipped when the
 reference tree is absent).
 
 The reference uses names that NumPy 2 / SciPy 1.15 removed (SURVEY.md section 0);
