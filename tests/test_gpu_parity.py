@@ -785,3 +785,20 @@ def test_dense_panel_apply_on_matrix_cores(hip, shape):
     hip.apply(Ad, Xd, 0, Y2, 0, 1)
     hip.apply(Ad, Xd, 1, Y2, 1, 1)
     assert np.allclose(Y1.download(), Y2.download(), rtol=1e-12, atol=1e-11)
+
+
+def test_abi_fuzz_random_calls_against_numpy(hip):
+    """tools/abi_fuzz.py, 40 fixed seeds: every vector / operator entry on random windows of random blocks (bit-level
+    for the CSR / banded SpMV and SpMM), and every fused entry (Arnoldi / Lanczos step with each option, residual,
+    MINRES / CG recurrences, projector) against the NumPy restatement of its semantics, real and complex."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import abi_fuzz
+    from tests.support.numpy_context import NumpyContext
+    dbl = NumpyContext()
+    total = 0
+    for seed in range(40):
+        total += abi_fuzz.one_round(hip, seed, 200_000)
+        total += abi_fuzz.step_round(hip, dbl, seed, 200_000)
+    assert total > 1000

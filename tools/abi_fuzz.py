@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Randomised differential test of the device library's vector / operator entry points against NumPy / SciPy:
+random lengths (odd ones, lengths around the padding threshold and the tile sizes), random column windows of wider
+blocks, real and complex data, every operator kind (CSR with empty rows / one long row, banded, dense, diagonal),
+single vectors and blocks (the SpMM kernels).  Seeds are fixed: a failure names (seed, call).
+    python tools/abi_fuzz.py [rounds=60] [max_n=300000]
+Runs on whatever context is installed (the GPU by default; tests/support/numpy_context for a dry run)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+
+def rnd(rng, cplx, *shape):
+    x = rng.standard_normal(shape)
+    return x + 1j * rng.standard_normal(shape) if cplx else x
+
+
+def pick_n(rng, max_n):
+    kind = rng.integers(0, 5)
+    if kind == 0:
+        return int(rng.integers(1, 70))
+    if kind == 1:
+        return int(rng.choice([255, 256, 257, 1023, 1025, 2047, 2048, 2049, 4096, 4097, 65535, 65536, 65537]))
+    if kind == 2:
+        return int(rng.integers(1000, 20000)) | 1          # odd
+    return int(rng.integers(70, max_n))
+
+
+def random_operator(rng, n, cplx):
+    kind = ["csr", "banded", "dense", "diag", "csr_holes"][rng.integers(0, 5)]
+    if kind == "dense":
+        n = min(n, 700)
+        return kind, rnd(rng, cplx, n, n), n
+    if kind == "diag":
+        d = rnd(rng, cplx, n)
+        return kind, sp.diags(d).tocsr(), n
+    if kind == "banded":
+        offs = sorted({0} | {int(o) for o in rng.integers(-min(n - 1, 900), min(n - 1, 900) + 1, size=rng.integers(1, 7))})
+        A = sp.diags([rnd(rng, cplx, n - abs(o)) for o in offs], offs, shape=(n, n), format="csr")
+        return kind, A, n
+    nnz = int(rng.uniform(2, 9) * n)
+    # (NOT scipy.sparse.random: it samples from n^2 integers - 671 GiB at n = 3e5; no lil / dense detours either)
+    rows, cols = rng.integers(0, n, nnz), rng.integers(0, n, nnz)
+    vals = rnd(rng, cplx, nnz)
+    if kind == "csr_holes" and n > 8:
+        holes = rng.integers(0, n, size=max(1, n // 50))
+        keep = ~np.isin(rows, holes)                               # empty rows
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+        m = min(n, 3000)                                           # one long row (beyond the LDS tile)
+        lr = int(rng.integers(0, n))
+        rows = np.r_[rows, np.full(m, lr)]
+        cols = np.r_[cols, rng.choice(n, size=m, replace=False)]
+        vals = np.r_[vals, rnd(rng, cplx, m)]
+    A = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    A = sp.csr_matrix(A, dtype=complex if cplx else float)
+    return kind, A.tocsr(), n
+
+
+def one_round(ctx, seed, max_n):
+    rng = np.random.default_rng(seed)
+    cplx = bool(rng.integers(0, 2))
+    n = pick_n(rng, max_n)
+    ncol = int(rng.integers(2, 21))
+    dt = complex if cplx else float
+    X, W = rnd(rng, cplx, n, ncol), rnd(rng, cplx, n, 3)
+    Xd, Wd = ctx.upload(X), ctx.upload(W)
+    tol = dict(rtol=1e-12, atol=1e-12 * np.sqrt(n) * 8)
+    checks = 0
+
+    def expect(name, got, want, **kw):
+        nonlocal checks
+        checks += 1
+        kw = kw or tol
+        if not np.allclose(got, want, **kw):
+            raise AssertionError("seed %d (n=%d, %s): %s deviates by %.3e" % (
+                seed, n, "complex" if cplx else "real", name, float(np.max(np.abs(np.asarray(got) - np.asarray(want))))))
+
+    j0 = int(rng.integers(0, ncol - 1))
+    k = int(rng.integers(1, ncol - j0 + 1))
+    wc = int(rng.integers(0, 3))
+    expect("download window", Xd.download(j0, k), X[:, j0:j0 + k], rtol=0, atol=0)
+    expect("dot_panel", ctx.dot_panel(Xd, j0, k, Wd, wc), X[:, j0:j0 + k].conj().T.dot(W[:, wc]))
+    expect("nrm2", ctx.nrm2(Wd, wc), np.linalg.norm(W[:, wc]), rtol=1e-13, atol=0)
+    nx2 = int(rng.integers(1, min(ncol, 6) + 1))
+    expect("gemm_tn", ctx.gemm_tn(Xd, 0, nx2, Xd, j0, k), X[:, :nx2].conj().T.dot(X[:, j0:j0 + k]))
+    h = rnd(rng, cplx, k)
+    w = W[:, wc].copy()
+    for j in range(k):
+        w = w - h[j] * X[:, j0 + j]
+    ctx.axpy_panel(Xd, j0, k, h, Wd, wc)
+    W[:, wc] = w
+    expect("axpy_panel", Wd.download()[:, wc], w, rtol=1e-13, atol=1e-13 * k)
+    C = rnd(rng, cplx, k, 2)
+    beta = float(rng.choice([0.0, 1.0, -0.5]))
+    Y = rnd(rng, cplx, n, 3)
+    Yd = ctx.upload(Y)
+    ctx.gemm_nn(Xd, j0, k, C, 1.0, beta, Yd, 1)
+    Y[:, 1:3] = beta * Y[:, 1:3] + X[:, j0:j0 + k].dot(C)
+    expect("gemm_nn", Yd.download(), Y, rtol=1e-12, atol=1e-12 * k)
+    a, b = (rnd(rng, cplx, 2) if cplx and rng.integers(0, 2) else rng.standard_normal(2))
+    ctx.waxpby(Yd, 0, a, Xd, j0, b, Wd, (wc + 1) % 3)
+    Y[:, 0] = a * X[:, j0] + b * W[:, (wc + 1) % 3]
+    expect("waxpby", Yd.download()[:, 0], Y[:, 0], rtol=1e-13, atol=1e-13)
+    s = float(rng.uniform(0.5, 2.0))
+    ctx.vdiv(Yd, 2, Xd, j0, s)
+    expect("vdiv", Yd.download()[:, 2], X[:, j0] / s, rtol=1e-15, atol=0)
+    Yd.copy_from(0, Xd, j0, min(k, 3))
+    expect("copy_from", Yd.download()[:, :min(k, 3)], X[:, j0:j0 + min(k, 3)], rtol=0, atol=0)
+    # operators: one vector, and a block through the same entry (SpMM kernels for CSR / banded)
+    kind, A, na = random_operator(rng, n, cplx)
+    if kind == "dense":
+        Ad = ctx.dense(A)
+        Adot = A.dot
+    elif kind == "diag":
+        Ad = ctx.diag(np.asarray(A.diagonal()))
+        Adot = A.dot
+    else:
+        Ad = ctx.csr(A)
+        Adot = A.dot
+    d = int(rng.choice([1, 2, 3, 5, 16, 17]))
+    Z = rnd(rng, cplx, na, d + 1)
+    Zd, Od = ctx.upload(Z), ctx.alloc(na, d + 2, dtype=dt)
+    x0c = int(rng.integers(0, 2))
+    ctx.apply(Ad, Zd, x0c, Od, 1, d)
+    want = Adot(Z[:, x0c:x0c + d])
+    got = Od.download()
+    # (a diagonal operator is a Hadamard product on the device: real bits only)
+    exact = (kind == "diag" and not cplx) or (kind in ("csr", "banded", "csr_holes") and A.getnnz(axis=1).max() <= 1024)
+    if exact:       # row sums left to right like SciPy: bit-identical
+        expect("apply %s x%d (bits)" % (kind, d), got[:, 1:1 + d], want, rtol=0, atol=0)
+    else:
+        expect("apply %s x%d" % (kind, d), got[:, 1:1 + d], want, rtol=1e-12, atol=1e-12 * np.sqrt(na) * 30)
+    expect("apply leaves the other columns alone", got[:, [0, d + 1]], 0.0, rtol=0, atol=0)
+    return checks
+
+
+def step_round(ctx, dbl, seed, max_n):
+    """The fused entry points (Arnoldi / Lanczos step with every option, residual, MINRES / CG updates, CG step,
+    projector) on random data: the device library against the NumPy restatement of each entry's semantics
+    (tests/support/numpy_context.py), blocks and returned numbers."""
+    rng = np.random.default_rng(10_000 + seed)
+    cplx = bool(rng.integers(0, 2))
+    dt = complex if cplx else float
+    n = min(pick_n(rng, max_n), 120_000)
+    n = max(n, 12)
+    m = int(rng.integers(2, 9))
+    k = int(rng.integers(0, m))
+    checks = 0
+
+    def expect(name, got, want, rtol=1e-10):
+        nonlocal checks
+        checks += 1
+        got, want = np.asarray(got), np.asarray(want)
+        scale = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+        if got.shape != want.shape or not np.allclose(got, want, rtol=rtol, atol=rtol * scale):
+            raise AssertionError("seed %d (n=%d, %s, k=%d of %d): %s deviates by %.3e" % (
+                seed, n, "complex" if cplx else "real", k, m, name,
+                float(np.max(np.abs(got - want))) if got.shape == want.shape else float("nan")))
+
+    offs = sorted({0, 1, -1} | {int(o) for o in rng.integers(-min(n - 1, 500), min(n - 1, 500) + 1, size=2)})
+    A = sp.diags([rnd(rng, cplx, n - abs(o)) + (4.0 if o == 0 else 0.0) for o in offs], offs, shape=(n, n), format="csr")
+    d = rng.uniform(0.5, 2.0, n)
+    with_m = bool(rng.integers(0, 2))
+    Q = np.linalg.qr(rnd(rng, cplx, n, m + 1))[0]
+    P0 = Q / np.sqrt(d)[:, None] if with_m else None          # V = D P, P^H D P = I
+    V0 = Q * np.sqrt(d)[:, None] if with_m else Q
+    mode = ["mgs", "dmgs", "cgs", "cgs2", "lanczos"][rng.integers(0, 5)]
+    gs = 1 if mode.startswith("cgs") else 0
+    sweeps = 2 if mode in ("dmgs", "cgs2") else 1
+    start = k if mode == "lanczos" else 0
+    hk = (complex(*rng.standard_normal(2)) if cplx else float(rng.standard_normal())) if (mode == "lanczos" and k > 0) else 0.0
+    outs = []
+    for c in (ctx, dbl):
+        Vd, Wd = c.alloc(n, m + 2, dtype=dt), c.alloc(n, 2, dtype=dt)
+        Vd.upload(0, V0[:, : k + 1])
+        Pd = None
+        Md = None
+        if with_m:
+            Pd = c.alloc(n, m + 2, dtype=dt)
+            Pd.upload(0, P0[:, : k + 1])
+            Md = c.diag(d, dtype=dt)
+        Ad = c.csr(A)
+        hcol = c.arnoldi_step(Ad, Md, Vd, Pd, Wd, 0, k, start, sweeps, gs, hk)
+        outs.append((np.array(hcol), Vd.download(0, k + 2), Pd.download(0, k + 2) if with_m else None))
+    expect("arnoldi_step %s%s H column" % (mode, " + Jacobi" if with_m else ""), outs[0][0][start:], outs[1][0][start:])
+    expect("arnoldi_step %s v_{k+1}" % mode, outs[0][1][:, k + 1], outs[1][1][:, k + 1])
+    if with_m:
+        expect("arnoldi_step %s p_{k+1}" % mode, outs[0][2][:, k + 1], outs[1][2][:, k + 1])
+    # residual, MINRES / CG recurrences
+    x, b_ = rnd(rng, cplx, n, 1), rnd(rng, cplx, n, 1)
+    r0, r1, r2, y0 = ((complex(*rng.standard_normal(2)) if cplx else float(rng.standard_normal())) for _ in range(4))
+    Vm, Wm, ym = rnd(rng, cplx, n, 3), rnd(rng, cplx, n, 2), rnd(rng, cplx, n, 1)
+    pv, rv, zv, yv = (rnd(rng, cplx, n, 1) for _ in range(4))
+    slot = int(rng.integers(0, 2))
+    first = bool(rng.integers(0, 2))
+    B = A + A.conj().T + sp.identity(n) * 12.0             # Hermitian, diagonally dominant: a CG operator
+    res = []
+    for c in (ctx, dbl):
+        Ad = c.csr(A)
+        Rd = c.alloc(n, 1, dtype=dt)
+        nr = c.residual(Ad, c.upload(b_), 0, c.upload(x), 0, Rd, 0)
+        Vd, Wd, Yd = c.upload(Vm), c.upload(Wm), c.upload(ym)
+        c.minres_update(Vd, 1, Wd, slot, r0, r1, r2, y0, Yd, 0)
+        Bd = c.csr(B.tocsr())
+        D2 = c.diag(np.repeat(d, 2) if cplx else d) if with_m else None
+        p_, r_, z_, y_, ap_ = c.upload(pv), c.upload(rv), c.upload(zv), c.upload(yv), c.alloc(n, 1, dtype=dt)
+        st = c.cg_step(Bd, D2, p_, 0, ap_, 0, y_, 0, r_, 0, z_ if with_m else None, 0, first, 0.37, 1.9)
+        p2, r2_, z2, y2, ap2 = c.upload(pv), c.upload(rv), c.upload(zv), c.upload(yv), c.upload(rnd(np.random.default_rng(seed), cplx, n, 1))
+        rho = c.cg_update(0.7, p2, 0, ap2, 0, y2, 0, r2_, 0, D2, z2 if with_m else None, 0)
+        res.append((nr, Rd.download(), Wd.download(), Yd.download(), st, p_.download(), r_.download(), y_.download(),
+                    ap_.download(), z_.download() if with_m else 0.0, rho, r2_.download(), y2.download()))
+    names = ("residual norm", "residual", "minres_update W", "minres_update yk", "cg_step scalars", "cg_step p", "cg_step r",
+             "cg_step yk", "cg_step Ap", "cg_step z", "cg_update rho", "cg_update r", "cg_update yk")
+    for nm, g_, w_ in zip(names, res[0], res[1]):
+        if nm == "cg_step scalars":
+            g_ = [g_[0], g_[1], complex(g_[2]).real, complex(g_[2]).imag / max(1.0, abs(complex(g_[2]).real))]
+            w_ = [w_[0], w_[1], complex(w_[2]).real, complex(w_[2]).imag / max(1.0, abs(complex(w_[2]).real))]
+        expect(nm, g_, w_)
+    # projector (deflation): complement of a random oblique projection, <Y, a> on request
+    dd = int(rng.integers(1, 6))
+    Wp, Vp = np.linalg.qr(rnd(rng, cplx, n, dd))[0], np.linalg.qr(rnd(rng, cplx, n, dd))[0]
+    T = np.linalg.inv(Wp.conj().T.dot(Vp))
+    WRH = rnd(rng, cplx, dd, dd)
+    a_ = rnd(rng, cplx, n, 1)
+    pr = []
+    for c in (ctx, dbl):
+        pj = c.proj_create(c.upload(Wp), c.upload(Vp), dd, T, WRH, 2)
+        Zd = c.alloc(n, 1, dtype=dt)
+        ya = c.proj_apply_complement(pj, c.upload(a_), 0, Zd, 0, want_ya=True)
+        pr.append((Zd.download(), ya))
+    expect("projector complement", pr[0][0], pr[1][0])
+    expect("projector <Y, a>", pr[0][1], pr[1][1])
+    return checks
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    max_n = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
+    from krypy_amd import _hip
+    ctx = _hip.get_context()
+    try:        # a generator bug must end in a MemoryError, not take the box down (tests/conftest.py does the same)
+        import resource
+        resource.setrlimit(resource.RLIMIT_DATA, (48 << 30, resource.getrlimit(resource.RLIMIT_DATA)[1]))
+    except Exception:
+        pass
+    total = 0
+    from tests.support.numpy_context import NumpyContext
+    dbl = NumpyContext()
+    for seed in range(rounds):
+        total += one_round(ctx, seed, max_n)
+        total += step_round(ctx, dbl, seed, max_n)
+    print("abi_fuzz: %d rounds, %d comparisons, all within tolerance" % (rounds, total))
