@@ -802,3 +802,15 @@ def test_abi_fuzz_random_calls_against_numpy(hip):
         total += abi_fuzz.one_round(hip, seed, 200_000)
         total += abi_fuzz.step_round(hip, dbl, seed, 200_000)
     assert total > 1000
+
+
+def test_solve_fuzz_random_solves_against_the_oracle(hip):
+    """tools/solve_fuzz.py, 16 fixed seeds: CG / MINRES / GMRES on random banded systems of random size with random
+    preconditioners, initial guesses, tolerances and Gram-Schmidt modes - same iteration count and residual history
+    as oracle/krylov_ref.py, up to the oracle's own movement under a last-bit perturbation of b."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import solve_fuzz
+    for seed in range(16):
+        solve_fuzz.one_solve(seed)

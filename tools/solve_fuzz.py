@@ -1,0 +1,116 @@
+#!/usr/bin/env python
+"""Randomised whole solves against the CPU oracle (oracle/krylov_ref.py, the pinned restatement of the reference):
+random size (500 ... 150,000: the short register shapes, windows, look-ahead), random banded operator (SPD for CG,
+symmetric indefinite for MINRES, non-symmetric for GMRES, all diagonally dominant so that rounding is not amplified),
+random preconditioners (Jacobi M, diagonal Ml / Mr), initial guess, tolerance, restart length and Gram-Schmidt mode.
+Same number of iterations and the same residual history (1e-9 relative, plus the cancellation of an explicitly
+computed residual: 2e-15 / its size) are required.
+    python tools/solve_fuzz.py [rounds=40]"""
+import os
+import sys
+import warnings
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+
+def one_solve(seed, max_n=150_000):
+    import oracle.krylov_ref as ref
+    from krypy_amd import linsys, utils
+    rng = np.random.default_rng(50_000 + seed)
+    n = int(rng.integers(500, max_n))
+    kind = ["gmres", "minres", "cg"][rng.integers(0, 3)]
+    offs = sorted({int(o) for o in rng.integers(1, min(n - 1, 700), size=rng.integers(1, 4))} | {1})
+    if kind == "gmres":
+        diags = [rng.uniform(-1, 1, n - o) for o in offs] + [rng.uniform(-1, 1, n - o) for o in offs]
+        A = sp.diags(diags, offs + [-o for o in offs], shape=(n, n), format="csr")
+    else:
+        L = sp.diags([rng.uniform(-1, 1, n - o) for o in offs], offs, shape=(n, n), format="csr")
+        A = (L + L.T).tocsr()
+    rowsum = np.asarray(abs(A).sum(axis=1)).ravel()
+    dd = rowsum * rng.uniform(1.05, 1.6) + 0.1
+    if kind == "minres":
+        dd = dd * np.where(rng.random(n) < 0.5, 1.0, -1.0)        # indefinite
+    A = (A + sp.diags(dd)).tocsr()
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n) * 0.1 if rng.integers(0, 2) else None
+    tol = float(10.0 ** rng.uniform(-10, -5))
+    kw, okw = {}, {}
+    if rng.integers(0, 2):
+        dM = rng.uniform(0.5, 2.0, n) if kind != "cg" else 1.0 / np.abs(dd)
+        kw.update(M=sp.diags(dM).tocsr(), Minv=sp.diags(1.0 / dM).tocsr())
+        okw["M"] = sp.diags(dM).tocsr()
+    if kind == "gmres" and rng.integers(0, 3) == 0:
+        dl, dr = rng.uniform(0.5, 2.0, n), rng.uniform(0.5, 2.0, n)
+        kw.update(Ml=sp.diags(dl).tocsr(), Mr=sp.diags(dr).tocsr())
+        okw.update(Ml=sp.diags(dl).tocsr(), Mr=sp.diags(dr).tocsr())
+    flags = dict(self_adjoint=kind != "gmres", positive_definite=kind == "cg")
+    maxiter = int(rng.integers(20, 120))
+    ortho = None
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ls = linsys.LinearSystem(A, b, **flags, **kw)
+        x0c = None if x0 is None else x0.reshape(-1, 1)
+        try:
+            if kind == "gmres":
+                ortho = ["mgs", "dmgs", "cgs2"][rng.integers(0, 3)]
+                s = linsys.Gmres(ls, x0=x0c, tol=tol, maxiter=maxiter, ortho=ortho)
+            elif kind == "minres":
+                s = linsys.Minres(ls, x0=x0c, tol=tol, maxiter=maxiter)
+            else:
+                s = linsys.Cg(ls, x0=x0c, tol=tol, maxiter=maxiter)
+            failed = False
+        except utils.ConvergenceError as e:
+            s, failed = e.solver, True
+        fn = {"gmres": ref.gmres, "minres": ref.minres, "cg": ref.cg}[kind]
+        extra = dict(ortho="dmgs" if ortho == "dmgs" else "mgs") if kind == "gmres" else {}
+        o = fn(A, b, x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
+        # how far the oracle's own history moves when b is perturbed in its last bit: un-reorthogonalised Lanczos on
+        # an indefinite matrix amplifies rounding by 1e10 and more (the policy of tests/parity_cases.py)
+        pert = np.random.default_rng(seed).standard_normal(n)
+        o2 = fn(A, b * (1.0 + 1e-15 * pert), x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
+    tag = "seed %d: %s n=%d maxiter=%d tol=%.1e %s%s" % (seed, kind, n, maxiter, tol, sorted(kw), " " + ortho if ortho else "")
+    got, want = np.array(s.resnorms), np.array(o.resnorms)
+    if len(o2.resnorms) == len(want):
+        assert failed == bool(o.failed), (tag, failed, o.failed)
+        assert len(got) == len(want), (tag, len(got), len(want))
+    else:
+        assert abs(len(got) - len(want)) <= abs(len(o2.resnorms) - len(want)) + 1, tag
+        m_ = min(len(got), len(want))
+        got, want, o2.resnorms = got[:m_], want[:m_], list(o2.resnorms)[:m_]
+        o2.resnorms = o2.resnorms + [want[-1]] * (m_ - len(o2.resnorms))
+    # recurrence residuals agree to rounding; an explicitly computed one, b - A x at relative size r, has lost
+    # log10(1/r) digits to cancellation on both sides: a few eps / r on top
+    big = want > 1e-13
+    rel = np.abs(got[big] - want[big]) / want[big]
+    w2 = np.array(o2.resnorms)
+    sens = 0.0
+    if len(w2) == len(want):
+        sens = float(np.max(np.abs(w2[big] - want[big]) / want[big]))
+    else:
+        sens = 1.0          # even the iteration count is not stable under rounding: only the shapes are compared
+    assert np.all(rel < 1e-9 + 2e-15 / want[big] + 30.0 * sens), (tag, float(rel.max()), sens)
+    dev = float(rel.max())
+    xo = o.xk.ravel()
+    xs = float(np.linalg.norm(o2.xk.ravel() - xo) / np.linalg.norm(xo))
+    assert np.linalg.norm(s.xk[:, 0] - xo) <= (1e-8 + 30.0 * xs) * np.linalg.norm(xo) + 1e-12, tag
+    return tag, len(got), float(dev), sens
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    from krypy_amd import _hip
+    _hip.get_context()
+    try:
+        import resource
+        resource.setrlimit(resource.RLIMIT_DATA, (48 << 30, resource.getrlimit(resource.RLIMIT_DATA)[1]))
+    except Exception:
+        pass
+    worst = 0.0
+    for seed in range(rounds):
+        tag, nres, dev, sens = one_solve(seed)
+        worst = max(worst, dev)
+        print("%-90s %3d residuals, deviation %.1e (oracle's own rounding sensitivity %.1e)" % (tag, nres, dev, sens),
+              flush=True)
+    print("solve_fuzz: %d solves agree with the oracle (worst deviation %.1e)" % (rounds, worst))
