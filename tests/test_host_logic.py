@@ -188,3 +188,13 @@ def test_reference_utils_matrix(cpu_double, case):
     """The reference's utils test matrix (test/test_utils.py: House, Givens, Projection, qr, angles,
     hegedus, Arnoldi in every ortho mode, Ritz pairs) on real AND complex matrices."""
     assert case() > 20
+
+
+def test_solve_fuzz_host_layer_against_the_oracle(cpu_double):
+    """The random solves of tools/solve_fuzz.py through the host layer on the NumPy double (sizes up to 20,000)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import solve_fuzz
+    for seed in range(24):
+        solve_fuzz.one_solve(seed, max_n=20_000)
