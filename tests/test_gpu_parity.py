@@ -814,3 +814,4 @@ def test_solve_fuzz_random_solves_against_the_oracle(hip):
     import solve_fuzz
     for seed in range(16):
         solve_fuzz.one_solve(seed)
+        solve_fuzz.one_solve_extra(seed)        # complex CG / MINRES / GMRES (oracle/krylov_ref_c.py), deflated GMRES

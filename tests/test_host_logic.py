@@ -198,3 +198,4 @@ def test_solve_fuzz_host_layer_against_the_oracle(cpu_double):
     import solve_fuzz
     for seed in range(24):
         solve_fuzz.one_solve(seed, max_n=20_000)
+        solve_fuzz.one_solve_extra(seed, max_n=20_000)

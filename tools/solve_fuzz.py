@@ -98,6 +98,78 @@ def one_solve(seed, max_n=150_000):
     return tag, len(got), float(dev), sens
 
 
+def one_solve_extra(seed, max_n=150_000):
+    """Complex CG / MINRES / GMRES (with and without a Jacobi preconditioner) against oracle/krylov_ref_c.py and
+    deflated GMRES with a random deflation space against oracle.krylov_ref.deflated_gmres."""
+    import oracle.krylov_ref as ref
+    import oracle.krylov_ref_c as refc
+    from krypy_amd import deflation, linsys, utils
+    rng = np.random.default_rng(70_000 + seed)
+    n = int(rng.integers(500, max_n))
+    kind = ["zgmres", "zminres", "zcg", "dgmres"][rng.integers(0, 4)]
+    offs = sorted({int(o) for o in rng.integers(1, min(n - 1, 700), size=rng.integers(1, 4))} | {1})
+    cplx = kind != "dgmres"
+
+    def rv(*sh):
+        x = rng.uniform(-1, 1, sh)
+        return x + 1j * rng.uniform(-1, 1, sh) if cplx else x
+
+    if kind in ("zgmres", "dgmres"):
+        A = sp.diags([rv(n - o) for o in offs] + [rv(n - o) for o in offs], offs + [-o for o in offs], shape=(n, n),
+                     format="csr")
+    else:
+        L = sp.diags([rv(n - o) for o in offs], offs, shape=(n, n), format="csr")
+        A = (L + L.conj().T).tocsr()
+    rowsum = np.asarray(abs(A).sum(axis=1)).ravel()
+    dd = rowsum * rng.uniform(1.05, 1.6) + 0.1
+    if kind == "zminres":
+        dd = dd * np.where(rng.random(n) < 0.5, 1.0, -1.0)
+    if kind == "zgmres":
+        dd = dd * np.exp(1j * rng.uniform(-0.4, 0.4, n))
+    A = (A + sp.diags(dd)).tocsr()
+    b = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0.0)
+    tol = float(10.0 ** rng.uniform(-10, -5))
+    maxiter = int(rng.integers(20, 100))
+    kw, okw = {}, {}
+    if cplx and rng.integers(0, 2):
+        dM = 1.0 / np.abs(dd) if kind == "zcg" else rng.uniform(0.5, 2.0, n)
+        kw.update(M=sp.diags(dM).tocsr(), Minv=sp.diags(1.0 / dM).tocsr())
+        okw["M"] = sp.diags(dM).tocsr()
+    pert = np.random.default_rng(seed).standard_normal(n)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flags = dict(self_adjoint=kind in ("zminres", "zcg"), positive_definite=kind == "zcg")
+        ls = linsys.LinearSystem(A, b, **flags, **kw)
+        try:
+            if kind == "dgmres":
+                U = np.linalg.qr(rng.standard_normal((n, int(rng.integers(1, 6)))))[0]
+                s = deflation.DeflatedGmres(ls, U=U, tol=tol, maxiter=maxiter)
+            else:
+                s = {"zgmres": linsys.Gmres, "zminres": linsys.Minres, "zcg": linsys.Cg}[kind](ls, tol=tol, maxiter=maxiter)
+        except utils.ConvergenceError as e:
+            s = e.solver
+        if kind == "dgmres":
+            o = ref.deflated_gmres(A, b, U, tol=tol, maxiter=maxiter)
+            o2 = ref.deflated_gmres(A, b * (1.0 + 1e-15 * pert), U, tol=tol, maxiter=maxiter)
+            want, w2, xo, xo2 = np.array(o.resnorms), np.array(o2.resnorms), o.xk.ravel(), o2.xk.ravel()
+        else:
+            fn = {"zgmres": refc.gmres, "zminres": refc.minres, "zcg": refc.cg}[kind]
+            r1, r2 = fn(A, b, tol=tol, maxiter=maxiter, **okw), fn(A, b * (1.0 + 1e-15 * pert), tol=tol, maxiter=maxiter, **okw)
+            xo, want, xo2, w2 = r1[0], np.array(r1[1]), r2[0], np.array(r2[1])
+    tag = "seed %d: %s n=%d maxiter=%d tol=%.1e %s" % (seed, kind, n, maxiter, tol, sorted(kw))
+    got = np.array(s.resnorms)
+    if len(w2) != len(want):
+        return tag, len(got), 0.0, 1.0        # the oracle's own iteration count moves under rounding
+    assert len(got) == len(want), (tag, len(got), len(want))
+    big = want > 1e-13
+    rel = np.abs(got[big] - want[big]) / want[big]
+    sens = float(np.max(np.abs(w2[big] - want[big]) / want[big]))
+    assert np.all(rel < 1e-9 + 2e-15 / want[big] + 30.0 * sens), (tag, float(rel.max()), sens)
+    xs = float(np.linalg.norm(xo2 - xo) / np.linalg.norm(xo))
+    assert np.linalg.norm(s.xk[:, 0] - xo) <= (1e-8 + 30.0 * xs) * np.linalg.norm(xo) + 1e-12, tag
+    return tag, len(got), float(rel.max()), sens
+
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     from krypy_amd import _hip
@@ -113,4 +185,8 @@ if __name__ == "__main__":
         worst = max(worst, dev)
         print("%-90s %3d residuals, deviation %.1e (oracle's own rounding sensitivity %.1e)" % (tag, nres, dev, sens),
               flush=True)
-    print("solve_fuzz: %d solves agree with the oracle (worst deviation %.1e)" % (rounds, worst))
+    for seed in range(rounds):
+        tag, nres, dev, sens = one_solve_extra(seed)
+        print("%-90s %3d residuals, deviation %.1e (oracle's own rounding sensitivity %.1e)" % (tag, nres, dev, sens),
+              flush=True)
+    print("solve_fuzz: %d + %d solves agree with the oracle (worst deviation of the real ones %.1e)" % (rounds, rounds, worst))
