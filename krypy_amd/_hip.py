@@ -482,8 +482,15 @@ class Context(object):
 
     def set_ghost(self, A, values):
         """Diagnostic: the ghost entries a halo exchange would deliver (``kh_mat_set_ghost``)."""
-        v = numpy.ascontiguousarray(values, dtype=numpy.float64)
-        _check(self._lib, self._lib.kh_mat_set_ghost(A.handle, _dptr(v), v.size), "kh_mat_set_ghost")
+        if A.dtype == _C128:          # (re, im) pairs, like the halo exchange of a complex shard delivers them
+            v = numpy.ascontiguousarray(values, dtype=numpy.complex128)
+            count = 2 * v.size
+        else:
+            if numpy.iscomplexobj(values) and numpy.any(numpy.imag(values)):
+                raise BackendError("set_ghost: complex ghost entries for a real operator")
+            v = numpy.ascontiguousarray(numpy.real(values), dtype=numpy.float64)
+            count = v.size
+        _check(self._lib, self._lib.kh_mat_set_ghost(A.handle, _dptr(v), count), "kh_mat_set_ghost")
 
     def set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
         _check(self._lib, self._lib.kh_mat_set_halo(self._h, A.handle, nsend_prev, nsend_next,

@@ -301,7 +301,7 @@ def test_complex_shard_with_ghost_columns_and_rccl_path(hip):
         Ad = hip.csr(Al, n_cols=Al.shape[1])
         hip.set_halo(Ad, 0, 0, nrp, nrn)
         ghost = np.concatenate([x[r0 - nrp:r0], x[r1:r1 + nrn]])
-        hip.set_ghost(Ad, np.ascontiguousarray(ghost).view(float))
+        hip.set_ghost(Ad, ghost)
         X, Y = hip.upload(x[r0:r1]), hip.alloc(r1 - r0, 1, dtype=complex)
         hip.apply(Ad, X, 0, Y, 0, 1)
         assert np.array_equal(Y.download()[:, 0], want[r0:r1]), p

@@ -801,6 +801,7 @@ def test_abi_fuzz_random_calls_against_numpy(hip):
     for seed in range(40):
         total += abi_fuzz.one_round(hip, seed, 200_000)
         total += abi_fuzz.step_round(hip, dbl, seed, 200_000)
+        total += abi_fuzz.shard_round(hip, seed)      # block-row shards with hand-written ghost entries, bit for bit
     assert total > 1000
 
 

@@ -237,6 +237,54 @@ def step_round(ctx, dbl, seed, max_n):
     return checks
 
 
+def shard_round(ctx, seed):
+    """Block-row shards on one device: a random banded / scattered matrix cut into random uneven slabs, ghost
+    entries written by hand (kh_mat_set_ghost) instead of the halo exchange - every slab must reproduce its rows of
+    the global product bit for bit, for one vector and for a block, real and complex."""
+    from krypy_amd import dist
+    rng = np.random.default_rng(90_000 + seed)
+    cplx = bool(rng.integers(0, 2))
+    dt = complex if cplx else float
+    n = int(rng.integers(400, 60_000))
+    bw = int(rng.integers(1, max(2, min(n // 8, 400))))
+    if rng.integers(0, 2):
+        offs = sorted({0} | {int(o) for o in rng.integers(-bw, bw + 1, size=rng.integers(2, 7))})
+        A = sp.diags([rnd(rng, cplx, n - abs(o)) for o in offs], offs, shape=(n, n), format="csr")
+    else:
+        nnz = 6 * n
+        rows = rng.integers(0, n, nnz)
+        cols = np.clip(rows + rng.integers(-bw, bw + 1, nnz), 0, n - 1)
+        A = sp.coo_matrix((rnd(rng, cplx, nnz), (rows, cols)), shape=(n, n)).tocsr()
+        A.sum_duplicates()
+    A = sp.csr_matrix(A, dtype=dt)
+    A.sort_indices()
+    nslab = int(rng.integers(2, 7))
+    inner = np.sort(rng.choice(np.arange(1, n // max(bw, 1)), size=nslab - 1, replace=False)) * max(bw, 1)
+    cuts = [0] + [int(c) for c in inner if bw <= c <= n - bw] + [n]
+    cuts = sorted(set(cuts))
+    d = int(rng.choice([1, 3]))
+    x = rnd(rng, cplx, n, d)
+    want = A.dot(x)
+    checks = 0
+    for p in range(len(cuts) - 1):
+        r0, r1 = cuts[p], cuts[p + 1]
+        if r1 - r0 < bw:
+            continue
+        A_local, nrp, nrn = dist.localize_columns(A[r0:r1], r0, n)
+        Ad = ctx.csr(A_local, n_cols=A_local.shape[1], dtype=dt)
+        ctx.set_halo(Ad, 0, 0, nrp, nrn)
+        X, Y = ctx.upload(x[r0:r1]), ctx.alloc(r1 - r0, d, dtype=dt)
+        for c in range(d):        # (the ghost buffer holds one vector's halo: a block is applied column by column)
+            ctx.set_ghost(Ad, np.concatenate([x[r0 - nrp:r0, c], x[r1:r1 + nrn, c]]))
+            ctx.apply(Ad, X, c, Y, c, 1)
+        got = Y.download()
+        checks += 1
+        if not np.array_equal(got, want[r0:r1]):
+            raise AssertionError("seed %d: slab %d of %s (n=%d, bandwidth %d, %s): %.3e" % (
+                seed, p, cuts, n, bw, "complex" if cplx else "real", float(np.max(np.abs(got - want[r0:r1])))))
+    return checks
+
+
 if __name__ == "__main__":
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     max_n = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
@@ -253,4 +301,5 @@ if __name__ == "__main__":
     for seed in range(rounds):
         total += one_round(ctx, seed, max_n)
         total += step_round(ctx, dbl, seed, max_n)
+        total += shard_round(ctx, seed)
     print("abi_fuzz: %d rounds, %d comparisons, all within tolerance" % (rounds, total))
