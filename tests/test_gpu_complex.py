@@ -323,6 +323,26 @@ def test_complex_shard_with_ghost_columns_and_rccl_path(hip):
             assert len(g.resnorms) == len(w.resnorms)
             assert np.allclose(g.resnorms[:40], w.resnorms[:40], rtol=1e-9)
             assert np.linalg.norm(g.xk - w.xk) < 1e-8 * np.linalg.norm(w.xk)
+        # the panel modes (register-resident complex panel kernels, their (re, im) panel all-reduced) and the
+        # complex CG step / MINRES with a Jacobi preconditioner through the same multi-rank code path
+        before = ctx.counters()["cgs_register"]
+        for ortho in ("cgs", "cgs2"):
+            g = linsys.Gmres(ls, tol=1e-10, maxiter=300, ortho=ortho)
+            assert len(g.resnorms) == len(want_s[0].resnorms), ortho
+            assert np.linalg.norm(g.xk - want_s[0].xk) < 1e-8 * np.linalg.norm(want_s[0].xk), ortho
+        assert ctx.counters()["cgs_register"] > before
+        d = np.asarray(c["hpd"].diagonal()).real
+        M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+        hpd = dict(self_adjoint=True, positive_definite=True)
+        for Aname, cls, flags, mi in (("hpd", linsys.Cg, hpd, 300), ("hind", linsys.Minres, dict(self_adjoint=True), 600)):
+            _hip._install_context_for_testing(old)
+            w = cls(linsys.LinearSystem(c[Aname], b, M=M, Minv=Minv, **flags), tol=1e-10, maxiter=mi)
+            _hip._install_context_for_testing(ctx)
+            g = cls(linsys.LinearSystem(kdist.ShardedCSROperator(c[Aname], 0, N, ctx), b, M=M, Minv=Minv, **flags),
+                    tol=1e-10, maxiter=mi)
+            assert len(g.resnorms) == len(w.resnorms), Aname
+            assert np.allclose(g.resnorms[:-1], w.resnorms[:-1], rtol=1e-8), Aname
+            assert np.linalg.norm(g.xk - w.xk) < 1e-8 * np.linalg.norm(w.xk), Aname
     finally:
         _hip._install_context_for_testing(old)
         ctx.close()

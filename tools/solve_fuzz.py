@@ -68,8 +68,17 @@ def one_solve(seed, max_n=150_000):
         o = fn(A, b, x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
         # how far the oracle's own history moves when b is perturbed in its last bit: un-reorthogonalised Lanczos on
         # an indefinite matrix amplifies rounding by 1e10 and more (the policy of tests/parity_cases.py)
-        pert = np.random.default_rng(seed).standard_normal(n)
-        o2 = fn(A, b * (1.0 + 1e-15 * pert), x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
+        # (three probes, the most sensitive one counts: the movement is chaotic, one probe can land a factor 50 low)
+        o2 = None
+        for ps in range(3):
+            pert = np.random.default_rng(1000 * ps + seed).standard_normal(n)
+            oc = fn(A, b * (1.0 + 1e-15 * pert), x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
+            if len(oc.resnorms) != len(o.resnorms):
+                o2 = oc
+                break
+            mv = np.max(np.abs(np.array(oc.resnorms) - np.array(o.resnorms)) / np.maximum(np.array(o.resnorms), 1e-300))
+            if o2 is None or mv > o2_mv:
+                o2, o2_mv = oc, mv
     tag = "seed %d: %s n=%d maxiter=%d tol=%.1e %s%s" % (seed, kind, n, maxiter, tol, sorted(kw), " " + ortho if ortho else "")
     got, want = np.array(s.resnorms), np.array(o.resnorms)
     if len(o2.resnorms) == len(want):
