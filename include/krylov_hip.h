@@ -56,7 +56,9 @@ typedef enum {
 const char* kh_last_error(void);
 int kh_version(void);
 int kh_device_count(int* count);
-/* create a context on HIP device `device` (one stream, scratch for reductions) */
+/* create a context on HIP device `device` (one stream, scratch for reductions).  One context = one device = one
+ * process: N GPUs are N processes that join with kh_comm_init (the blueprint sketched (ndev, devs) here; with one
+ * process per GPU a context never spans devices). */
 int kh_ctx_create(int device, kh_ctx* out);
 int kh_ctx_destroy(kh_ctx ctx);
 int kh_ctx_sync(kh_ctx ctx);
