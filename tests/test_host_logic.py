@@ -199,3 +199,33 @@ def test_solve_fuzz_host_layer_against_the_oracle(cpu_double):
     for seed in range(24):
         solve_fuzz.one_solve(seed, max_n=20_000)
         solve_fuzz.one_solve_extra(seed, max_n=20_000)
+
+
+def test_committed_bench_line_fractions_are_fractions():
+    """profiles/r02_bench.json (a bench.py line from the MI355X): no roofline fraction above 1, each one a single
+    division of numbers in the same object, the traffic from a stamped PMC profile, the contract's fields present."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r02_bench.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "iterations/s" and d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    assert abs(d["config"]["iterations_timed"] / (d["ms_per_step"] * d["steps"] / 1e3) - d["value"]) < 1e-6 * d["value"]
+
+    def walk(x, path):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                walk(v, path + "/" + str(k))
+        elif isinstance(x, (int, float)) and not isinstance(x, bool) and "frac" in path.rsplit("/", 1)[-1]:
+            assert 0.0 < x <= 1.0, (path, x)
+    walk(d, "")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(r["frac_compulsory"] - r["compulsory_bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-9
+    assert r["traffic"] is None or (r["traffic"] == r["bytes_per_launch"] and r["traffic"] >= r["compulsory_bytes_per_launch"])
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s"
