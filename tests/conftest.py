@@ -90,7 +90,12 @@ def hip():
             import __graft_entry__
             __graft_entry__.build()
         _hip._install_context_for_testing(None)
+        forced = os.environ.get("KRYPY_AMD_TEST_FORCE_MULTI", "") == "1"
+        if forced:      # robustness runs: the WHOLE suite through the multi-rank code path (all-reduces of every
+            os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"      # inner product, no chain kernel) on a 1-rank communicator
         _real_ctx.append(_hip.get_context())
+        if forced:
+            _real_ctx[0].comm_init(0, 1, _real_ctx[0].comm_unique_id())
         _cap_host_memory()
     _hip._install_context_for_testing(_real_ctx[0])
     return _real_ctx[0]
