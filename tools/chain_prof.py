@@ -1,5 +1,5 @@
 """Where a link of the chain kernel spends its time: phase SUMS of the light diagnostic build
-(`hipcc ... -DKH_CHAIN_TRACE=2 -o krypy_amd/lib/libkrylov_hip_trace2.so`, see chain.h CH_STAMP mode 2).
+(`make -C krypy_amd/csrc prof` builds krypy_amd/lib/libkrylov_hip_trace2.so with -DKH_CHAIN_TRACE=2, see chain.h CH_STAMP mode 2).
 
 Every wave adds up, in scalar registers, the 100 MHz clock between the phase boundaries of every link of one 64-link
 launch; wave 0 and wave 7 of every workgroup write their sums at the end.  Unlike the per-link stamps of
