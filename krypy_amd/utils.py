@@ -1057,6 +1057,12 @@ class Arnoldi(object):
             md = self.M._device_matrix()
             if md is not None and md.kind == "diag":
                 self._Md = md
+            elif (md is not None and md.kind in ("csr", "dense") and md.dtype == _hip._F64
+                  and ortho in _GS_OF_ORTHO and not self._win):
+                # a preconditioner given as a matrix (a sparse approximate inverse, a dense SPD block): the step
+                # applies it itself - coefficients against V = M P, updates with P, M w for the norm - one C call
+                # per step instead of a host loop over the Gram-Schmidt links (the matrix form of `Md`, as for ip_B)
+                self._Md = md
         elif self.M is not None and self.M._real_diag_image(ctx) is not None:
             # complex data, real Jacobi scaling: the complex step takes it as a c128 diagonal
             self._Md = self.M._device_matrix(ctx, numpy.dtype(complex))
@@ -1083,7 +1089,8 @@ class Arnoldi(object):
             Pop, inner = self.A.args
             kp = getattr(Pop, "_kh_proj", None)
             im = inner._device_matrix(ctx, bdt) if kp is not None else None
-            if kp is not None and im is not None and bool(getattr(kp, "cplx", False)) == cplx:
+            if (kp is not None and im is not None and bool(getattr(kp, "cplx", False)) == cplx
+                    and (self._Md is None or self._Md.kind == "diag")):      # (a matrix Md takes no projector)
                 self._Amat, self._proj, self._on_ya = im, kp, Pop._on_ya
         # Look-ahead: when the operator is a plain device matrix, step k+1 depends on device data
         # only, so it is enqueued BEFORE the host waits for step k's Hessenberg column; the GPU

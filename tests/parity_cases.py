@@ -361,6 +361,36 @@ def case_edge_cases():
             assert abs(err - float(g["err"][i])) <= 1e-6 * float(g["err"][i]), (name, err)
 
 
+def case_matrix_preconditioner():
+    """A preconditioner given as a MATRIX (here a sparse approximate inverse: two Jacobi-Richardson sweeps written out
+    as a pentadiagonal SPD matrix, and a dense SPD block) runs inside the fused step - V = M P, coefficients against
+    V, updates with P, M w for the norm (utils.py:1012-1045) - like the Jacobi diagonal does: one device call per
+    iteration, the oracle's iterates."""
+    from krypy_amd import _hip
+    A, b = lap2d_system(24, rhs="rng1")
+    N = A.shape[0]
+    D = sp.identity(N) * 0.25
+    Msp = (2 * D - D @ A @ D).tocsr()                 # ~ A^-1 to first order, SPD, same sparsity as A
+    Minv = sp.linalg.inv(Msp.tocsc()).toarray() if hasattr(sp, "linalg") else np.linalg.inv(Msp.toarray())
+    ctx = _hip.get_context()
+    for Mname, M in (("sparse", Msp), ("dense", np.asarray(Msp.toarray()))):
+        for name, cls, kw, orun in (("gmres", linsys.Gmres, {}, ref.gmres),
+                                    ("minres", linsys.Minres, dict(self_adjoint=True), ref.minres),
+                                    ("gmres dmgs", linsys.Gmres, {}, ref.gmres)):
+            extra = dict(ortho="dmgs") if name.endswith("dmgs") else {}
+            if hasattr(ctx, "calls"):
+                ctx.calls.clear()
+            s = cls(linsys.LinearSystem(A, b, M=M, Minv=Minv, **kw), tol=1e-9, maxiter=300, **extra)
+            o = orun(A, b, tol=1e-9, maxiter=300, M=sp.csr_matrix(M), **extra)
+            assert len(s.resnorms) == len(o.resnorms), (Mname, name, len(s.resnorms), len(o.resnorms))
+            assert np.allclose(s.resnorms[:-1], o.resnorms[:-1], rtol=1e-8, atol=0), (Mname, name)
+            assert rel(s.xk[:, 0], o.xk) < 1e-9, (Mname, name)
+            if hasattr(ctx, "calls"):        # (the NumPy double counts the device calls)
+                n = len(s.resnorms) - 1
+                assert ctx.calls.get("arnoldi_step", 0) >= n and ctx.calls.get("dot_panel", 0) + ctx.calls.get("axpy_panel", 0) <= 4, \
+                    (Mname, name, dict(ctx.calls))
+
+
 def case_arnoldi_interleaved():
     """Several Arnoldi objects advanced alternately on one context - the reference handles that
     (every object owns its arrays); here the look-ahead H-column slots belong to the context, so each
