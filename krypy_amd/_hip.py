@@ -671,8 +671,8 @@ class Context(object):
     def arnoldi_step_begin(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, slot,
                            proj=None):
         if _same_dtype("arnoldi_step_begin", V, W):
-            if (Md is None) != (P is None) or (Md is not None and (Md.dtype != _C128 or Md.kind != "diag")):
-                raise BackendError("arnoldi_step_begin: the complex step takes a complex diagonal Md with its block P")
+            if (Md is None) != (P is None) or (Md is not None and Md.dtype != _C128):
+                raise BackendError("arnoldi_step_begin: the complex step takes a complex operator Md with its block P")
             hk = numpy.array([numpy.real(h_km1), numpy.imag(h_km1)], dtype=numpy.float64)
             _check(self._lib, self._lib.kh_zarnoldi_step_begin_md(
                 self._h, A.handle if A is not None else None, proj.handle if proj is not None else None,

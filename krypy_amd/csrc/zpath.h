@@ -636,8 +636,10 @@ static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol,
     // Md: the Jacobi preconditioner as a complex diagonal, V = Md P (utils.py:1026-1045): dots against V, updates
     // with P, norm sqrt(Re <w, Md w>), both blocks get their next column
     KH_ARG((Md == nullptr) == (P == nullptr), "kh_zarnoldi_step: P and Md go together");
-    KH_ARG(Md == nullptr || (Md->kind == KH_MAT_ZDIAG && 2 * Md->n_rows == V->n && P->n == V->n && P->ncols >= V->ncols),
-           "kh_zarnoldi_step: Md must be a complex diagonal of the vectors' length, P a block like V");
+    // (Md may also be a complex CSR / dense matrix - a preconditioner given as a matrix: the tail applies it)
+    KH_ARG(Md == nullptr || (Md->kind >= KH_MAT_ZCSR && 2 * Md->n_rows == V->n && Md->n_cols == Md->n_rows &&
+                             P->n == V->n && P->ncols >= V->ncols),
+           "kh_zarnoldi_step: Md must be a complex operator of the vectors' length, P a block like V");
     kh_vec Bk = P ? P : V;
     KH_ARG(V->n == W->n && start >= 0 && start <= k && sweeps >= 1 && sweeps <= 4, "kh_zarnoldi_step: arguments");
     const int64_t n = V->n / 2;

@@ -1066,6 +1066,10 @@ class Arnoldi(object):
         elif self.M is not None and self.M._real_diag_image(ctx) is not None:
             # complex data, real Jacobi scaling: the complex step takes it as a c128 diagonal
             self._Md = self.M._device_matrix(ctx, numpy.dtype(complex))
+        elif self.M is not None and ortho in _GS_OF_ORTHO:
+            md = self.M._device_matrix(ctx, numpy.dtype(complex))
+            if md is not None and md.kind in ("csr", "dense"):       # a matrix preconditioner on complex data
+                self._Md = md
         self._fused = self._euclid and (self.M is None or self._Md is not None)
         # Non-Euclidean inner product <x, y> = x^T B y with B a real matrix on the device (utils.py:184-193) and no
         # preconditioner: the step kernel's preconditioned recurrence with the roles of its two blocks swapped -

@@ -206,8 +206,41 @@ def case_complex_deflation():
     check_run(s, g, "dgmres_realsys", tol=1e-8, explicit_tol=1e-4)
 
 
+def case_complex_matrix_preconditioner():
+    """A preconditioner given as a matrix on complex data: a real SPD approximate inverse (uploaded as its c128 image)
+    and a Hermitian positive definite complex one, inside the complex step (kh_zarnoldi_step_begin_md with a CSR /
+    dense `Md`) for GMRES and MINRES - the complex oracle's iterates, one device call per iteration."""
+    from krypy_amd import _hip
+    c = complex_systems(16)
+    b = c["b"]
+    N = b.shape[0]
+    L = c["L"].tocsr()
+    D = sp.identity(N) * 0.25
+    Mr = (2 * D - D @ L @ D).tocsr()                                    # real SPD, sparsity of the Laplacian
+    H = c["hpd"].tocsr()
+    Dh = sp.diags(1.0 / np.asarray(H.diagonal()).real)
+    Mc = (2 * Dh - Dh @ H @ Dh).tocsr()                                 # Hermitian positive definite, complex
+    ctx = _hip.get_context()
+    for Mname, M in (("real sparse", Mr), ("complex sparse", Mc), ("complex dense", np.asarray(Mc.toarray()))):
+        Minv = np.linalg.inv(np.asarray(M.toarray()) if sp.issparse(M) else M)
+        for name, cls, A, kw, orun in (("gmres", linsys.Gmres, c["nonh"], {}, lambda *a, **k: refc.gmres(*a, **k)[:2]),
+                                       # (MINRES on the HPD matrix these M approximate the inverse of: a short, stable
+                                       # Lanczos run - an unrelated preconditioner on the indefinite matrix loses
+                                       # orthogonality and amplifies rounding beyond any fixed tolerance)
+                                       ("minres", linsys.Minres, c["hpd"], dict(self_adjoint=True), refc.minres)):
+            if hasattr(ctx, "calls"):
+                ctx.calls.clear()
+            s = cls(linsys.LinearSystem(A, b, M=M, Minv=Minv, **kw), tol=1e-9, maxiter=400)
+            xo, reso = orun(A, b, tol=1e-9, maxiter=400, M=sp.csr_matrix(M))
+            assert s.xk.dtype.kind == "c" and len(s.resnorms) == len(reso), (Mname, name, len(s.resnorms), len(reso))
+            assert np.max(np.abs(np.array(s.resnorms[:-1]) - reso[:-1]) / reso[:-1]) < 1e-7, (Mname, name)
+            assert crel(s.xk[:, 0], xo) < 1e-8, (Mname, name)
+            if hasattr(ctx, "calls"):
+                assert ctx.calls.get("dot_panel", 0) + ctx.calls.get("axpy_panel", 0) <= 4, (Mname, name, dict(ctx.calls))
+
+
 CASES = [case_complex_kernels, case_complex_operator_algebra, case_complex_arnoldi, case_complex_solvers,
-         case_complex_deflation]
+         case_complex_deflation, case_complex_matrix_preconditioner]
 
 
 # ---------------------------------------------------------------------------------------------

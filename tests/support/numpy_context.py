@@ -252,8 +252,8 @@ class NumpyContext(object):
         self._count("arnoldi_step")
         B = P if P is not None else V
         cplx = _same("arnoldi_step", V, W)
-        if cplx and ((Md is None) != (P is None) or (Md is not None and (Md.kind != "diag" or Md.dtype.kind != "c"))):
-            raise BackendError("arnoldi_step: the complex step takes a complex diagonal Md with its block P")
+        if cplx and ((Md is None) != (P is None) or (Md is not None and Md.dtype.kind != "c")):
+            raise BackendError("arnoldi_step: the complex step takes a complex operator Md with its block P")
         hcol = np.zeros(k + 2, dtype=V.dtype)
         if A is not None:
             if (A.dtype.kind == "c") != cplx:
