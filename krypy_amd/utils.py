@@ -1058,7 +1058,11 @@ class Arnoldi(object):
             if md is not None and md.kind == "diag":
                 self._Md = md
             elif (md is not None and md.kind in ("csr", "dense") and md.dtype == _hip._F64
-                  and ortho in _GS_OF_ORTHO and not self._win):
+                  and ortho in _GS_OF_ORTHO and not self._win
+                  and not (ortho in ("mgs", "dmgs") and N >= self._MATRIX_M_EXTERNAL_FROM and self._euclid)):
+                # (long recurrences on long vectors: the register-resident chain kernel, which the matrix form of Md
+                # does not use, is worth more than the look-ahead - those go the `_Mext` way below; measured
+                # GMRES(60), N = 9e6: 753 vs 608 it/s; N = 1e6: 3630 vs 3400; N = 9e4: 5800 vs 6600)
                 # a preconditioner given as a matrix (a sparse approximate inverse, a dense SPD block): the step
                 # applies it itself - coefficients against V = M P, updates with P, M w for the norm - one C call
                 # per step instead of a host loop over the Gram-Schmidt links (the matrix form of `Md`, as for ip_B)
@@ -1112,6 +1116,18 @@ class Arnoldi(object):
             self._fused, self._lookahead = False, 0
             self._Hv = ctx.alloc(N, min(self.maxiter + 1, N) + 1, dtype=bdt)
 
+        # A preconditioner that is NOT a device matrix (a callable such as an incomplete-factorisation solve, a
+        # composite operator): the Gram-Schmidt part of the step does not depend on M at all - coefficients against
+        # V_j, updates with P_j - so it runs in the fused step with a UNIT diagonal in M's place, which leaves
+        # p' = w / ||w||_2 in column k+1; M is then applied once to p' and the column pair is rescaled:
+        #   s = sqrt(<p', M p'>),  P_{k+1} = p'/s,  V_{k+1} = M p'/s,  H[k+1,k] = ||w||_2 s
+        # (= sqrt(<w, M w>), w / H[k+1,k], M w / H[k+1,k] of utils.py:1030-1045 up to rounding).  Three host
+        # synchronisations per step instead of k+3; real data, Euclidean inner product.
+        self._Mext = None
+        if (self.M is not None and self._Md is None and not cplx and self._euclid and ortho in _GS_OF_ORTHO
+                and not self._win):
+            self._Mext = ctx.diag(numpy.ones(N))
+
         v = _as_dvec(v, ctx, dtype=bdt)
         if ortho == "house":
             self.houses = [_DevHouse(ctx, self._Hv, 0, v.block, v.col)]
@@ -1133,6 +1149,7 @@ class Arnoldi(object):
             ctx.apply(self._ipB, self._V, 0, self._BV, 0, 1)
 
     _WINDOW_COLS = 66        # columns of the sliding Lanczos window (re-based every 64 steps)
+    _MATRIX_M_EXTERNAL_FROM = 1_500_000   # vector length from which a matrix preconditioner is applied outside the step
     _BASIS_SHARE = 0.30      # share of device memory the first allocation of V (and P) may take
     _max_initial_cols = None  # tests: force a small first allocation to exercise _grow()
 
@@ -1326,6 +1343,8 @@ class Arnoldi(object):
             self._release(0)
             H[start: k + 1, k] += hcol[start: k + 1]
             hn = float(hcol[k + 1])
+        elif self._Mext is not None:
+            hn = self._advance_external_m(k, start, h_km1)
         else:
             hn = self._advance_general(k, start, h_km1)
         H[k + 1, k] = hn
@@ -1382,6 +1401,27 @@ class Arnoldi(object):
                 a = float(numpy.real(a)) if numpy.imag(a) == 0 else complex(a)
                 ctx.waxpby(V, k + 1, a, V, k + 1, 0.0, V, k + 1)
         return hn
+
+    def _advance_external_m(self, k, start, h_km1):
+        """One step with a preconditioner that is a callable / composite operator (see __init__)."""
+        ctx = self._ctx
+        V, P, W, H = self._V, self._P, self._W, self.H
+        self.A._apply_dev(V, k, W, 0, 1)
+        self._claim(0)
+        hcol = ctx.arnoldi_step(None, self._Mext, V, P, W, 0, k, start, self._sweeps, self._gs_mode, h_km1)
+        self._release(0)
+        H[start: k + 1, k] += hcol[start: k + 1]
+        h2 = float(hcol[k + 1])                      # ||w||_2
+        if not (h2 > 0.0):
+            return 0.0                               # w = 0: invariant (the caller clears column k+1)
+        self.M._apply_dev(P, k + 1, W, 1, 1)         # M p'
+        s2 = _inner_dev(P, k + 1, 1, W, 1, 1, None)[0, 0]
+        s1 = float(numpy.sqrt(abs(numpy.real(s2))))
+        if not (s1 > 0.0):
+            return 0.0
+        ctx.vdiv(P, k + 1, P, k + 1, s1)
+        ctx.vdiv(V, k + 1, W, 1, s1)
+        return h2 * s1
 
     def _advance_general(self, k, start, h_km1):
         """Arnoldi step for a non-Euclidean inner product or a general preconditioner ``M``:

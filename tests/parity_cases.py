@@ -389,6 +389,59 @@ def case_matrix_preconditioner():
                 n = len(s.resnorms) - 1
                 assert ctx.calls.get("arnoldi_step", 0) >= n and ctx.calls.get("dot_panel", 0) + ctx.calls.get("axpy_panel", 0) <= 4, \
                     (Mname, name, dict(ctx.calls))
+        # long vectors take the other route for GMRES (M applied between the fused Gram-Schmidt and a rescaling, so
+        # that the chain kernel serves the long recurrence): same iterates
+        old_from = utils.Arnoldi._MATRIX_M_EXTERNAL_FROM
+        utils.Arnoldi._MATRIX_M_EXTERNAL_FROM = 0
+        try:
+            s = linsys.Gmres(linsys.LinearSystem(A, b, M=M, Minv=Minv), tol=1e-9, maxiter=300)
+        finally:
+            utils.Arnoldi._MATRIX_M_EXTERNAL_FROM = old_from
+        o = ref.gmres(A, b, tol=1e-9, maxiter=300, M=sp.csr_matrix(M))
+        assert len(s.resnorms) == len(o.resnorms) and np.allclose(s.resnorms[:-1], o.resnorms[:-1], rtol=1e-8, atol=0)
+        assert rel(s.xk[:, 0], o.xk) < 1e-9, Mname
+
+
+def case_callable_preconditioner():
+    """A preconditioner that is a CALLABLE (what an incomplete-factorisation or multigrid solve looks like to krypy:
+    `LinearOperator(shape, dtype, dot=f)`), and one that is a composite operator: the vectors make the round trip
+    through the callback once per step, but the Gram-Schmidt part stays in the fused step (unit diagonal in M's
+    place, then one rescaling of the new column pair) - the oracle's iterates, three device calls with a host
+    synchronisation per step instead of one per Gram-Schmidt link."""
+    from krypy_amd import _hip
+    A, b = lap2d_system(24, rhs="rng1")
+    N = A.shape[0]
+    D = sp.identity(N) * 0.25
+    Msp = (2 * D - D @ A @ D).tocsr()
+    calls = []
+
+    def apply_m(X):
+        calls.append(X.shape)
+        return Msp.dot(X)
+
+    Mcall = utils.LinearOperator((N, N), float, dot=apply_m, dot_adj=apply_m)
+    Mcomp = utils.MatrixLinearOperator(sp.csr_matrix(D)) * (2 * utils.IdentityLinearOperator((N, N))
+                                                            - utils.MatrixLinearOperator(A) * utils.MatrixLinearOperator(sp.csr_matrix(D)))
+    ctx = _hip.get_context()
+    for Mname, M in (("callable", Mcall), ("composite", Mcomp)):
+        for name, cls, kw, orun, extra in (("gmres", linsys.Gmres, {}, ref.gmres, {}),
+                                           ("gmres dmgs", linsys.Gmres, {}, ref.gmres, dict(ortho="dmgs")),
+                                           ("minres", linsys.Minres, dict(self_adjoint=True), ref.minres, {})):
+            if hasattr(ctx, "calls"):
+                ctx.calls.clear()
+            del calls[:]
+            s = cls(linsys.LinearSystem(A, b, M=M, **kw), tol=1e-9, maxiter=300, **extra)
+            o = orun(A, b, tol=1e-9, maxiter=300, M=Msp, **extra)
+            assert len(s.resnorms) == len(o.resnorms), (Mname, name, len(s.resnorms), len(o.resnorms))
+            assert np.allclose(s.resnorms[:-1], o.resnorms[:-1], rtol=1e-8, atol=0), (Mname, name)
+            assert rel(s.xk[:, 0], o.xk) < 1e-9, (Mname, name)
+            n = len(s.resnorms) - 1
+            if Mname == "callable":
+                assert n <= len(calls) <= n + 6, (name, n, len(calls))       # once per step (+ residuals)
+            if hasattr(ctx, "calls"):
+                assert ctx.calls.get("arnoldi_step", 0) == n, (Mname, name, dict(ctx.calls))
+                assert ctx.calls.get("axpy_panel", 0) <= 4 and ctx.calls.get("dot_panel", 0) <= 2 * n + 8, \
+                    (Mname, name, dict(ctx.calls))
 
 
 def case_arnoldi_interleaved():

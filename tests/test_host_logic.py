@@ -21,7 +21,7 @@ SIMPLE = [
     pc.case_recycling_gmres_lap3d, pc.case_recycling_factories_toy, pc.case_inner_product_matrix_B,
     pc.case_solver_zoo, pc.case_ritz, pc.case_arnoldi_house, pc.case_basis_growth,
     pc.case_lanczos_window, pc.case_api_surface, pc.case_arnoldi_interleaved, pc.case_estimate_time,
-    pc.case_input_kinds, pc.case_edge_cases, pc.case_matrix_preconditioner,
+    pc.case_input_kinds, pc.case_edge_cases, pc.case_matrix_preconditioner, pc.case_callable_preconditioner,
 ] + pcc.CASES
 
 

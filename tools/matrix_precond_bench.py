@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""GMRES / MINRES with a preconditioner given as a sparse MATRIX (a first-order approximate inverse with the sparsity
-of A): the fused step (`Md` as a matrix) against the general loop (the same matrix hidden behind a product operator,
-so that the host walks the Gram-Schmidt links).  python tools/matrix_precond_bench.py [nx]"""
+"""GMRES / MINRES with a preconditioner (a first-order approximate inverse with the sparsity of A) given three ways:
+as a sparse MATRIX (inside the fused step), as a composite device operator and as a host callable (the Gram-Schmidt
+part in the fused step, M applied once per step outside it).  python tools/matrix_precond_bench.py [nx]"""
 import os
 import sys
 import time
@@ -21,8 +21,10 @@ M = (2 * D - D @ A @ D).tocsr()
 b = np.random.default_rng(0).standard_normal(N)
 ctx = _hip.get_context()
 for label, Mop in (("matrix M inside the fused step", M),
-                   ("same M behind a product operator (general loop)",
-                    utils.MatrixLinearOperator(M) * utils.IdentityLinearOperator((N, N)) * utils.MatrixLinearOperator(sp.identity(N).tocsr() * 1.0 + M * 0.0) )):
+                   ("same M as a composite operator (device, applied between the fused GS and a rescaling)",
+                    utils.MatrixLinearOperator(M) * utils.MatrixLinearOperator(sp.identity(N).tocsr())),
+                   ("same M as a host callable (download -> callback -> upload once per step)",
+                    utils.LinearOperator((N, N), float, dot=M.dot, dot_adj=M.dot))):
     for cls, kw, m in ((linsys.Gmres, {}, 60), (linsys.Minres, dict(self_adjoint=True), 200)):
         ls = linsys.LinearSystem(A, b, M=Mop, **kw)
         best = 1e9
@@ -36,4 +38,4 @@ for label, Mop in (("matrix M inside the fused step", M),
             ctx.sync()
             best = min(best, time.perf_counter() - t0)
         n_it = len(s.resnorms) - 1
-        print("N = %d %-8s %-50s %7.0f it/s (%.0f us per iteration)" % (N, cls.__name__, label, n_it / best, best / n_it * 1e6))
+        print("N = %d %-8s %-90s %7.0f it/s (%.0f us per iteration)" % (N, cls.__name__, label, n_it / best, best / n_it * 1e6))
