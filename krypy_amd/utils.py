@@ -1122,11 +1122,10 @@ class Arnoldi(object):
         # p' = w / ||w||_2 in column k+1; M is then applied once to p' and the column pair is rescaled:
         #   s = sqrt(<p', M p'>),  P_{k+1} = p'/s,  V_{k+1} = M p'/s,  H[k+1,k] = ||w||_2 s
         # (= sqrt(<w, M w>), w / H[k+1,k], M w / H[k+1,k] of utils.py:1030-1045 up to rounding).  Three host
-        # synchronisations per step instead of k+3; real data, Euclidean inner product.
+        # synchronisations per step instead of k+3; Euclidean inner product, real or complex data.
         self._Mext = None
-        if (self.M is not None and self._Md is None and not cplx and self._euclid and ortho in _GS_OF_ORTHO
-                and not self._win):
-            self._Mext = ctx.diag(numpy.ones(N))
+        if self.M is not None and self._Md is None and self._euclid and ortho in _GS_OF_ORTHO and not self._win:
+            self._Mext = ctx.diag(numpy.ones(N), dtype=bdt)
 
         v = _as_dvec(v, ctx, dtype=bdt)
         if ortho == "house":
@@ -1410,8 +1409,10 @@ class Arnoldi(object):
         self._claim(0)
         hcol = ctx.arnoldi_step(None, self._Mext, V, P, W, 0, k, start, self._sweeps, self._gs_mode, h_km1)
         self._release(0)
+        if self.ortho == "lanczos" and hcol.dtype.kind == "c":
+            hcol = hcol.real                         # alpha = real(alpha), utils.py:1024-1027
         H[start: k + 1, k] += hcol[start: k + 1]
-        h2 = float(hcol[k + 1])                      # ||w||_2
+        h2 = float(numpy.real(hcol[k + 1]))          # ||w||_2
         if not (h2 > 0.0):
             return 0.0                               # w = 0: invariant (the caller clears column k+1)
         self.M._apply_dev(P, k + 1, W, 1, 1)         # M p'

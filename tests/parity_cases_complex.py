@@ -239,8 +239,41 @@ def case_complex_matrix_preconditioner():
                 assert ctx.calls.get("dot_panel", 0) + ctx.calls.get("axpy_panel", 0) <= 4, (Mname, name, dict(ctx.calls))
 
 
+def case_complex_callable_preconditioner():
+    """A callable preconditioner on complex data: Gram-Schmidt in the fused complex step (unit complex diagonal in M's
+    place), M applied once per step - the complex oracle's iterates."""
+    from krypy_amd import _hip, utils
+    c = complex_systems(16)
+    b = c["b"]
+    N = b.shape[0]
+    H = c["hpd"].tocsr()
+    Dh = sp.diags(1.0 / np.asarray(H.diagonal()).real)
+    Mc = (2 * Dh - Dh @ H @ Dh).tocsr()
+    seen = []
+
+    def apply_m(X):
+        seen.append(X.dtype.kind)
+        return Mc.dot(X)
+
+    M = utils.LinearOperator((N, N), complex, dot=apply_m, dot_adj=apply_m)
+    ctx = _hip.get_context()
+    for name, cls, A, kw, orun in (("gmres", linsys.Gmres, c["nonh"], {}, lambda *a, **k: refc.gmres(*a, **k)[:2]),
+                                   ("minres", linsys.Minres, c["hpd"], dict(self_adjoint=True), refc.minres)):
+        if hasattr(ctx, "calls"):
+            ctx.calls.clear()
+        s = cls(linsys.LinearSystem(A, b, M=M, **kw), tol=1e-9, maxiter=400)
+        xo, reso = orun(A, b, tol=1e-9, maxiter=400, M=Mc)
+        assert s.xk.dtype.kind == "c" and len(s.resnorms) == len(reso), (name, len(s.resnorms), len(reso))
+        assert np.max(np.abs(np.array(s.resnorms[:-1]) - reso[:-1]) / reso[:-1]) < 1e-7, name
+        assert crel(s.xk[:, 0], xo) < 1e-8, name
+        if hasattr(ctx, "calls"):
+            assert ctx.calls.get("arnoldi_step", 0) == len(s.resnorms) - 1 and ctx.calls.get("axpy_panel", 0) <= 4, \
+                (name, dict(ctx.calls))
+    assert set(seen) == {"c"}
+
+
 CASES = [case_complex_kernels, case_complex_operator_algebra, case_complex_arnoldi, case_complex_solvers,
-         case_complex_deflation, case_complex_matrix_preconditioner]
+         case_complex_deflation, case_complex_matrix_preconditioner, case_complex_callable_preconditioner]
 
 
 # ---------------------------------------------------------------------------------------------
