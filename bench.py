@@ -191,10 +191,13 @@ def main():
         out, rank, dist = _run()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    # from here on nothing may reach stdout any more: RCCL prints its version banner from a library destructor at
+    # process exit, i.e. AFTER the JSON line (seen with --force-sharded: "Extra data" for a JSON parser)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if dist is not None:
-        with _StdoutToStderr():
-            dist.barrier()
-            dist.destroy_process_group()
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _run():
