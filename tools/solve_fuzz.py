@@ -15,7 +15,7 @@ import numpy as np  # noqa: E402
 import scipy.sparse as sp  # noqa: E402
 
 
-def one_solve(seed, max_n=150_000):
+def one_solve(seed, max_n=150_000, check=True):
     import oracle.krylov_ref as ref
     from krypy_amd import linsys, utils
     rng = np.random.default_rng(50_000 + seed)
@@ -39,8 +39,18 @@ def one_solve(seed, max_n=150_000):
     kw, okw = {}, {}
     if rng.integers(0, 2):
         dM = rng.uniform(0.5, 2.0, n) if kind != "cg" else 1.0 / np.abs(dd)
-        kw.update(M=sp.diags(dM).tocsr(), Minv=sp.diags(1.0 / dM).tocsr())
-        okw["M"] = sp.diags(dM).tocsr()
+        Mm = sp.diags(dM).tocsr()
+        form = ["jacobi", "jacobi", "matrix", "callable"][rng.integers(0, 4)]
+        if form != "jacobi":        # a tridiagonal SPD matrix: inside the step as a matrix, or behind a host callable
+            off = 0.2 * float(dM.min()) * rng.uniform(-1, 1, n - 1)
+            Mm = sp.diags([dM, off, off], [0, 1, -1], format="csr")
+        okw["M"] = Mm
+        if form == "callable":
+            kw.update(M=utils.LinearOperator((n, n), float, dot=Mm.dot, dot_adj=Mm.dot))
+        elif form == "matrix":
+            kw.update(M=Mm)
+        else:
+            kw.update(M=Mm, Minv=sp.diags(1.0 / dM).tocsr())
     if kind == "gmres" and rng.integers(0, 3) == 0:
         dl, dr = rng.uniform(0.5, 2.0, n), rng.uniform(0.5, 2.0, n)
         kw.update(Ml=sp.diags(dl).tocsr(), Mr=sp.diags(dr).tocsr())
@@ -63,6 +73,8 @@ def one_solve(seed, max_n=150_000):
             failed = False
         except utils.ConvergenceError as e:
             s, failed = e.solver, True
+        if not check:          # (replaying a sequence of device solves without the oracle: hunting state left behind)
+            return "seed %d: %s n=%d" % (seed, kind, n), len(s.resnorms), 0.0, 0.0
         fn = {"gmres": ref.gmres, "minres": ref.minres, "cg": ref.cg}[kind]
         extra = dict(ortho="dmgs" if ortho == "dmgs" else "mgs") if kind == "gmres" else {}
         o = fn(A, b, x0=x0, tol=tol, maxiter=maxiter, **okw, **extra)
@@ -79,7 +91,8 @@ def one_solve(seed, max_n=150_000):
             mv = np.max(np.abs(np.array(oc.resnorms) - np.array(o.resnorms)) / np.maximum(np.array(o.resnorms), 1e-300))
             if o2 is None or mv > o2_mv:
                 o2, o2_mv = oc, mv
-    tag = "seed %d: %s n=%d maxiter=%d tol=%.1e %s%s" % (seed, kind, n, maxiter, tol, sorted(kw), " " + ortho if ortho else "")
+    tag = "seed %d: %s n=%d maxiter=%d tol=%.1e %s%s%s" % (seed, kind, n, maxiter, tol, sorted(kw), " " + ortho if ortho else "",
+                                                     " M:" + form if "M" in kw else "")
     got, want = np.array(s.resnorms), np.array(o.resnorms)
     if len(o2.resnorms) == len(want):
         assert failed == bool(o.failed), (tag, failed, o.failed)
@@ -107,7 +120,7 @@ def one_solve(seed, max_n=150_000):
     return tag, len(got), float(dev), sens
 
 
-def one_solve_extra(seed, max_n=150_000):
+def one_solve_extra(seed, max_n=150_000, check=True):
     """Complex CG / MINRES / GMRES (with and without a Jacobi preconditioner) against oracle/krylov_ref_c.py and
     deflated GMRES with a random deflation space against oracle.krylov_ref.deflated_gmres."""
     import oracle.krylov_ref as ref
@@ -157,6 +170,8 @@ def one_solve_extra(seed, max_n=150_000):
                 s = {"zgmres": linsys.Gmres, "zminres": linsys.Minres, "zcg": linsys.Cg}[kind](ls, tol=tol, maxiter=maxiter)
         except utils.ConvergenceError as e:
             s = e.solver
+        if not check:
+            return "seed %d: %s n=%d" % (seed, kind, n), len(s.resnorms), 0.0, 0.0
         if kind == "dgmres":
             o = ref.deflated_gmres(A, b, U, tol=tol, maxiter=maxiter)
             o2 = ref.deflated_gmres(A, b * (1.0 + 1e-15 * pert), U, tol=tol, maxiter=maxiter)
