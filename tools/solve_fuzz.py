@@ -184,7 +184,11 @@ def one_solve_extra(seed, max_n=150_000, check=True):
     got = np.array(s.resnorms)
     if len(w2) != len(want):
         return tag, len(got), 0.0, 1.0        # the oracle's own iteration count moves under rounding
-    assert len(got) == len(want), (tag, len(got), len(want))
+    if len(got) != len(want):       # diagnostics: where do the two histories part?
+        m_ = min(len(got), len(want))
+        first = int(np.argmax(np.abs(got[:m_] - want[:m_]) > 1e-6 * want[:m_])) if m_ else 0
+        raise AssertionError((tag, len(got), len(want), "histories part at", first, got[max(0, first - 1): first + 3].tolist(),
+                              want[max(0, first - 1): first + 3].tolist()))
     big = want > 1e-13
     rel = np.abs(got[big] - want[big]) / want[big]
     sens = float(np.max(np.abs(w2[big] - want[big]) / want[big]))
