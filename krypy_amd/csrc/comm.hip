@@ -188,7 +188,9 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
     const int64_t ng = nrecv_prev + nrecv_next;
     if (ng > 0) {
         KH_HIP(hipMalloc(&A->ghost, sizeof(double) * width * ng));
-        KH_HIP(hipMemset(A->ghost, 0, sizeof(double) * width * ng));
+        // (on the context's stream: a memset on the null stream is not ordered with the non-blocking streams the
+        // halo exchange and kh_mat_set_ghost write this buffer on)
+        KH_HIP(hipMemsetAsync(A->ghost, 0, sizeof(double) * width * ng, ctx->stream));
     }
     if (A->kind == KH_MAT_ZCSR) return 0;       // (no banded copy / split launches for complex operators)
     return kh::dia_rebuild_for_halo(ctx, A);
