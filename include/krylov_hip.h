@@ -17,10 +17,12 @@
  *  - one HIP stream per context; a context is single-threaded by contract (like
  *    the reference).  Calls that return host scalars synchronise the stream
  *    before returning; all others are asynchronous on the context's stream.
- *  - all vectors are real fp64.  A kh_vec is a block of `ncols` column vectors of
+ *  - all storage is fp64.  A kh_vec is a block of `ncols` column vectors of
  *    length n, each column contiguous and 256-byte aligned (leading dimension
  *    rounded up to 32 doubles): the reference's (N, k) ndarrays, stored
- *    column-major so that basis vectors stream at full HBM width.
+ *    column-major so that basis vectors stream at full HBM width.  A COMPLEX
+ *    (c128) N-vector block is a kh_vec of length 2N (re, im interleaved) handed
+ *    to the kh_z* entry points, which take complex coefficients as (re, im) pairs.
  *  - reductions are deterministic: fixed grid, fixed-order tree, no float atomics.
  */
 #ifndef KRYLOV_HIP_H
@@ -223,8 +225,14 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
 /* One whole CG iteration (linsys.py:622-665) in one call, one host synchronisation:
  *   p = z + omega*p (skipped when `first`);  Ap = A p;  pAp = <p, Ap>;  alpha = rho / pAp (on the
  *   device);  yk += alpha p;  r -= alpha Ap;  z = Md r (z is r when Md == NULL);  rho_new = <r, z>
- * out[0] = <p, Ap>, out[1] = rho_new.  omega = rho/rho_prev and rho are the host's values (the host
+ * out[0] = <p, Ap>, out[1] = rho_new, out[2] = sanity word (KH_CG_* bits, 0 = fine): the step length is formed
+ * on the device, so a divisor that is not a positive finite number is reported with the scalars; with a step length
+ * that is not finite yk and r are left untouched.  omega = rho/rho_prev and rho are the host's values (the host
  * may have replaced rho by an explicit residual, linsys.py:667-669). */
+#define KH_CG_NONFINITE_PAP 1     /* <p, Ap> (or the divisor formed from it) is inf / nan */
+#define KH_CG_NONPOSITIVE_PAP 2   /* Re <p, Ap> <= 0: not a positive definite operator in this inner product */
+#define KH_CG_NONFINITE_RHO 4     /* <r, z> is inf / nan */
+#define KH_CG_NEGATIVE_RHO 8      /* <r, z> < 0: the preconditioner is not positive definite */
 int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol,
                kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first,
                double omega, double rho, double* out);
@@ -282,7 +290,8 @@ int kh_zminres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, cons
                       const double r2[2], const double y0[2], kh_vec YK, int64_t ycol);
 /* Complex kh_cg_step (krypy/linsys.py:622-665), one host synchronisation per iteration.  A complex; the vectors are
  * complex blocks (real kh_vec of length 2N); Md NULL or a REAL diagonal of length 2N (each Jacobi entry twice).
- * out[0] = d with step length alpha = rho / d = Re(rho / <p, Ap>), out[1] = <r, z>, out[2..3] = <p, Ap>. */
+ * out[0] = d with step length alpha = rho / d = Re(rho / <p, Ap>), out[1] = <r, z>, out[2..3] = <p, Ap>,
+ * out[4] = sanity word (KH_CG_* bits as for kh_cg_step). */
 int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
                 int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega, double rho,
                 double* out);

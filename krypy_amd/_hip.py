@@ -29,6 +29,10 @@ _D = ctypes.c_double
 _INT = ctypes.c_int
 
 
+# sanity word of the fused CG step (KH_CG_* of include/krylov_hip.h)
+CG_NONFINITE_PAP, CG_NONPOSITIVE_PAP, CG_NONFINITE_RHO, CG_NEGATIVE_RHO = 1, 2, 4, 8
+
+
 class BackendError(RuntimeError):
     """HIP / RCCL failure, or the device library is unavailable.
 
@@ -753,24 +757,25 @@ class Context(object):
 
 
     def cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
-        """One CG iteration in one call; returns ``(d, rho_new, <p, Ap>)`` where ``alpha = rho / d`` is the step
+        """One CG iteration in one call; returns ``(d, rho_new, <p, Ap>, flags)`` (``flags``: the ``KH_CG_*`` sanity
+        word of the header, 0 = fine) where ``alpha = rho / d`` is the step
         the device took: ``d = <p, Ap>`` for real data, ``rho / d = Re(rho / <p, Ap>)`` for complex data (then ``A``
         is a complex operator and ``Md`` a REAL diagonal of length 2N, every Jacobi entry twice)."""
         if _same_dtype("cg_step", Pd, AP, YK, R):
             if A.dtype != _C128 or (Md is not None and (Md.dtype != _F64 or Md.shape[0] != 2 * R.n)):
                 raise BackendError("cg_step on complex blocks: complex operator and real diagonal of length 2N needed")
-            out = numpy.empty(4, dtype=numpy.float64)
+            out = numpy.empty(5, dtype=numpy.float64)
             _check(self._lib, self._lib.kh_zcg_step(
                 self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle,
                 apcol, YK.handle, ycol, R.handle, rcol, Z.handle if Z is not None else None, zcol,
                 1 if first else 0, omega, rho, _dptr(out)), "kh_zcg_step")
-            return float(out[0]), float(out[1]), complex(out[2], out[3])
-        out = numpy.empty(2, dtype=numpy.float64)
+            return float(out[0]), float(out[1]), complex(out[2], out[3]), int(out[4])
+        out = numpy.empty(3, dtype=numpy.float64)
         _check(self._lib, self._lib.kh_cg_step(
             self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle,
             apcol, YK.handle, ycol, R.handle, rcol, Z.handle if Z is not None else None, zcol,
             1 if first else 0, omega, rho, _dptr(out)), "kh_cg_step")
-        return float(out[0]), float(out[1]), float(out[0])
+        return float(out[0]), float(out[1]), float(out[0]), int(out[2])
 
     def bench_kernel(self, which, V, W, reps):
         ms = _D(0.0)

@@ -393,7 +393,10 @@ __global__ __launch_bounds__(BS) void k_cg_update(int64_t n, double alpha,
     const int64_t stride = (int64_t)gridDim.x * BS;
     // kh_cg_step: `alpha` carries rho and the step length is rho / <p, Ap> with the inner product
     // still on the device (same IEEE division the host would do)
-    if (pap != nullptr) alpha = alpha / pap[0];
+    if (pap != nullptr) {
+        alpha = alpha / pap[0];
+        if (!(fabs(alpha) <= 1.79769313486231570e308)) alpha = 0.0;   // not finite: leave yk and r as they are, the caller's sanity word tells the host (kh_cg_step)
+    }
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) {
         yk[i] = yk[i] + alpha * p[i];

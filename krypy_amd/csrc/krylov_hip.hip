@@ -1904,6 +1904,18 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
     return fetch_scalars(ctx, tmp, 1, rho_new);
 }
 
+// sanity word of a fused CG step (KH_CG_* bits of the header): the step length never visits the host, so a divisor
+// that is not a positive finite number (an operator that is not positive definite - or a fault) is reported with
+// the scalars; k_cg_update leaves yk and r untouched when the step length is not finite
+static inline int cg_sanity(double d, double rho_new) {
+    int f = 0;
+    if (!std::isfinite(d)) f |= KH_CG_NONFINITE_PAP;
+    else if (!(d > 0.0)) f |= KH_CG_NONPOSITIVE_PAP;
+    if (!std::isfinite(rho_new)) f |= KH_CG_NONFINITE_RHO;
+    else if (rho_new < 0.0) f |= KH_CG_NEGATIVE_RHO;
+    return f;
+}
+
 int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
                int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega,
                double rho, double* out) {
@@ -1945,7 +1957,9 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp + 1, 0);
     KH_HIP(hipGetLastError());
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
-    return fetch_scalars(ctx, tmp, 2, out);
+    KH_TRY(fetch_scalars(ctx, tmp, 2, out));
+    out[2] = (double)cg_sanity(out[0], out[1]);
+    return 0;
 }
 
 int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH,

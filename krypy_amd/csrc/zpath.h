@@ -846,7 +846,9 @@ int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp + 1, 0);
     KH_HIP(hipGetLastError());
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
-    return fetch_scalars(ctx, tmp, 4, out);
+    KH_TRY(fetch_scalars(ctx, tmp, 4, out));
+    out[4] = (double)(cg_sanity(out[0], out[1]) | ((std::isfinite(out[2]) && std::isfinite(out[3])) ? 0 : KH_CG_NONFINITE_PAP));
+    return 0;
 }
 
 // complex projector: W, V complex blocks (real kh_vec of length 2N), T = R^{-1} Q^H and WRH = WR^H as d x d

@@ -9,6 +9,8 @@ Givens rotations and the small triangular solves stay on the host like in the re
 
 Reference lines are cited as ``linsys.py:<line>`` (= ``/root/reference/krypy/linsys.py``).
 """
+import collections
+import os
 import warnings
 
 import numpy
@@ -461,8 +463,14 @@ class Cg(_KrylovSolver):
 
         # whole iteration in one device call (one host synchronisation) when the operator is a plain
         # device matrix as well: direction update, A p, <p, Ap>, the fused update, <r, z>
+        # (KRYPY_AMD_CG_STEP=0: the step-by-step path - operator, inner product and updates as separate calls, the
+        # step length formed on the host - for diagnosis)
         Amat = self.MlAMr._device_matrix(ctx, bdt) if fused else None
-        one_call = Amat is not None and hasattr(ctx, "cg_step")
+        one_call = (Amat is not None and hasattr(ctx, "cg_step")
+                    and os.environ.get("KRYPY_AMD_CG_STEP", "1") != "0")
+        # the last steps' scalars (k, rho, d, <p, Ap>, rho_new, sanity word): what a ConvergenceError's solver
+        # carries for diagnosis when the fused step is in use (the step length never visits the host there)
+        self.cg_trace = trace = collections.deque(maxlen=16)
 
         while self.resnorms[-1] > self.tol and self.iter < self.maxiter:
             k = self.iter
@@ -470,11 +478,20 @@ class Cg(_KrylovSolver):
                 # p = MMlrk + rhos[-1]/rhos[-2] * p   (linsys.py:627)
                 omega = rhos[-1] / rhos[-2]
             if one_call:
-                den, rho_new, pAp = ctx.cg_step(
+                den, rho_new, pAp, flags = ctx.cg_step(
                     Amat, None if M_id else Md, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
                     self._Mlrk.block, self._Mlrk.col, None if M_id else self._MMlrk.block,
                     0 if M_id else self._MMlrk.col, k == 0, float(omega) if k > 0 else 0.0,
                     float(rhos[-1]))
+                trace.append((k, float(rhos[-1]), den, pAp, rho_new, flags))
+                if flags & (_hip.CG_NONFINITE_PAP | _hip.CG_NONFINITE_RHO) and numpy.isfinite(rhos[-1]):
+                    # finite data in, inf / nan out: nothing to iterate on (yk and r were left as they were)
+                    self.xk = self._get_xk(yk)
+                    raise _hip.BackendError(
+                        "Cg: the fused step %d returned non-finite scalars (flags %d); last steps "
+                        "(k, rho, d, <p,Ap>, rho_new, flags): %s" % (k, flags, list(trace)))
+                # (a divisor <= 0 - an operator that is not positive definite - is recorded in the trace only: the
+                # reference iterates on, linsys.py:640-648)
             else:
                 if k > 0:
                     ctx.waxpby(p.block, p.col, 1.0, self._MMlrk.block, self._MMlrk.col, float(omega),

@@ -393,7 +393,10 @@ def _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first
         pap = complex(pap)
     else:
         den = pap = float(pap)
-    alpha = rho / den
+    with np.errstate(all="ignore"):
+        alpha = np.float64(rho) / np.float64(den)
+    if not np.isfinite(alpha):        # (the device leaves yk and r untouched and reports it in the sanity word)
+        alpha = 0.0
     YK.a[:, ycol] = YK.a[:, ycol] + alpha * p
     r = R.a[:, rcol] - alpha * ap
     R.a[:, rcol] = r
@@ -401,7 +404,17 @@ def _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first
     if Md is not None:
         zz = _jacobi(Md, r, cplx, "cg_step") * r
         Z.a[:, zcol] = zz
-    return den, float(self._allreduce(np.array([np.vdot(r, zz).real]))[0]), pap
+    rho_new = float(self._allreduce(np.array([np.vdot(r, zz).real]))[0])
+    flags = 0                     # KH_CG_* of include/krylov_hip.h
+    if not (np.isfinite(den) and np.isfinite(complex(pap).real) and np.isfinite(complex(pap).imag)):
+        flags |= 1
+    elif not den > 0.0:
+        flags |= 2
+    if not np.isfinite(rho_new):
+        flags |= 4
+    elif rho_new < 0.0:
+        flags |= 8
+    return den, rho_new, pap, flags
 
 
 NumpyContext.cg_step = _cg_step

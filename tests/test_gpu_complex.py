@@ -259,12 +259,13 @@ def test_complex_minres_update_and_cg_step_kernels(hip, n):
             p, r, zv, y = _crand(rng, n, 1), _crand(rng, n, 1), _crand(rng, n, 1), _crand(rng, n, 1)
             pd_, rd, zd, yd, apd = hip.upload(p), hip.upload(r), hip.upload(zv), hip.upload(y), hip.alloc(n, 1, dtype=complex)
             omega, rho = 0.37, 1.9
-            den, rho_new, pap = hip.cg_step(Ad, Dd if jac else None, pd_, 0, apd, 0, yd, 0, rd, 0, zd if jac else None, 0,
+            den, rho_new, pap, flags = hip.cg_step(Ad, Dd if jac else None, pd_, 0, apd, 0, yd, 0, rd, 0, zd if jac else None, 0,
                                             first, omega, rho)
             pp = p[:, 0] if first else (zv[:, 0] if jac else r[:, 0]) + omega * p[:, 0]
             ap = A.dot(pp)
             want = np.vdot(pp, ap)
             assert abs(pap - want) <= 1e-13 * abs(want) * max(1.0, np.sqrt(n) / 30)
+            assert flags == (0 if den > 0 else 2), flags        # (random p: <p, Ap> > 0 for this positive definite A)
             alpha = (rho / pap).real
             assert abs(rho / den - alpha) <= 4e-16 * abs(alpha)
             alpha = rho / den

@@ -78,6 +78,55 @@ def test_complex_deflated_gmres_projects_inside_the_step(cpu_double):
     assert np.linalg.norm(r) <= 1.01e-9 * np.linalg.norm(c["b"])
 
 
+def test_fused_cg_step_is_fenced(cpu_double, monkeypatch):
+    """The fused CG step forms its step length on the device, so the host never sees a garbage ``<p, Ap>`` unless the
+    library reports it: every step's scalars and sanity word land in ``solver.cg_trace``; finite data in and
+    non-finite scalars out raise a ``BackendError`` that carries the trace (the iterate is left as it was) instead of
+    iterating on; a divisor <= 0 (indefinite operator) is recorded only - the reference iterates on;
+    ``KRYPY_AMD_CG_STEP=0`` sends CG to the step-by-step path with the same iterates."""
+    import numpy as np
+    import pytest
+    import scipy.sparse as sp
+    from krypy_amd import _hip, linsys, utils
+    from oracle.inputs import complex_systems
+
+    c = complex_systems(16)
+    hpd = dict(self_adjoint=True, positive_definite=True)
+    for A, b in ((c["hpd"], c["b"]), (sp.csr_matrix(c["hpd"].real + sp.identity(256) * 0.0), c["b"].real)):
+        s = linsys.Cg(linsys.LinearSystem(A, b, **hpd), tol=1e-10, maxiter=300)
+        assert len(s.cg_trace) == min(16, len(s.resnorms) - 1)
+        assert all(t[5] == 0 and t[2] > 0 for t in s.cg_trace), list(s.cg_trace)
+        monkeypatch.setenv("KRYPY_AMD_CG_STEP", "0")
+        cpu_double.calls.clear()
+        s0 = linsys.Cg(linsys.LinearSystem(A, b, **hpd), tol=1e-10, maxiter=300)
+        monkeypatch.delenv("KRYPY_AMD_CG_STEP")
+        assert "cg_step" not in cpu_double.calls and len(s0.cg_trace) == 0
+        assert len(s0.resnorms) == len(s.resnorms) and np.allclose(s0.resnorms, s.resnorms, rtol=1e-9)
+    # an indefinite operator: the divisor goes negative somewhere, recorded, not raised (linsys.py:640-648)
+    Aind = sp.diags(np.r_[np.linspace(1, 2, 50), -np.linspace(1, 2, 50)]).tocsr()
+    with pytest.warns(UserWarning):
+        try:
+            s = linsys.Cg(linsys.LinearSystem(Aind, np.ones(100), self_adjoint=True), tol=1e-12, maxiter=8)
+        except utils.ConvergenceError as e:
+            s = e.solver
+    assert any(t[5] & _hip.CG_NONPOSITIVE_PAP for t in s.cg_trace), list(s.cg_trace)
+    # a fault: the step hands back nan for finite input
+    real_step = type(cpu_double).cg_step
+    calls = []
+
+    def faulty(self, *a):
+        den, rho_new, pap, flags = real_step(self, *a)
+        calls.append(1)
+        if len(calls) == 3:
+            return float("nan"), rho_new, pap, _hip.CG_NONFINITE_PAP
+        return den, rho_new, pap, flags
+
+    monkeypatch.setattr(type(cpu_double), "cg_step", faulty)
+    with pytest.raises(_hip.BackendError) as ei:
+        linsys.Cg(linsys.LinearSystem(c["hpd"], c["b"], **hpd), tol=1e-10, maxiter=300)
+    assert "non-finite" in str(ei.value) and "flags 1" in str(ei.value)
+
+
 def test_complex_cg_minres_gmres_with_jacobi_stay_on_the_fused_entries(cpu_double):
     """Complex CG runs one ``kh_zcg_step`` per iteration (real recurrences on the real views, the Jacobi scaling as a
     real diagonal of length 2N); complex MINRES / GMRES with a Jacobi preconditioner run the complex step with its

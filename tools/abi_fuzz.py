@@ -217,6 +217,7 @@ def step_round(ctx, dbl, seed, max_n):
              "cg_step yk", "cg_step Ap", "cg_step z", "cg_update rho", "cg_update r", "cg_update yk")
     for nm, g_, w_ in zip(names, res[0], res[1]):
         if nm == "cg_step scalars":
+            assert g_[3] == w_[3], ("cg_step sanity word", g_[3], w_[3])
             g_ = [g_[0], g_[1], complex(g_[2]).real, complex(g_[2]).imag / max(1.0, abs(complex(g_[2]).real))]
             w_ = [w_[0], w_[1], complex(w_[2]).real, complex(w_[2]).imag / max(1.0, abs(complex(w_[2]).real))]
         expect(nm, g_, w_)
