@@ -314,8 +314,10 @@ def _run():
     orth = {}
     try:
         orth[ortho] = basis_orthogonality(ortho)
-        if ortho != "mgs" and not sharded:
-            orth["mgs"] = basis_orthogonality("mgs")
+        if not sharded:          # one GPU: both the reference order and the panel form the N > 1 runs default to
+            for mode in ("mgs", "cgs"):
+                if mode not in orth:
+                    orth[mode] = basis_orthogonality(mode)
     except Exception as exc:
         orth["error"] = repr(exc)
 

@@ -75,11 +75,15 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
 /* named switches of a context (1 = on, the default; the environment variables of INTEGRATION.md set the
  * initial values): "spmv_dia" banded SpMV for stencil CSR operators, "chain" register-resident MGS chain,
  * "chain_lds" column head parked in LDS, "chain_spmv" operator fused into the chain prologue.  bench.py
- * uses it to time the CSR-stream and the banded SpMV kernel on the same operator. */
+ * uses it to time the CSR-stream and the banded SpMV kernel on the same operator.  Test-only switches (0 by
+ * default): "chain_fault" the next chain launch fakes a timeout, "halo_loopback" a 1-rank communicator exchanges
+ * the halo of a sharded operator with ITSELF (grouped ncclSend / ncclRecv to its own rank: the slab of an operator
+ * that is periodic across the slab boundary) - the real exchange on one GPU. */
 int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value);
 /* read a switch back, or a counter: "n_spmm" panel applications of a CSR operator that streamed the matrix
  * once (k_spmm_stream / k_spmm_dia), "n_chain_recovered" Arnoldi steps re-run on the per-column kernels after
- * a timeout of the chain kernel's grid-wide reduction */
+ * a timeout of the chain kernel's grid-wide reduction, "n_spmv_split" sharded SpMVs run as interior / boundary
+ * launches around the halo exchange, "n_halo_exchange" grouped ncclSend / ncclRecv exchanges issued */
 int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value);
 /* event timing on the context's stream (for bench.py's per-kernel roofline numbers) */
 int kh_timer_start(kh_ctx ctx);
@@ -101,6 +105,8 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
 /* diagnostic: write the nrecv_prev + nrecv_next ghost entries directly (what the halo exchange would
  * deliver); lets a single process check a shard's SpMV against the global operator */
 int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count);
+/* diagnostic: read the ghost entries back (what the last halo exchange delivered) */
+int kh_mat_get_ghost(kh_mat A, double* values, int64_t count);
 
 /* ---- vectors ---------------------------------------------------------------------- */
 int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out);   /* zero-filled */
@@ -213,6 +219,14 @@ int kh_residual(kh_ctx ctx, kh_mat A, kh_vec B, int64_t bcol, kh_vec X, int64_t 
  * receives z): no copies. */
 int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
                      double r2, double y0, kh_vec YK, int64_t ycol);
+/* The same update, DEFERRED: it is carried by the next Lanczos step launch (kh_arnoldi_step_begin with a banded
+ * operator: krypy_amd/csrc/lanczos.h - six independent streams in the shadow of that launch's last pass) or, failing
+ * that, run by kh_minres_flush / the next kh_minres_update[_deferred] call.  Updates take effect in the order given.
+ * Nothing but these entries reads W or yk in between: call kh_minres_flush before yk is used (krypy/linsys.py:844-847:
+ * yk is needed only when an iterate is formed). */
+int kh_minres_update_deferred(kh_ctx ctx, kh_vec V, int64_t k, kh_vec W, int slot, double r0, double r1, double r2,
+                              double y0, kh_vec YK, int64_t ycol);
+int kh_minres_flush(kh_ctx ctx);
 
 /* One CG step after Ap is known (linsys.py:655-665), fused:
  *   yk += alpha*p;  r -= alpha*Ap;  z = Md r (or r);  *rho_new = <r, z>

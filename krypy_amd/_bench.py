@@ -27,7 +27,7 @@ K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN, K_CG
 K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
-_SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h")
+_SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h")
 
 
 def source_stamp():
@@ -37,6 +37,11 @@ def source_stamp():
     for fn in _SOURCES:
         with open(os.path.join(base, fn), "rb") as f:
             h.update(f.read())
+    # the compiler flags too (-ffp-contract, -O: a flag change is a different kernel)
+    with open(os.path.join(base, "Makefile"), "r") as f:
+        for line in f:
+            if line.startswith("FLAGS") or line.startswith("  ") and "-I" in line:
+                h.update(line.encode())
     return h.hexdigest()[:16]
 
 

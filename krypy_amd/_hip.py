@@ -60,6 +60,7 @@ _SIGNATURES = {
     "kh_comm_allreduce_host": [_H, _c_double_p, _I64],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
     "kh_mat_set_ghost": [_H, _c_double_p, _I64],
+    "kh_mat_get_ghost": [_H, _c_double_p, _I64],
     "kh_vec_alloc": [_H, _I64, _I64, ctypes.POINTER(_H)],
     "kh_vec_free": [_H],
     "kh_vec_shape": [_H, _c_int64_p, _c_int64_p, _c_int64_p],
@@ -92,6 +93,8 @@ _SIGNATURES = {
     "kh_arnoldi_step_end": [_H, _INT, _I64, _c_double_p],
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
+    "kh_minres_update_deferred": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
+    "kh_minres_flush": [_H],
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
     "kh_cg_step": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _INT, _D, _D,
                    _c_double_p],
@@ -496,6 +499,13 @@ class Context(object):
             count = v.size
         _check(self._lib, self._lib.kh_mat_set_ghost(A.handle, _dptr(v), count), "kh_mat_set_ghost")
 
+    def get_ghost(self, A, count):
+        """Diagnostic: the ``count`` ghost entries the last halo exchange delivered (``kh_mat_get_ghost``)."""
+        cplx = A.dtype == _C128
+        out = numpy.empty(2 * count if cplx else count, dtype=numpy.float64)
+        _check(self._lib, self._lib.kh_mat_get_ghost(A.handle, _dptr(out), out.size), "kh_mat_get_ghost")
+        return out.view(numpy.complex128) if cplx else out
+
     def set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
         _check(self._lib, self._lib.kh_mat_set_halo(self._h, A.handle, nsend_prev, nsend_next,
                                                     nrecv_prev, nrecv_next), "kh_mat_set_halo")
@@ -732,7 +742,14 @@ class Context(object):
                                                 R.handle, rcol, ctypes.byref(out)), "kh_residual")
         return out.value
 
-    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
+    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol, defer=False):
+        """``defer``: the (real) update may wait for the next Lanczos launch to carry it
+        (``kh_minres_update_deferred``); :meth:`minres_flush` before ``yk`` is read."""
+        if defer and V.dtype == _F64:
+            _same_dtype("minres_update", V, Wk, YK)
+            _check(self._lib, self._lib.kh_minres_update_deferred(self._h, V.handle, k, Wk.handle, slot, r0, r1,
+                                                                  r2, y0, YK.handle, ycol), "kh_minres_update_deferred")
+            return
         if _same_dtype("minres_update", V, Wk, YK):
             # z = (V_k - r0 W0 - r1 W1)/r2 written over W0 (= column `slot`);  yk += y0 z: one pass, complex scalars
             c = [_zarr([x]) for x in (r0, r1, r2, y0)]
@@ -741,6 +758,10 @@ class Context(object):
             return
         _check(self._lib, self._lib.kh_minres_update(self._h, V.handle, k, Wk.handle, slot, r0, r1,
                                                      r2, y0, YK.handle, ycol), "kh_minres_update")
+
+    def minres_flush(self):
+        """Run a deferred MINRES update now (``kh_minres_flush``)."""
+        _check(self._lib, self._lib.kh_minres_flush(self._h), "kh_minres_flush")
 
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
         """``yk += alpha p; r -= alpha Ap; z = Md r; return <r, z>`` in one pass.  The recurrences have real

@@ -75,6 +75,18 @@ struct kh_ctx_s {
     int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
     int chain_pf = 1;       // ... and keep HBM busy through the update phase (k_mgs_chain_pf; KRYPY_AMD_CHAIN_PF)
     int64_t n_chain_pf = 0;
+    int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)
+    int64_t n_lanczos_fused = 0;
+    int mr_taken = 0;       // the last chain launch carried a MINRES recurrence job (lanczos.h)
+    // a MINRES recurrence update waiting for the next Lanczos launch to carry it (kh_minres_update_deferred)
+    struct {
+        int on = 0;
+        kh_vec V = nullptr, W = nullptr, YK = nullptr;
+        int64_t vcol = 0, ycol = 0;
+        int slot = 0;
+        double r0 = 0, r1 = 0, r2 = 0, y0 = 0;
+    } mr_pending;
+    int64_t n_minres_rides = 0;   // deferred MINRES updates that went along with a Lanczos launch
     int chain_lds = 1;      // park the head of every column in LDS (k_mgs_chain_lds; KRYPY_AMD_CHAIN_LDS)
     int spmv_dia = 1;       // use the banded copy of a CSR operator when it has one (kh_ctx_set "spmv_dia")
     unsigned long long* chain_gran = nullptr;
@@ -99,6 +111,8 @@ struct kh_ctx_s {
     hipEvent_t ev_x = nullptr, ev_halo = nullptr;
     int spmv_split = 1;
     int64_t n_spmv_split = 0;
+    int halo_loopback = 0;          // tests: a 1-rank communicator exchanges its halo with itself (periodic slab)
+    int64_t n_halo_exchange = 0;    // grouped ncclSend / ncclRecv exchanges issued
     double* commbuf = nullptr;  // device staging for host all-reduces
 };
 

@@ -10,6 +10,7 @@
 
 #include "kernels.h"
 #include "chain.h"
+#include "lanczos.h"
 #include <stdlib.h>
 
 namespace kh {
@@ -94,7 +95,12 @@ static int ensure_hcap(kh_ctx ctx, int64_t need) {
                         hipGetErrorString(e));
         }
         if (ctx->hslot_dev[s]) {
-            KH_HIP(hipMemcpy(dev, ctx->hslot_dev[s], sizeof(double) * ctx->hcap, hipMemcpyDeviceToDevice));
+            e = hipMemcpy(dev, ctx->hslot_dev[s], sizeof(double) * ctx->hcap, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {       // (the old buffers stay in place: slots already moved are simply larger)
+                (void)hipFree(dev);
+                (void)hipHostFree(pin);
+                return fail(KH_ERR_HIP, "ensure_hcap: hipMemcpy: %s", hipGetErrorString(e));
+            }
             (void)hipFree(ctx->hslot_dev[s]);
         }
         if (ctx->hslot_pin[s]) {
@@ -318,10 +324,13 @@ static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, 
     } while (0)
         if (split) {
             KH_HIP(hipEventRecord(ctx->ev_x, ctx->stream));                   // x is complete
+            // the interior launch is ENQUEUED first: issuing the grouped send / recv costs the host ~10 us, and in the
+            // other order the interior rows start that much later (profiles/r03_halo_overlap.md: the RCCL kernel was
+            // over 3 us after the interior launch began - nothing overlapped)
+            KH_SPMV(SpmvRange::interior(lo, hi));
             KH_HIP(hipStreamWaitEvent(ctx->comm_stream, ctx->ev_x, 0));
             if (halo) KH_TRY(comm_halo_exchange(ctx, A, x, ctx->comm_stream));
             KH_HIP(hipEventRecord(ctx->ev_halo, ctx->comm_stream));
-            KH_SPMV(SpmvRange::interior(lo, hi));
             KH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_halo, 0));
             KH_SPMV(SpmvRange::boundary(lo, hi, nblk));
             ctx->n_spmv_split += 1;
@@ -417,6 +426,27 @@ static hipError_t launch_chain_pf(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// one Lanczos step in three passes (lanczos.h)
+template <int R2, int FND, bool JAC>
+static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJob& mr) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = (size_t)(LanczosShape<R2>::WL + (JAC ? LanczosShape<R2>::DL : 0)) * CH_BS * sizeof(double2);
+    if (blocks_per_cu < 0) {
+        if (lds > 0) {
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0 != hipSuccess) return e0;
+        }
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC>, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
+    return hipGetLastError();
+}
+
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
 static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
     if (n < 2) return false;
@@ -448,7 +478,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
                      const double* h_km1_dev, double* hdev, int slot, bool cplx = false, double* hpin = nullptr,
-                     int hcount = 0, kh_mat Afuse = nullptr, const double* xk = nullptr) {
+                     int hcount = 0, kh_mat Afuse = nullptr, const double* xk = nullptr, const MinresJob* mr = nullptr) {
     // Afuse: compute w = Afuse * xk in the kernel's prologue instead of reading w (banded operators;
     // returns 0 without launching anything when that variant does not apply - the caller then runs the
     // SpMV and calls again without Afuse)
@@ -549,6 +579,37 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // and cost what they save (17.4 vs 16.3 us per link at N = 10^7)
     const bool use_pf = use_lds && ctx->chain_pf && (r2 <= 24 || (ctx->chain_pf == 2 && r2 <= 40));   // (2: measurement)
 #define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
+    // a step with ONE Gram-Schmidt link (Lanczos / MINRES, the first Arnoldi step): three passes instead of six
+    if (fused && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
+        if (!presub) {                 // no previous column: subtract 0 * (some valid column)
+            a.bprev = B->col(k);
+            a.h_km1 = 0.0;
+            a.h_km1_dev = nullptr;
+        }
+        MinresJob job;
+        if (mr != nullptr) job = *mr;
+        else job.on = 0;
+#define KH_LZ(R, D) (dg != nullptr ? launch_lanczos<R, D, true>(ctx, G, a, job) : launch_lanczos<R, D, false>(ctx, G, a, job))
+        if (r2 == 40) e = (a.offs.nd == 5) ? KH_LZ(40, 5) : KH_LZ(40, 7);
+        else if (r2 == 32) e = (a.offs.nd == 5) ? KH_LZ(32, 5) : KH_LZ(32, 7);
+        else if (r2 == 24) e = (a.offs.nd == 5) ? KH_LZ(24, 5) : KH_LZ(24, 7);
+        else e = (a.offs.nd == 5) ? KH_LZ(16, 5) : KH_LZ(16, 7);
+#undef KH_LZ
+        if (e == hipSuccess) {
+            if (a.debug == 4) ctx->chain_fault = 0;
+            ctx->n_chain += 1;
+            ctx->n_chain_fused += 1;
+            ctx->n_lanczos_fused += 1;
+            ctx->chain_epoch += 2u;          // the coefficient's and the norm's grid-wide sums
+            if (hpin == nullptr)
+                KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+            ctx->mr_taken = (mr != nullptr && mr->on) ? 1 : 0;     // (the MINRES job - if any - went along)
+            return 1;
+        }
+        (void)hipGetLastError();             // e.g. the dynamic LDS was refused: the general chain kernel below
+        if (!presub) a.bprev = nullptr;
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fused) {
 #define KH_FUSED(R, D)                                                                                   \
@@ -786,6 +847,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_PF");
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_LANCZOS_FUSED");
+        ctx->lanczos_fused = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_ROCTX");
         ctx->roctx = (e == nullptr) ? 0 : atoi(e);
     }
@@ -869,6 +932,8 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
     else if (!strcmp(key, "chain_fault")) ctx->chain_fault = value != 0;
     else if (!strcmp(key, "spmv_split")) ctx->spmv_split = value != 0;
+    else if (!strcmp(key, "halo_loopback")) ctx->halo_loopback = value != 0;
+    else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
 }
@@ -884,6 +949,11 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_spmm")) *value = ctx->n_spmm;
     else if (!strcmp(key, "spmv_split")) *value = ctx->spmv_split;
     else if (!strcmp(key, "n_spmv_split")) *value = ctx->n_spmv_split;
+    else if (!strcmp(key, "halo_loopback")) *value = ctx->halo_loopback;
+    else if (!strcmp(key, "lanczos_fused")) *value = ctx->lanczos_fused;
+    else if (!strcmp(key, "n_lanczos_fused")) *value = ctx->n_lanczos_fused;
+    else if (!strcmp(key, "n_minres_rides")) *value = ctx->n_minres_rides;
+    else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
     return 0;
@@ -929,9 +999,23 @@ int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out) {
     return 0;
 }
 
+// a freed handle must not be dereferenced by the recovery of a chain timeout (kh_arnoldi_step_end re-runs the step
+// from the slot's record): forget every record that names it
+static void forget_steps(kh_ctx ctx, const void* handle) {
+    if (ctx->mr_pending.on && (ctx->mr_pending.V == handle || ctx->mr_pending.W == handle || ctx->mr_pending.YK == handle))
+        ctx->mr_pending.on = 0;          // (a deferred MINRES update whose owner went away: nobody will read its result)
+    for (int s = 0; s < KH_NSLOT; ++s) {
+        kh_step_s& st = ctx->step[s];
+        if (st.kind != 0 && (st.A == handle || st.Md == handle || st.proj == handle || st.V == handle ||
+                             st.P == handle || st.W == handle))
+            st = kh_step_s();
+    }
+}
+
 int kh_vec_free(kh_vec v) {
     if (!v) return 0;
     (void)hipStreamSynchronize(v->ctx->stream);
+    forget_steps(v->ctx, v);
     (void)hipFree(v->d);
     delete v;
     return 0;
@@ -1205,6 +1289,20 @@ int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count) {
     return 0;
 }
 
+int kh_mat_get_ghost(kh_mat A, double* values, int64_t count) {
+    KH_ARG(A && (values || count == 0), "kh_mat_get_ghost: NULL");
+    KH_ARG((A->kind == KH_MAT_CSR && count == A->nrecv_prev + A->nrecv_next) ||
+               (A->kind == KH_MAT_ZCSR && count == 2 * (A->nrecv_prev + A->nrecv_next)),
+           "kh_mat_get_ghost: %lld doubles for %lld ghost columns", (long long)count,
+           (long long)(A->nrecv_prev + A->nrecv_next));
+    if (count == 0) return 0;
+    // (the exchange may have run on the communication stream: the compute stream waited for it before the boundary
+    // rows were multiplied, so the compute stream is the one to wait for)
+    KH_HIP(hipStreamSynchronize(A->ctx->stream));
+    KH_HIP(hipMemcpy(values, A->ghost, sizeof(double) * count, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
                   const int32_t* indices, const double* data, kh_mat* out) {
     KH_ARG(ctx && out && indptr, "kh_csr_upload: NULL argument");
@@ -1307,6 +1405,7 @@ int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
 int kh_mat_free(kh_mat A) {
     if (!A) return 0;
     (void)hipStreamSynchronize(A->ctx->stream);
+    forget_steps(A->ctx, A);
     (void)hipFree(A->indptr);
     (void)hipFree(A->indices);
     (void)hipFree(A->data);
@@ -1635,10 +1734,33 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         if (want_chain && proj == nullptr && A->kind == KH_MAT_CSR && A->dia != nullptr) {
             // banded operator: the chain kernel computes w = A v_k in its prologue (no SpMV launch, w
             // never touches HBM); returns 0 when that instantiation does not apply
+            // a deferred MINRES update of an earlier iteration rides along when the step runs as the three-pass
+            // Lanczos kernel and the update's blocks have the same padded geometry (lanczos.h)
+            MinresJob job;
+            job.on = 0;
+            {
+                const auto& j = ctx->mr_pending;
+                if (j.on && j.V->n == n && j.V->ld == V->ld && j.W->ld == V->ld && j.YK->ld == V->ld &&
+                    !(j.V == V && j.vcol == k + 1)) {
+                    job.on = 1;
+                    job.v = j.V->col(j.vcol);
+                    job.w0 = j.W->col(j.slot);
+                    job.w1 = j.W->col(1 - j.slot);
+                    job.yk = j.YK->col(j.ycol);
+                    job.r0 = j.r0; job.r1 = j.r1; job.r2 = j.r2; job.y0 = j.y0;
+                }
+            }
+            ctx->mr_taken = 0;
             const int rc = try_chain(ctx, V, B, w, W->ld, dg, P, k, start, sweeps, presub, h_km1, hk_dev, hdev,
-                                     slot, false, ctx->hslot_pin[slot], (int)(k + 2 + pd), A, V->col(k));
+                                     slot, false, ctx->hslot_pin[slot], (int)(k + 2 + pd), A, V->col(k),
+                                     job.on ? &job : nullptr);
             if (rc < 0) return rc;
             fused_chain = (rc == 1);
+            if (ctx->mr_taken) {
+                ctx->mr_pending.on = 0;
+                ctx->n_minres_rides += 1;
+                ctx->mr_taken = 0;
+            }
         }
         if (fused_chain) {
         } else if (fuse_dot0)
@@ -1858,6 +1980,39 @@ int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t
     return kh_nrm2(ctx, R, rcol, nrm);
 }
 
+// run a deferred MINRES recurrence update now, as a launch of its own
+static int minres_flush(kh_ctx ctx) {
+    if (!ctx->mr_pending.on) return 0;
+    auto& j = ctx->mr_pending;
+    j.on = 0;
+    const int64_t n = j.V->n;
+    hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, j.V->col(j.vcol),
+                       j.W->col(j.slot), j.W->col(1 - j.slot), j.r0, j.r1, j.r2, j.y0, j.YK->col(j.ycol));
+    KH_HIP(hipGetLastError());
+    return 0;
+}
+
+int kh_minres_flush(kh_ctx ctx) {
+    KH_ARG(ctx, "kh_minres_flush: NULL ctx");
+    return minres_flush(ctx);
+}
+
+int kh_minres_update_deferred(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
+                              double r2, double y0, kh_vec YK, int64_t ycol) {
+    KH_ARG(ctx, "kh_minres_update_deferred: NULL ctx");
+    KH_TRY(check_vec(V, k, 1, "kh_minres_update_deferred(V)"));
+    KH_TRY(check_vec(Wk, 0, 2, "kh_minres_update_deferred(W)"));
+    KH_TRY(check_vec(YK, ycol, 1, "kh_minres_update_deferred(yk)"));
+    KH_ARG(slot == 0 || slot == 1, "kh_minres_update_deferred: slot");
+    KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_minres_update_deferred: length mismatch");
+    KH_TRY(minres_flush(ctx));          // updates run in the order they were given
+    auto& j = ctx->mr_pending;
+    j.V = V; j.vcol = k; j.W = Wk; j.slot = slot; j.YK = YK; j.ycol = ycol;
+    j.r0 = r0; j.r1 = r1; j.r2 = r2; j.y0 = y0;
+    j.on = 1;
+    return 0;
+}
+
 int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
                      double r2, double y0, kh_vec YK, int64_t ycol) {
     KH_ARG(ctx, "kh_minres_update: NULL ctx");
@@ -1866,6 +2021,7 @@ int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, doubl
     KH_TRY(check_vec(YK, ycol, 1, "kh_minres_update(yk)"));
     KH_ARG(slot == 0 || slot == 1, "kh_minres_update: slot");
     KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_minres_update: length mismatch");
+    KH_TRY(minres_flush(ctx));
     const int64_t n = V->n;
     hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, V->col(k),
                        Wk->col(slot), Wk->col(1 - slot), r0, r1, r2, y0, YK->col(ycol));
@@ -1973,16 +2129,24 @@ int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, c
     p->V = V;
     p->d = d;
     p->iterations = iterations;
-    KH_HIP(hipMalloc(&p->c0, sizeof(double) * 3 * d));
-    p->c1 = p->c0 + d;
-    p->ya = p->c0 + 2 * d;
-    if (T) {
-        KH_HIP(hipMalloc(&p->T, sizeof(double) * d * d));
-        KH_HIP(hipMemcpy(p->T, T, sizeof(double) * d * d, hipMemcpyHostToDevice));
-    }
-    if (WRH) {
-        KH_HIP(hipMalloc(&p->WRH, sizeof(double) * d * d));
-        KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * d * d, hipMemcpyHostToDevice));
+    auto body = [&]() -> int {
+        KH_HIP(hipMalloc(&p->c0, sizeof(double) * 3 * d));
+        p->c1 = p->c0 + d;
+        p->ya = p->c0 + 2 * d;
+        if (T) {
+            KH_HIP(hipMalloc(&p->T, sizeof(double) * d * d));
+            KH_HIP(hipMemcpy(p->T, T, sizeof(double) * d * d, hipMemcpyHostToDevice));
+        }
+        if (WRH) {
+            KH_HIP(hipMalloc(&p->WRH, sizeof(double) * d * d));
+            KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * d * d, hipMemcpyHostToDevice));
+        }
+        return 0;
+    };
+    const int rc = body();
+    if (rc != 0) {          // nothing half-built stays behind
+        kh_proj_free(p);
+        return rc;
     }
     *out = p;
     return 0;
@@ -1991,6 +2155,7 @@ int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, c
 int kh_proj_free(kh_proj p) {
     if (!p) return 0;
     (void)hipStreamSynchronize(p->ctx->stream);
+    forget_steps(p->ctx, p);
     (void)hipFree(p->c0);
     (void)hipFree(p->T);
     (void)hipFree(p->WRH);

@@ -1,0 +1,243 @@
+// One Lanczos step (MINRES, utils.py:1008-1045 with ortho='lanczos') in one launch with THREE passes over the vector
+// instead of six.
+//
+// The general chain kernel (chain.h) runs a Lanczos step as  w = A v_k | w -= h p_{k-1} | <v_k, w> | sum |
+// w -= alpha p_k | <w, D w> | sum | store : six streaming phases, each with its own latency ramp, and v_k, the
+// Jacobi diagonal and w's own bytes pass by more often than needed (1.04 GB at N = 10^7, 4.9 TB/s: the launch is
+// bound by its phase boundaries, not by HBM).  A step has ONE Gram-Schmidt link, so nothing forces that split:
+//
+//   pass 1   row by row: (A v_k)_r from the diagonal-major copy (as k_spmv_dia / chain_apply_banded compute it),
+//            minus h_{k-1,k} p_{k-1}[r], into the register that holds w_r; the same row of v_k - its cache line was
+//            just gathered for the operator - feeds <v_k, w> at once                      (dia + v_k + p_{k-1})
+//   sum      alpha = <v_k, w>
+//   pass 2   w_r -= alpha p_k[r]  and  <w, D w> (or <w, w>) in the same sweep; the rows of the Jacobi diagonal are
+//            parked in LDS as they pass                                                    (p_k + D)
+//   sum      h = sqrt <w, D w>
+//   pass 3   p_{k+1} = w / h, v_{k+1} = (D w) / h from registers and the parked rows      (rest of D; 2 stores)
+//
+// 0.92 GB instead of 1.04 GB and three ramps instead of six.  Every floating-point operation and the order of
+// every sum are those of k_mgs_chain with presub (rows ascending, one accumulator pair for the dot, one accumulator
+// for the norm): H and the vectors come out bit for bit as before (test_lanczos_fused_step_bit_identical).
+//
+// Optional fourth job, `mr` (MINRES, linsys.py:844-846): the recurrence update of an EARLIER iteration j,
+//   z = (v_j - R0 W0 - R1 W1) / R2;  W0 <- z;  yk += y0 z
+// whose coefficients the host has produced from H column j in the meantime (the launch for step k is enqueued while
+// the host still works on step k-2: look-ahead) - six more streams that touch nothing this step reads or writes,
+// issued in pass 3's shadow instead of as a launch of their own.
+#pragma once
+#include "chain.h"
+
+namespace kh {
+
+struct MinresJob {
+    const double* v;      // v_j
+    double* w0;           // W0 (overwritten with z)
+    const double* w1;     // W1
+    double* yk;
+    double r0, r1, r2, y0;
+    int on;
+};
+
+template <int R2>
+struct LanczosShape {
+    static constexpr int WL = (R2 == 40) ? 8 : 0;                     // rows of w in LDS
+    static constexpr int DL_MAX = 19 - WL;                            // 8 KB per row: 19 rows fit beside the static arrays
+    static constexpr int DL = R2 < DL_MAX ? R2 : DL_MAX;              // rows of the Jacobi diagonal parked in LDS
+    static constexpr size_t LDS_BYTES = (size_t)(WL + DL) * CH_BS * sizeof(double2);
+};
+
+template <int R2, int FND, bool JAC>
+__global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob mr) {
+    constexpr int WL = LanczosShape<R2>::WL;
+    constexpr int DL = JAC ? LanczosShape<R2>::DL : 0;
+    constexpr int RW = R2 - WL;
+    extern __shared__ __attribute__((aligned(16))) double2 lsm[];   // [WL rows of w][DL rows of D][CH_BS]
+    double2* const wl = lsm;
+    double2* const dl = lsm + (size_t)WL * CH_BS;
+#define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
+#define W_PUT(r, val)                                   \
+    do {                                                \
+        if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
+        else wl[((r) - RW) * CH_BS + tid] = (val);      \
+    } while (0)
+    __shared__ double smd[4 * (CH_BS / 64)];
+    __shared__ unsigned smu[2 * CH_GMAX];
+    __shared__ int slead;
+    const int tid = threadIdx.x;
+    const int G = gridDim.x;
+    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+    double2 w[RW];
+    unsigned epoch = a.epoch0;
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
+    // ---- pass 1: w = A v_k - h_{k-1,k} p_{k-1}, <v_k, w> ----
+    double acc0 = 0.0, acc1 = 0.0;
+    {
+        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
+        const double* __restrict__ xk = a.xk;
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev);
+        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld);
+        const int64_t last = a.n_last;
+        int64_t i2 = first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const int64_t row = 2 * i2;
+            double2 av[FND];
+            double x0[FND], x1[FND];
+#pragma unroll
+            for (int d = 0; d < FND; ++d) {
+                const int64_t off = a.offs.off[d];
+                av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
+                int64_t c0 = row + off, c1 = row + 1 + off;
+                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+                x0[d] = xk[c0];
+                x1[d] = xk[c1];
+            }
+            const double2 pp = ld_nt2(p2 + i2);
+            const double2 vv = v2[i2];               // (the line the operator's centre entries came from)
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int d = 0; d < FND; ++d) {
+                const double q0 = av[d].x * x0[d], q1 = av[d].y * x1[d];
+                s0 = (av[d].x != 0.0) ? s0 + q0 : s0;
+                s1 = (av[d].y != 0.0) ? s1 + q1 : s1;
+            }
+            double2 t;
+            t.x = s0 - hk * pp.x;
+            t.y = s1 - hk * pp.y;
+            W_PUT(r, t);
+            acc0 = fma(vv.x, t.x, acc0);
+            acc1 = fma(vv.y, t.y, acc1);
+            i2 += CH_BS;
+            if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight
+        }
+    }
+    double alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    if (blockIdx.x == 0 && tid == 0) a.hdev[a.col0] = 0.0 + alpha;
+    if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
+    // ---- pass 2: w -= alpha p_k, <w, D w> ----
+    double acc = 0.0;
+    {
+        const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + a.col0 * a.ld) + first;
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r0 = 0; r0 < R2; r0 += 4) {
+            double2 p[4], d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                p[i] = ld_nt2(b2 + (int64_t)(r0 + i) * CH_BS);
+                if (JAC) d[i] = ld_nt2(d2 + (int64_t)(r0 + i) * CH_BS);
+            }
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i;
+                double2 wr = W_GET(r);
+                wr.x = wr.x - alpha * p[i].x;
+                wr.y = wr.y - alpha * p[i].y;
+                W_PUT(r, wr);
+                if (JAC) {
+                    if (r < DL) dl[r * CH_BS + tid] = d[i];
+                    acc = fma(wr.x, d[i].x * wr.x, acc);
+                    acc = fma(wr.y, d[i].y * wr.y, acc);
+                } else {
+                    acc = fma(wr.x, wr.x, acc);
+                    acc = fma(wr.y, wr.y, acc);
+                }
+            }
+        }
+    }
+    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    const double h = sqrt(fabs(h2));
+    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    // ---- pass 3: p_{k+1} = w / h, v_{k+1} = (D w) / h ----
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+    if (JAC) {
+        double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
+        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+#pragma unroll
+        for (int r0 = 0; r0 < R2; r0 += 4) {
+            double2 d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i;
+                if (r < DL) d[i] = dl[r * CH_BS + tid];
+                else d[i] = ld_nt2(d2 + (int64_t)r * CH_BS);
+            }
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + i;
+                if (r * CH_BS < rem) {
+                    const double2 wr = W_GET(r);
+                    double2 o, m;
+                    o.x = wr.x / h;
+                    o.y = wr.y / h;
+                    m.x = (d[i].x * wr.x) / h;
+                    m.y = (d[i].y * wr.y) / h;
+                    pn2[(int64_t)r * CH_BS] = o;
+                    vn2[(int64_t)r * CH_BS] = m;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            if (r * CH_BS < rem) {
+                const double2 wr = W_GET(r);
+                double2 o;
+                o.x = wr.x / h;
+                o.y = wr.y / h;
+                vn2[(int64_t)r * CH_BS] = o;
+            }
+        }
+    }
+    // ---- MINRES recurrences of an earlier iteration (independent streams) ----
+    if (mr.on) {
+        const double2* __restrict__ vj = reinterpret_cast<const double2*>(mr.v) + first;
+        double2* __restrict__ w0 = reinterpret_cast<double2*>(mr.w0) + first;
+        const double2* __restrict__ w1 = reinterpret_cast<const double2*>(mr.w1) + first;
+        double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
+#pragma unroll
+        for (int r0 = 0; r0 < R2; r0 += 2) {
+            double2 v[2], u0[2], u1[2], y[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t o = (int64_t)(r0 + i) * CH_BS;
+                v[i] = ld_nt2(vj + o);
+                u0[i] = ld_nt2(w0 + o);
+                u1[i] = ld_nt2(w1 + o);
+                y[i] = ld_nt2(yk + o);
+            }
+            CH_ISSUE_FENCE();
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = r0 + i;
+                if (r * CH_BS < rem) {
+                    // k_minres_update's formulas (kernels.h), operation for operation
+                    double2 z;
+                    z.x = (v[i].x - mr.r0 * u0[i].x - mr.r1 * u1[i].x) / mr.r2;
+                    z.y = (v[i].y - mr.r0 * u0[i].y - mr.r1 * u1[i].y) / mr.r2;
+                    w0[(int64_t)r * CH_BS] = z;
+                    double2 yo;
+                    yo.x = y[i].x + mr.y0 * z.x;
+                    yo.y = y[i].y + mr.y0 * z.y;
+                    yk[(int64_t)r * CH_BS] = yo;
+                }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by thread 0 of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#undef W_PUT
+#undef W_GET
+}
+
+}  // namespace kh

@@ -866,16 +866,24 @@ int kh_zproj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, 
     p->d = d;
     p->iterations = iterations;
     p->cplx = 1;
-    KH_HIP(hipMalloc(&p->c0, sizeof(double) * 6 * d));
-    p->c1 = p->c0 + 2 * d;
-    p->ya = p->c0 + 4 * d;
-    if (T) {
-        KH_HIP(hipMalloc(&p->T, sizeof(double) * 2 * d * d));
-        KH_HIP(hipMemcpy(p->T, T, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
-    }
-    if (WRH) {
-        KH_HIP(hipMalloc(&p->WRH, sizeof(double) * 2 * d * d));
-        KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
+    auto body = [&]() -> int {
+        KH_HIP(hipMalloc(&p->c0, sizeof(double) * 6 * d));
+        p->c1 = p->c0 + 2 * d;
+        p->ya = p->c0 + 4 * d;
+        if (T) {
+            KH_HIP(hipMalloc(&p->T, sizeof(double) * 2 * d * d));
+            KH_HIP(hipMemcpy(p->T, T, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
+        }
+        if (WRH) {
+            KH_HIP(hipMalloc(&p->WRH, sizeof(double) * 2 * d * d));
+            KH_HIP(hipMemcpy(p->WRH, WRH, sizeof(double) * 2 * d * d, hipMemcpyHostToDevice));
+        }
+        return 0;
+    };
+    const int rc = body();
+    if (rc != 0) {
+        kh_proj_free(p);
+        return rc;
     }
     *out = p;
     return 0;

@@ -651,16 +651,24 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             R2 = _pyscalar(g.r)
             y = list(rot(G2, y[0], y[1]))
             # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
+            # (deferred: the next Lanczos launch carries the update in the shadow of its last pass; whoever reads
+            # yk - _get_xk - flushes first)
             ctx.minres_update(self.lanczos._V, k - self.lanczos._base, W, slot, R0, R1, R2, y[0],
-                              yk.block, yk.col)
+                              yk.block, yk.col, defer=True)
             slot = 1 - slot
             y = [y[1], 0.0]
             self._finalize_iteration(yk, numpy.abs(y[0]))
 
+        ctx.minres_flush()
         if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(yk)
 
+    def _get_xk(self, yk):
+        self._ctx.minres_flush()         # a deferred recurrence update may still be waiting for its launch
+        return super(Minres, self)._get_xk(yk)
+
     def _finalize(self):
+        self._ctx.minres_flush()
         super(Minres, self)._finalize()
         if hasattr(self, "lanczos"):
             self.lanczos._settle()      # drop a speculative look-ahead step, if any (as Gmres does)

@@ -1145,7 +1145,11 @@ class Arnoldi(object):
             self.invariant = True
         if self._ipB is not None and ortho != "house":
             self._BV = ctx.alloc(N, self._cols, dtype=bdt, zero=False)
-            ctx.apply(self._ipB, self._V, 0, self._BV, 0, 1)
+            if self.vnorm > 0:
+                ctx.apply(self._ipB, self._V, 0, self._BV, 0, 1)
+            else:                    # v = 0: column 0 of V was never written (zero=False) - nothing uninitialised is
+                self._V.zero(0, 1)   # multiplied into BV or handed back to the block pool
+                self._BV.zero(0, 1)
 
     _WINDOW_COLS = 66        # columns of the sliding Lanczos window (re-based every 64 steps)
     _MATRIX_M_EXTERNAL_FROM = 1_500_000   # vector length from which a matrix preconditioner is applied outside the step
@@ -1312,7 +1316,11 @@ class Arnoldi(object):
                 hcol = ctx.arnoldi_step_end(k % 4, kp + 2 + pd, cplx=self._cplx)
                 self._release(k % 4)
                 if pd:
-                    self._on_ya()(hcol[kp + 2:].reshape(-1, 1).copy())
+                    cb = self._on_ya()          # (weak: the deflated solver owns the projected operator, not the reverse)
+                    if cb is None:
+                        raise RuntimeError("Arnoldi on a deflated solver's projected operator outlived the solver: "
+                                           "keep the solver alive while its Arnoldi object / MlAMr is in use")
+                    cb(hcol[kp + 2:].reshape(-1, 1).copy())
                     hcol = hcol[: kp + 2]
 
             elif self._Amat is not None:
@@ -1417,7 +1425,12 @@ class Arnoldi(object):
             return 0.0                               # w = 0: invariant (the caller clears column k+1)
         self.M._apply_dev(P, k + 1, W, 1, 1)         # M p'
         s2 = _inner_dev(P, k + 1, 1, W, 1, 1, None)[0, 0]
-        s1 = float(numpy.sqrt(abs(numpy.real(s2))))
+        # the reference's norm(Av, MAv) (utils.py:226-238): sqrt of the MODULUS - an indefinite M is not reported -
+        # but an inner product with an imaginary part is
+        if abs(numpy.imag(s2)) > abs(s2) * 1e-10:
+            raise InnerProductError("inner product defined by ip_B not positive definite? "
+                                    "||diag(ip).imag||/||diag(ip)||={}".format(abs(numpy.imag(s2)) / abs(s2)))
+        s1 = float(numpy.sqrt(abs(s2)))
         if not (s1 > 0.0):
             return 0.0
         ctx.vdiv(P, k + 1, P, k + 1, s1)

@@ -79,9 +79,14 @@ def rounding_sensitivity(run, A, b, scale=1e-15, seeds=(11, 12), elementwise=())
     return out
 
 
-def ptol(sens, key, floor=RTOL, factor=10.0):
-    """Comparison tolerance for output ``key``: 1e-10, or ten times its measured rounding sensitivity."""
-    return max(floor, factor * sens[key])
+def ptol(sens, key, floor=RTOL, factor=10.0, cap=1e-3):
+    """Comparison tolerance for output ``key``: 1e-10, or ten times its measured rounding sensitivity.  A
+    sensitivity that is not finite (the oracle's own iteration count moved) or so large that the comparison would
+    accept anything (``cap``) is an error of the test, not a tolerance."""
+    v = float(sens[key])
+    if not np.isfinite(v) or factor * v >= cap:
+        raise AssertionError("rounding sensitivity of %r is %r: nothing meaningful to compare at (cap %g)" % (key, v, cap))
+    return max(floor, factor * v)
 
 
 KNOWN = {  # reference test/test_convenience_wrappers.py:10-12 and 37-39

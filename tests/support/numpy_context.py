@@ -342,7 +342,11 @@ class NumpyContext(object):
         R.a[:, rcol] = r
         return float(np.sqrt(self._allreduce(np.array([np.vdot(r, r).real]))[0]))
 
-    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol):
+    def minres_flush(self):
+        """kh_minres_flush (the double applies every update at once: nothing is ever pending)"""
+        self._count("minres_flush")
+
+    def minres_update(self, V, k, Wk, slot, r0, r1, r2, y0, YK, ycol, defer=False):
         self._count("minres_update")
         _same("minres_update", V, Wk, YK)
         r0, r1, r2, y0 = (_coef(t, V, "minres_update") for t in (r0, r1, r2, y0))

@@ -1,5 +1,5 @@
-"""Full-size GPU runs of BASELINE.json configs 3, 4 and (single-GPU shape of) 5: size-independent
-properties, since the CPU oracle cannot finish these sizes in seconds.  Marked gpu (and slow)."""
+"""Full-size GPU runs of BASELINE.json configs 2, 3, 4 against the CPU oracle (a minute or two of host time each) and
+of the single-GPU shapes of config 5 through size-independent properties.  Marked gpu (and slow)."""
 import time
 
 import numpy as np
@@ -86,6 +86,79 @@ def test_config3_minres_jacobi_full_size(hip):
     rn = np.sqrt(np.dot(r, r / d)) / np.sqrt(np.dot(b, b / d))
     assert abs(rn - res[-1]) < 1e-8 * res[-1]
     print("config 3: %.1f MINRES iterations/s" % (200 / dt))
+
+
+def _one_blas_thread():
+    try:
+        from threadpoolctl import threadpool_limits
+        return threadpool_limits(limits=1)
+    except ImportError:
+        return None
+
+
+def test_config3_against_the_oracle_at_full_size(hip):
+    """BASELINE.json config 3 at its stated size against the CPU oracle, iterate for iterate: 60 steps of MINRES with the
+    Jacobi preconditioner on the N = 10^7 Laplacian (reference: linsys.py:791-853).  What runs here and in no golden
+    fixture: the one-column Lanczos chain launch with the operator in its prologue at 40 rows per lane
+    (k_mgs_chain<40, ., ., 5>) and the fused MINRES update on 80 MB vectors.  Residual history, the tridiagonal
+    Lanczos matrix and the iterate's norm at 1e-10 - or ten times what the oracle's own output moves under one rounding
+    error per datum (un-reorthogonalised Lanczos; measured, tests/parity_cases.rounding_sensitivity)."""
+    from krypy_amd import linsys, utils
+    from tests.parity_cases import ptol, rounding_sensitivity
+
+    A = ref.laplace2d(4000, 2500)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+    d = A.diagonal()
+    M, Minv = sp.diags(1.0 / d).tocsr(), sp.diags(d).tocsr()
+    steps = 60
+    try:
+        sol = linsys.Minres(linsys.LinearSystem(A, b, M=M, Minv=Minv, self_adjoint=True), ortho="lanczos", tol=1e-8,
+                            maxiter=steps, store_arnoldi=False)
+        raise AssertionError("tolerance cannot be reached in 60 steps at this N")
+    except utils.ConvergenceError as e:
+        sol = e.solver
+    res, H, xn = np.array(sol.resnorms), np.array(sol.lanczos.H[: steps + 1, :steps]), float(np.linalg.norm(sol.xk))
+    del sol
+
+    def run(A_, b_):
+        o = ref.minres(A_, b_, tol=1e-8, maxiter=steps, M=sp.diags(1.0 / A_.diagonal()).tocsr())
+        return dict(resnorms=np.array(o.resnorms), H=np.array(o.H), xnorm=np.array([np.linalg.norm(o.xk)]))
+
+    lim = _one_blas_thread()
+    t0 = time.perf_counter()
+    want = run(A, b)
+    sens = rounding_sensitivity(run, A, b, seeds=(11,), elementwise=("resnorms",))
+    print("oracle: 3 x 60 MINRES steps in %.1f s; rounding sensitivity %r" % (time.perf_counter() - t0, sens))
+    if lim is not None:
+        lim.restore_original_limits()
+    assert len(res) == len(want["resnorms"]) == steps + 1
+    # (the last entry is the explicitly computed residual the failing solve ends with; the recurrence's are compared)
+    dev = np.max(np.abs(res[:-1] - want["resnorms"][:-1]) / want["resnorms"][:-1])
+    assert dev < ptol(sens, "resnorms"), (dev, sens)
+    assert np.linalg.norm(H - want["H"]) < ptol(sens, "H") * np.linalg.norm(want["H"])
+    assert abs(xn - want["xnorm"][0]) < ptol(sens, "xnorm") * want["xnorm"][0]
+    assert max(ptol(sens, k) for k in sens) < 1e-7, sens          # (the bar stays a bar)
+
+
+def test_config4_against_the_oracle_at_full_size(hip):
+    """BASELINE.json config 4 at its stated size against the CPU oracle: the whole CG solve on the dense SPD matrix
+    of order 32768 (8.6 GB streamed per step by k_gemv_dense; reference: linsys.py:593-689).  Same number of
+    iterations, residual history and iterate at 1e-10 (the system is well conditioned: kappa about 5)."""
+    from krypy_amd import linsys
+    from oracle.inputs import dense_spd_system
+
+    n = 32768
+    A, b = dense_spd_system(n)
+    sol = linsys.Cg(linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True), tol=1e-8, maxiter=200)
+    t0 = time.perf_counter()
+    want = ref.cg(A, b, tol=1e-8, maxiter=200)
+    print("oracle: %d CG steps at n = %d in %.1f s" % (len(want.resnorms) - 1, n, time.perf_counter() - t0))
+    got, wres = np.array(sol.resnorms), np.array(want.resnorms)
+    assert len(got) == len(wres)
+    assert np.max(np.abs(got - wres) / wres) < 1e-10
+    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-10 * np.linalg.norm(want.xk)
+    assert all(t[5] == 0 for t in sol.cg_trace)              # every fused step's sanity word is clean
 
 
 def test_config4_dense_cg_full_size(hip):

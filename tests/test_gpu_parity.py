@@ -498,9 +498,13 @@ def test_operator_fused_into_the_chain_prologue(hip, shape):
         Ad, Md = ctx.csr(A), ctx.diag(dj)
         assert Ad.diagonals in (5, 7)
         res = {}
-        # plain / double-sweep MGS (LDS-parking kernel), Lanczos with its pre-subtraction, Jacobi (plain kernel)
-        for name, use_m, lanczos in (("mgs", False, False), ("lanczos", False, True), ("jacobi", True, False)):
+        # plain / double-sweep MGS (LDS-parking kernel), Lanczos with its pre-subtraction, Jacobi (plain kernel),
+        # Lanczos with Jacobi (MINRES + M: config 3).  Steps with ONE Gram-Schmidt link - every Lanczos step, the
+        # first step of the others - run the three-pass kernel of lanczos.h when the operator is fused
+        for name, use_m, lanczos in (("mgs", False, False), ("lanczos", False, True), ("jacobi", True, False),
+                                     ("lanczos_jacobi", True, True)):
             before = ctx.counters()
+            lz0 = ctx.get("n_lanczos_fused")
             V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
             P = ctx.alloc(n, m + 1) if use_m else None
             if use_m:
@@ -516,20 +520,24 @@ def test_operator_fused_into_the_chain_prologue(hip, shape):
                 hcol = ctx.arnoldi_step(Ad, Md if use_m else None, V, P, W, 0, k, start,
                                         2 if (k == 4 and not lanczos) else 1, 0, hk)
                 H[start: k + 2, k] = hcol[start: k + 2]
-            res[name] = (H, V.download())
+            res[name] = (H, V.download(), P.download() if use_m else np.zeros(1))
             c = ctx.counters()
             assert c["chain"] - before["chain"] == m, (name, c)
             lds_on = os.environ.get("KRYPY_AMD_CHAIN_LDS", "1") != "0"
-            assert c["chain_lds"] - before["chain_lds"] == (m if (lds_on and not use_m) else 0), (name, c)
+            lz = ctx.get("n_lanczos_fused") - lz0
+            lz_on = fused and os.environ.get("KRYPY_AMD_LANCZOS_FUSED", "1") != "0"
+            assert lz == ((m if lanczos else 1) if lz_on else 0), (name, lz)
+            assert c["chain_lds"] - before["chain_lds"] == ((m - lz) if (lds_on and not use_m) else 0), (name, c)
             assert c["chain_fused"] - before["chain_fused"] == (m if fused else 0), (name, c)
             del V, W, P
         out.append(res)
         ctx.close()
     for name in out[0]:
-        (Hf, Vf), (Hs, Vs) = out[0][name], out[1][name]
+        (Hf, Vf, Pf), (Hs, Vs, Ps) = out[0][name], out[1][name]
         assert np.array_equal(Hf, Hs), name
         assert np.array_equal(Vf, Vs), name
-    Hf, Vf = out[0]["mgs"]
+        assert np.array_equal(Pf, Ps), name
+    Hf, Vf, _ = out[0]["mgs"]
     assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
 
 

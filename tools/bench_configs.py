@@ -35,11 +35,20 @@ def config3(ctx, steps=400):
         dt = time.perf_counter() - t0
         n_it = len(s.resnorms) - 1
         del s
-    # algorithmic bytes per iteration (SURVEY 8d fused lower bound): SpMV + ~12 vector passes
+    # bytes the iteration MOVES (what the kernels request; the banded copy of the operator, not CSR):
+    #   Lanczos launch (lanczos.h)  5 diagonals 40 N + v_k 8 N + p_{k-1} 8 N | p_k 8 N + D 8 N | D again (21 of 40 rows
+    #                               come back from memory) 4.2 N + two stores 16 N                     = 92.2 N
+    #   MINRES recurrences          v_k, W0, W1, yk in, z and yk out                                   = 48 N
+    # SURVEY 8(d)'s fused lower bound (CSR bytes + 12 vector passes) is kept beside it for reference.
+    fused = ctx.get("n_lanczos_fused") > 0
+    moved = (92.2 if fused else 104.0) * N + 48.0 * N
     nb = 12.0 * A.nnz + 4.0 * (N + 1) + 16.0 * N + 12 * 8.0 * N
     out.update(config="3: MINRES + Jacobi, 2-D Laplacian N=1e7, ortho=lanczos, %d steps" % steps,
                iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
-               algorithmic_gbs=nb * n_it / dt / 1e9, frac_of_8TBs=nb * n_it / dt / 8e12)
+               moved_gb_per_iteration=moved / 1e9, moved_gbs=moved * n_it / dt / 1e9,
+               frac_moved_of_8TBs=moved * n_it / dt / 8e12,
+               survey_8d_gbs=nb * n_it / dt / 1e9,
+               lanczos_fused_launches=ctx.get("n_lanczos_fused"), minres_updates_carried=ctx.get("n_minres_rides"))
     return out
 
 
