@@ -66,9 +66,59 @@ def laplace2d(nx, ny, row0=None, row1=None):
     return A
 
 
+def laplace3d(nx, ny, nz, z0=None, z1=None, chunk=8):
+    """7-point Laplacian on an nx x ny x nz grid (x fastest, z slowest) as sorted int32 CSR with GLOBAL column
+    indices; optionally only the rows of the planes [z0, z1) (a rank's slab).  Built plane-chunk by plane-chunk with
+    array arithmetic straight into the CSR arrays (698.7 M entries at 500 x 500 x 400: no 7 x N temporaries)."""
+    import scipy.sparse as sp
+
+    z0 = 0 if z0 is None else z0
+    z1 = nz if z1 is None else z1
+    plane = nx * ny
+    N = plane * nz
+    nrow = plane * (z1 - z0)
+    ii = np.arange(plane, dtype=np.int64) % nx
+    jj = np.arange(plane, dtype=np.int64) // nx
+    in_plane_ok = [None, jj > 0, ii > 0, None, ii < nx - 1, jj < ny - 1, None]
+    offs = [-plane, -nx, -1, 0, 1, nx, plane]
+    vals = np.array([-1.0, -1.0, -1.0, 6.0, -1.0, -1.0, -1.0])
+    per_plane = np.full(plane, 7, dtype=np.int64) - (jj == 0) - (ii == 0) - (ii == nx - 1) - (jj == ny - 1)
+    counts = np.tile(per_plane, z1 - z0)
+    if z0 == 0:
+        counts[:plane] -= 1
+    if z1 == nz:
+        counts[nrow - plane:] -= 1
+    indptr = np.zeros(nrow + 1, dtype=np.int64)
+    np.cumsum(counts, out=indptr[1:])
+    del counts
+    indices = np.empty(int(indptr[-1]), dtype=np.int32)
+    data = np.empty(int(indptr[-1]), dtype=np.float64)
+    for c0 in range(z0, z1, chunk):
+        c1 = min(z1, c0 + chunk)
+        kk = np.repeat(np.arange(c0, c1, dtype=np.int64), plane)
+        row = kk * plane + np.tile(np.arange(plane, dtype=np.int64), c1 - c0)
+        K = np.ones((row.size, 7), dtype=bool)
+        for d in (1, 2, 4, 5):
+            K[:, d] = np.tile(in_plane_ok[d], c1 - c0)
+        K[:, 0] = kk > 0
+        K[:, 6] = kk < nz - 1
+        C = row[:, None] + np.array(offs, dtype=np.int64)[None, :]
+        lo, hi = indptr[(c0 - z0) * plane], indptr[(c1 - z0) * plane]
+        indices[lo:hi] = C[K]
+        data[lo:hi] = np.broadcast_to(vals, C.shape)[K]
+        del K, C, row, kk
+    return sp.csr_matrix((data, indices, indptr), shape=(nrow, N))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+                    help="BASELINE.json config: 2 = GMRES(100) on the 2-D Laplacian N = 10^7 (the metric; default), "
+                         "5 = DeflatedGmres with 16 recycled Ritz vectors on the 3-D 7-point Laplacian "
+                         "500 x 500 x 400 (N = 10^8), z-slabs over the ranks")
+    ap.add_argument("--nz", type=int, default=400, help="config 5: planes of the grid (nx, ny default to 500 there)")
+    ap.add_argument("--defl", type=int, default=16, help="config 5: recycled Ritz vectors")
     ap.add_argument("--steps", type=int, default=8, help="timed GMRES(100) restart cycles")
     ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up cycles")
     ap.add_argument("--nx", type=int, default=4000)
@@ -202,6 +252,8 @@ def main():
 
 def _run():
     args = parse_args()
+    if args.config == 5:
+        return _run_config5(args)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -377,6 +429,137 @@ def _run():
             out["cpu_baseline"] = cpu_baseline(A_for_ls, b, m, args.cpu_budget_s)
         except Exception as exc:
             out["cpu_baseline"] = {"error": repr(exc)}
+    return out, rank, dist
+
+
+def _run_config5(args):
+    """BASELINE.json configs[4]: 3-D 7-point Laplacian on 500 x 500 x 400 points (N = 10^8, nnz = 698,700,000), rows in
+    z-slabs over the ranks (400 / 8 = 50 planes = 12.5 M rows per GPU), b = rng(0) normal.  Solve 1: plain GMRES(m)
+    (DeflatedGmres without U) to harvest the `defl` smallest-magnitude Ritz vectors ON THE DEVICE (every rank keeps its
+    slab of them; the small eigenproblem is replicated host work); solve 2: DeflatedGmres(U, maxiter=m), timed - a
+    *step* is one such solve of m iterations from x0 = 0 (reference flow: recycling/linsys.py:51-103,
+    deflation.py:93-163).  Same JSON contract as config 2; `scaling` is "strong" (the grid is fixed)."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
+    sharded = world > 1 or args.force_sharded
+    if args.force_sharded:
+        os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
+    dist = None
+    if sharded:
+        import torch.distributed as dist  # plumbing only: unique-id broadcast + barrier
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from krypy_amd import _hip, deflation, linsys, utils
+
+    if not os.path.exists(_hip.library_path()):
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        if dist is not None:
+            dist.barrier()
+    ctx = _hip.get_context()
+    nx = 500 if args.nx == 4000 else args.nx          # (4000 / 2500 are config 2's defaults)
+    ny = 500 if args.ny == 2500 else args.ny
+    nz, m, d = args.nz, args.restart, args.defl
+    plane = nx * ny
+    N = plane * nz
+    ortho = args.ortho
+    if ortho == "auto":
+        ortho = "cgs" if sharded else "mgs"
+    b_rng = np.random.default_rng(0)
+    if sharded:
+        from krypy_amd import dist as kdist
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(rank, world, uid[0])
+        cuts = [(nz * p) // world for p in range(world + 1)]          # whole planes per rank
+        z0, z1 = cuts[rank], cuts[rank + 1]
+        Aloc = laplace3d(nx, ny, nz, z0, z1)
+        op = kdist.ShardedCSROperator(Aloc, z0 * plane, N, ctx)
+        del Aloc
+        # every rank draws the same stream and keeps its slab (the right-hand side of the unsharded run)
+        b = None
+        for p in range(world):
+            seg = b_rng.standard_normal(plane * (cuts[p + 1] - cuts[p]))
+            if p == rank:
+                b = seg
+        A_for_ls = op
+    else:
+        A_for_ls = laplace3d(nx, ny, nz)
+        b = b_rng.standard_normal(N)
+    nnz_global = 7 * N - 2 * (nx * ny + ny * nz + nx * nz)
+    ls = linsys.LinearSystem(A_for_ls, b, self_adjoint=True)
+
+    def barrier():
+        ctx.sync()
+        if dist is not None:
+            dist.barrier()
+
+    def solve(U):
+        try:
+            return deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, ortho=ortho, store_arnoldi=U is None)
+        except utils.ConvergenceError as e:
+            return e.solver
+
+    # solve 1 (untimed): harvest the Ritz vectors on the device
+    s0 = solve(None)
+    ritz = deflation.Ritz(s0)
+    U = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:d])
+    plain_relres = float(s0.resnorms[-1])
+    ritz_values = np.sort(np.abs(ritz.values))[:d]
+    del s0, ritz
+    for _ in range(args.warmup):
+        solve(U)
+    barrier()
+    cycle_marks = []
+    t0 = time.perf_counter()
+    n_iters = 0
+    for _ in range(args.steps):
+        s1 = solve(U)
+        n_iters += len(s1.resnorms) - 1
+        cycle_marks.append(time.perf_counter())
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    assert n_iters == args.steps * m, (n_iters, args.steps, m)
+    its = n_iters / dt
+    nloc = ls.N
+    # bytes one deflated iteration has to move at least (SURVEY 8d): the operator, the Gram-Schmidt columns once per
+    # use, the projector's two sweeps over the 2 d vectors (560 N for d = 16)
+    it_bytes = (12.0 * nnz_global + 4.0 * (N + 1) + 16.0 * N) + 16.0 * N * (m + 1) / 2.0 + 48.0 * N + \
+        (32.0 * d + 48.0) * N
+    out = {
+        "metric": "DeflatedGmres iterations/sec, 3-D 7-pt Laplacian n=10^8 row-sharded, 16 recycled Ritz vectors, fp64",
+        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "DeflatedGmres(%d) solves with %d recycled Ritz vectors, 3-D 7-pt Laplacian %dx%dx%d CSR "
+                               "(N=%d, nnz=%d), b=rng(0) normal, x0=0 (BASELINE.json configs[4]); Ritz vectors harvested "
+                               "from one plain GMRES(%d) solve, untimed" % (m, d, nx, ny, nz, N, nnz_global, m),
+                   "n": N, "rows_per_gpu": nloc, "ortho": ortho, "restart": m, "deflation_vectors": d,
+                   "iterations_timed": n_iters,
+                   "parallelism": "1 GPU" if not sharded else "z-slabs x%d (RCCL)" % world,
+                   "plain_relres": plain_relres, "deflated_relres": float(s1.resnorms[-1]),
+                   "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
+                   "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms))},
+        "roofline": {"bound": "hbm", "achieved": it_bytes / world * its / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": it_bytes / world * its / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                     "bytes_source": "SURVEY 8(d) algorithmic bytes of one deflated iteration per GPU (operator as CSR, "
+                                     "every basis column twice, projector 560 N for d = 16), whole-solve average - not "
+                                     "a per-kernel figure"},
+    }
+    if rank == 0 and not sharded and not args.no_cpu_baseline:
+        out["cpu_baseline"] = {"value": None, "note": "config 2 carries the CPU baseline (bench.py without --config)"}
     return out, rank, dist
 
 

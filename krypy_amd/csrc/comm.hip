@@ -117,6 +117,42 @@ int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream
     return 0;
 }
 
+// the halo of a BLOCK of vectors in one grouped exchange: column c's ghost entries land in
+// A->ghost_panel + c * (nrecv_prev + nrecv_next) (the caller sized it); 2 sends + 2 receives per column, all in one
+// group - RCCL fuses them into one kernel
+int comm_halo_exchange_panel(kh_ctx ctx, kh_mat A, const double* X, int64_t ldx, int64_t ncols, hipStream_t stream) {
+    if (ctx->comm == nullptr) return 0;
+    const int64_t nloc = A->n_rows, ng = A->nrecv_prev + A->nrecv_next;
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    const bool loop = ctx->halo_loopback && ctx->nranks == 1;
+    if (loop)
+        KH_ARG(A->nsend_prev == A->nrecv_next && A->nsend_next == A->nrecv_prev, "halo_loopback: a periodic slab sends what it receives");
+    if (!loop && ctx->nranks == 1) return 0;
+    KH_NCCL(g_rccl.GroupStart());
+    for (int64_t c = 0; c < ncols; ++c) {
+        const double* x = X + c * ldx;
+        double* g = A->ghost_panel + c * ng;
+        if (loop) {         // (see comm_halo_exchange: receives posted next-region first)
+            if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, A->nsend_prev, ncclDouble, 0, comm, stream));
+            if (A->nsend_next) KH_NCCL(g_rccl.Send(x + (nloc - A->nsend_next), A->nsend_next, ncclDouble, 0, comm, stream));
+            if (A->nrecv_next) KH_NCCL(g_rccl.Recv(g + A->nrecv_prev, A->nrecv_next, ncclDouble, 0, comm, stream));
+            if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(g, A->nrecv_prev, ncclDouble, 0, comm, stream));
+            continue;
+        }
+        if (ctx->rank > 0) {
+            if (A->nsend_prev) KH_NCCL(g_rccl.Send(x, A->nsend_prev, ncclDouble, ctx->rank - 1, comm, stream));
+            if (A->nrecv_prev) KH_NCCL(g_rccl.Recv(g, A->nrecv_prev, ncclDouble, ctx->rank - 1, comm, stream));
+        }
+        if (ctx->rank + 1 < ctx->nranks) {
+            if (A->nsend_next) KH_NCCL(g_rccl.Send(x + (nloc - A->nsend_next), A->nsend_next, ncclDouble, ctx->rank + 1, comm, stream));
+            if (A->nrecv_next) KH_NCCL(g_rccl.Recv(g + A->nrecv_prev, A->nrecv_next, ncclDouble, ctx->rank + 1, comm, stream));
+        }
+    }
+    KH_NCCL(g_rccl.GroupEnd());
+    ctx->n_halo_exchange += 1;
+    return 0;
+}
+
 }  // namespace kh
 
 extern "C" {

@@ -532,7 +532,11 @@ __global__ __launch_bounds__(BS) void k_spmm_stream(const int32_t* __restrict__ 
                                                     const double* __restrict__ data,
                                                     const int32_t* __restrict__ rowblk, int nblk, int tile,
                                                     const double* __restrict__ X, int64_t ldx,
-                                                    double* __restrict__ Y, int64_t ldy, int ncols) {
+                                                    double* __restrict__ Y, int64_t ldy, int ncols,
+                                                    int64_t nloc = (int64_t)1 << 62,
+                                                    const double* __restrict__ ghost = nullptr, int64_t ldg = 0) {
+    // (a block-row shard: column ids >= nloc address the ghost entries the halo exchange delivered, one run of
+    // ldg doubles per column of X)
     extern __shared__ __attribute__((aligned(16))) double prod[];   // [DC][tile]
     __shared__ double sm[8];
     const int bid = xcd_remap(blockIdx.x, nblk);
@@ -558,9 +562,10 @@ __global__ __launch_bounds__(BS) void k_spmm_stream(const int32_t* __restrict__ 
                 for (int dc = 0; dc < DC; ++dc) {
                     if (dc < nc) {
                         const double* __restrict__ x = X + (int64_t)(j0 + dc) * ldx;
+                        const double* __restrict__ gx = ghost + (int64_t)(j0 + dc) * ldg;
                         double pv[ITEMS];
 #pragma unroll
-                        for (int i = 0; i < ITEMS; ++i) pv[i] = a[i] * x[c[i]];
+                        for (int i = 0; i < ITEMS; ++i) pv[i] = a[i] * ((c[i] < nloc) ? x[c[i]] : gx[c[i] - nloc]);
 #pragma unroll
                         for (int i = 0; i < ITEMS; ++i) {
                             const int t = threadIdx.x + i * BS;
@@ -584,8 +589,12 @@ __global__ __launch_bounds__(BS) void k_spmm_stream(const int32_t* __restrict__ 
     } else {  // one long row: tree reduction per column (not bit-ordered, like k_spmv_stream)
         for (int j = 0; j < ncols; ++j) {
             const double* __restrict__ x = X + (int64_t)j * ldx;
+            const double* __restrict__ gx = ghost + (int64_t)j * ldg;
             double s = 0.0;
-            for (int t = threadIdx.x; t < cnt; t += BS) s += data[nz0 + t] * x[indices[nz0 + t]];
+            for (int t = threadIdx.x; t < cnt; t += BS) {
+                const int cc = indices[nz0 + t];
+                s += data[nz0 + t] * ((cc < nloc) ? x[cc] : gx[cc - nloc]);
+            }
             s = block_sum(s, sm);
             if (threadIdx.x == 0) Y[(int64_t)j * ldy + r0] = s;
             __syncthreads();

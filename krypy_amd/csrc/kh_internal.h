@@ -151,6 +151,8 @@ struct kh_mat_s {
     // halo of a block-row shard
     int64_t nsend_prev = 0, nsend_next = 0, nrecv_prev = 0, nrecv_next = 0;
     double* ghost = nullptr;    // nrecv_prev + nrecv_next doubles
+    double* ghost_panel = nullptr;   // [ghost_panel_cols][nrecv_prev + nrecv_next]: ghost entries of a block of vectors (sharded SpMM)
+    int64_t ghost_panel_cols = 0;
     // row blocks [b0, b1) of the banded / the CSR-stream kernel touch no ghost column (interior of the slab)
     int dia_b0 = 0, dia_b1 = 0, csr_b0 = 0, csr_b1 = 0;
 };
@@ -176,6 +178,7 @@ namespace kh {
 // comm.hip
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
 int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream, int width = 1);
+int comm_halo_exchange_panel(kh_ctx ctx, kh_mat A, const double* X, int64_t ldx, int64_t ncols, hipStream_t stream);
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
 }  // namespace kh

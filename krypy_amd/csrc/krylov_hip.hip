@@ -427,23 +427,23 @@ static hipError_t launch_chain_pf(kh_ctx ctx, int G, ChainArgs& a) {
 }
 
 // one Lanczos step in three passes (lanczos.h)
-template <int R2, int FND, bool JAC>
+template <int R2, int FND, bool JAC, bool MR, bool ST>
 static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJob& mr) {
     static int blocks_per_cu = -1;
     constexpr size_t lds = (size_t)(LanczosShape<R2>::WL + (JAC ? LanczosShape<R2>::DL : 0)) * CH_BS * sizeof(double2);
     if (blocks_per_cu < 0) {
         if (lds > 0) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC>),
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC, MR, ST>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e0 != hipSuccess) return e0;
         }
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC>, CH_BS, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC, MR, ST>, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
+    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC, MR, ST>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
     return hipGetLastError();
 }
 
@@ -548,7 +548,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && padded && !cplx && (a.debug == 0 || a.debug == 4) && r2 >= 16 && r2 <= 40 && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && r2 >= 16 && r2 <= 40 && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -588,8 +588,31 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         }
         MinresJob job;
         if (mr != nullptr) job = *mr;
-        else job.on = 0;
-#define KH_LZ(R, D) (dg != nullptr ? launch_lanczos<R, D, true>(ctx, G, a, job) : launch_lanczos<R, D, false>(ctx, G, a, job))
+        else {
+            job.on = 0;
+            job.v = job.w1 = w;           // (never dereferenced)
+            job.w0 = job.yk = const_cast<double*>(w);
+            job.r0 = job.r1 = job.y0 = 0.0;
+            job.r2 = 1.0;
+        }
+        // symmetric-pattern stencil (offsets -o_m .. -o_1, -1, 0, 1, o_1 .. o_m, every o_i even): aligned 16-byte
+        // loads of x (lanczos.h, ST); anything else takes the scalar gathers and leaves a MINRES job to its own launch
+        bool st = a.xk == V->col(a.col0);
+        {
+            const int mid = a.offs.nd / 2;
+            for (int d_ = 0; d_ < a.offs.nd; ++d_) {
+                const int o_ = a.offs.off[d_];
+                if (d_ == mid) st = st && o_ == 0;
+                else if (d_ == mid - 1) st = st && o_ == -1;
+                else if (d_ == mid + 1) st = st && o_ == 1;
+                else st = st && (o_ & 1) == 0;
+            }
+        }
+        if (!st) job.on = 0;
+#define KH_LZ(R, D)                                                                                             \
+    (st ? (dg != nullptr ? (job.on ? launch_lanczos<R, D, true, true, true>(ctx, G, a, job) : launch_lanczos<R, D, true, false, true>(ctx, G, a, job)) \
+                         : (job.on ? launch_lanczos<R, D, false, true, true>(ctx, G, a, job) : launch_lanczos<R, D, false, false, true>(ctx, G, a, job))) \
+        : (dg != nullptr ? launch_lanczos<R, D, true, false, false>(ctx, G, a, job) : launch_lanczos<R, D, false, false, false>(ctx, G, a, job)))
         if (r2 == 40) e = (a.offs.nd == 5) ? KH_LZ(40, 5) : KH_LZ(40, 7);
         else if (r2 == 32) e = (a.offs.nd == 5) ? KH_LZ(32, 5) : KH_LZ(32, 7);
         else if (r2 == 24) e = (a.offs.nd == 5) ? KH_LZ(24, 5) : KH_LZ(24, 7);
@@ -604,7 +627,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             if (hpin == nullptr)
                 KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                                       ctx->stream));
-            ctx->mr_taken = (mr != nullptr && mr->on) ? 1 : 0;     // (the MINRES job - if any - went along)
+            ctx->mr_taken = job.on ? 1 : 0;     // (the MINRES job - if any - went along)
             return 1;
         }
         (void)hipGetLastError();             // e.g. the dynamic LDS was refused: the general chain kernel below
@@ -934,6 +957,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "spmv_split")) ctx->spmv_split = value != 0;
     else if (!strcmp(key, "halo_loopback")) ctx->halo_loopback = value != 0;
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
+    else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
 }
@@ -1415,6 +1439,7 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->a);
     (void)hipFree(A->diag);
     (void)hipFree(A->ghost);
+    (void)hipFree(A->ghost_panel);
     delete A;
     return 0;
 }
@@ -1443,11 +1468,27 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
         KH_HIP(hipGetLastError());
         return 0;
     }
-    if (A->kind == KH_MAT_CSR && ncols >= 2 && A->nblk > 0 &&
-        (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) == 0) {
-        // a panel: the matrix is streamed once for all columns (a sharded operator exchanges one halo per
-        // column and stays on the loop below)
-        if (use_dia(ctx, A, Y->col(ycol)) && (Y->ld & 1) == 0) {
+    const bool shard = (A->kind == KH_MAT_CSR) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0;
+    if (A->kind == KH_MAT_CSR && ncols >= 2 && A->nblk > 0) {
+        // a panel: the matrix is streamed once for all columns.  A block-row shard first exchanges the halo of ALL
+        // columns in one group (one RCCL kernel instead of ncols) into a ghost panel, then takes the CSR kernel with
+        // ghost columns; on one rank without neighbours the ghost entries are the ones kh_mat_set_ghost wrote,
+        // repeated per column by the caller's choice of set_ghost - so only a communicator's shard goes this way
+        const int64_t ng = A->nrecv_prev + A->nrecv_next;
+        const bool exchange = shard && kh_multi(ctx) && ctx->comm != nullptr && (ctx->nranks > 1 || ctx->halo_loopback);
+        if (shard && !exchange) goto column_loop;
+        if (shard) {
+            if (A->ghost_panel_cols < ncols) {
+                KH_HIP(hipStreamSynchronize(ctx->stream));
+                (void)hipFree(A->ghost_panel);
+                A->ghost_panel = nullptr;
+                A->ghost_panel_cols = 0;
+                KH_HIP(hipMalloc(&A->ghost_panel, sizeof(double) * std::max<int64_t>(ng, 1) * ncols));
+                A->ghost_panel_cols = ncols;
+            }
+            KH_TRY(comm_halo_exchange_panel(ctx, A, X->col(xcol), X->ld, ncols, ctx->stream));
+        }
+        if (!shard && use_dia(ctx, A, Y->col(ycol)) && (Y->ld & 1) == 0) {
             constexpr int DC = 8;
             DiaOffs o;
             o.nd = A->dia_nd;
@@ -1477,7 +1518,8 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
         }
 #define KH_SPMM(I)                                                                                             \
     hipLaunchKernelGGL((k_spmm_stream<I, DC>), dim3(A->nblk), dim3(BS), lds, ctx->stream, A->indptr, A->indices, \
-                       A->data, A->rowblk, A->nblk, A->tile, X->col(xcol), X->ld, Y->col(ycol), Y->ld, (int)ncols)
+                       A->data, A->rowblk, A->nblk, A->tile, X->col(xcol), X->ld, Y->col(ycol), Y->ld, (int)ncols, \
+                       shard ? (int64_t)A->n_rows : ((int64_t)1 << 62), A->ghost_panel, ng)
         switch (A->tile / BS) {
             case 4: KH_SPMM(4); break;
             case 16: KH_SPMM(16); break;
@@ -1488,6 +1530,7 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
         ctx->n_spmm += 1;
         return 0;
     }
+column_loop:
     for (int64_t c = 0; c < ncols; ++c)
         KH_TRY(apply_one(ctx, A, X->col(xcol + c), Y->col(ycol + c), EPI_NONE, nullptr, nullptr, 0));
     return 0;

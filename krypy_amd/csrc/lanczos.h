@@ -46,7 +46,11 @@ struct LanczosShape {
     static constexpr size_t LDS_BYTES = (size_t)(WL + DL) * CH_BS * sizeof(double2);
 };
 
-template <int R2, int FND, bool JAC>
+// ST: the operator is a symmetric-pattern stencil - offsets (-o_m, ..., -o_1, -1, 0, 1, o_1, ..., o_m) with every o_i
+// even (2-D 5-point, 3-D 7-point with even grid lines: what the launcher checks).  The x values of a row pair then
+// come as aligned 16-byte loads for the even offsets and from the centre pair plus its two outer neighbours for +-1:
+// 3 + 2 (5 + 2) load instructions per row pair instead of 10 (14) scalar ones.  Same values, same products, same sums.
+template <int R2, int FND, bool JAC, bool MR, bool ST = false>
 __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob mr) {
     constexpr int WL = LanczosShape<R2>::WL;
     constexpr int DL = JAC ? LanczosShape<R2>::DL : 0;
@@ -74,7 +78,10 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
     if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
     // ---- pass 1: w = A v_k - h_{k-1,k} p_{k-1}, <v_k, w> ----
     double acc0 = 0.0, acc1 = 0.0;
-    {
+    if (a.debug & 8) {               // measurement only (kh_ctx_set "chain_debug"): pass 1 switched off
+#pragma unroll
+        for (int r = 0; r < R2; ++r) W_PUT(r, make_double2(1.0, 1.0));
+    } else {
         const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
         const double* __restrict__ xk = a.xk;
         const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev);
@@ -86,18 +93,47 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             const int64_t row = 2 * i2;
             double2 av[FND];
             double x0[FND], x1[FND];
+            double2 vv;
+            if constexpr (ST) {
+                constexpr int MID = FND / 2;
+                const int64_t last2 = last >> 1;     // index of the last whole pair
 #pragma unroll
-            for (int d = 0; d < FND; ++d) {
-                const int64_t off = a.offs.off[d];
-                av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
-                int64_t c0 = row + off, c1 = row + 1 + off;
-                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
-                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
-                x0[d] = xk[c0];
-                x1[d] = xk[c1];
+                for (int d = 0; d < FND; ++d)
+                    av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
+#pragma unroll
+                for (int d = 0; d < FND; ++d) {
+                    if (d == MID - 1 || d == MID + 1) continue;
+                    // even offset: the pair (x[row + off], x[row + 1 + off]) is an aligned double2; beyond the ends the
+                    // diagonal has no entry (the product is skipped), any valid address will do
+                    int64_t j2 = i2 + (a.offs.off[d] >> 1);
+                    j2 = j2 < 0 ? 0 : (j2 > last2 ? last2 : j2);
+                    const double2 xv = reinterpret_cast<const double2*>(xk)[j2];
+                    x0[d] = xv.x;
+                    x1[d] = xv.y;
+                }
+                int64_t cl = row - 1, cr = row + 2;
+                cl = cl < 0 ? 0 : cl;
+                cr = cr > last ? last : cr;
+                x0[MID - 1] = xk[cl];                // offset -1: (x[row - 1], x[row])
+                x1[MID - 1] = x0[MID];
+                x0[MID + 1] = x1[MID];               // offset +1: (x[row + 1], x[row + 2])
+                x1[MID + 1] = xk[cr];
+                vv.x = x0[MID];                      // the row pair of v_k itself is the centre pair
+                vv.y = x1[MID];
+            } else {
+#pragma unroll
+                for (int d = 0; d < FND; ++d) {
+                    const int64_t off = a.offs.off[d];
+                    av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
+                    int64_t c0 = row + off, c1 = row + 1 + off;
+                    c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+                    c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+                    x0[d] = xk[c0];
+                    x1[d] = xk[c1];
+                }
+                vv = v2[i2];                         // (the line the operator's centre entries came from)
             }
             const double2 pp = ld_nt2(p2 + i2);
-            const double2 vv = v2[i2];               // (the line the operator's centre entries came from)
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int d = 0; d < FND; ++d) {
@@ -115,34 +151,49 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight
         }
     }
+    // ---- pass 2: w -= alpha p_k, <w, D w>; a two-deep ring of PB2 rows, its first batch in flight across the sum ----
+    constexpr int PB2 = 4, NB2 = R2 / PB2;
+    static_assert(NB2 * PB2 == R2, "rows per lane are a multiple of four");
+    const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + a.col0 * a.ld) + first;
+    const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+    double2 rp[2][PB2], rd[2][PB2];
+    const bool run2 = !(a.debug & 16);
+    if (run2) {
+#pragma unroll
+        for (int i = 0; i < PB2; ++i) {
+            rp[0][i] = ld_nt2(b2 + (int64_t)i * CH_BS);
+            if (JAC) rd[0][i] = ld_nt2(d2 + (int64_t)i * CH_BS);
+        }
+        CH_ISSUE_FENCE();
+    }
     double alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
     if (blockIdx.x == 0 && tid == 0) a.hdev[a.col0] = 0.0 + alpha;
     if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
-    // ---- pass 2: w -= alpha p_k, <w, D w> ----
     double acc = 0.0;
-    {
-        const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + a.col0 * a.ld) + first;
-        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
+    if (run2) {
 #pragma unroll
-        for (int r0 = 0; r0 < R2; r0 += 4) {
-            double2 p[4], d[4];
+        for (int b = 0; b < NB2; ++b) {
+            if (b + 1 < NB2) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                p[i] = ld_nt2(b2 + (int64_t)(r0 + i) * CH_BS);
-                if (JAC) d[i] = ld_nt2(d2 + (int64_t)(r0 + i) * CH_BS);
+                for (int i = 0; i < PB2; ++i) {
+                    rp[(b + 1) & 1][i] = ld_nt2(b2 + (int64_t)((b + 1) * PB2 + i) * CH_BS);
+                    if (JAC) rd[(b + 1) & 1][i] = ld_nt2(d2 + (int64_t)((b + 1) * PB2 + i) * CH_BS);
+                }
             }
             CH_ISSUE_FENCE();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + i;
+            for (int i = 0; i < PB2; ++i) {
+                const int r = b * PB2 + i;
+                const double2 p = rp[b & 1][i];
                 double2 wr = W_GET(r);
-                wr.x = wr.x - alpha * p[i].x;
-                wr.y = wr.y - alpha * p[i].y;
+                wr.x = wr.x - alpha * p.x;
+                wr.y = wr.y - alpha * p.y;
                 W_PUT(r, wr);
                 if (JAC) {
-                    if (r < DL) dl[r * CH_BS + tid] = d[i];
-                    acc = fma(wr.x, d[i].x * wr.x, acc);
-                    acc = fma(wr.y, d[i].y * wr.y, acc);
+                    const double2 d = rd[b & 1][i];
+                    if (r < DL) dl[r * CH_BS + tid] = d;
+                    acc = fma(wr.x, d.x * wr.x, acc);
+                    acc = fma(wr.y, d.y * wr.y, acc);
                 } else {
                     acc = fma(wr.x, wr.x, acc);
                     acc = fma(wr.y, wr.y, acc);
@@ -150,86 +201,73 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             }
         }
     }
+    // ---- pass 3 (+ the MINRES recurrences of an earlier iteration): a two-deep ring of PB3 rows ----
+    constexpr int PB3 = 2, NB3 = R2 / PB3;
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+    double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
+    const double2* __restrict__ vj = reinterpret_cast<const double2*>(mr.v) + first;
+    double2* __restrict__ w0 = reinterpret_cast<double2*>(mr.w0) + first;
+    const double2* __restrict__ w1 = reinterpret_cast<const double2*>(mr.w1) + first;
+    double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
+    double2 qd[2][PB3], qv[2][PB3], qu0[2][PB3], qu1[2][PB3], qy[2][PB3];
+    const bool run3 = !(a.debug & 32), runm = MR && !(a.debug & 64);
+#define LZ_ISSUE3(b_, s_)                                                               \
+    do {                                                                                \
+        _Pragma("unroll") for (int i = 0; i < PB3; ++i) {                               \
+            const int r_ = (b_) * PB3 + i;                                              \
+            const int64_t o_ = (int64_t)r_ * CH_BS;                                     \
+            if (JAC && run3 && r_ >= DL) qd[s_][i] = ld_nt2(d2 + o_);                   \
+            if (runm) {                                                                 \
+                qv[s_][i] = ld_nt2(vj + o_);                                            \
+                qu0[s_][i] = ld_nt2(w0 + o_);                                           \
+                qu1[s_][i] = ld_nt2(w1 + o_);                                           \
+                qy[s_][i] = ld_nt2(yk + o_);                                            \
+            }                                                                           \
+        }                                                                               \
+    } while (0)
+    LZ_ISSUE3(0, 0);
+    CH_ISSUE_FENCE();
     const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
     const double h = sqrt(fabs(h2));
     if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
-    // ---- pass 3: p_{k+1} = w / h, v_{k+1} = (D w) / h ----
-    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
-    if (JAC) {
-        double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
-        const double2* __restrict__ d2 = reinterpret_cast<const double2*>(a.dg) + first;
 #pragma unroll
-        for (int r0 = 0; r0 < R2; r0 += 4) {
-            double2 d[4];
+    for (int b = 0; b < NB3; ++b) {
+        if (b + 1 < NB3) LZ_ISSUE3(b + 1, (b + 1) & 1);
+        CH_ISSUE_FENCE();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + i;
-                if (r < DL) d[i] = dl[r * CH_BS + tid];
-                else d[i] = ld_nt2(d2 + (int64_t)r * CH_BS);
-            }
-            CH_ISSUE_FENCE();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r0 + i;
-                if (r * CH_BS < rem) {
+        for (int i = 0; i < PB3; ++i) {
+            const int r = b * PB3 + i;
+            if (r * CH_BS < rem) {
+                if (run3) {
                     const double2 wr = W_GET(r);
-                    double2 o, m;
+                    double2 o;
                     o.x = wr.x / h;
                     o.y = wr.y / h;
-                    m.x = (d[i].x * wr.x) / h;
-                    m.y = (d[i].y * wr.y) / h;
-                    pn2[(int64_t)r * CH_BS] = o;
-                    vn2[(int64_t)r * CH_BS] = m;
+                    if (JAC) {
+                        const double2 d = (r < DL) ? dl[r * CH_BS + tid] : qd[b & 1][i];
+                        double2 m;
+                        m.x = (d.x * wr.x) / h;
+                        m.y = (d.y * wr.y) / h;
+                        pn2[(int64_t)r * CH_BS] = o;
+                        vn2[(int64_t)r * CH_BS] = m;
+                    } else {
+                        vn2[(int64_t)r * CH_BS] = o;
+                    }
                 }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            if (r * CH_BS < rem) {
-                const double2 wr = W_GET(r);
-                double2 o;
-                o.x = wr.x / h;
-                o.y = wr.y / h;
-                vn2[(int64_t)r * CH_BS] = o;
-            }
-        }
-    }
-    // ---- MINRES recurrences of an earlier iteration (independent streams) ----
-    if (mr.on) {
-        const double2* __restrict__ vj = reinterpret_cast<const double2*>(mr.v) + first;
-        double2* __restrict__ w0 = reinterpret_cast<double2*>(mr.w0) + first;
-        const double2* __restrict__ w1 = reinterpret_cast<const double2*>(mr.w1) + first;
-        double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
-#pragma unroll
-        for (int r0 = 0; r0 < R2; r0 += 2) {
-            double2 v[2], u0[2], u1[2], y[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int64_t o = (int64_t)(r0 + i) * CH_BS;
-                v[i] = ld_nt2(vj + o);
-                u0[i] = ld_nt2(w0 + o);
-                u1[i] = ld_nt2(w1 + o);
-                y[i] = ld_nt2(yk + o);
-            }
-            CH_ISSUE_FENCE();
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = r0 + i;
-                if (r * CH_BS < rem) {
-                    // k_minres_update's formulas (kernels.h), operation for operation
-                    double2 z;
-                    z.x = (v[i].x - mr.r0 * u0[i].x - mr.r1 * u1[i].x) / mr.r2;
-                    z.y = (v[i].y - mr.r0 * u0[i].y - mr.r1 * u1[i].y) / mr.r2;
+                if (runm) {      // k_minres_update's formulas (kernels.h), operation for operation
+                    const double2 v = qv[b & 1][i], u0 = qu0[b & 1][i], u1 = qu1[b & 1][i], y = qy[b & 1][i];
+                    double2 z, yo;
+                    z.x = ((v.x - mr.r0 * u0.x) - mr.r1 * u1.x) / mr.r2;
+                    z.y = ((v.y - mr.r0 * u0.y) - mr.r1 * u1.y) / mr.r2;
                     w0[(int64_t)r * CH_BS] = z;
-                    double2 yo;
-                    yo.x = y[i].x + mr.y0 * z.x;
-                    yo.y = y[i].y + mr.y0 * z.y;
+                    yo.x = y.x + mr.y0 * z.x;
+                    yo.y = y.y + mr.y0 * z.y;
                     yk[(int64_t)r * CH_BS] = yo;
                 }
             }
         }
     }
+#undef LZ_ISSUE3
     if (blockIdx.x == 0 && a.hpin != nullptr) {
         __syncthreads();          // the H entries were written by thread 0 of this workgroup
         for (int i = tid; i < a.hcount; i += CH_BS)

@@ -308,6 +308,67 @@ def test_bench_sharded_path_runs_on_n_ranks(world):
         _hip._install_context_for_testing(old)
 
 
+def _bench5_worker(rank, world, port, q):
+    """bench.py --config 5 as torch.distributed.run starts it, NumPy double as the device."""
+    try:
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port))
+        from krypy_amd import _hip
+        from tests.support.numpy_context import NumpyContext
+        ctx = NumpyContext()
+        _hip._install_context_for_testing(ctx)
+        import sys
+        import bench
+        sys.argv = ["bench.py", "--config", "5", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--nx", "12",
+                    "--ny", "10", "--nz", "16", "--restart", "30", "--defl", "5", "--no-cpu-baseline"]
+        out, r, dist = bench._run()
+        assert r == rank and ctx.nranks == world and ctx.rank == rank
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", out))
+    except BaseException:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_config5_leg_on_n_ranks(world):
+    """The config-5 leg of bench.py (z-slabs of the 3-D grid, plain GMRES to harvest Ritz vectors that stay sharded on
+    the device, DeflatedGmres timed) on gloo ranks at a toy size: same JSON contract as config 2, every rank sees the
+    same numbers, and those are the CPU oracle's (gmres -> Ritz vectors of smallest magnitude -> deflated_gmres;
+    reference flow recycling/linsys.py:51-103, deflation.py:93-163)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench5_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        rank, status, payload = q.get(timeout=600)
+        assert status == "ok", payload
+        outs[rank] = payload
+    for p in procs:
+        p.join(timeout=60)
+    o = outs[0]
+    assert o["n_gpus"] == world and o["steps"] == 2 and o["unit"] == "iterations/s" and o["scaling"] == "strong"
+    assert o["config"]["iterations_timed"] == 60 and o["config"]["deflation_vectors"] == 5
+    assert o["config"]["parallelism"] == "z-slabs x%d (RCCL)" % world and o["config"]["ortho"] == "cgs"
+    assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 60) < 1e-6
+    for key in ("plain_relres", "deflated_relres"):
+        assert len({outs[r]["config"][key] for r in outs}) == 1, key
+    import bench
+    from oracle import krylov_ref as ref
+    A = bench.laplace3d(12, 10, 16)
+    b = np.random.default_rng(0).standard_normal(A.shape[0])
+    o0 = ref.gmres(A, b, tol=1e-12, maxiter=30)
+    vals, U = ref.ritz_vectors_smallest(o0, 5, self_adjoint=True)
+    o1 = ref.deflated_gmres(A, b, U, tol=1e-12, maxiter=30)
+    assert abs(o["config"]["plain_relres"] - o0.resnorms[-1]) <= 1e-8 * o0.resnorms[-1]
+    assert np.allclose(o["config"]["smallest_ritz_values"], np.sort(np.abs(vals))[:4], rtol=1e-8)
+    assert abs(o["config"]["deflated_relres"] - o1.resnorms[-1]) <= 1e-6 * o1.resnorms[-1]
+    assert o["config"]["deflated_relres"] < o["config"]["plain_relres"]
+
+
 def test_slab_cuts_and_localize():
     from krypy_amd import dist as kdist
     assert kdist.slab_cuts(100, 4) == [0, 25, 50, 75, 100]

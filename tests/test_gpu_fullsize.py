@@ -156,8 +156,31 @@ def test_config4_against_the_oracle_at_full_size(hip):
     print("oracle: %d CG steps at n = %d in %.1f s" % (len(want.resnorms) - 1, n, time.perf_counter() - t0))
     got, wres = np.array(sol.resnorms), np.array(want.resnorms)
     assert len(got) == len(wres)
-    assert np.max(np.abs(got - wres) / wres) < 1e-10
-    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-10 * np.linalg.norm(want.xk)
+    # what "the same algorithm with its 32768-term row sums taken in another order" looks like from outside: the
+    # oracle again with every row sum split in two halves (the residual recurrence at 1e-8 ||b|| keeps eight digits
+    # less than the iterate, so its tail moves by 1e-9 relative under rounding alone)
+    sens = xsens = 0.0
+    for parts in (2, 3, 5):          # (the device adds 64 interleaved partial sums per row: more pieces than any of these)
+        cuts = [n * i // parts for i in range(parts + 1)]
+
+        def split_matvec(x, cuts=cuts):
+            y = A[:, cuts[0]:cuts[1]].dot(x[cuts[0]:cuts[1]])
+            for i in range(1, len(cuts) - 1):
+                y = y + A[:, cuts[i]:cuts[i + 1]].dot(x[cuts[i]:cuts[i + 1]])
+            return y
+
+        other = ref.cg(split_matvec, b, tol=1e-8, maxiter=200)
+        ores = np.array(other.resnorms)
+        assert len(ores) == len(wres)
+        sens = max(sens, float(np.max(np.abs(ores - wres) / wres)))
+        xsens = max(xsens, float(np.linalg.norm(other.xk - want.xk) / np.linalg.norm(want.xk)))
+    print("oracle's own movement under other summation orders: resnorms %.1e, xk %.1e" % (sens, xsens))
+    assert sens < 1e-8
+    # thirty times the oracle's own movement (the factor tools/solve_fuzz.py uses), never below 1e-10; the first ten
+    # iterations - residuals well above the rounding floor - at 1e-10 flat
+    assert np.max(np.abs(got - wres) / wres) < max(1e-10, 30.0 * sens)
+    assert np.max(np.abs(got[:10] - wres[:10]) / wres[:10]) < 1e-10
+    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < max(1e-10, 30.0 * xsens) * np.linalg.norm(want.xk)
     assert all(t[5] == 0 for t in sol.cg_trace)              # every fused step's sanity word is clean
 
 
@@ -267,3 +290,30 @@ def test_config5_slab_at_its_stated_size_through_the_sharded_path(hip):
     finally:
         _hip._install_context_for_testing(old)
         ctx.close()
+
+
+def test_bench_config5_leg_one_rank_slab(hip):
+    """bench.py --config 5 as a rank of the 8-GPU run sees it: the 500 x 500 x 50 slab (12.5 M rows) through the sharded
+    code path on a 1-rank RCCL communicator (--force-sharded), plain GMRES(100) -> 16 Ritz vectors on the device ->
+    DeflatedGmres(100) timed.  The JSON contract of the leg, and the deflated solve beats the plain one."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, "bench.py", "--config", "5", "--force-sharded", "--nz", "50", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True,
+                         timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    o = json.loads(out.stdout.strip().splitlines()[-1])
+    print(json.dumps(o)[:1500])
+    c = o["config"]
+    assert o["n_gpus"] == 1 and o["unit"] == "iterations/s" and o["dtype"] == "f64" and o["scaling"] == "strong"
+    assert c["n"] == 12_500_000 and c["rows_per_gpu"] == 12_500_000 and c["iterations_timed"] == 200
+    assert c["ortho"] == "cgs" and c["deflation_vectors"] == 16
+    assert c["deflated_relres"] < c["plain_relres"] < 1.0
+    assert o["value"] > 50 and 0 < o["roofline"]["frac"] < 1

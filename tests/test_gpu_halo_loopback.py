@@ -99,6 +99,34 @@ def test_periodic_slab_exchanges_its_halo_with_itself(loop_ctx, kind):
     ctx.set("spmv_split", 1)
 
 
+@pytest.mark.parametrize("kind", ["lap2d", "random"])
+def test_sharded_panel_apply_exchanges_once_and_streams_the_matrix_once(loop_ctx, kind):
+    """kh_apply of a shard to a block of d vectors (A U of the deflation set-up, deflation.py:47; Ritz residuals,
+    deflation.py:849-855): ONE grouped exchange for all d columns' halos and ONE pass over the matrix
+    (k_spmm_stream with ghost columns) instead of d exchanges + d passes - bit-identical to the column loop and to
+    SciPy on the periodic operator."""
+    from krypy_amd import dist
+
+    ctx = loop_ctx
+    rng = np.random.default_rng(7)
+    Abig, n = _stencil(kind, rng)
+    A_local, nrp, nrn = dist.localize_columns(Abig[n:2 * n], n, 3 * n)
+    Ad = ctx.csr(A_local, n_cols=A_local.shape[1])
+    ctx.set_halo(Ad, nrn, nrp, nrp, nrn)
+    for d in (2, 5, 16):
+        X = rng.standard_normal((n, d))
+        want = Abig[n:2 * n].dot(np.vstack([X, X, X]))
+        Xd, Y, Y1 = ctx.upload(X), ctx.alloc(n, d + 1), ctx.alloc(n, d)
+        e0, m0 = ctx.get("n_halo_exchange"), ctx.get("n_spmm")
+        ctx.apply(Ad, Xd, 0, Y, 1, d)                       # (an offset in the output block)
+        assert ctx.get("n_halo_exchange") == e0 + 1 and ctx.get("n_spmm") == m0 + 1
+        assert np.array_equal(Y.download()[:, 1:], want), (kind, d)
+        for c in range(d):                                  # the column loop: d exchanges, d passes
+            ctx.apply(Ad, Xd, c, Y1, c, 1)
+        assert ctx.get("n_halo_exchange") == e0 + 1 + d
+        assert np.array_equal(Y1.download(), want), (kind, d)
+
+
 def test_complex_periodic_slab(loop_ctx):
     """(re, im) pairs through the same exchange: complex CSR shard (k_zspmv_stream with ghost columns)."""
     from krypy_amd import dist

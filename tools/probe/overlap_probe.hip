@@ -233,6 +233,121 @@ __global__ __launch_bounds__(CH_BS) void k_bw(const double2* cols, int64_t ld2, 
     if (tid == 0) out[blockIdx.x] = acc;
 }
 
+// All working workgroups on ONE XCD (short vectors: the sum is the whole link).  8 G + 8 workgroups are launched; a
+// workgroup that does not run on XCD `target` leaves at once, the others draw a ticket and the first G of them work.
+// MODE 0: the library's protocol unchanged (granules with agent-scope stores, the one leader sweeps with agent-scope
+// loads, the others poll its result pair); MODE 1: granules published with PLAIN stores (they stay in this XCD's L2),
+// the leader sweeps with L1-bypassing loads (sc1: an L2 hit here).
+template <int MODE>
+__global__ __launch_bounds__(CH_BS) void k_onexcd(int Gw, int links, unsigned long long* gran, unsigned* ticket,
+                                                  unsigned long long* xcc_res, int* err, unsigned epoch0, unsigned target,
+                                                  double* out) {
+    __shared__ double smd[4 * (CH_BS / 64)];
+    __shared__ int svb;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = CH_BS / 64;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 0xfu;
+    if (xcc != target) return;
+    if (tid == 0) svb = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    const int vb = svb;
+    if (vb >= Gw) return;
+    unsigned epoch = epoch0;
+    double total = 0.0;
+    unsigned long long* res = xcc_res + ((size_t)target * 2) * 4;
+    for (int t = 0; t < links; ++t) {
+        const double part = (double)((vb * CH_BS + tid) % 1000 + t % 7) * 1e-3;
+        const double ws = wave_sum_dpp(part);
+        if (lane == 0) smd[wid] = ws;
+        __syncthreads();
+        unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
+        unsigned long long* rs = res + (epoch & 1u) * 4;
+        if (tid == 0) {
+            double s = smd[0];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) s += smd[i];
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            if (MODE == 0) {
+                st_agent(slot + 2 * vb, tag | (bits & 0xffffffffull));
+                st_agent(slot + 2 * vb + 1, tag | (bits >> 32));
+            } else {
+                slot[2 * vb] = tag | (bits & 0xffffffffull);
+                slot[2 * vb + 1] = tag | (bits >> 32);
+            }
+        }
+        double s;
+        if (vb == 0) {
+            unsigned mine = 0;
+            if (tid < 2 * Gw) {
+                unsigned long long x;
+                unsigned spins = 0;
+                while (true) {
+                    if (MODE == 0) x = ld_agent(slot + tid);
+                    else asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(slot + tid) : "memory");
+                    if ((unsigned)(x >> 32) == epoch) break;
+                    if (++spins > (1u << 22)) { __hip_atomic_store(err, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                mine = (unsigned)x;
+            }
+            const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);
+            const unsigned long long bits = ((unsigned long long)mine << 32) | low;
+            const double v = ((lane & 1) && tid < 2 * Gw) ? __longlong_as_double((long long)bits) : 0.0;
+            const double wv = wave_sum_dpp(v);
+            if (lane == 0) smd[NW + wid] = wv;
+            __syncthreads();
+            s = smd[NW];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) s += smd[NW + i];
+            if (tid == 0) {
+                const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+                const unsigned long long tag = (unsigned long long)epoch << 32;
+                rs[0] = tag | (sb & 0xffffffffull);
+                rs[1] = tag | (sb >> 32);
+            }
+        } else {
+            s = gs_wait_vec(epoch, rs, err);
+        }
+        ++epoch;
+        total += s;
+    }
+    if (tid == 0) out[vb] = total;
+}
+
+template <int MODE>
+static void run_onexcd(int Gw, int links, unsigned long long* gran, unsigned* ticket, unsigned long long* xcc_res, int* err,
+                       unsigned& epoch, double* out) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; ++rep) {
+        CK(hipMemsetAsync(ticket, 0, sizeof(unsigned), 0));
+        CK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL((k_onexcd<MODE>), dim3(8 * Gw + 8), dim3(CH_BS), 0, 0, Gw, links, gran, ticket, xcc_res, err, epoch,
+                           0u, out);
+        CK(hipEventRecord(e1, 0));
+        CK(hipEventSynchronize(e1));
+        epoch += links;
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    std::vector<double> h(Gw);
+    int herr = 0;
+    unsigned tk = 0;
+    CK(hipMemcpy(h.data(), out, sizeof(double) * Gw, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&herr, err, sizeof(int), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&tk, ticket, sizeof(unsigned), hipMemcpyDeviceToHost));
+    int same = 1;
+    for (int i = 1; i < Gw; ++i) if (h[i] != h[0]) same = 0;
+    printf("one XCD mode=%d G=%2d (%u workgroups landed on XCD 0 of %d launched): %.3f us per sum  (agree: %s, err=%d)\n", MODE, Gw,
+           tk, 8 * Gw + 8, best * 1e3 / links, same ? "yes" : "NO", herr);
+    if (herr) CK(hipMemset(err, 0, sizeof(int)));
+    fflush(stdout);
+}
+
 struct Dev {
     double2* cols; int64_t ld2; int ncols;
     unsigned long long* gran; unsigned* xcc_leader; unsigned long long* xcc_res; int* err; double* out;
@@ -299,6 +414,15 @@ int main() {
     CK(hipMalloc(&d.xcc_res, sizeof(unsigned long long) * 16 * 8)); CK(hipMemset(d.xcc_res, 0, sizeof(unsigned long long) * 16 * 8));
     CK(hipMalloc(&d.err, sizeof(int))); CK(hipMemset(d.err, 0, sizeof(int)));
     CK(hipMalloc(&d.out, sizeof(double) * 512));
+    if (getenv("PROBE_ONEXCD")) {       // sums of short vectors: all workgroups on one XCD vs spread over eight
+        unsigned* ticket; CK(hipMalloc(&ticket, sizeof(unsigned)));
+        for (int Gw : {4, 13, 25, 32}) {
+            run_onexcd<0>(Gw, 4000, d.gran, ticket, d.xcc_res, d.err, d.epoch, d.out);
+            run_onexcd<1>(Gw, 4000, d.gran, ticket, d.xcc_res, d.err, d.epoch, d.out);
+            run_overlap<0, 0, 0>(d, Gw, 4000);       // the library's sum, workgroups on all XCDs
+        }
+        return 0;
+    }
     const int links = 512;
     // 1. bandwidth: fresh column only; the same column again and again (Infinity Cache); fresh + lagged re-reads
     run_bw(d, G, links, 40, 0, 1, 0);
