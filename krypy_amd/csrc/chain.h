@@ -74,6 +74,12 @@ struct ChainArgs {
     const double* xk;
     int64_t n_last;    // n - 1
     DiaOffs offs;
+    // short vectors, all working workgroups on ONE XCD (ONEX instantiations): 8 G + 8 workgroups are launched, those
+    // that do not run on XCD `onex_target` leave at once, the others draw a ticket and the first onex_G of them work
+    int onex_G;
+    unsigned onex_target;
+    unsigned* onex_ticket;     // zero when the launch begins
+    unsigned* onex_clear;      // the ticket word of a launch far in the future: zeroed by this one
 #ifdef KH_CHAIN_TRACE
     unsigned long long* trace;   // diagnostic build only (make trace): [G][links][2 waves][8] 100 MHz stamps
 #endif
@@ -399,6 +405,108 @@ __device__ __forceinline__ void grid_sum2(double& p0, double& p1, unsigned epoch
     p1 = s1;
 }
 
+// ------------------------------------------------------------------------------------------
+// Short vectors: all working workgroups on ONE XCD.
+// With 4 ... 32 workgroups a Gram-Schmidt link IS its grid-wide sum (1.1 - 2.1 us over the fabric; the stream is
+// a few hundred bytes per lane), 50 of them per Arnoldi step.  Workgroups of one XCD share its L2, so when all of
+// them run there the granules never leave it: publish with plain stores, EVERY workgroup sweeps the 2 G granules
+// itself with L1-bypassing loads (L2 hits) - one L2 round trip, no leader, no fabric: 0.81 - 0.84 us per sum for
+// 4 ... 32 workgroups (tools/probe/overlap_probe.hip, PROBE_ONEXCD=1; 1.02 - 1.10 with a leader's extra hop).
+// Placement: workgroups are dealt round-robin over the XCDs, so of 8 G + 8 launched G + 1 land on each; those on
+// the other XCDs leave at once, the first G ticket holders on the target work.  Nothing depends on the deal being
+// exact - only on G workgroups reaching the target, and the bounded spins cover the case that they do not (the
+// step is then re-run on the per-column kernels like after any other timeout).  Same partials, same order of
+// additions as grid_sum: the same bits.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long ld_l2(const unsigned long long* p) {
+    unsigned long long x;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(x) : "v"(p) : "memory");
+    return x;
+}
+
+// returns false when this workgroup has nothing to do (not on the target XCD, or no ticket left)
+__device__ __forceinline__ bool onex_enter(const ChainArgs& a, int* sflag, int& bid, int& G, GridRole& role) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    v &= 0xfu;
+    if (v != a.onex_target) return false;
+    if (threadIdx.x == 0) *sflag = (int)atomicAdd(a.onex_ticket, 1u);
+    __syncthreads();
+    bid = *sflag;
+    G = a.onex_G;
+    if (bid >= G) return false;
+    __syncthreads();          // (sflag may be reused)
+    role.xcc = v;
+    role.leader = false;
+    if (bid == 0 && threadIdx.x == 0) *a.onex_clear = 0u;
+    return true;
+}
+
+// NV values (1: a real coefficient / norm, 2: both parts of a complex coefficient) over the G <= 32 workgroups of
+// one XCD; granule g = 2 NV bid + 2 kind + half.  smd holds 4 * 8 doubles.
+template <int NV>
+__device__ __forceinline__ void onex_sum(double (&p)[NV], unsigned epoch, unsigned long long* gran, int G, int bid,
+                                         int* err, double* smd) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    constexpr int NW = CH_BS / 64;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double ws = wave_sum_dpp(p[k]);
+        if (lane == 0) smd[k * NW + wid] = ws;
+    }
+    __syncthreads();
+    unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
+    if (tid < NV) {
+        double s = smd[tid * NW];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += smd[tid * NW + i];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        slot[2 * NV * bid + 2 * tid] = tag | (bits & 0xffffffffull);          // plain stores: they stay in this XCD's L2
+        slot[2 * NV * bid + 2 * tid + 1] = tag | (bits >> 32);
+    }
+    unsigned mine = 0;
+    const int ng = 2 * NV * G;          // <= 128
+    if (tid < ng) {
+        unsigned long long x = ld_l2(slot + tid);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch) {
+            x = ld_l2(slot + tid);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1u << 22)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        mine = (unsigned)x;
+    }
+    const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);   // from lane - 1
+    const unsigned long long bits = ((unsigned long long)mine << 32) | low;
+    const double d = ((lane & 1) && tid < ng) ? __longlong_as_double((long long)bits) : 0.0;
+    if (NV == 1) {
+        const double wv = wave_sum_dpp(d);
+        if (lane == 0) smd[2 * NW + wid] = wv;
+    } else {
+        const bool kind1 = ((lane >> 1) & 1) != 0;
+        const double w0 = wave_sum_dpp(kind1 ? 0.0 : d), w1 = wave_sum_dpp(kind1 ? d : 0.0);
+        if (lane == 0) {
+            smd[2 * NW + wid] = w0;
+            smd[3 * NW + wid] = w1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double s = smd[(2 + k) * NW];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += smd[(2 + k) * NW + i];
+        p[k] = s;
+    }
+    __syncthreads();          // smd is reused by the next sum
+}
+
 // Every vector this kernel reads is a kh_vec / diag buffer allocated with CH_SLACK zeroed doubles
 // behind its last column, so loads need no clamping: an out-of-range lane reads finite data of a
 // neighbouring chunk/column (or zeros) and its w stays exactly 0 (select on registers).
@@ -474,7 +582,7 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
 // 256 CUs): the last WL rows of w live in LDS (8 KB per row and workgroup, each lane touches only its own
 // entries: no barrier), the first R2 - WL in registers as ever.  R2 = 48 / 56 (WL = 8 / 16) take N to
 // 12.58 M / 14.68 M per GPU with the same single launch per Arnoldi step and the same arithmetic.
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0, bool ONEX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
     static_assert(WL == 0 || FND == 0, "the fused operator writes registers only");
@@ -492,10 +600,16 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
     const int tid = threadIdx.x;
-    const int G = gridDim.x;
-    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    int G = gridDim.x;
+    int bid = blockIdx.x;
+    GridRole role;
+    if constexpr (ONEX) {
+        if (!onex_enter(a, &slead, bid, G, role)) return;
+    } else {
+        role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    }
     // chunk2 == R2 * CH_BS: thread `tid` owns elements first + r*CH_BS, r < R2
-    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    const int64_t first = (int64_t)bid * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
@@ -572,16 +686,29 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
-            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-            if (blockIdx.x == 0 && tid == 0) {
+            if constexpr (ONEX) {
+                double pv[2] = {alpha, alpha_i};
+                onex_sum<2>(pv, epoch++, a.gran, G, bid, a.err, smd);
+                alpha = pv[0];
+                alpha_i = pv[1];
+            } else {
+                grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+            }
+            if (bid == 0 && tid == 0) {
                 // first sweep assigns (the caller does not clear the H column for a chain launch)
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
                 a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
-            alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-            if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
+            if constexpr (ONEX) {
+                double pv[1] = {acc0 + acc1};
+                onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
+                alpha = pv[0];
+            } else {
+                alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                       : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+            }
+            if (bid == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
         if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
         // ---- update phase: w -= alpha * b_j ----
@@ -634,9 +761,16 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             acc = fma(wr.y, wr.y, acc);
         }
     }
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    double h2;
+    if constexpr (ONEX) {
+        double pv[1] = {acc};
+        onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
+        h2 = pv[0];
+    } else {
+        h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    }
     const double h = sqrt(fabs(h2));
-    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    if (bid == 0 && tid == 0) a.hdev[a.hnext] = h;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
     if (a.dg != nullptr) {
         double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
@@ -667,7 +801,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             }
         }
     }
-    if (blockIdx.x == 0 && a.hpin != nullptr) {
+    if (bid == 0 && a.hpin != nullptr) {
         __syncthreads();          // the H entries were written by thread 0 of this workgroup
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1042,7 +1176,7 @@ __device__ __forceinline__ void ch_dma16(const double2* gsrc, unsigned lds_dst) 
                  : "memory");
 }
 
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, bool ONEX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
     static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
     constexpr int PB = ChainShapePf<R2>::PB;
@@ -1056,9 +1190,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
     __shared__ unsigned smu[2 * CH_GMAX];
     __shared__ int slead;
     const int tid = threadIdx.x;
-    const int G = gridDim.x;
-    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
-    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
+    int G = gridDim.x;
+    int bid = blockIdx.x;
+    GridRole role;
+    if constexpr (ONEX) {
+        if (!onex_enter(a, &slead, bid, G, role)) return;
+    } else {
+        role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    }
+    const int64_t first = (int64_t)bid * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
     // LDS byte address of this wave's 64 lanes in row 0 (the DMA destination is wave-uniform + lane * 16)
@@ -1157,15 +1297,28 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
         if (CPLX) {
             alpha = acc0;
             alpha_i = acc1;
-            grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-            if (blockIdx.x == 0 && tid == 0) {
+            if constexpr (ONEX) {
+                double pv[2] = {alpha, alpha_i};
+                onex_sum<2>(pv, epoch++, a.gran, G, bid, a.err, smd);
+                alpha = pv[0];
+                alpha_i = pv[1];
+            } else {
+                grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+            }
+            if (bid == 0 && tid == 0) {
                 a.hdev[2 * j] = (t < a.ncol ? 0.0 : a.hdev[2 * j]) + alpha;
                 a.hdev[2 * j + 1] = (t < a.ncol ? 0.0 : a.hdev[2 * j + 1]) + alpha_i;
             }
         } else {
-            alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-            if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
+            if constexpr (ONEX) {
+                double pv[1] = {acc0 + acc1};
+                onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
+                alpha = pv[0];
+            } else {
+                alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
+                                       : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+            }
+            if (bid == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
         if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
         // ---- update phase: w -= alpha * v_j ----
@@ -1238,9 +1391,16 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
         acc = fma(w[r].x, w[r].x, acc);
         acc = fma(w[r].y, w[r].y, acc);
     }
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    double h2;
+    if constexpr (ONEX) {
+        double pv[1] = {acc};
+        onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
+        h2 = pv[0];
+    } else {
+        h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    }
     const double h = sqrt(fabs(h2));
-    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
+    if (bid == 0 && tid == 0) a.hdev[a.hnext] = h;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
@@ -1251,7 +1411,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
             vn2[(int64_t)r * CH_BS] = o;
         }
     }
-    if (blockIdx.x == 0 && a.hpin != nullptr) {
+    if (bid == 0 && a.hpin != nullptr) {
         __syncthreads();          // the H entries were written by thread 0 of this workgroup
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

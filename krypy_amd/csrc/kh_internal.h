@@ -75,6 +75,9 @@ struct kh_ctx_s {
     int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
     int chain_pf = 1;       // ... and keep HBM busy through the update phase (k_mgs_chain_pf; KRYPY_AMD_CHAIN_PF)
     int64_t n_chain_pf = 0;
+    int chain_onex = 1;     // short vectors: all working workgroups of the chain kernel on one XCD (KRYPY_AMD_CHAIN_ONEX)
+    int64_t n_chain_onex = 0;
+    unsigned* onex_ticket = nullptr;   // 256 rotating ticket words
     int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)
     int64_t n_lanczos_fused = 0;
     int mr_taken = 0;       // the last chain launch carried a MINRES recurrence job (lanczos.h)

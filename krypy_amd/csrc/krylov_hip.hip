@@ -426,33 +426,70 @@ static hipError_t launch_chain_pf(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// short vectors: all working workgroups on one XCD (chain.h, ONEX).  8 G + 8 workgroups are launched; the G that
+// work must be co-resident on the 1/8 of the CUs one XCD has.
+template <int R2, bool MASKED, bool CPLX, bool PF>
+static hipError_t launch_chain_onex(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = PF ? ChainShapePf<R2>::LDS_BYTES : 0;
+    auto kern = PF ? k_mgs_chain_pf<R2, MASKED, CPLX, 0, true> : k_mgs_chain<R2, MASKED, CPLX, 0, 0, true>;
+    if (blocks_per_cu < 0) {
+        if (lds > 0) {
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0 != hipSuccess) return e0;
+        }
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * (ctx->ncu / 8) < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(kern, dim3(8 * G + 8), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
 // one Lanczos step in three passes (lanczos.h)
-template <int R2, int FND, bool JAC, bool MR, bool ST>
+template <int R2, int FND, bool JAC, bool MR>
 static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJob& mr) {
     static int blocks_per_cu = -1;
     constexpr size_t lds = (size_t)(LanczosShape<R2>::WL + (JAC ? LanczosShape<R2>::DL : 0)) * CH_BS * sizeof(double2);
     if (blocks_per_cu < 0) {
         if (lds > 0) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC, MR, ST>),
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC, MR>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e0 != hipSuccess) return e0;
         }
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC, MR, ST>, CH_BS, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC, MR>, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC, MR, ST>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
+    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC, MR>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
     return hipGetLastError();
 }
 
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
-static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
+static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, bool onex = false) {
     if (n < 2) return false;
     // an odd n is handled as n+1: the extra element is the (always zero) padding behind the column
     const int64_t n2 = (n + 1) >> 1;
     static const int kR2[] = {4, 8, 16, 24, 32, 40, 48, 56};   // 48 / 56: the last 8 / 16 rows of w live in LDS
+    // short vectors: as few workgroups as one XCD has CUs, so that all of them can run there (chain.h, ONEX) - 8 rows
+    // per lane on 32 workgroups beat 4 rows on 64 spread over the chip, the sum being the whole link
+    if (onex) {
+        if (!ctx->chain_onex || ctx->ncu % 8 != 0) return false;
+        for (int c : {4, 8}) {
+            const int64_t g = (n2 + (int64_t)c * CH_BS - 1) / ((int64_t)c * CH_BS);
+            if (g <= ctx->ncu / 8 && g <= 32) {
+                *r2_out = c;
+                *g_out = (int)g;
+                return true;
+            }
+        }
+        return false;
+    }
     for (int c : kR2) {
         const int64_t g = (n2 + (int64_t)c * CH_BS - 1) / ((int64_t)c * CH_BS);
         if (g <= ctx->ncu && g <= CH_GMAX) {
@@ -470,6 +507,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     int64_t ld = ((n + 31) / 32) * 32;
     int r2 = 0, g = 0;
     if (n >= (1 << 16) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
+    if (n >= (1 << 16) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
     return ld == 0 ? 32 : ld;
 }
 
@@ -489,6 +527,18 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     const int64_t n2 = (n + 1) >> 1;
     int r2 = 0, G = 0;
     if (!chain_geometry(ctx, n, &r2, &G)) return 0;
+    // short vectors with at least a few links in the launch: as few workgroups as one XCD has CUs, all of them
+    // there (chain.h, ONEX) - the sum is the whole link.  (One or two links - Lanczos, the first Arnoldi steps - do
+    // not pay for the larger grid: MINRES + Jacobi at N = 10^5 32,400 vs 27,400 it/s.)
+    bool want_onex = false;
+    if (Afuse == nullptr && (k - start + 1) * sweeps >= 3 && (ctx->chain_debug == 0) && ctx->onex_ticket != nullptr) {
+        int r2x = 0, Gx = 0;
+        if (chain_geometry(ctx, n, &r2x, &Gx, true)) {
+            r2 = r2x;
+            G = Gx;
+            want_onex = true;
+        }
+    }
     if (cplx && 4 * G > 2 * CH_GMAX) return 0;      // grid_sum2: four granules per workgroup
     if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n || (P && P->ld <= n))) return 0;
     const int64_t chunk2 = (int64_t)r2 * CH_BS;
@@ -595,24 +645,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             job.r0 = job.r1 = job.y0 = 0.0;
             job.r2 = 1.0;
         }
-        // symmetric-pattern stencil (offsets -o_m .. -o_1, -1, 0, 1, o_1 .. o_m, every o_i even): aligned 16-byte
-        // loads of x (lanczos.h, ST); anything else takes the scalar gathers and leaves a MINRES job to its own launch
-        bool st = a.xk == V->col(a.col0);
-        {
-            const int mid = a.offs.nd / 2;
-            for (int d_ = 0; d_ < a.offs.nd; ++d_) {
-                const int o_ = a.offs.off[d_];
-                if (d_ == mid) st = st && o_ == 0;
-                else if (d_ == mid - 1) st = st && o_ == -1;
-                else if (d_ == mid + 1) st = st && o_ == 1;
-                else st = st && (o_ & 1) == 0;
-            }
-        }
-        if (!st) job.on = 0;
 #define KH_LZ(R, D)                                                                                             \
-    (st ? (dg != nullptr ? (job.on ? launch_lanczos<R, D, true, true, true>(ctx, G, a, job) : launch_lanczos<R, D, true, false, true>(ctx, G, a, job)) \
-                         : (job.on ? launch_lanczos<R, D, false, true, true>(ctx, G, a, job) : launch_lanczos<R, D, false, false, true>(ctx, G, a, job))) \
-        : (dg != nullptr ? launch_lanczos<R, D, true, false, false>(ctx, G, a, job) : launch_lanczos<R, D, false, false, false>(ctx, G, a, job)))
+    (dg != nullptr ? (job.on ? launch_lanczos<R, D, true, true>(ctx, G, a, job) : launch_lanczos<R, D, true, false>(ctx, G, a, job)) \
+                   : (job.on ? launch_lanczos<R, D, false, true>(ctx, G, a, job) : launch_lanczos<R, D, false, false>(ctx, G, a, job)))
         if (r2 == 40) e = (a.offs.nd == 5) ? KH_LZ(40, 5) : KH_LZ(40, 7);
         else if (r2 == 32) e = (a.offs.nd == 5) ? KH_LZ(32, 5) : KH_LZ(32, 7);
         else if (r2 == 24) e = (a.offs.nd == 5) ? KH_LZ(24, 5) : KH_LZ(24, 7);
@@ -633,6 +668,37 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         (void)hipGetLastError();             // e.g. the dynamic LDS was refused: the general chain kernel below
         if (!presub) a.bprev = nullptr;
     }
+    // short vectors (4 ... 32 workgroups of 4 / 8 rows per lane): a link is its grid-wide sum - all working
+    // workgroups on ONE XCD, where the sum is an L2 round trip (chain.h, ONEX)
+    if (want_onex && !fused) {
+        const unsigned slot_ = (unsigned)(ctx->n_chain_onex & 255);
+        a.onex_G = G;
+        a.onex_target = 0u;
+        a.onex_ticket = ctx->onex_ticket + slot_;
+        a.onex_clear = ctx->onex_ticket + ((slot_ + 128u) & 255u);
+        const bool pf_ = (B == V && dg == nullptr && ctx->chain_pf != 0 && ctx->chain_lds != 0);
+#define KH_OX(R)                                                                                                    \
+    (pf_ ? (cplx ? (padded ? launch_chain_onex<R, false, true, true>(ctx, G, a) : launch_chain_onex<R, true, true, true>(ctx, G, a))     \
+                 : (padded ? launch_chain_onex<R, false, false, true>(ctx, G, a) : launch_chain_onex<R, true, false, true>(ctx, G, a)))  \
+         : (cplx ? (padded ? launch_chain_onex<R, false, true, false>(ctx, G, a) : launch_chain_onex<R, true, true, false>(ctx, G, a))   \
+                 : (padded ? launch_chain_onex<R, false, false, false>(ctx, G, a) : launch_chain_onex<R, true, false, false>(ctx, G, a))))
+        e = (r2 == 4) ? KH_OX(4) : KH_OX(8);
+#undef KH_OX
+        if (e == hipSuccess) {
+            if (a.debug == 4) ctx->chain_fault = 0;
+            ctx->n_chain += 1;
+            ctx->n_chain_onex += 1;
+            ctx->n_chain_lds += pf_ ? 1 : 0;
+            ctx->n_chain_pf += pf_ ? 1 : 0;
+            ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);
+            if (hpin == nullptr)
+                KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+            return 1;
+        }
+        (void)hipGetLastError();
+    }
+    a.onex_G = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (fused) {
 #define KH_FUSED(R, D)                                                                                   \
@@ -853,6 +919,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
     KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
     // XCD-leader hand-off of the chain kernel's grid-wide sums: [16][2][4] result granules + [16] election stamps
     KH_HIP(hipMalloc(&ctx->chain_xcc, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
+    KH_HIP(hipMalloc(&ctx->onex_ticket, sizeof(unsigned) * 256));
+    KH_HIP(hipMemset(ctx->onex_ticket, 0, sizeof(unsigned) * 256));
     KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
     KH_HIP(hipMalloc(&ctx->chain_err, sizeof(int)));
     KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
@@ -870,6 +938,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_PF");
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_ONEX");
+        ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_LANCZOS_FUSED");
         ctx->lanczos_fused = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_ROCTX");
@@ -892,6 +962,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipFree(ctx->cgs_part);
     (void)hipFree(ctx->chain_gran);
     (void)hipFree(ctx->chain_xcc);
+    (void)hipFree(ctx->onex_ticket);
     (void)hipFree(ctx->chain_err);
     for (int s = 0; s < KH_NSLOT; ++s)
         if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
@@ -957,6 +1028,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "spmv_split")) ctx->spmv_split = value != 0;
     else if (!strcmp(key, "halo_loopback")) ctx->halo_loopback = value != 0;
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
+    else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
@@ -977,6 +1049,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "lanczos_fused")) *value = ctx->lanczos_fused;
     else if (!strcmp(key, "n_lanczos_fused")) *value = ctx->n_lanczos_fused;
     else if (!strcmp(key, "n_minres_rides")) *value = ctx->n_minres_rides;
+    else if (!strcmp(key, "chain_onex")) *value = ctx->chain_onex;
+    else if (!strcmp(key, "n_chain_onex")) *value = ctx->n_chain_onex;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);

@@ -46,11 +46,7 @@ struct LanczosShape {
     static constexpr size_t LDS_BYTES = (size_t)(WL + DL) * CH_BS * sizeof(double2);
 };
 
-// ST: the operator is a symmetric-pattern stencil - offsets (-o_m, ..., -o_1, -1, 0, 1, o_1, ..., o_m) with every o_i
-// even (2-D 5-point, 3-D 7-point with even grid lines: what the launcher checks).  The x values of a row pair then
-// come as aligned 16-byte loads for the even offsets and from the centre pair plus its two outer neighbours for +-1:
-// 3 + 2 (5 + 2) load instructions per row pair instead of 10 (14) scalar ones.  Same values, same products, same sums.
-template <int R2, int FND, bool JAC, bool MR, bool ST = false>
+template <int R2, int FND, bool JAC, bool MR>
 __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob mr) {
     constexpr int WL = LanczosShape<R2>::WL;
     constexpr int DL = JAC ? LanczosShape<R2>::DL : 0;
@@ -93,46 +89,19 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             const int64_t row = 2 * i2;
             double2 av[FND];
             double x0[FND], x1[FND];
-            double2 vv;
-            if constexpr (ST) {
-                constexpr int MID = FND / 2;
-                const int64_t last2 = last >> 1;     // index of the last whole pair
 #pragma unroll
-                for (int d = 0; d < FND; ++d)
-                    av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
-#pragma unroll
-                for (int d = 0; d < FND; ++d) {
-                    if (d == MID - 1 || d == MID + 1) continue;
-                    // even offset: the pair (x[row + off], x[row + 1 + off]) is an aligned double2; beyond the ends the
-                    // diagonal has no entry (the product is skipped), any valid address will do
-                    int64_t j2 = i2 + (a.offs.off[d] >> 1);
-                    j2 = j2 < 0 ? 0 : (j2 > last2 ? last2 : j2);
-                    const double2 xv = reinterpret_cast<const double2*>(xk)[j2];
-                    x0[d] = xv.x;
-                    x1[d] = xv.y;
-                }
-                int64_t cl = row - 1, cr = row + 2;
-                cl = cl < 0 ? 0 : cl;
-                cr = cr > last ? last : cr;
-                x0[MID - 1] = xk[cl];                // offset -1: (x[row - 1], x[row])
-                x1[MID - 1] = x0[MID];
-                x0[MID + 1] = x1[MID];               // offset +1: (x[row + 1], x[row + 2])
-                x1[MID + 1] = xk[cr];
-                vv.x = x0[MID];                      // the row pair of v_k itself is the centre pair
-                vv.y = x1[MID];
-            } else {
-#pragma unroll
-                for (int d = 0; d < FND; ++d) {
-                    const int64_t off = a.offs.off[d];
-                    av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
-                    int64_t c0 = row + off, c1 = row + 1 + off;
-                    c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
-                    c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
-                    x0[d] = xk[c0];
-                    x1[d] = xk[c1];
-                }
-                vv = v2[i2];                         // (the line the operator's centre entries came from)
+            for (int d = 0; d < FND; ++d) {
+                const int64_t off = a.offs.off[d];
+                av[d] = ld_nt2(reinterpret_cast<const double2*>(a.dia + (int64_t)d * a.dia_ld) + i2);
+                int64_t c0 = row + off, c1 = row + 1 + off;
+                c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
+                c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
+                x0[d] = xk[c0];
+                x1[d] = xk[c1];
             }
+            // (tried: aligned 16-byte loads of x for the even offsets of a stencil pattern, the +-1 neighbours from the
+            // centre pair - 7 load instructions per row pair instead of 12: pass 1 went from 110 to 127 us, not kept)
+            const double2 vv = v2[i2];               // (the line the operator's centre entries came from)
             const double2 pp = ld_nt2(p2 + i2);
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll

@@ -53,10 +53,12 @@ def _stencil(kind, rng):
         A = sp.diags([rng.uniform(0.5, 1.5, 3 * n - abs(o)) for o in offs], offs, format="csr")
         A.sort_indices()
         return A, n
-    # random pattern inside a band (CSR-stream kernel: no diagonal structure)
-    B = sp.random(3 * n, 3 * n, density=3e-4, random_state=11, format="coo")
-    keep = np.abs(B.row - B.col) < 900
-    A = (sp.coo_matrix((B.data[keep], (B.row[keep], B.col[keep])), shape=B.shape) + sp.identity(3 * n)).tocsr()
+    # random pattern inside a band (CSR-stream kernel: no diagonal structure); about nine entries per row
+    r = np.random.default_rng(11)
+    rows = np.repeat(np.arange(3 * n), 8)
+    cols = np.clip(rows + r.integers(-899, 900, rows.size), 0, 3 * n - 1)
+    A = (sp.coo_matrix((r.standard_normal(rows.size), (rows, cols)), shape=(3 * n, 3 * n)) + sp.identity(3 * n)).tocsr()
+    A.sum_duplicates()
     A.sort_indices()
     return A, n
 

@@ -591,6 +591,67 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
+@pytest.mark.parametrize("n", [14400, 65538, 100000, 210000, 262144])
+def test_short_vectors_run_on_one_xcd(hip, n):
+    """4 ... 32 workgroups: a Gram-Schmidt link is its grid-wide sum.  The ONEX instantiations of the chain kernels put
+    all working workgroups on one XCD, where the sum is an L2 round trip (chain.h).  Same partials, same order of the
+    additions: H and the basis bit for bit as with the workgroups spread over the eight XCDs - plain, double sweep,
+    Jacobi (plain kernel), Lanczos, complex; masked (n < 65536) and padded blocks."""
+    from krypy_amd import _hip
+
+    nx = 100
+    A = ref.laplace2d(nx, n // nx) if n % nx == 0 else _banded(n, (-700, -1, 0, 1, 700), 3)
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal(n)
+    dj = np.linspace(0.5, 1.5, n)
+    Az = (A + 0.3j * sp.diags(rng.standard_normal(n))).tocsr()
+    vz = v + 1j * rng.standard_normal(n)
+    m = 12
+    ctx = _hip.Context(0)
+    out = []
+    for onex in (1, 0):
+        ctx.set("chain_onex", onex)
+        c0 = ctx.get("n_chain_onex")
+        res = {}
+        Ad, Md, Azd = ctx.csr(A), ctx.diag(dj), ctx.csr(Az)
+        for name, use_m, lanczos, cplx in (("mgs", False, False, False), ("jacobi", True, False, False),
+                                           ("lanczos", False, True, False), ("complex", False, False, True)):
+            dt = complex if cplx else float
+            V, W = ctx.alloc(n, m + 1, dtype=dt), ctx.alloc(n, 2, dtype=dt)
+            P = ctx.alloc(n, m + 1) if use_m else None
+            v0 = vz if cplx else v
+            if use_m:
+                nrm = np.sqrt(np.dot(v, dj * v))
+                P.upload(0, v / nrm)
+                V.upload(0, dj * v / nrm)
+            else:
+                V.upload(0, v0 / np.linalg.norm(v0))
+            H = np.zeros((m + 1, m), dtype=dt)
+            for k in range(m):
+                start = k if lanczos else 0
+                hk = float(H[k, k - 1].real) if (lanczos and k > 0) else 0.0
+                hcol = ctx.arnoldi_step(Azd if cplx else Ad, Md if use_m else None, V, P, W, 0, k, start,
+                                        2 if (k == 5 and not lanczos and not cplx) else 1, 0, hk)
+                H[start: k + 2, k] = hcol[start: k + 2]
+            res[name] = (H, V.download())
+        used = ctx.get("n_chain_onex") - c0
+        assert (used > 0) == bool(onex), (onex, used)
+        out.append(res)
+    ctx.close()
+    for name in out[0]:
+        if n * (2 if name == "complex" else 1) <= 131072 and name != "lanczos":      # the same 4 rows per lane either way: the same bits
+            assert np.array_equal(out[0][name][0], out[1][name][0]), name
+            assert np.array_equal(out[0][name][1], out[1][name][1]), name
+        elif name == "lanczos":       # (one link per step: never on one XCD - the same kernel both times)
+            assert np.array_equal(out[0][name][0], out[1][name][0]), name
+            assert np.array_equal(out[0][name][1], out[1][name][1]), name
+        else:                    # 8 rows per lane on <= 32 workgroups against 4 rows on twice as many: other partial sums
+            assert np.linalg.norm(out[0][name][0] - out[1][name][0]) < 1e-12 * np.linalg.norm(out[1][name][0]), name
+            assert np.linalg.norm(out[0][name][1] - out[1][name][1]) < 1e-10, name
+    Hf, Vf = out[0]["mgs"]
+    assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
+
+
 @pytest.mark.parametrize("rows", [8, 16, 24, 32, 40, 48, 56])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_mgs_chain_every_register_shape(hip, rows, cplx):

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(CH_BS) void k_onexcd(int Gw, int links, unsigned lo
             }
         }
         double s;
-        if (vb == 0) {
+        if (MODE == 2 || vb == 0) {
             unsigned mine = 0;
             if (tid < 2 * Gw) {
                 unsigned long long x;
@@ -301,12 +301,13 @@ __global__ __launch_bounds__(CH_BS) void k_onexcd(int Gw, int links, unsigned lo
             s = smd[NW];
 #pragma unroll
             for (int i = 1; i < NW; ++i) s += smd[NW + i];
-            if (tid == 0) {
+            if (MODE != 2 && tid == 0) {
                 const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
                 const unsigned long long tag = (unsigned long long)epoch << 32;
                 rs[0] = tag | (sb & 0xffffffffull);
                 rs[1] = tag | (sb >> 32);
             }
+            if (MODE == 2) __syncthreads();      // smd is reused by the next link's wave sums
         } else {
             s = gs_wait_vec(epoch, rs, err);
         }
@@ -419,6 +420,7 @@ int main() {
         for (int Gw : {4, 13, 25, 32}) {
             run_onexcd<0>(Gw, 4000, d.gran, ticket, d.xcc_res, d.err, d.epoch, d.out);
             run_onexcd<1>(Gw, 4000, d.gran, ticket, d.xcc_res, d.err, d.epoch, d.out);
+            run_onexcd<2>(Gw, 4000, d.gran, ticket, d.xcc_res, d.err, d.epoch, d.out);
             run_overlap<0, 0, 0>(d, Gw, 4000);       // the library's sum, workgroups on all XCDs
         }
         return 0;
