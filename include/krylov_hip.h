@@ -208,6 +208,26 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                           double h_km1, int slot);
 int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out);
 
+/* A run of GMRES iterations in ONE call (krypy/linsys.py:951-997; SURVEY 8b "fused cycle"): Arnoldi steps
+ * k0 .. k_stop-1 with look-ahead on the device (kh_arnoldi_step_begin / _end, slots k mod 4), and on the host - in C,
+ * not in the caller's interpreter - what the reference does between two steps: the new Hessenberg column through the
+ * previous Givens rotations and its own (BLAS drotg convention), R, the rotated right-hand side y and the residual
+ * recurrence |y[k+1]|.  H and R are (ldh = ldr >= k_stop) row-major like the reference's arrays; cs holds (c, s) per
+ * step; *h2_io the running squared Frobenius norm of H; *enq_io the number of steps begun on the device (in: steps the
+ * caller has already begun, out: k_done + what is still in flight - at most step k_last is ever begun).
+ * Stops  KH_CYCLE_TOL    after the step whose |y[k+1]| / bnorm <= tol (that step IS recorded),
+ *        KH_CYCLE_CHECK  at a step whose H[k+1,k] / ||H||_F is not > 1e-14: maybe an invariant subspace - the step is
+ *                        NOT recorded (its column stays in its slot for kh_arnoldi_step_end), the caller decides,
+ *        KH_CYCLE_LIMIT  at k_stop.
+ * *k_done = number of recorded steps (counted from 0). */
+#define KH_CYCLE_LIMIT 0
+#define KH_CYCLE_TOL 1
+#define KH_CYCLE_CHECK 2
+int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
+                   int64_t k_last, int sweeps, int gs_mode, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
+                   double* R, int64_t ldr, double* cs, double* y, double* h2_io, double* resn, int64_t* k_done,
+                   int* reason);
+
 /* r = b - A x fused with its squared norm: R[:, rcol] = B[:, bcol] - A X[:, xcol]; *nrm = ||r||_2
  * (LinearSystem.get_residual linsys.py:156-160 for M = Ml = identity) */
 int kh_residual(kh_ctx ctx, kh_mat A, kh_vec B, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,

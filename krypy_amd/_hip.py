@@ -31,6 +31,8 @@ _INT = ctypes.c_int
 
 # sanity word of the fused CG step (KH_CG_* of include/krylov_hip.h)
 CG_NONFINITE_PAP, CG_NONPOSITIVE_PAP, CG_NONFINITE_RHO, CG_NEGATIVE_RHO = 1, 2, 4, 8
+# stop reasons of kh_gmres_cycle (KH_CYCLE_* of the header)
+CYCLE_LIMIT, CYCLE_TOL, CYCLE_CHECK = 0, 1, 2
 
 
 class BackendError(RuntimeError):
@@ -92,6 +94,9 @@ _SIGNATURES = {
     "kh_proj_apply_complement": [_H, _H, _H, _I64, _H, _I64, _c_double_p],
     "kh_arnoldi_step_end": [_H, _INT, _I64, _c_double_p],
     "kh_residual": [_H, _H, _H, _I64, _H, _I64, _H, _I64, _c_double_p],
+    "kh_gmres_cycle": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_int64_p, _D, _D, _c_double_p, _I64,
+                       _c_double_p, _I64, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_int64_p,
+                       ctypes.POINTER(ctypes.c_int)],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_minres_update_deferred": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_minres_flush": [_H],
@@ -758,6 +763,25 @@ class Context(object):
             return
         _check(self._lib, self._lib.kh_minres_update(self._h, V.handle, k, Wk.handle, slot, r0, r1,
                                                      r2, y0, YK.handle, ycol), "kh_minres_update")
+
+    def gmres_cycle(self, A, Md, V, P, W, k0, k_stop, k_last, sweeps, gs_mode, enq, tol, bnorm, H, R, cs, y, h2, resn):
+        """Steps ``k0 .. k_stop-1`` of a GMRES cycle in one call (``kh_gmres_cycle``): Arnoldi with look-ahead on the
+        device, Givens QR / residual recurrence on the host in C.  ``H``, ``R``: C-ordered float64 2-D arrays of the
+        solver, ``cs`` (2 per step), ``y``, ``resn``: float64 1-D arrays, all updated in place.  Returns
+        ``(k_done, enq, h2, reason)``."""
+        for a in (H, R, cs, y, resn):
+            if a.dtype != numpy.float64 or not a.flags.c_contiguous:
+                raise BackendError("gmres_cycle: C-ordered float64 arrays needed")
+        enq_ = ctypes.c_int64(int(enq))
+        h2_ = _D(float(h2))
+        kd = ctypes.c_int64(0)
+        why = ctypes.c_int(0)
+        _check(self._lib, self._lib.kh_gmres_cycle(
+            self._h, A.handle, Md.handle if Md is not None else None, V.handle, P.handle if P is not None else None,
+            W.handle, k0, k_stop, k_last, sweeps, gs_mode, ctypes.byref(enq_), float(tol), float(bnorm), _dptr(H), H.shape[1],
+            _dptr(R), R.shape[1], _dptr(cs), _dptr(y), ctypes.byref(h2_), _dptr(resn), ctypes.byref(kd),
+            ctypes.byref(why)), "kh_gmres_cycle")
+        return kd.value, enq_.value, h2_.value, why.value
 
     def minres_flush(self):
         """Run a deferred MINRES update now (``kh_minres_flush``)."""

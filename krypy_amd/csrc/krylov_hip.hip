@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <vector>
 
 #include "kernels.h"
@@ -449,6 +450,28 @@ static hipError_t launch_chain_onex(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// ... with the banded operator in the prologue (no SpMV launch in front of the step)
+template <int R2, int FND, bool PF>
+static hipError_t launch_chain_onex_fused(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = PF ? ChainShapePf<R2>::LDS_BYTES : 0;
+    auto kern = PF ? k_mgs_chain_pf<R2, false, false, FND, true> : k_mgs_chain<R2, false, false, FND, 0, true>;
+    if (blocks_per_cu < 0) {
+        if (lds > 0) {
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e0 != hipSuccess) return e0;
+        }
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * (ctx->ncu / 8) < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(kern, dim3(8 * G + 8), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
 // one Lanczos step in three passes (lanczos.h)
 template <int R2, int FND, bool JAC, bool MR>
 static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJob& mr) {
@@ -531,7 +554,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // there (chain.h, ONEX) - the sum is the whole link.  (One or two links - Lanczos, the first Arnoldi steps - do
     // not pay for the larger grid: MINRES + Jacobi at N = 10^5 32,400 vs 27,400 it/s.)
     bool want_onex = false;
-    if (Afuse == nullptr && (k - start + 1) * sweeps >= 3 && (ctx->chain_debug == 0) && ctx->onex_ticket != nullptr) {
+    if ((k - start + 1) * sweeps >= 3 && (ctx->chain_debug == 0) && ctx->onex_ticket != nullptr) {
         int r2x = 0, Gx = 0;
         if (chain_geometry(ctx, n, &r2x, &Gx, true)) {
             r2 = r2x;
@@ -598,7 +621,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && r2 >= 16 && r2 <= 40 && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex) && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -670,7 +693,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     }
     // short vectors (4 ... 32 workgroups of 4 / 8 rows per lane): a link is its grid-wide sum - all working
     // workgroups on ONE XCD, where the sum is an L2 round trip (chain.h, ONEX)
-    if (want_onex && !fused) {
+    if (want_onex) {
         const unsigned slot_ = (unsigned)(ctx->n_chain_onex & 255);
         a.onex_G = G;
         a.onex_target = 0u;
@@ -682,12 +705,17 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                  : (padded ? launch_chain_onex<R, false, false, true>(ctx, G, a) : launch_chain_onex<R, true, false, true>(ctx, G, a)))  \
          : (cplx ? (padded ? launch_chain_onex<R, false, true, false>(ctx, G, a) : launch_chain_onex<R, true, true, false>(ctx, G, a))   \
                  : (padded ? launch_chain_onex<R, false, false, false>(ctx, G, a) : launch_chain_onex<R, true, false, false>(ctx, G, a))))
-        e = (r2 == 4) ? KH_OX(4) : KH_OX(8);
+#define KH_OXF(R) (pf_ ? (a.offs.nd == 5 ? launch_chain_onex_fused<R, 5, true>(ctx, G, a) : launch_chain_onex_fused<R, 7, true>(ctx, G, a)) \
+                      : (a.offs.nd == 5 ? launch_chain_onex_fused<R, 5, false>(ctx, G, a) : launch_chain_onex_fused<R, 7, false>(ctx, G, a)))
+        if (fused) e = (r2 == 4) ? KH_OXF(4) : KH_OXF(8);
+        else e = (r2 == 4) ? KH_OX(4) : KH_OX(8);
+#undef KH_OXF
 #undef KH_OX
         if (e == hipSuccess) {
             if (a.debug == 4) ctx->chain_fault = 0;
             ctx->n_chain += 1;
             ctx->n_chain_onex += 1;
+            ctx->n_chain_fused += fused ? 1 : 0;
             ctx->n_chain_lds += pf_ ? 1 : 0;
             ctx->n_chain_pf += pf_ ? 1 : 0;
             ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);
@@ -1051,6 +1079,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_minres_rides")) *value = ctx->n_minres_rides;
     else if (!strcmp(key, "chain_onex")) *value = ctx->chain_onex;
     else if (!strcmp(key, "n_chain_onex")) *value = ctx->n_chain_onex;
+    else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
@@ -2071,6 +2100,92 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
     KH_ARG(hcol_out != nullptr, "kh_arnoldi_step: NULL argument");
     KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1, 0));
     return kh_arnoldi_step_end(ctx, 0, k + 2, hcol_out);
+}
+
+// BLAS drotg (reference implementation): c, s with [c s; -s c] [a; b] = [r; 0]
+static inline void host_drotg(double a, double b, double* c, double* s) {
+    const double roe = std::fabs(a) > std::fabs(b) ? a : b;
+    const double scale = std::fabs(a) + std::fabs(b);
+    if (scale == 0.0) {
+        *c = 1.0;
+        *s = 0.0;
+        return;
+    }
+    double r = scale * std::sqrt((a / scale) * (a / scale) + (b / scale) * (b / scale));
+    if (roe < 0.0) r = -r;
+    *c = a / r;
+    *s = b / r;
+}
+
+int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
+                   int64_t k_last, int sweeps, int gs_mode, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
+                   double* R, int64_t ldr, double* cs, double* y, double* h2_io, double* resn, int64_t* k_done,
+                   int* reason) {
+    KH_ARG(ctx && A && V && W && enq_io && H && R && cs && y && h2_io && resn && k_done && reason, "kh_gmres_cycle: NULL");
+    KH_ARG(k0 >= 0 && k0 <= k_stop && k_stop <= k_last + 1 && k_last + 2 <= V->ncols, "kh_gmres_cycle: steps [%lld, %lld), last %lld, %lld basis columns",
+           (long long)k0, (long long)k_stop, (long long)k_last, (long long)V->ncols);
+    KH_ARG(*enq_io >= k0 && *enq_io <= k0 + KH_NSLOT - 1, "kh_gmres_cycle: %lld steps in flight", (long long)(*enq_io - k0));
+    KH_ARG(ldh >= k_stop && ldr >= k_stop, "kh_gmres_cycle: leading dimensions");
+    RoctxScope range_(ctx, "kh_gmres_cycle");
+    int64_t enq = *enq_io;
+    double h2 = *h2_io;
+    *reason = KH_CYCLE_LIMIT;
+    int64_t k = k0;
+    std::vector<double> col((size_t)k_stop + 2);
+    for (; k < k_stop; ++k) {
+        // look-ahead: step k + 1 depends on device data only - it is enqueued before the host waits for step k
+        const int64_t last = std::min<int64_t>(k + 1, k_last);
+        while (enq <= last) {
+            KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, 0, enq, 0, sweeps, gs_mode, 0.0, (int)(enq % KH_NSLOT)));
+            ++enq;
+        }
+        KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), k + 2, col.data()));
+        const double hn = col[(size_t)k + 1];
+        // invariance pre-test of the host layer (utils.py:1035-1039 through the Frobenius norm): when it does not
+        // clear the step, the caller decides - the column stays in its slot, nothing of it is recorded here
+        double c2 = 0.0;
+        for (int64_t i = 0; i <= k + 1; ++i) c2 += col[(size_t)i] * col[(size_t)i];
+        const double fro = std::sqrt(h2 + c2);
+        if (!(fro > 0.0) || !(hn / fro > 1e-14) || !std::isfinite(fro)) {
+            *reason = KH_CYCLE_CHECK;
+            break;
+        }
+        h2 += c2;
+        for (int64_t i = 0; i <= k + 1; ++i) H[i * ldh + k] = col[(size_t)i];
+        // the new column through the previous rotations, then its own (linsys.py:980-991)
+        for (int64_t i = 0; i < k; ++i) {
+            const double c = cs[2 * i], s = cs[2 * i + 1];
+            const double t0 = col[(size_t)i], t1 = col[(size_t)i + 1];
+            col[(size_t)i] = c * t0 + s * t1;
+            col[(size_t)i + 1] = -s * t0 + c * t1;
+        }
+        double c, s;
+        host_drotg(col[(size_t)k], col[(size_t)k + 1], &c, &s);
+        cs[2 * k] = c;
+        cs[2 * k + 1] = s;
+        {
+            const double t0 = col[(size_t)k], t1 = col[(size_t)k + 1];
+            col[(size_t)k] = c * t0 + s * t1;
+            col[(size_t)k + 1] = -s * t0 + c * t1;
+        }
+        for (int64_t i = 0; i <= k + 1; ++i) R[i * ldr + k] = col[(size_t)i];
+        {
+            const double t0 = y[k], t1 = y[k + 1];
+            y[k] = c * t0 + s * t1;
+            y[k + 1] = -s * t0 + c * t1;
+        }
+        resn[k] = std::fabs(y[k + 1]);
+        if (!(resn[k] / bnorm > tol)) {      // the caller's own test, linsys.py:476 (also a nan: its loop sees it)
+            ++k;
+            *reason = KH_CYCLE_TOL;
+            break;
+        }
+    }
+    *k_done = k;
+    *enq_io = enq;
+    *h2_io = h2;
+    ctx->n_cycle_steps += k - k0;
+    return 0;
 }
 
 int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,

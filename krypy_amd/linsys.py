@@ -731,8 +731,19 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
         y[0] = self.MMlr0_norm
         R = self.R
 
+        # The iterations whose bookkeeping is a single append - no explicit residual, no error norm, not the last one -
+        # run in ONE C call each time round: Arnoldi steps with look-ahead on the device, Givens QR and the residual
+        # recurrence in C instead of in this interpreter (kh_gmres_cycle; what the per-step loop below does, minus
+        # 30-40 us of Python per step - at N <= 10^5 that is the larger part of an iteration).  The call stops after the
+        # step that reaches the tolerance (finalised below like any other), at a step that may have found an
+        # invariant subspace (decided by Arnoldi.advance below) and before the last iteration.
+        cyc = self._cycle_state(cs, y)
         while (self.resnorms[-1] > self.tol and self.arnoldi.iter < self.arnoldi.maxiter
                and not self.arnoldi.invariant):
+            if cyc is not None and self.arnoldi.iter + 1 < self.arnoldi.maxiter:
+                done = self._run_cycle(cyc, cs, y)
+                if done:
+                    continue
             k = self.iter = self.arnoldi.iter
             self.arnoldi.advance()
             # new Hessenberg column through the previous rotations (linsys.py:980-991); plain
@@ -757,6 +768,63 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
 
         if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(y[: self.arnoldi.iter])
+
+    def _cycle_state(self, cs, y):
+        """Scratch of the C cycle, or None when this solve is not eligible: real data, Euclidean inner product, the
+        fused step on a plain device matrix (Jacobi M allowed), whole basis allocated, and nothing but the residual
+        recurrence to record per iteration."""
+        ar = self.arnoldi
+        ctx = self._ctx
+        if (os.environ.get("KRYPY_AMD_GMRES_CYCLE", "1") == "0" or not hasattr(ctx, "gmres_cycle")
+                or not (ar._fused and ar._lookahead == 1 and ar._Amat is not None and ar._proj is None)
+                or ar._cplx or self.R.dtype != numpy.float64 or ar.H.dtype != numpy.float64 or ar._win
+                or ar.ortho not in ("mgs", "dmgs", "cgs", "cgs2") or ar._BV is not None
+                or self.explicit_residual or self.linear_system.exact_solution is not None
+                or type(self)._finalize_iteration is not _KrylovSolver._finalize_iteration      # (a subclass watches every step)
+                or ar._cols < ar.maxiter + 1 or ar._base != 0 or ar.maxiter < 3
+                or not (ar.H.flags.c_contiguous and self.R.flags.c_contiguous)):
+            return None
+        m = ar.maxiter
+        return dict(cs=numpy.zeros(2 * m), y=numpy.zeros(m + 1), resn=numpy.zeros(m))
+
+    def _run_cycle(self, cyc, cs, y):
+        """One kh_gmres_cycle call from the current iteration on; returns True when at least one iteration was
+        recorded (the caller re-tests its loop condition)."""
+        ar = self.arnoldi
+        ctx = self._ctx
+        k0 = ar.iter
+        m = ar.maxiter
+        for i in range(len(cs)):                       # rotations so far (the per-step path may have produced some)
+            cyc["cs"][2 * i], cyc["cs"][2 * i + 1] = cs[i]
+        cyc["y"][: k0 + 2] = y[: k0 + 2, 0]
+        for sl in range(4):
+            ar._claim(sl)
+        bnorm = self.linear_system.MMlb_norm
+        k_done, enq, h2, why = ctx.gmres_cycle(
+            ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, m - 1, m - 1, ar._sweeps, ar._gs_mode, max(ar._enq, k0),
+            float(self.tol), float(bnorm), ar.H, self.R, cyc["cs"], cyc["y"], ar._h2, cyc["resn"])
+        ar._enq, ar._h2 = enq, h2
+        in_flight = {j % 4 for j in range(k_done, enq)}       # (their slots stay claimed until advance() / _settle())
+        for sl in range(4):
+            if sl not in in_flight:
+                ar._release(sl)
+        if k_done == k0:
+            return False                                # (an invariance check is due: the per-step path takes it)
+        for i in range(len(cs), k_done):
+            cs.append((float(cyc["cs"][2 * i]), float(cyc["cs"][2 * i + 1])))
+        y[: k_done + 1, 0] = cyc["y"][: k_done + 1]
+        ar.iter = k_done
+        # every recorded iteration but (possibly) the last is a plain append (linsys.py:476-477)
+        last_plain = k_done if why != _hip.CYCLE_TOL else k_done - 1
+        for i in range(k0, last_plain):
+            self.resnorms.append(float(cyc["resn"][i]) / bnorm)
+        self.iter = k_done - 1
+        if why == _hip.CYCLE_TOL:
+            self.xk = None
+            self._finalize_iteration(y[: k_done], float(cyc["resn"][k_done - 1]))
+        else:
+            self.xk = None
+        return True
 
     def _finalize(self):
         super(Gmres, self)._finalize()

@@ -101,7 +101,7 @@ def test_csr_spmv_bit_identical_to_scipy(hip, kind):
     if kind == "lap2d":
         A = ref.laplace2d(97, 53)
     elif kind == "random":
-        A = sp.random(20000, 20000, density=2e-3, random_state=3, format="csr")
+        A = _random_csr(20000, 20000, 40, 3)
     elif kind == "empty_rows":
         A = sp.random(5000, 5000, density=1e-3, random_state=4, format="csr")
         A = sp.vstack([A[:100], sp.csr_matrix((300, 5000)), A[400:]]).tocsr()
@@ -182,7 +182,7 @@ def test_csr_panel_apply_streams_the_matrix_once(hip, kind, d):
     if kind.startswith("lap2d"):
         A = ref.laplace2d(301, 97)
     elif kind == "random":
-        A = sp.random(30011, 30011, density=1e-3, random_state=8, format="csr")
+        A = _random_csr(30011, 30011, 30, 8)
     else:
         A = sp.random(300, 40000, density=1e-3, random_state=5, format="lil")
         A[11, :] = rng.standard_normal(40000)
@@ -207,6 +207,19 @@ def test_csr_panel_apply_streams_the_matrix_once(hip, kind, d):
         assert np.allclose(got[11], want[11], rtol=1e-12)   # tree-reduced row: not bit-ordered
     else:
         assert np.array_equal(got, want)
+
+
+def _random_csr(n_rows, n_cols, per_row, seed):
+    """About `per_row` random entries per row, sorted, no duplicates (scipy.sparse.random draws without replacement
+    from n_rows * n_cols positions: half a minute at 30,000^2)."""
+    r = np.random.default_rng(seed)
+    rows = np.repeat(np.arange(n_rows), per_row)
+    cols = r.integers(0, n_cols, rows.size)
+    A = sp.coo_matrix((r.standard_normal(rows.size), (rows, cols)), shape=(n_rows, n_cols)).tocsr()
+    A.sum_duplicates()
+    A.eliminate_zeros()
+    A.sort_indices()
+    return A
 
 
 def _banded(n, offsets, seed, holes=0.0):
@@ -591,6 +604,73 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
+def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
+    """kh_gmres_cycle (Arnoldi steps with look-ahead on the device, Givens QR and the residual recurrence on the host
+    in C: linsys.py:951-997 in one call) against the per-step Python loop (KRYPY_AMD_GMRES_CYCLE=0): same iteration
+    counts, same residual histories, same H / R / iterate - converging solves (the call stops at the tolerance), an
+    exhausted maxiter (the last iteration is the Python loop's), restarts, Jacobi, the panel Gram-Schmidt, and a solve
+    that finds an invariant subspace (the C loop hands that step back)."""
+    from oracle.inputs import toy_system
+
+    A, b = lap2d_system(70, rhs="rng1")
+    d = A.diagonal()
+    M = sp.diags(1.0 / d).tocsr()
+    At, bt = toy_system()[:2]
+    cases = [("converge", lambda: linsys.Gmres(linsys.LinearSystem(A, b), tol=1e-9, maxiter=400, store_arnoldi=True)),
+             ("jacobi cgs2", lambda: linsys.Gmres(linsys.LinearSystem(A, b, M=M), tol=1e-9, maxiter=400, ortho="cgs2")),
+             ("maxiter", lambda: linsys.Gmres(linsys.LinearSystem(A, b), tol=1e-12, maxiter=30)),
+             ("restarted", lambda: linsys.RestartedGmres(linsys.LinearSystem(A, b), tol=1e-8, maxiter=25, max_restarts=40)),
+             ("invariant", lambda: linsys.Gmres(linsys.LinearSystem(sp.diags(np.r_[np.ones(50), 2 * np.ones(50)]).tocsr(),
+                                                                    np.ones(100)), tol=1e-12, maxiter=50)),
+             ("toy", lambda: linsys.Gmres(linsys.LinearSystem(At, bt), tol=1e-5))]
+
+    def run(make):
+        try:
+            return make(), False
+        except utils.ConvergenceError as e:
+            return e.solver, True
+
+    for name, make in cases:
+        c0 = hip.get("n_cycle_steps")
+        s1, f1 = run(make)
+        used = hip.get("n_cycle_steps") - c0
+        monkeypatch.setenv("KRYPY_AMD_GMRES_CYCLE", "0")
+        c1 = hip.get("n_cycle_steps")
+        s0, f0 = run(make)
+        assert hip.get("n_cycle_steps") == c1
+        monkeypatch.delenv("KRYPY_AMD_GMRES_CYCLE")
+        assert used > 0, name
+        assert f1 == f0 and len(s1.resnorms) == len(s0.resnorms), (name, len(s1.resnorms), len(s0.resnorms))
+        r1, r0 = np.array(s1.resnorms), np.array(s0.resnorms)
+        if name == "restarted":      # open loop over restarts: last-bit differences of the two Givens generators grow
+            assert np.max(np.abs(r1[:26] - r0[:26]) / r0[:26]) < 1e-11, name       # (SURVEY 0); the first cycle is tight
+            assert np.max(np.abs(r1[:-1] - r0[:-1]) / r0[:-1]) < 1e-6, name
+            assert np.linalg.norm(s1.xk - s0.xk) <= 1e-7 * np.linalg.norm(s0.xk), name
+            continue
+        assert np.max(np.abs(r1[:-1] - r0[:-1]) / r0[:-1]) < 1e-11, name
+        assert np.linalg.norm(s1.xk - s0.xk) <= 1e-10 * np.linalg.norm(s0.xk), name
+        if hasattr(s1, "R") and hasattr(s0, "R"):
+            k = len(r1) - 1
+            assert np.linalg.norm(s1.R[:k, :k] - s0.R[:k, :k]) <= 1e-12 * np.linalg.norm(s0.R[:k, :k]), name
+        if name == "converge":
+            assert np.linalg.norm(s1.H - s0.H) <= 1e-12 * np.linalg.norm(s0.H)
+            assert np.linalg.norm(s1.V - s0.V) <= 1e-10
+        if name == "invariant":
+            assert s1.arnoldi.invariant and s0.arnoldi.invariant and len(r1) == 3
+    # a timeout of the chain kernel's reduction inside the C loop: the step is re-run on the per-column kernels by
+    # kh_arnoldi_step_end, the look-ahead step behind it too - same solve
+    try:
+        good, _ = run(cases[0][1])
+        before = hip.get("n_chain_recovered")
+        hip.set("chain_fault", 1)
+        bad, _ = run(cases[0][1])
+        assert hip.get("n_chain_recovered") > before
+    finally:
+        hip.set("chain", 1)
+    assert len(bad.resnorms) == len(good.resnorms)
+    assert np.max(np.abs(np.array(bad.resnorms[:-1]) - np.array(good.resnorms[:-1])) / np.array(good.resnorms[:-1])) < 1e-9
+
+
 @pytest.mark.parametrize("n", [14400, 65538, 100000, 210000, 262144])
 def test_short_vectors_run_on_one_xcd(hip, n):
     """4 ... 32 workgroups: a Gram-Schmidt link is its grid-wide sum.  The ONEX instantiations of the chain kernels put
@@ -871,6 +951,7 @@ def test_abi_fuzz_random_calls_against_numpy(hip):
         total += abi_fuzz.one_round(hip, seed, 200_000)
         total += abi_fuzz.step_round(hip, dbl, seed, 200_000)
         total += abi_fuzz.shard_round(hip, seed)      # block-row shards with hand-written ghost entries, bit for bit
+        total += abi_fuzz.cycle_round(hip, dbl, seed)  # kh_gmres_cycle against step-by-step + NumPy Givens, deferred MINRES update
     assert total > 1000
 
 

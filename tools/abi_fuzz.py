@@ -238,6 +238,103 @@ def step_round(ctx, dbl, seed, max_n):
     return checks
 
 
+def cycle_round(ctx, dbl, seed):
+    """kh_gmres_cycle (a run of GMRES iterations in one C call) against the same steps taken one at a time on the NumPy
+    double with the Givens recurrences in NumPy (krypy/linsys.py:980-997), and the deferred MINRES update + flush against
+    the immediate one (bit for bit)."""
+    rng = np.random.default_rng(130_000 + seed)
+    n = int(rng.integers(30, 40_000))
+    m = int(rng.integers(3, 14))
+    offs = sorted({0, 1, -1} | {int(o) for o in rng.integers(-min(n - 1, 300), min(n - 1, 300) + 1, size=2)})
+    A = sp.diags([rng.standard_normal(n - abs(o)) + (5.0 if o == 0 else 0.0) for o in offs], offs, shape=(n, n), format="csr")
+    with_m = bool(rng.integers(0, 2))
+    d = rng.uniform(0.5, 2.0, n)
+    v = rng.standard_normal(n)
+    gs, sweeps = [(0, 1), (0, 2), (1, 1), (1, 2)][rng.integers(0, 4)]
+    tol, bnorm = float(10.0 ** rng.uniform(-9, -1)), float(rng.uniform(0.5, 2.0))
+    checks = 0
+    if not hasattr(ctx, "gmres_cycle"):
+        return 0
+    # device: one call
+    Vd, Wd = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+    Pd = ctx.alloc(n, m + 1) if with_m else None
+    Md = ctx.diag(d) if with_m else None
+    nrm = np.sqrt(np.dot(v, d * v)) if with_m else np.linalg.norm(v)
+    if with_m:
+        Pd.upload(0, (v / nrm).reshape(-1, 1))
+        Vd.upload(0, (d * v / nrm).reshape(-1, 1))
+    else:
+        Vd.upload(0, (v / nrm).reshape(-1, 1))
+    H, R = np.zeros((m + 1, m)), np.zeros((m + 1, m))
+    cs, y, resn = np.zeros(2 * m), np.zeros(m + 1), np.zeros(m)
+    y[0] = nrm
+    k_done, enq, h2, why = ctx.gmres_cycle(ctx.csr(A), Md, Vd, Pd, Wd, 0, m - 1, m - 1, sweeps, gs, 0, tol, bnorm, H, R, cs,
+                                            y, 0.0, resn)
+    for j in range(k_done, enq):            # speculative steps: fetched and dropped
+        ctx.arnoldi_step_end(j % 4, j + 2)
+    # double: the same steps one at a time
+    V2, W2 = dbl.alloc(n, m + 1), dbl.alloc(n, 2)
+    P2 = dbl.alloc(n, m + 1) if with_m else None
+    M2 = dbl.diag(d) if with_m else None
+    if with_m:
+        P2.upload(0, (v / nrm).reshape(-1, 1))
+        V2.upload(0, (d * v / nrm).reshape(-1, 1))
+    else:
+        V2.upload(0, (v / nrm).reshape(-1, 1))
+    A2 = dbl.csr(A)
+    H2, R2, y2, rot, res2 = np.zeros((m + 1, m)), np.zeros((m + 1, m)), np.zeros(m + 1), [], []
+    y2[0] = nrm
+    kk = 0
+    stop = 0
+    for k in range(m - 1):
+        col = np.array(dbl.arnoldi_step(A2, M2, V2, P2, W2, 0, k, 0, sweeps, gs, 0.0), dtype=float)
+        H2[: k + 2, k] = col
+        for i, (c, s_) in enumerate(rot):
+            col[i], col[i + 1] = c * col[i] + s_ * col[i + 1], -s_ * col[i] + c * col[i + 1]
+        a_, b_ = col[k], col[k + 1]
+        r_ = np.hypot(a_, b_) * (1.0 if (a_ if abs(a_) > abs(b_) else b_) >= 0 else -1.0)
+        c, s_ = (1.0, 0.0) if r_ == 0 else (a_ / r_, b_ / r_)
+        rot.append((c, s_))
+        col[k], col[k + 1] = c * a_ + s_ * b_, -s_ * a_ + c * b_
+        R2[: k + 2, k] = col
+        y2[k], y2[k + 1] = c * y2[k] + s_ * y2[k + 1], -s_ * y2[k] + c * y2[k + 1]
+        kk = k + 1
+        res2.append(abs(y2[k + 1]))
+        if not (abs(y2[k + 1]) / bnorm > tol):
+            stop = 1
+            break
+
+    def expect(name, got, want, rtol=1e-10):
+        nonlocal checks
+        checks += 1
+        got, want = np.asarray(got), np.asarray(want)
+        scale = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+        if got.shape != want.shape or not np.allclose(got, want, rtol=rtol, atol=rtol * scale):
+            raise AssertionError("seed %d (n=%d, m=%d, gs=%d x %d%s): gmres_cycle %s deviates" % (
+                seed, n, m, gs, sweeps, ", Jacobi" if with_m else "", name))
+
+    expect("number of recorded steps / stop reason", [k_done, why], [kk, stop])
+    expect("H", H[:, :kk], H2[:, :kk])
+    expect("R", R[:, :kk], R2[:, :kk])
+    expect("y", y[: kk + 1], y2[: kk + 1])
+    expect("residual recurrence", resn[:kk], res2)
+    expect("basis", Vd.download(0, kk + 1), V2.download(0, kk + 1))
+    # deferred MINRES update + flush == the immediate update
+    Vm, Wm, ym = rng.standard_normal((n, 2)), rng.standard_normal((n, 2)), rng.standard_normal((n, 1))
+    co = [float(x) for x in rng.standard_normal(4)]
+    co[2] += 3.0
+    outs = []
+    for defer in (True, False):
+        Vx, Wx, Yx = ctx.upload(Vm), ctx.upload(Wm), ctx.upload(ym)
+        ctx.minres_update(Vx, 1, Wx, 1, co[0], co[1], co[2], co[3], Yx, 0, defer=defer)
+        ctx.minres_flush()
+        outs.append((Wx.download(), Yx.download()))
+    checks += 1
+    if not (np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])):
+        raise AssertionError("seed %d: deferred MINRES update differs from the immediate one" % seed)
+    return checks
+
+
 def shard_round(ctx, seed):
     """Block-row shards on one device: a random banded / scattered matrix cut into random uneven slabs, ghost
     entries written by hand (kh_mat_set_ghost) instead of the halo exchange - every slab must reproduce its rows of
@@ -276,7 +373,10 @@ def shard_round(ctx, seed):
         ctx.set_halo(Ad, 0, 0, nrp, nrn)
         X, Y = ctx.upload(x[r0:r1]), ctx.alloc(r1 - r0, d, dtype=dt)
         for c in range(d):        # (the ghost buffer holds one vector's halo: a block is applied column by column)
-            ctx.set_ghost(Ad, np.concatenate([x[r0 - nrp:r0, c], x[r1:r1 + nrn, c]]))
+            gh = np.concatenate([x[r0 - nrp:r0, c], x[r1:r1 + nrn, c]])
+            ctx.set_ghost(Ad, gh)
+            if hasattr(ctx, "get_ghost") and not np.array_equal(ctx.get_ghost(Ad, nrp + nrn), gh):
+                raise AssertionError("seed %d: kh_mat_get_ghost does not return what kh_mat_set_ghost wrote" % seed)
             ctx.apply(Ad, X, c, Y, c, 1)
         got = Y.download()
         checks += 1
@@ -303,4 +403,5 @@ if __name__ == "__main__":
         total += one_round(ctx, seed, max_n)
         total += step_round(ctx, dbl, seed, max_n)
         total += shard_round(ctx, seed)
+        total += cycle_round(ctx, dbl, seed)
     print("abi_fuzz: %d rounds, %d comparisons, all within tolerance" % (rounds, total))

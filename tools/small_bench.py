@@ -35,8 +35,11 @@ def one(nx):
         ctx.sync()
         dt = time.perf_counter() - t0
         out.append("%s %.0f it/s" % (name, (len(s2.resnorms) - 1) / dt))
-    print("N = %7d, onex = %s (%d one-XCD launches): %s" % (A.shape[0], os.environ.get("KRYPY_AMD_CHAIN_ONEX", "1"),
-                                                          ctx.get("n_chain_onex"), ", ".join(out)), flush=True)
+    c = ctx.counters()
+    print("N = %7d, onex = %s (%d one-XCD launches, %d chain launches of which %d with the operator in the prologue, %d "
+          "iterations through kh_gmres_cycle): %s" % (A.shape[0], os.environ.get("KRYPY_AMD_CHAIN_ONEX", "1"),
+                                                      ctx.get("n_chain_onex"), c["chain"], c["chain_fused"],
+                                                      ctx.get("n_cycle_steps"), ", ".join(out)), flush=True)
 
 
 if __name__ == "__main__":
