@@ -632,34 +632,35 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
         def rot(G, u, v):      # [[c, s], [-conj(s), c]] (utils.py:430)
             return G[0] * u + G[1] * v, -G[1].conjugate() * u + G[0] * v
 
-        while (self.resnorms[-1] > self.tol and self.lanczos.iter < self.lanczos.maxiter
-               and not self.lanczos.invariant):
-            k = self.iter = self.lanczos.iter
-            self.lanczos.advance()
-            H = self.lanczos.H
-            # QR update of the Lanczos matrix (linsys.py:826-841), scalars only
-            R0 = 0.0
-            R1 = H[k - 1, k].item()   # k == 0 reads H[-1, 0] like the reference: zero
-            if G1 is not None:
-                R0, R1 = rot(G1, R0, R1)
-            R2, R3 = H[k, k].item(), H[k + 1, k].item()
-            if G2 is not None:
-                R1, R2 = rot(G2, R1, R2)
-            G1 = G2
-            g = utils.Givens(numpy.array([[R2], [R3]]))
-            G2 = (_pyscalar(g.c), _pyscalar(g.s))
-            R2 = _pyscalar(g.r)
-            y = list(rot(G2, y[0], y[1]))
-            # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
-            # (deferred: the next Lanczos launch carries the update in the shadow of its last pass; whoever reads
-            # yk - _get_xk - flushes first)
-            ctx.minres_update(self.lanczos._V, k - self.lanczos._base, W, slot, R0, R1, R2, y[0],
-                              yk.block, yk.col, defer=True)
-            slot = 1 - slot
-            y = [y[1], 0.0]
-            self._finalize_iteration(yk, numpy.abs(y[0]))
-
-        ctx.minres_flush()
+        try:      # (whatever ends the loop - an exception included - a deferred update must not outlive W and yk)
+            while (self.resnorms[-1] > self.tol and self.lanczos.iter < self.lanczos.maxiter
+                   and not self.lanczos.invariant):
+                k = self.iter = self.lanczos.iter
+                self.lanczos.advance()
+                H = self.lanczos.H
+                # QR update of the Lanczos matrix (linsys.py:826-841), scalars only
+                R0 = 0.0
+                R1 = H[k - 1, k].item()   # k == 0 reads H[-1, 0] like the reference: zero
+                if G1 is not None:
+                    R0, R1 = rot(G1, R0, R1)
+                R2, R3 = H[k, k].item(), H[k + 1, k].item()
+                if G2 is not None:
+                    R1, R2 = rot(G2, R1, R2)
+                G1 = G2
+                g = utils.Givens(numpy.array([[R2], [R3]]))
+                G2 = (_pyscalar(g.c), _pyscalar(g.s))
+                R2 = _pyscalar(g.r)
+                y = list(rot(G2, y[0], y[1]))
+                # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
+                # (deferred: the next Lanczos launch carries the update in the shadow of its last pass; whoever reads
+                # yk - _get_xk - flushes first)
+                ctx.minres_update(self.lanczos._V, k - self.lanczos._base, W, slot, R0, R1, R2, y[0],
+                                  yk.block, yk.col, defer=True)
+                slot = 1 - slot
+                y = [y[1], 0.0]
+                self._finalize_iteration(yk, numpy.abs(y[0]))
+        finally:
+            ctx.minres_flush()
         if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(yk)
 
