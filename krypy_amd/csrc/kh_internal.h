@@ -81,7 +81,6 @@ struct kh_ctx_s {
     unsigned* onex_ticket = nullptr;   // 256 rotating ticket words
     int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)
     int64_t n_lanczos_fused = 0;
-    int lanczos_mr_pass = 1;   // where a riding MINRES job runs inside the Lanczos kernel: 1 = inside pass 1, 3 = behind pass 3
     int mr_taken = 0;       // the last chain launch carried a MINRES recurrence job (lanczos.h)
     // a MINRES recurrence update waiting for the next Lanczos launch to carry it (kh_minres_update_deferred)
     struct {

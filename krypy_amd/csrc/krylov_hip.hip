@@ -473,23 +473,23 @@ static hipError_t launch_chain_onex_fused(kh_ctx ctx, int G, ChainArgs& a) {
 }
 
 // one Lanczos step in three passes (lanczos.h)
-template <int R2, int FND, bool JAC, bool MR, bool MRP1 = false>
+template <int R2, int FND, bool JAC, bool MR>
 static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJob& mr) {
     static int blocks_per_cu = -1;
-    constexpr size_t lds = (size_t)(LanczosShape<R2, MRP1>::WL + (JAC ? LanczosShape<R2, MRP1>::DL : 0)) * CH_BS * sizeof(double2);
+    constexpr size_t lds = (size_t)(LanczosShape<R2>::WL + (JAC ? LanczosShape<R2>::DL : 0)) * CH_BS * sizeof(double2);
     if (blocks_per_cu < 0) {
         if (lds > 0) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC, MR, MRP1>),
+            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lanczos_fused<R2, FND, JAC, MR>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e0 != hipSuccess) return e0;
         }
         int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC, MR, MRP1>, CH_BS, lds);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lanczos_fused<R2, FND, JAC, MR>, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC, MR, MRP1>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
+    hipLaunchKernelGGL((k_lanczos_fused<R2, FND, JAC, MR>), dim3(G), dim3(CH_BS), lds, ctx->stream, a, mr);
     return hipGetLastError();
 }
 
@@ -668,12 +668,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             job.r0 = job.r1 = job.y0 = 0.0;
             job.r2 = 1.0;
         }
-        const bool p1 = ctx->lanczos_mr_pass == 1;
 #define KH_LZ(R, D)                                                                                             \
-    (dg != nullptr ? (job.on ? (p1 ? launch_lanczos<R, D, true, true, true>(ctx, G, a, job) : launch_lanczos<R, D, true, true>(ctx, G, a, job)) \
-                             : launch_lanczos<R, D, true, false>(ctx, G, a, job))                                  \
-                   : (job.on ? (p1 ? launch_lanczos<R, D, false, true, true>(ctx, G, a, job) : launch_lanczos<R, D, false, true>(ctx, G, a, job)) \
-                             : launch_lanczos<R, D, false, false>(ctx, G, a, job)))
+    (dg != nullptr ? (job.on ? launch_lanczos<R, D, true, true>(ctx, G, a, job) : launch_lanczos<R, D, true, false>(ctx, G, a, job)) \
+                   : (job.on ? launch_lanczos<R, D, false, true>(ctx, G, a, job) : launch_lanczos<R, D, false, false>(ctx, G, a, job)))
         if (r2 == 40) e = (a.offs.nd == 5) ? KH_LZ(40, 5) : KH_LZ(40, 7);
         else if (r2 == 32) e = (a.offs.nd == 5) ? KH_LZ(32, 5) : KH_LZ(32, 7);
         else if (r2 == 24) e = (a.offs.nd == 5) ? KH_LZ(24, 5) : KH_LZ(24, 7);
@@ -971,8 +968,6 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
-        e = getenv("KRYPY_AMD_LANCZOS_MR_PASS");
-        ctx->lanczos_mr_pass = (e != nullptr && atoi(e) == 3) ? 3 : 1;
         e = getenv("KRYPY_AMD_LANCZOS_FUSED");
         ctx->lanczos_fused = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_ROCTX");
@@ -1062,7 +1057,6 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "halo_loopback")) ctx->halo_loopback = value != 0;
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
-    else if (!strcmp(key, "lanczos_mr_pass")) ctx->lanczos_mr_pass = (value == 1) ? 1 : 3;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;

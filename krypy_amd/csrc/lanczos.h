@@ -38,21 +38,18 @@ struct MinresJob {
     int on;
 };
 
-// MRP1: the MINRES job's six streams run INSIDE pass 1 (which is latency-bound: their loads fill its bubbles) instead
-// of behind pass 3; they need 32 registers there, so more rows of w move to LDS and fewer rows of D are parked
-template <int R2, bool MRP1 = false>
+template <int R2>
 struct LanczosShape {
-    static constexpr int WL = (R2 == 40) ? (MRP1 ? 19 : 8) : ((R2 == 32 && MRP1) ? 8 : 0);   // rows of w in LDS
+    static constexpr int WL = (R2 == 40) ? 8 : 0;                     // rows of w in LDS
     static constexpr int DL_MAX = 19 - WL;                            // 8 KB per row: 19 rows fit beside the static arrays
     static constexpr int DL = R2 < DL_MAX ? R2 : DL_MAX;              // rows of the Jacobi diagonal parked in LDS
     static constexpr size_t LDS_BYTES = (size_t)(WL + DL) * CH_BS * sizeof(double2);
 };
 
-template <int R2, int FND, bool JAC, bool MR, bool MRP1 = false>
+template <int R2, int FND, bool JAC, bool MR>
 __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob mr) {
-    static_assert(MR || !MRP1, "MRP1 places the MINRES job");
-    constexpr int WL = LanczosShape<R2, MRP1>::WL;
-    constexpr int DL = JAC ? LanczosShape<R2, MRP1>::DL : 0;
+    constexpr int WL = LanczosShape<R2>::WL;
+    constexpr int DL = JAC ? LanczosShape<R2>::DL : 0;
     constexpr int RW = R2 - WL;
     extern __shared__ __attribute__((aligned(16))) double2 lsm[];   // [WL rows of w][DL rows of D][CH_BS]
     double2* const wl = lsm;
@@ -75,11 +72,6 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
     double2 w[RW];
     unsigned epoch = a.epoch0;
     if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
-    const double2* __restrict__ vj = reinterpret_cast<const double2*>(mr.v) + first;
-    double2* __restrict__ w0 = reinterpret_cast<double2*>(mr.w0) + first;
-    const double2* __restrict__ w1 = reinterpret_cast<const double2*>(mr.w1) + first;
-    double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
-    const bool runm = MR && !(a.debug & 64);
     // ---- pass 1: w = A v_k - h_{k-1,k} p_{k-1}, <v_k, w> ----
     double acc0 = 0.0, acc1 = 0.0;
     if (a.debug & 8) {               // measurement only (kh_ctx_set "chain_debug"): pass 1 switched off
@@ -108,17 +100,11 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
                 x1[d] = xk[c1];
             }
             // (tried: aligned 16-byte loads of x for the even offsets of a stencil pattern, the +-1 neighbours from the
-            // centre pair - 7 load instructions per row pair instead of 12: pass 1 went from 110 to 127 us, not kept)
+            // centre pair - 7 load instructions per row pair instead of 12: pass 1 went from 110 to 127 us, not kept;
+            // the MINRES job's six streams interleaved with this loop to fill its bubbles, 19 rows of w in LDS to make
+            // room: 213 us for the pair against 108 + 73 apart, not kept either)
             const double2 vv = v2[i2];               // (the line the operator's centre entries came from)
             const double2 pp = ld_nt2(p2 + i2);
-            double2 mv, mu0, mu1, my;
-            if constexpr (MRP1) {                    // the MINRES job's row: four more loads in the same flight
-                const int64_t o_ = (int64_t)r * CH_BS;       // (no run-time condition in here: control flow in this
-                mv = ld_nt2(vj + o_);                        // unrolled loop costs a thousand spilled registers)
-                mu0 = ld_nt2(w0 + o_);
-                mu1 = ld_nt2(w1 + o_);
-                my = ld_nt2(yk + o_);
-            }
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int d = 0; d < FND; ++d) {
@@ -132,18 +118,6 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             W_PUT(r, t);
             acc0 = fma(vv.x, t.x, acc0);
             acc1 = fma(vv.y, t.y, acc1);
-            if constexpr (MRP1) {                    // k_minres_update's formulas (kernels.h), operation for operation
-                const bool in = r * CH_BS < rem;     // (rows of the padding: zeros are stored over zeros - a select, not a branch)
-                double2 z, yo;
-                z.x = ((mv.x - mr.r0 * mu0.x) - mr.r1 * mu1.x) / mr.r2;
-                z.y = ((mv.y - mr.r0 * mu0.y) - mr.r1 * mu1.y) / mr.r2;
-                z.x = in ? z.x : 0.0;
-                z.y = in ? z.y : 0.0;
-                w0[(int64_t)r * CH_BS] = z;
-                yo.x = in ? my.x + mr.y0 * z.x : 0.0;
-                yo.y = in ? my.y + mr.y0 * z.y : 0.0;
-                yk[(int64_t)r * CH_BS] = yo;
-            }
             i2 += CH_BS;
             if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight
         }
@@ -202,15 +176,19 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
     constexpr int PB3 = 2, NB3 = R2 / PB3;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
     double2* __restrict__ pn2 = reinterpret_cast<double2*>(a.pnext) + first;
+    const double2* __restrict__ vj = reinterpret_cast<const double2*>(mr.v) + first;
+    double2* __restrict__ w0 = reinterpret_cast<double2*>(mr.w0) + first;
+    const double2* __restrict__ w1 = reinterpret_cast<const double2*>(mr.w1) + first;
+    double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
     double2 qd[2][PB3], qv[2][PB3], qu0[2][PB3], qu1[2][PB3], qy[2][PB3];
-    const bool run3 = !(a.debug & 32), runm3 = runm && !MRP1;
+    const bool run3 = !(a.debug & 32), runm = MR && !(a.debug & 64);
 #define LZ_ISSUE3(b_, s_)                                                               \
     do {                                                                                \
         _Pragma("unroll") for (int i = 0; i < PB3; ++i) {                               \
             const int r_ = (b_) * PB3 + i;                                              \
             const int64_t o_ = (int64_t)r_ * CH_BS;                                     \
             if (JAC && run3 && r_ >= DL) qd[s_][i] = ld_nt2(d2 + o_);                   \
-            if (runm3) {                                                                \
+            if (runm) {                                                                 \
                 qv[s_][i] = ld_nt2(vj + o_);                                            \
                 qu0[s_][i] = ld_nt2(w0 + o_);                                           \
                 qu1[s_][i] = ld_nt2(w1 + o_);                                           \
@@ -247,7 +225,7 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
                         vn2[(int64_t)r * CH_BS] = o;
                     }
                 }
-                if (runm3) {     // k_minres_update's formulas (kernels.h), operation for operation
+                if (runm) {      // k_minres_update's formulas (kernels.h), operation for operation
                     const double2 v = qv[b & 1][i], u0 = qu0[b & 1][i], u1 = qu1[b & 1][i], y = qy[b & 1][i];
                     double2 z, yo;
                     z.x = ((v.x - mr.r0 * u0.x) - mr.r1 * u1.x) / mr.r2;

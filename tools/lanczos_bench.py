@@ -38,11 +38,9 @@ def run(nx=4000, ny=2500):
         for c in range(5):
             blk.upload(c, rng.standard_normal((n, 1)) / np.sqrt(n))
     print("N = %d" % n)
-    for fused in (1, 2, 0):          # 1: MINRES job behind pass 3, 2: inside pass 1, 0: the old kernel pair
-        ctx.set("lanczos_fused", 1 if fused else 0)
-        ctx.set("lanczos_mr_pass", 1 if fused == 2 else 3)
-        for name, bits in (VARIANTS if fused == 1 else [("MINRES job inside pass 1: all phases", 0), ("MINRES job inside pass 1: pass 1 only", 32 | 16)]
-                           if fused == 2 else [("general chain kernel + k_minres_update", 0)]):
+    for fused in (1, 0):
+        ctx.set("lanczos_fused", fused)
+        for name, bits in (VARIANTS if fused else [("general chain kernel + k_minres_update", 0)]):
             ctx.set("chain_debug", bits)
             for rep in range(3 + REPS):
                 if rep == 3:
@@ -67,11 +65,6 @@ def report(src):
     print("| variant | kernel time, median of %d launches (us) |\n|---|---:|" % REPS)
     for i, (name, bits) in enumerate(VARIANTS):
         chunk = lz[i * per + 3:(i + 1) * per]
-        if chunk:
-            print("| %s | %.1f |" % (name, st.median(chunk)))
-    base = len(VARIANTS) * per
-    for i, name in enumerate(("MINRES job inside pass 1: all phases", "MINRES job inside pass 1: pass 1 only")):
-        chunk = lz[base + i * per + 3: base + (i + 1) * per]
         if chunk:
             print("| %s | %.1f |" % (name, st.median(chunk)))
     old_chain = [(e - s) / 1e3 for nm, s, e in rows if "k_mgs_chain" in nm]
