@@ -424,6 +424,13 @@ __device__ __forceinline__ unsigned long long ld_l2(const unsigned long long* p)
     return x;
 }
 
+// how many workgroups of a launch land on each XCD (kh_ctx_create checks the deal once)
+__global__ void k_onex_probe(unsigned* count) {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    if (threadIdx.x == 0) atomicAdd(count + (v & 0xfu), 1u);
+}
+
 // returns false when this workgroup has nothing to do (not on the target XCD, or no ticket left)
 __device__ __forceinline__ bool onex_enter(const ChainArgs& a, int* sflag, int& bid, int& G, GridRole& role) {
     unsigned v;

@@ -968,6 +968,17 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
+        if (ctx->chain_onex) {
+            // the one-XCD launches rely on workgroups being dealt round-robin over the XCDs (8 G + 8 launched, G + 1
+            // land on each): checked once here - a device that deals differently (a partition mode, masked CUs)
+            // simply keeps the spread launches
+            hipLaunchKernelGGL(k_onex_probe, dim3(8 * 32 + 8), dim3(64), 0, ctx->stream, ctx->onex_ticket);
+            unsigned cnt[16];
+            KH_HIP(hipMemcpyAsync(cnt, ctx->onex_ticket, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+            KH_HIP(hipStreamSynchronize(ctx->stream));
+            KH_HIP(hipMemset(ctx->onex_ticket, 0, sizeof(unsigned) * 256));
+            if (cnt[0] < 33u) ctx->chain_onex = 0;
+        }
         e = getenv("KRYPY_AMD_LANCZOS_FUSED");
         ctx->lanczos_fused = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_ROCTX");

@@ -772,8 +772,8 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
 
     def _cycle_state(self, cs, y):
         """Scratch of the C cycle, or None when this solve is not eligible: real data, Euclidean inner product, the
-        fused step on a plain device matrix (Jacobi M allowed), whole basis allocated, and nothing but the residual
-        recurrence to record per iteration."""
+        fused step on a plain device matrix (Jacobi M allowed), and nothing but the residual recurrence to record
+        per iteration."""
         ar = self.arnoldi
         ctx = self._ctx
         if (os.environ.get("KRYPY_AMD_GMRES_CYCLE", "1") == "0" or not hasattr(ctx, "gmres_cycle")
@@ -782,7 +782,7 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
                 or ar.ortho not in ("mgs", "dmgs", "cgs", "cgs2") or ar._BV is not None
                 or self.explicit_residual or self.linear_system.exact_solution is not None
                 or type(self)._finalize_iteration is not _KrylovSolver._finalize_iteration      # (a subclass watches every step)
-                or ar._cols < ar.maxiter + 1 or ar._base != 0 or ar.maxiter < 3
+                or ar._base != 0 or ar.maxiter < 3
                 or not (ar.H.flags.c_contiguous and self.R.flags.c_contiguous)):
             return None
         m = ar.maxiter
@@ -795,6 +795,12 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
         ctx = self._ctx
         k0 = ar.iter
         m = ar.maxiter
+        # (a basis that grows on demand - the default maxiter = N - holds ar._cols columns now: steps up to cols - 2 can be
+        # begun; beyond that Arnoldi.advance grows the blocks and the next call takes over again)
+        k_last = min(m - 1, ar._cols - 2)
+        k_stop = min(m - 1, k_last)
+        if k_stop <= k0 or ar._enq > k_last + 1:
+            return False
         for i in range(len(cs)):                       # rotations so far (the per-step path may have produced some)
             cyc["cs"][2 * i], cyc["cs"][2 * i + 1] = cs[i]
         cyc["y"][: k0 + 2] = y[: k0 + 2, 0]
@@ -802,7 +808,7 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
             ar._claim(sl)
         bnorm = self.linear_system.MMlb_norm
         k_done, enq, h2, why = ctx.gmres_cycle(
-            ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, m - 1, m - 1, ar._sweeps, ar._gs_mode, max(ar._enq, k0),
+            ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, k_stop, k_last, ar._sweeps, ar._gs_mode, max(ar._enq, k0),
             float(self.tol), float(bnorm), ar.H, self.R, cyc["cs"], cyc["y"], ar._h2, cyc["resn"])
         ar._enq, ar._h2 = enq, h2
         in_flight = {j % 4 for j in range(k_done, enq)}       # (their slots stay claimed until advance() / _settle())

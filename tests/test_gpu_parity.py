@@ -622,7 +622,10 @@ def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
              ("restarted", lambda: linsys.RestartedGmres(linsys.LinearSystem(A, b), tol=1e-8, maxiter=25, max_restarts=40)),
              ("invariant", lambda: linsys.Gmres(linsys.LinearSystem(sp.diags(np.r_[np.ones(50), 2 * np.ones(50)]).tocsr(),
                                                                     np.ones(100)), tol=1e-12, maxiter=50)),
-             ("toy", lambda: linsys.Gmres(linsys.LinearSystem(At, bt), tol=1e-5))]
+             ("toy", lambda: linsys.Gmres(linsys.LinearSystem(At, bt), tol=1e-5)),
+             # default maxiter = N: the basis starts small and doubles on demand - the C call runs up to the last
+             # column there is, Arnoldi.advance grows the blocks, the next call takes over
+             ("growing", lambda: linsys.Gmres(linsys.LinearSystem(A, b), tol=1e-9))]
 
     def run(make):
         try:
@@ -631,6 +634,8 @@ def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
             return e.solver, True
 
     for name, make in cases:
+        if name == "growing":
+            monkeypatch.setattr(utils.Arnoldi, "_max_initial_cols", 8)
         c0 = hip.get("n_cycle_steps")
         s1, f1 = run(make)
         used = hip.get("n_cycle_steps") - c0
