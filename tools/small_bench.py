@@ -10,6 +10,13 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def linsys_minres(linsys, utils, A, b, sp):
+    try:
+        return linsys.Minres(linsys.LinearSystem(A, b, M=sp.diags(1.0 / A.diagonal()).tocsr(), self_adjoint=True), maxiter=150, tol=1e-30)
+    except utils.ConvergenceError as e:
+        return e.solver
+
+
 def one(nx):
     import numpy as np
     import scipy.sparse as sp
@@ -22,7 +29,8 @@ def one(nx):
     out = []
     for name, make in (("gmres mgs", lambda x0, n: linsys.RestartedGmres(linsys.LinearSystem(A, b), x0=x0, maxiter=100, max_restarts=n - 1, tol=1e-14, ortho="mgs")),
                        ("gmres cgs", lambda x0, n: linsys.RestartedGmres(linsys.LinearSystem(A, b), x0=x0, maxiter=100, max_restarts=n - 1, tol=1e-14, ortho="cgs")),
-                       ("minres jacobi", lambda x0, n: linsys.Minres(linsys.LinearSystem(A, b, M=sp.diags(1.0 / A.diagonal()).tocsr(), self_adjoint=True), x0=x0, maxiter=100 * n, tol=1e-14))):
+                       # (the solve converges within a few hundred iterations at these sizes: fixed runs of 150 steps, n of them)
+                       ("minres jacobi", lambda x0, n: [linsys_minres(linsys, utils, A, b, sp) for _ in range(n)][-1])):
         def run(x0, n):
             try:
                 return make(x0, n)
@@ -34,7 +42,7 @@ def one(nx):
         s2 = run(None, 10)
         ctx.sync()
         dt = time.perf_counter() - t0
-        out.append("%s %.0f it/s" % (name, (len(s2.resnorms) - 1) / dt))
+        out.append("%s %.0f it/s" % (name, ((len(s2.resnorms) - 1) * (10 if name.startswith("minres") else 1)) / dt))
     c = ctx.counters()
     print("N = %7d, onex = %s (%d one-XCD launches, %d chain launches of which %d with the operator in the prologue, %d "
           "iterations through kh_gmres_cycle): %s" % (A.shape[0], os.environ.get("KRYPY_AMD_CHAIN_ONEX", "1"),
