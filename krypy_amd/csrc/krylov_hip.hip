@@ -621,7 +621,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
-        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex) && xk != nullptr &&
+        // (a step with one Gram-Schmidt link has the three-pass kernel of lanczos.h for every shape up to 40 rows)
+        const bool lz_shape = ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr) &&
+                              (r2 == 4 || r2 == 8);
+        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex || lz_shape) && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -674,7 +677,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         if (r2 == 40) e = (a.offs.nd == 5) ? KH_LZ(40, 5) : KH_LZ(40, 7);
         else if (r2 == 32) e = (a.offs.nd == 5) ? KH_LZ(32, 5) : KH_LZ(32, 7);
         else if (r2 == 24) e = (a.offs.nd == 5) ? KH_LZ(24, 5) : KH_LZ(24, 7);
-        else e = (a.offs.nd == 5) ? KH_LZ(16, 5) : KH_LZ(16, 7);
+        else if (r2 == 16) e = (a.offs.nd == 5) ? KH_LZ(16, 5) : KH_LZ(16, 7);
+        else if (r2 == 8) e = (a.offs.nd == 5) ? KH_LZ(8, 5) : KH_LZ(8, 7);
+        else e = (a.offs.nd == 5) ? KH_LZ(4, 5) : KH_LZ(4, 7);
 #undef KH_LZ
         if (e == hipSuccess) {
             if (a.debug == 4) ctx->chain_fault = 0;
@@ -732,6 +737,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 #define KH_FUSED(R, D)                                                                                   \
     (use_lds ? (use_pf ? launch_chain_pf<R, false, false, D>(ctx, G, a) : launch_chain_lds<R, false, false, D>(ctx, G, a)) \
              : launch_chain<R, false, false, D>(ctx, G, a))
+            if (r2 < 16) return 0;       // (4 / 8 rows: only the Lanczos and the one-XCD kernels have the prologue)
             if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
             else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
             else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);

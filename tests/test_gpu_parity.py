@@ -554,6 +554,53 @@ def test_operator_fused_into_the_chain_prologue(hip, shape):
     assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
 
 
+@pytest.mark.parametrize("shape", [(300, 300), (500, 500), (1000, 700), (1500, 800)])
+def test_lanczos_kernel_on_short_vectors(hip, shape):
+    """The three-pass Lanczos kernel (lanczos.h) also serves the 4 / 8-rows-per-lane shapes (N from 65,536 up: padded
+    blocks): a MINRES iteration at N = 10^5 is ONE launch instead of SpMV + chain + update.  Bit for bit the SpMV +
+    chain pair, with and without the Jacobi diagonal, a deferred MINRES update riding along."""
+    nx, ny = shape
+    A = ref.laplace2d(nx, ny)
+    n = A.shape[0]
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(n)
+    dj = np.linspace(0.5, 1.5, n)
+    Vm, Wm0, y0 = rng.standard_normal((n, 1)), rng.standard_normal((n, 2)), rng.standard_normal((n, 1))
+    m = 6
+    out = []
+    for fused in (True, False):
+        ctx = _second_context(True, fused)
+        Ad, Md = ctx.csr(A), ctx.diag(dj)
+        res = {}
+        for name, use_m in (("lanczos", False), ("lanczos_jacobi", True)):
+            lz0, rides0 = ctx.get("n_lanczos_fused"), ctx.get("n_minres_rides")
+            V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+            P = ctx.alloc(n, m + 1) if use_m else None
+            Wm, yk = ctx.upload(Wm0), ctx.upload(y0)
+            if use_m:
+                nrm = np.sqrt(np.dot(v, dj * v))
+                P.upload(0, v / nrm)
+                V.upload(0, dj * v / nrm)
+            else:
+                V.upload(0, v / np.linalg.norm(v))
+            H = np.zeros((m + 1, m))
+            for k in range(m):
+                if k >= 2:          # the recurrences of iteration k - 2, as Minres defers them
+                    ctx.minres_update(V, k - 2, Wm, k & 1, 0.3, -0.2, 1.7, 0.4, yk, 0, defer=True)
+                hk = float(H[k, k - 1]) if k > 0 else 0.0
+                hcol = ctx.arnoldi_step(Ad, Md if use_m else None, V, P, W, 0, k, k, 1, 0, hk)
+                H[k: k + 2, k] = hcol[k: k + 2]
+            ctx.minres_flush()
+            res[name] = (H, V.download(), P.download() if use_m else np.zeros(1), Wm.download(), yk.download())
+            assert ctx.get("n_lanczos_fused") - lz0 == (m if fused else 0), (name, fused)
+            assert ctx.get("n_minres_rides") - rides0 == (m - 2 if fused else 0), (name, fused)
+        out.append(res)
+        ctx.close()
+    for name in out[0]:
+        for a_, b_ in zip(out[0][name], out[1][name]):
+            assert np.array_equal(a_, b_), name
+
+
 @pytest.mark.parametrize("shape", [(120, 120), (39, 41), (700, 300)])
 def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     """The one-launch register-resident chain (chain.h) and the per-column link kernels are two

