@@ -229,6 +229,53 @@ def test_config5_shape_deflated_gmres_single_gpu(hip):
     assert np.linalg.norm(G) < 1e-9
 
 
+def test_config5_flow_against_the_oracle(hip):
+    """Config 5's flow - plain GMRES(60), the 16 Ritz vectors of smallest magnitude harvested on the device,
+    DeflatedGmres(60) with them (recycling/linsys.py:51-103, deflation.py:93-163) - iterate for iterate against the
+    CPU oracle (gmres -> ritz_vectors_smallest -> deflated_gmres) on a 100^3 grid (N = 10^6: long enough for the
+    fused step, the device projector and the SpMM of the set-up to run as they do at full size, short enough for the
+    oracle).  The deflated solve depends on span(U) only; tolerances from the oracle's own movement when the Ritz
+    vectors are perturbed by one rounding error per entry."""
+    import bench
+    from krypy_amd import deflation, linsys, utils
+
+    A = bench.laplace3d(100, 100, 100)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+    m, d = 60, 16
+    ls = linsys.LinearSystem(A, b, self_adjoint=True)
+
+    def run(U):
+        try:
+            return deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, store_arnoldi=U is None)
+        except utils.ConvergenceError as e:
+            return e.solver
+
+    s0 = run(None)
+    ritz = deflation.Ritz(s0)
+    idx = np.argsort(np.abs(ritz.values))[:d]
+    U = ritz._get_vectors_dev(idx)
+    s1 = run(U)
+    o0 = ref.gmres(A, b, tol=1e-12, maxiter=m)
+    vals, Uo = ref.ritz_vectors_smallest(o0, d, self_adjoint=True)
+    o1 = ref.deflated_gmres(A, b, Uo, tol=1e-12, maxiter=m)
+    o1p = ref.deflated_gmres(A, b, Uo * (1.0 + 1e-15 * np.random.default_rng(1).standard_normal(Uo.shape)), tol=1e-12,
+                             maxiter=m)
+    r0, w0 = np.array(s0.resnorms), np.array(o0.resnorms)
+    assert len(r0) == len(w0) and np.max(np.abs(r0[:-1] - w0[:-1]) / w0[:-1]) < 1e-10
+    assert np.allclose(np.sort(np.abs(ritz.values[idx])), np.sort(np.abs(vals)), rtol=1e-8)
+    r1, w1, w1p = np.array(s1.resnorms), np.array(o1.resnorms), np.array(o1p.resnorms)
+    sens = float(np.max(np.abs(w1p[:-1] - w1[:-1]) / w1[:-1]))
+    print("deflated history: deviation %.2e, oracle's own movement %.2e" % (np.max(np.abs(r1[:-1] - w1[:-1]) / w1[:-1]), sens))
+    assert len(r1) == len(w1)
+    assert np.max(np.abs(r1[:-1] - w1[:-1]) / w1[:-1]) < max(1e-10, 30.0 * sens)          # (measured: 2e-12)
+    assert r1[-1] < r0[-1]
+    # the same subspace: the oracle's Ritz vectors lie in the span of the device's
+    Ud = U.download()
+    Q = np.linalg.qr(Ud)[0]
+    assert np.linalg.norm(Uo - Q.dot(Q.T.dot(Uo))) < 1e-7 * np.linalg.norm(Uo)
+
+
 def test_config5_slab_at_its_stated_size_through_the_sharded_path(hip):
     """Config 5 puts 12.5 M rows (a 500 x 500 x 50 slab of the 500 x 500 x 400 grid) on every GPU.  That is beyond
     what the register file holds (10.48 M): the 48-rows-per-lane kernels keep eight rows of w in LDS.  One such
