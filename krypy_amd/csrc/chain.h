@@ -451,6 +451,14 @@ __device__ __forceinline__ bool onex_enter(const ChainArgs& a, int* sflag, int& 
 
 // NV values (1: a real coefficient / norm, 2: both parts of a complex coefficient) over the G <= 32 workgroups of
 // one XCD; granule g = 2 NV bid + 2 kind + half.  smd holds 4 * 8 doubles.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + barrier, and on this target the fence
+// waits for the wave's outstanding VECTOR-MEMORY operations too (s_waitcnt vmcnt(0)): every barrier of a sum would
+// drain the columns a wave has requested ahead.  The sums exchange their data through LDS (and through global memory
+// only in the one wave that polls), so the LDS counter is all that has to be waited for.
+__device__ __forceinline__ void ch_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int NV>
 __device__ __forceinline__ void onex_sum(double (&p)[NV], unsigned epoch, unsigned long long* gran, int G, int bid,
                                          int* err, double* smd) {
@@ -461,7 +469,7 @@ __device__ __forceinline__ void onex_sum(double (&p)[NV], unsigned epoch, unsign
         const double ws = wave_sum_dpp(p[k]);
         if (lane == 0) smd[k * NW + wid] = ws;
     }
-    __syncthreads();
+    ch_lds_barrier();
     unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
     if (tid < NV) {
         double s = smd[tid * NW];
@@ -503,7 +511,7 @@ __device__ __forceinline__ void onex_sum(double (&p)[NV], unsigned epoch, unsign
             smd[3 * NW + wid] = w1;
         }
     }
-    __syncthreads();
+    ch_lds_barrier();
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         double s = smd[(2 + k) * NW];
@@ -511,7 +519,64 @@ __device__ __forceinline__ void onex_sum(double (&p)[NV], unsigned epoch, unsign
         for (int i = 1; i < NW; ++i) s += smd[(2 + k) * NW + i];
         p[k] = s;
     }
-    __syncthreads();          // smd is reused by the next sum
+    ch_lds_barrier();          // smd is reused by the next sum
+}
+
+// The same sum with a COMMUNICATION WAVE: a fifth wave of the workgroup that owns no rows and does nothing but the
+// exchange.  Vector-memory results return to a wave in order, so a poll issued by a wave that has requested columns
+// ahead waits for those columns first (a miss to HBM: ~2 us, twice the sum); in the wave that only polls nothing is
+// ever in front of the poll.  The four working waves leave their partial in LDS and wait at two LDS-only barriers.
+// Same partials, same order of additions as onex_sum<1>: the same bits.
+__device__ __forceinline__ double onex_sum_work(double part, double* smd) {
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const double ws = wave_sum_dpp(part);
+    if (lane == 0) smd[wid] = ws;
+    ch_lds_barrier();          // partials are in LDS
+    ch_lds_barrier();          // the communication wave has left the total there
+    return smd[CH_BS / 64];
+}
+
+__device__ __forceinline__ double onex_sum_comm(unsigned epoch, unsigned long long* gran, int G, int bid, int* err,
+                                                double* smd) {
+    constexpr int NW = CH_BS / 64;
+    const int lane = threadIdx.x & 63;
+    ch_lds_barrier();
+    unsigned long long* slot = gran + (size_t)(epoch & 1u) * (2 * CH_GMAX);
+    if (lane == 0) {
+        double s = smd[0];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += smd[i];
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(s);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        slot[2 * bid] = tag | (bits & 0xffffffffull);
+        slot[2 * bid + 1] = tag | (bits >> 32);
+    }
+    unsigned mine = 0;
+    const int ng = 2 * G;          // <= 64
+    if (lane < ng) {
+        unsigned long long x = ld_l2(slot + lane);
+        unsigned spins = 0;
+        while ((unsigned)(x >> 32) != epoch) {
+            x = ld_l2(slot + lane);
+            if ((++spins & 1023u) == 0) {
+                if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                if (spins > (1u << 22)) {
+                    __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        mine = (unsigned)x;
+    }
+    const unsigned low = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111, 0xf, 0xf, false);   // from lane - 1
+    const unsigned long long bits = ((unsigned long long)mine << 32) | low;
+    const double d = ((lane & 1) && lane < ng) ? __longlong_as_double((long long)bits) : 0.0;
+    double tot = wave_sum_dpp(d);
+#pragma unroll
+    for (int i = 1; i < NW; ++i) tot += 0.0;          // (onex_sum adds the empty partials of the other waves)
+    if (lane == 0) smd[NW] = tot;
+    ch_lds_barrier();
+    return tot;
 }
 
 // Every vector this kernel reads is a kh_vec / diag buffer allocated with CH_SLACK zeroed doubles
@@ -1426,6 +1491,156 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
     }
 #undef CH_REUSE
 #undef CH_LD
+#undef CH_OK
+}
+
+// ------------------------------------------------------------------------------------------
+// k_mgs_chain_small: the chain for SHORT vectors (4 / 8 rows per lane), where a link is latency, not bandwidth.
+//
+// With w in 16 or 32 registers there is room for whole COLUMNS: a ring of LA + 1 of them.  Column t + LA + 1 is
+// requested when column t has been used, i.e. LA links (LA grid-wide sums) before it is needed - the memory latency
+// the one-column look-ahead of k_mgs_chain_pf leaves exposed (a link took 1.4 - 1.9 us around a 0.84 us sum) is
+// hidden - and the update takes the column from the same registers the dot used: every column is read once.
+// Same accumulators, same row order, same sums as the other chain kernels: the same bits.  B == V only (no
+// preconditioner), real data; ONEX as above, FND > 0: the banded operator in the prologue.
+// ------------------------------------------------------------------------------------------
+template <int R2, int LA, bool MASKED, int FND = 0, bool ONEX = false>
+__global__ __launch_bounds__(ONEX ? CH_BS + 64 : CH_BS) void k_mgs_chain_small(ChainArgs a) {
+    static_assert(FND == 0 || !MASKED, "the fused operator exists for padded blocks");
+    constexpr int NS = LA + 1;
+    __shared__ double smd[4 * (CH_BS / 64)];
+    __shared__ unsigned smu[2 * CH_GMAX];
+    __shared__ int slead;
+    const int tid = threadIdx.x;
+    int G = gridDim.x;
+    int bid = blockIdx.x;
+    GridRole role;
+    if constexpr (ONEX) {
+        if (!onex_enter(a, &slead, bid, G, role)) return;
+    } else {
+        role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    }
+    unsigned epoch = a.epoch0;
+    const int total = a.ncol * a.sweeps;
+    if constexpr (ONEX) {
+        if (tid >= CH_BS) {          // the communication wave: the sums and the H entries, no rows
+            const bool writer = bid == 0 && tid == CH_BS;
+            for (int t = 0; t < total; ++t) {
+                const double alpha = onex_sum_comm(epoch++, a.gran, G, bid, a.err, smd);
+                const int64_t j = a.col0 + (t % a.ncol);
+                if (writer) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
+            }
+            const double h2 = onex_sum_comm(epoch++, a.gran, G, bid, a.err, smd);
+            if (writer) a.hdev[a.hnext] = sqrt(fabs(h2));
+            if (bid == 0 && a.hpin != nullptr) __syncthreads();          // (the copy at the end, by the working waves)
+            return;
+        }
+    }
+    const int64_t first = (int64_t)bid * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    // the first columns are requested before anything else: they arrive under the operator / the load of w
+    double2 ring[NS][R2];
+    // column of link t (beyond the last link: the last column again - a harmless reload instead of a branch)
+#define CH_COL(t) (reinterpret_cast<const double2*>(a.V + (a.col0 + (((t) < total ? (t) : total - 1) % a.ncol)) * a.ld) + first)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const double2* __restrict__ c = CH_COL(s);
+#pragma unroll
+        for (int r = 0; r < R2; ++r) ring[s][r] = c[(int64_t)r * CH_BS];
+    }
+    CH_ISSUE_FENCE();
+    double2 w[R2];
+    if constexpr (FND > 0) {
+        chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { w[r] = make_double2(s0, s1); });
+    } else {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+        }
+    }
+    if (a.presub) {
+        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 p = p2[(int64_t)r * CH_BS];
+            w[r].x = CH_OK(r) ? w[r].x - hk * p.x : 0.0;
+            w[r].y = CH_OK(r) ? w[r].y - hk * p.y : 0.0;
+        }
+    }
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
+    for (int tb = 0; tb < total; tb += NS) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int t = tb + s;
+            if (t < total) {
+                const int64_t j = a.col0 + (t % a.ncol);
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int r = 0; r < R2; ++r) {
+                    double2 v = ring[s][r];
+                    if (MASKED && !CH_OK(r)) v = make_double2(0.0, 0.0);
+                    ring[s][r] = v;
+                    acc0 = fma(v.x, w[r].x, acc0);
+                    acc1 = fma(v.y, w[r].y, acc1);
+                }
+                double alpha;
+                if constexpr (ONEX) {
+                    alpha = onex_sum_work(acc0 + acc1, smd);
+                } else {
+                    alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+                    if (bid == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
+                }
+                if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
+#pragma unroll
+                for (int r = 0; r < R2; ++r) {
+                    w[r].x = CH_OK(r) ? w[r].x - alpha * ring[s][r].x : 0.0;
+                    w[r].y = CH_OK(r) ? w[r].y - alpha * ring[s][r].y : 0.0;
+                }
+                // the slot is free: the column LA + 1 links ahead
+                const double2* __restrict__ c = CH_COL(t + NS);
+#pragma unroll
+                for (int r = 0; r < R2; ++r) ring[s][r] = c[(int64_t)r * CH_BS];
+                CH_ISSUE_FENCE();
+            }
+        }
+    }
+#undef CH_COL
+    double acc = 0.0;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        acc = fma(w[r].x, w[r].x, acc);
+        acc = fma(w[r].y, w[r].y, acc);
+    }
+    double h2;
+    if constexpr (ONEX) {
+        h2 = onex_sum_work(acc, smd);
+    } else {
+        h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    }
+    const double h = sqrt(fabs(h2));
+    if (!ONEX && bid == 0 && tid == 0) a.hdev[a.hnext] = h;
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        if (r * CH_BS < rem) {
+            double2 o;
+            o.x = w[r].x / h;
+            o.y = w[r].y / h;
+            vn2[(int64_t)r * CH_BS] = o;
+        }
+    }
+    if (bid == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by thread 0 of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #undef CH_OK
 }
 

@@ -77,6 +77,8 @@ struct kh_ctx_s {
     int64_t n_chain_pf = 0;
     int chain_onex = 1;     // short vectors: all working workgroups of the chain kernel on one XCD (KRYPY_AMD_CHAIN_ONEX)
     int64_t n_chain_onex = 0;
+    int chain_small = 1;    // short vectors without a preconditioner: the column-ring kernel k_mgs_chain_small (KRYPY_AMD_CHAIN_SMALL)
+    int64_t n_chain_small = 0;
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
     unsigned* onex_ticket = nullptr;   // 256 rotating ticket words
     int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)

@@ -450,6 +450,28 @@ static hipError_t launch_chain_onex(kh_ctx ctx, int G, ChainArgs& a) {
     return hipGetLastError();
 }
 
+// short vectors without a preconditioner: whole columns in a register ring, requested several links ahead
+// (chain.h, k_mgs_chain_small); ONEX or spread over the chip
+template <int R2, bool MASKED, int FND, bool ONEX>
+static hipError_t launch_chain_small(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+#ifndef KH_SMALL_LA4
+#define KH_SMALL_LA4 3
+#define KH_SMALL_LA8 2
+#endif
+    constexpr int LA = (R2 == 4) ? KH_SMALL_LA4 : KH_SMALL_LA8;          // columns requested ahead
+    auto kern = k_mgs_chain_small<R2, LA, MASKED, FND, ONEX>;
+    if (blocks_per_cu < 0) {
+        int nb = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, ONEX ? CH_BS + 64 : CH_BS, 0);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * (ONEX ? ctx->ncu / 8 : ctx->ncu) < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(kern, dim3(ONEX ? 8 * G + 8 : G), dim3(ONEX ? CH_BS + 64 : CH_BS), 0, ctx->stream, a);   // ONEX: + the communication wave
+    return hipGetLastError();
+}
+
 // ... with the banded operator in the prologue (no SpMV launch in front of the step)
 template <int R2, int FND, bool PF>
 static hipError_t launch_chain_onex_fused(kh_ctx ctx, int G, ChainArgs& a) {
@@ -529,8 +551,9 @@ static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, bool 
 static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     int64_t ld = ((n + 31) / 32) * 32;
     int r2 = 0, g = 0;
-    if (n >= (1 << 16) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
-    if (n >= (1 << 16) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
+    // (from 4096 rows on: below that a vector is a fraction of one workgroup's chunk)
+    if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
+    if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
     return ld == 0 ? 32 : ld;
 }
 
@@ -556,7 +579,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     bool want_onex = false;
     if ((k - start + 1) * sweeps >= 3 && (ctx->chain_debug == 0) && ctx->onex_ticket != nullptr) {
         int r2x = 0, Gx = 0;
-        if (chain_geometry(ctx, n, &r2x, &Gx, true)) {
+        // (the column-ring kernel with 8 rows per lane - 1.3e5 < N <= 2.6e5 - is faster spread over the chip with 4:
+        // a one-XCD link moves the whole column through one XCD's port; 7,240 vs 6,770 it/s at N = 2.5e5)
+        const bool ring_kernel = ctx->chain_small && B == V && dg == nullptr && !cplx;
+        if (chain_geometry(ctx, n, &r2x, &Gx, true) && !(ring_kernel && r2x == 8 && r2 == 4)) {
             r2 = r2x;
             G = Gx;
             want_onex = true;
@@ -624,7 +650,8 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         // (a step with one Gram-Schmidt link has the three-pass kernel of lanczos.h for every shape up to 40 rows)
         const bool lz_shape = ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr) &&
                               (r2 == 4 || r2 == 8);
-        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex || lz_shape) && xk != nullptr &&
+        const bool small_shape = ctx->chain_small && r2 <= 8 && B == V && dg == nullptr;
+        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex || lz_shape || small_shape) && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -698,6 +725,37 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     }
     // short vectors (4 ... 32 workgroups of 4 / 8 rows per lane): a link is its grid-wide sum - all working
     // workgroups on ONE XCD, where the sum is an L2 round trip (chain.h, ONEX)
+    // short vectors, no preconditioner, real data: the column-ring kernel (one read per column, several links of look-ahead)
+    if (ctx->chain_small && r2 <= 8 && B == V && dg == nullptr && !cplx && (a.debug == 0 || a.debug == 4) &&
+        !(fused && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1)) {
+        if (want_onex) {
+            const unsigned slot_ = (unsigned)(ctx->n_chain_onex & 255);
+            a.onex_G = G;
+            a.onex_target = 0u;
+            a.onex_ticket = ctx->onex_ticket + slot_;
+            a.onex_clear = ctx->onex_ticket + ((slot_ + 128u) & 255u);
+        }
+#define KH_SM(R, X)                                                                                          \
+    (fused ? (a.offs.nd == 5 ? launch_chain_small<R, false, 5, X>(ctx, G, a) : launch_chain_small<R, false, 7, X>(ctx, G, a)) \
+           : (padded ? launch_chain_small<R, false, 0, X>(ctx, G, a) : launch_chain_small<R, true, 0, X>(ctx, G, a)))
+        if (want_onex) e = (r2 == 4) ? KH_SM(4, true) : KH_SM(8, true);
+        else e = (r2 == 4) ? KH_SM(4, false) : KH_SM(8, false);
+#undef KH_SM
+        if (e == hipSuccess) {
+            if (a.debug == 4) ctx->chain_fault = 0;
+            ctx->n_chain += 1;
+            ctx->n_chain_small += 1;
+            ctx->n_chain_onex += want_onex ? 1 : 0;
+            ctx->n_chain_fused += fused ? 1 : 0;
+            ctx->n_chain_lds += 1;          // (the column is used twice from the chip: counted with the LDS / ring family)
+            ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);
+            if (hpin == nullptr)
+                KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                                      ctx->stream));
+            return 1;
+        }
+        (void)hipGetLastError();
+    }
     if (want_onex) {
         const unsigned slot_ = (unsigned)(ctx->n_chain_onex & 255);
         a.onex_G = G;
@@ -972,6 +1030,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_PF");
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_SMALL");
+        ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
         if (ctx->chain_onex) {
@@ -1074,6 +1134,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "halo_loopback")) ctx->halo_loopback = value != 0;
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
+    else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
@@ -1096,6 +1157,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_minres_rides")) *value = ctx->n_minres_rides;
     else if (!strcmp(key, "chain_onex")) *value = ctx->chain_onex;
     else if (!strcmp(key, "n_chain_onex")) *value = ctx->n_chain_onex;
+    else if (!strcmp(key, "chain_small")) *value = ctx->chain_small;
+    else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
