@@ -651,6 +651,62 @@ def test_mgs_chain_kernel_equals_link_kernels(hip, shape):
     assert np.linalg.norm(results[0]["mgs"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
+@pytest.mark.parametrize("n", [3000, 4100, 20000, 99856, 130000, 250000, 700000])
+def test_column_ring_kernel_for_short_vectors(hip, n):
+    """k_mgs_chain_small (chain.h): vectors of 4 / 8 double2 rows per lane without a preconditioner keep a ring of whole
+    basis columns in registers, requested several links ahead; on one XCD a ninth wave per workgroup does the sums.  Same
+    partials, same order of additions as the general chain kernels - the same bits wherever both run the same geometry
+    (everything but 1.3e5 < N <= 2.6e5, where the general kernel runs 8 rows per lane on one XCD and this one 4 rows on
+    the whole chip) - for the operator in the prologue (padded blocks, N >= 4096) and a separate SpMV (masked blocks,
+    a CSR operator that is not banded, with two double sweeps); a faked timeout inside it is recovered; the Arnoldi
+    relation holds and the oracle's H is reproduced."""
+    from krypy_amd import _hip
+
+    nx = 100
+    A = ref.laplace2d(nx, n // nx) if n % nx == 0 else _banded(n, (-700, -1, 0, 1, 700), 3)
+    Ar = (A + sp.diags(np.random.default_rng(2).standard_normal(n - 37) * 0.01, 37, shape=(n, n))).tocsr()   # 6 diagonals: no banded copy
+    v = np.random.default_rng(4).standard_normal(n)
+    m = 14
+    ctx = _hip.Context(0)
+    res = {}
+    for small in (1, 0):
+        ctx.set("chain_small", small)
+        c0 = ctx.get("n_chain_small")
+        for name, mat in (("prologue", A), ("spmv", Ar)):
+            Ad = ctx.csr(mat)
+            V, W = ctx.alloc(n, m + 1), ctx.alloc(n, 2)
+            V.upload(0, v / np.linalg.norm(v))
+            H = np.zeros((m + 1, m))
+            for k in range(m):
+                if small and name == "spmv" and k == 9:
+                    ctx.set("chain_fault", 1)          # this launch reports a timeout: re-run on the link kernels
+                hcol = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if (name == "spmv" and k in (5, 6)) else 1, 0, 0.0)
+                H[: k + 2, k] = hcol[: k + 2]
+                if small and name == "spmv" and k == 9:
+                    assert ctx.get("chain") == 0       # (the recovery switches the chain off: back on for the rest)
+                    ctx.set("chain", 1)
+            res[small, name] = (H, V.download())
+        used = ctx.get("n_chain_small") - c0
+        assert (used >= 2 * m - 1) == bool(small), (small, used)
+    ctx.close()
+    same_geometry = not (131072 < n <= 262144)
+    for name, mat in (("prologue", A), ("spmv", Ar)):
+        Hs, Vs = res[1, name]
+        Hg, Vg = res[0, name]
+        if same_geometry and name == "prologue":
+            assert np.array_equal(Hs, Hg), name
+            assert np.array_equal(Vs, Vg), name
+        else:            # (other partial sums, or - "spmv" - one step of the ring run on the link kernels)
+            assert np.linalg.norm(Hs - Hg) < 1e-12 * np.linalg.norm(Hg), name
+            assert np.linalg.norm(Vs - Vg) < 1e-10, name
+        assert np.linalg.norm(mat.dot(Vs[:, :m]) - Vs.dot(Hs)) < 1e-12 * np.linalg.norm(Hs), name
+    if n <= 100000:
+        st = ref.arnoldi_init(A, v, m)
+        for _ in range(m):
+            ref.arnoldi_step(st)
+        assert np.linalg.norm(res[1, "prologue"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
+
+
 def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
     """kh_gmres_cycle (Arnoldi steps with look-ahead on the device, Givens QR and the residual recurrence on the host
     in C: linsys.py:951-997 in one call) against the per-step Python loop (KRYPY_AMD_GMRES_CYCLE=0): same iteration
