@@ -611,6 +611,9 @@ struct ChainShape {
 // multiply of NumPy (separate roundings), H entries are (re, im) pairs in hdev.
 // Fused operator of the chain kernels (FND > 0 diagonals of a banded operator, krylov_hip.hip builds the
 // diagonal-major copy): this lane's rows of w = A x_k, computed straight into the registers that hold w.
+#ifndef KH_RIF
+#define KH_RIF 3          // rows of the fused operator in flight - 1 (a mask: 1 = two rows, 3 = four)
+#endif
 template <int R2, int FND, class Put>
 __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, Put&& put) {
     // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
@@ -618,10 +621,18 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
     // The padding rows behind n hold zeros in every diagonal and come out as w = 0.
     const double* __restrict__ xk = a.xk;
     const int64_t last = a.n_last;
-    int64_t i2 = first;      // advanced through an opaque asm every two rows: that is what bounds the
-                             // loads in flight (and the live temporaries) of this fully unrolled loop
+    int64_t fb = first;      // passed through an opaque asm every two rows: that is what bounds the
+                             // loads in flight (and the live temporaries) of this fully unrolled loop.
+                             // Row r sits at a CONSTANT distance from fb.  (Until late in round 3 the index itself was
+                             // advanced by CH_BS per row through the asm: the same loads in the same order, but
+                             // rocprofv3 FETCH_SIZE of the MINRES iteration at N = 10^7 read 1223 MB where the streams
+                             // add up to 1082 - lines of x fetched again for the +-nx neighbours - and 1126 MB in this
+                             // form; pass 1 of the Lanczos kernel 108.6 -> 99.4 us.  Walking the rows in the order
+                             // c, c + 4, c + 8, ..., which puts the three uses of a line of x into consecutive steps,
+                             // changes neither figure any further: 1123 MB, 99.4 us.)
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
+        const int64_t i2 = fb + (int64_t)r * CH_BS;
         const int64_t row = 2 * i2;
         double2 av[FND];
         double x0[FND], x1[FND];
@@ -645,8 +656,7 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
             s1 = (av[d].y != 0.0) ? s1 + p1 : s1;
         }
         put(r, s0, s1);         // (row r of w: a register, or - long shapes - this lane's LDS entry)
-        i2 += CH_BS;
-        if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight (one: 1023 it/s, two: 1028-1037, four: 1018-1030)
+        if ((r & KH_RIF) == KH_RIF) asm volatile("" : "+v"(fb) : : "memory");   // four rows of loads in flight (with the running index of rounds 1-2: one 1023 it/s, two 1028-1037, four 1018-1030; with the constant distances: two 1087-1089, four 1093-1095 on one box)
     }
 }
 
@@ -857,8 +867,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
                 o.y = wr.y / h;
                 m.x = (d.x * wr.x) / h;
                 m.y = (d.y * wr.y) / h;
-                pn2[(int64_t)r * CH_BS] = o;
-                vn2[(int64_t)r * CH_BS] = m;
+                st_nt2(pn2 + (int64_t)r * CH_BS, o);
+                st_nt2(vn2 + (int64_t)r * CH_BS, m);
             }
         }
     } else {
@@ -869,7 +879,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
                 double2 o;
                 o.x = wr.x / h;
                 o.y = wr.y / h;
-                vn2[(int64_t)r * CH_BS] = o;
+                st_nt2(vn2 + (int64_t)r * CH_BS, o);
             }
         }
     }
@@ -1165,8 +1175,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                 o.y = wr.y / h;
                 m.x = (d.x * wr.x) / h;
                 m.y = (d.y * wr.y) / h;
-                pn2[(int64_t)r * CH_BS] = o;
-                vn2[(int64_t)r * CH_BS] = m;
+                st_nt2(pn2 + (int64_t)r * CH_BS, o);
+                st_nt2(vn2 + (int64_t)r * CH_BS, m);
             }
         }
     } else {
@@ -1177,7 +1187,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
                 double2 o;
                 o.x = wr.x / h;
                 o.y = wr.y / h;
-                vn2[(int64_t)r * CH_BS] = o;
+                st_nt2(vn2 + (int64_t)r * CH_BS, o);
             }
         }
     }
@@ -1480,7 +1490,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
             double2 o;
             o.x = w[r].x / h;
             o.y = w[r].y / h;
-            vn2[(int64_t)r * CH_BS] = o;
+            st_nt2(vn2 + (int64_t)r * CH_BS, o);
         }
     }
     if (bid == 0 && a.hpin != nullptr) {
@@ -1632,7 +1642,7 @@ __global__ __launch_bounds__(ONEX ? CH_BS + 64 : CH_BS) void k_mgs_chain_small(C
             double2 o;
             o.x = w[r].x / h;
             o.y = w[r].y / h;
-            vn2[(int64_t)r * CH_BS] = o;
+            st_nt2(vn2 + (int64_t)r * CH_BS, o);
         }
     }
     if (bid == 0 && a.hpin != nullptr) {
@@ -1875,8 +1885,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
                 m.y = d.y * wr.y;
                 acc = fma(wr.x, m.x, acc);
                 acc = fma(wr.y, m.y, acc);
-                m2[(int64_t)r * CH_BS] = m;
-                w2[(int64_t)r * CH_BS] = wr;
+                st_nt2(m2 + (int64_t)r * CH_BS, m);
+                st_nt2(w2 + (int64_t)r * CH_BS, wr);
             }
         }
     } else {
@@ -1886,7 +1896,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
                 const double2 wr = CGS_W_GET(r);
                 acc = fma(wr.x, wr.x, acc);
                 acc = fma(wr.y, wr.y, acc);
-                w2[(int64_t)r * CH_BS] = wr;
+                st_nt2(w2 + (int64_t)r * CH_BS, wr);
             }
         }
     }

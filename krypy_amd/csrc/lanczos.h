@@ -83,9 +83,10 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
         const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev);
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld);
         const int64_t last = a.n_last;
-        int64_t i2 = first;
+        int64_t fb = first;          // (row r at a constant distance from the opaque base: chain.h, chain_apply_banded)
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
+            const int64_t i2 = fb + (int64_t)r * CH_BS;
             const int64_t row = 2 * i2;
             double2 av[FND];
             double x0[FND], x1[FND];
@@ -118,8 +119,7 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
             W_PUT(r, t);
             acc0 = fma(vv.x, t.x, acc0);
             acc1 = fma(vv.y, t.y, acc1);
-            i2 += CH_BS;
-            if ((r & 1) == 1) asm volatile("" : "+v"(i2) : : "memory");   // two rows of loads in flight
+            if ((r & KH_RIF) == KH_RIF) asm volatile("" : "+v"(fb) : : "memory");   // four rows of loads in flight
         }
     }
     // ---- pass 2: w -= alpha p_k, <w, D w>; a two-deep ring of PB2 rows, its first batch in flight across the sum ----
@@ -182,6 +182,7 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
     double2* __restrict__ yk = reinterpret_cast<double2*>(mr.yk) + first;
     double2 qd[2][PB3], qv[2][PB3], qu0[2][PB3], qu1[2][PB3], qy[2][PB3];
     const bool run3 = !(a.debug & 32), runm = MR && !(a.debug & 64);
+#define LZ_ST(ptr_, val_) st_nt2(ptr_, val_)          // (kernels.h: nobody reads these before the kernel ends)
 #define LZ_ISSUE3(b_, s_)                                                               \
     do {                                                                                \
         _Pragma("unroll") for (int i = 0; i < PB3; ++i) {                               \
@@ -219,10 +220,10 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
                         double2 m;
                         m.x = (d.x * wr.x) / h;
                         m.y = (d.y * wr.y) / h;
-                        pn2[(int64_t)r * CH_BS] = o;
-                        vn2[(int64_t)r * CH_BS] = m;
+                        LZ_ST(pn2 + (int64_t)r * CH_BS, o);
+                        LZ_ST(vn2 + (int64_t)r * CH_BS, m);
                     } else {
-                        vn2[(int64_t)r * CH_BS] = o;
+                        LZ_ST(vn2 + (int64_t)r * CH_BS, o);
                     }
                 }
                 if (runm) {      // k_minres_update's formulas (kernels.h), operation for operation
@@ -230,15 +231,16 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
                     double2 z, yo;
                     z.x = ((v.x - mr.r0 * u0.x) - mr.r1 * u1.x) / mr.r2;
                     z.y = ((v.y - mr.r0 * u0.y) - mr.r1 * u1.y) / mr.r2;
-                    w0[(int64_t)r * CH_BS] = z;
+                    LZ_ST(w0 + (int64_t)r * CH_BS, z);
                     yo.x = y.x + mr.y0 * z.x;
                     yo.y = y.y + mr.y0 * z.y;
-                    yk[(int64_t)r * CH_BS] = yo;
+                    LZ_ST(yk + (int64_t)r * CH_BS, yo);
                 }
             }
         }
     }
 #undef LZ_ISSUE3
+#undef LZ_ST
     if (blockIdx.x == 0 && a.hpin != nullptr) {
         __syncthreads();          // the H entries were written by thread 0 of this workgroup
         for (int i = tid; i < a.hcount; i += CH_BS)
