@@ -361,14 +361,14 @@ __global__ __launch_bounds__(BS) void k_waxpby(int64_t n, double* z, double alph
 __global__ __launch_bounds__(BS) void k_vdiv(int64_t n, double* __restrict__ z,
                                              const double* __restrict__ x, double s) {
     const int64_t stride = (int64_t)gridDim.x * BS;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) z[i] = x[i] / s;
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) st_nt(z + i, x[i] / s);
 }
 
 __global__ __launch_bounds__(BS) void k_diag_apply(int64_t n, const double* __restrict__ d,
                                                    const double* __restrict__ x,
                                                    double* __restrict__ y) {
     const int64_t stride = (int64_t)gridDim.x * BS;
-    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) y[i] = d[i] * x[i];
+    for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) st_nt(y + i, d[i] * x[i]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(BS) void k_spmm_stream(const int32_t* __restrict__ 
                     const double* __restrict__ pr = prod + dc * tile;
                     double s = 0.0;
                     for (int p = p0; p < p1; ++p) s += pr[p];
-                    Y[(int64_t)(j0 + dc) * ldy + r] = s;
+                    st_nt(Y + (int64_t)(j0 + dc) * ldy + r, s);
                 }
             }
             __syncthreads();
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(BS) void k_spmm_dia(DiaOffs o, const double* __rest
     for (int j = 0; j < DC; ++j) {
         if (j < nc) {
             double* __restrict__ y = Y + (int64_t)j * ldy;
-            if (r + 1 < n) *reinterpret_cast<double2*>(y + r) = make_double2(s0[j], s1[j]);
+            if (r + 1 < n) st_nt2(reinterpret_cast<double2*>(y + r), make_double2(s0[j], s1[j]));
             else y[r] = s0[j];
         }
     }

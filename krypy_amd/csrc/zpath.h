@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BS) void k_zmultiaxpy(int64_t n, ZColPtrs cols, con
             wv.x = wv.x - tr;
             wv.y = wv.y - ti;
         }
-        w[i] = wv;
+        st_nt2(w + i, wv);
         if (NRM) {
             acc = fma(wv.x, wv.x, acc);
             acc = fma(wv.y, wv.y, acc);
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(BS) void k_zwaxpby(int64_t n, double2* z, double2 a
             r.x = r.x + (beta.x * yv.x - beta.y * yv.y);
             r.y = r.y + (beta.x * yv.y + beta.y * yv.x);
         }
-        z[i] = r;
+        st_nt2(z + i, r);
     }
 }
 
@@ -141,11 +141,11 @@ __global__ __launch_bounds__(BS) void k_zminres_update(int64_t n, const double2*
             z.x = (t.x * rat + t.y) * scl;
             z.y = (t.y * rat - t.x) * scl;
         }
-        w0[i] = z;
+        st_nt2(w0 + i, z);
         double2 o = yk[i];
         o.x = o.x + (y0.x * z.x - y0.y * z.y);
         o.y = o.y + (y0.x * z.y + y0.y * z.x);
-        yk[i] = o;
+        st_nt2(yk + i, o);
     }
 }
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BS) void k_zdiag_apply(int64_t n, const double2* __
         double2 r;
         r.x = a.x * b.x - a.y * b.y;
         r.y = a.x * b.y + a.y * b.x;
-        y[i] = r;
+        st_nt2(y + i, r);
     }
 }
 
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__
                 s.x += zprod[p].x;
                 s.y += zprod[p].y;
             }
-            y[r] = s;
+            st_nt2(y + r, s);
         }
     } else {  // one long row: tree reduction
         double sr = 0.0, si = 0.0;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(BS) void k_zfrom_real(int64_t n, const double* __re
         double2 r;
         r.x = x[i];
         r.y = 0.0;
-        z[i] = r;
+        st_nt2(z + i, r);
     }
 }
 
