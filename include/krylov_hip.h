@@ -74,7 +74,9 @@ int kh_ctx_counters(kh_ctx ctx, int64_t out[4]);
 int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile);
 /* named switches of a context (1 = on, the default; the environment variables of INTEGRATION.md set the
  * initial values): "spmv_dia" banded SpMV for stencil CSR operators, "chain" register-resident MGS chain,
- * "chain_lds" column head parked in LDS, "chain_spmv" operator fused into the chain prologue.  bench.py
+ * "chain_lds" column head parked in LDS, "chain_spmv" operator fused into the chain prologue, "chain_onex" short vectors
+ * on one XCD, "chain_small" the column-ring kernel for them, "lanczos_fused" the three-pass Lanczos kernel, "tag_wait"
+ * completion tags in pinned memory instead of an event per Arnoldi step.  bench.py
  * uses it to time the CSR-stream and the banded SpMV kernel on the same operator.  Test-only switches (0 by
  * default): "chain_fault" the next chain launch fakes a timeout, "halo_loopback" a 1-rank communicator exchanges
  * the halo of a sharded operator with ITSELF (grouped ncclSend / ncclRecv to its own rank: the slab of an operator

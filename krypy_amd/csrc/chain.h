@@ -67,6 +67,10 @@ struct ChainArgs {
     double* hpin;
     int hcount;
     int* errpin;
+    // ... and, when donepin != nullptr, finally stores done_tag there (system scope, behind the H column): the host
+    // polls that word instead of waiting for an event (CH_SIGNAL_DONE)
+    int* donepin;
+    int done_tag;
     // fused operator (k_mgs_chain_lds<..., FND > 0>): w = A x computed by the prologue straight into
     // registers from the diagonal-major copy of a banded operator instead of being loaded
     const double* dia;
@@ -84,6 +88,19 @@ struct ChainArgs {
     unsigned long long* trace;   // diagnostic build only (make trace): [G][links][2 waves][8] 100 MHz stamps
 #endif
 };
+
+// Completion tag of a launch, written by workgroup 0 behind its copy of the H column (every thread of the workgroup
+// takes this path): each thread's stores to the pinned buffer are performed at system scope before the barrier, the
+// tag follows them.
+#define CH_SIGNAL_DONE(a_)                                                                               \
+    do {                                                                                                 \
+        if ((a_).donepin != nullptr) {                                                                   \
+            __threadfence_system();                                                                      \
+            __syncthreads();                                                                             \
+            if (threadIdx.x == 0)                                                                        \
+                __hip_atomic_store((a_).donepin, (a_).done_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); \
+        }                                                                                                \
+    } while (0)
 
 // Phase stamps of the diagnostic build (tools/chain_trace.py): wave 0 and wave 7 of every workgroup
 // note the constant 100 MHz clock at the phase boundaries of every link.  Compiled out of the product.
@@ -888,6 +905,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
     }
 #undef W_PUT
 #undef W_GET
@@ -1196,6 +1214,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
     }
 #undef W_PUT
 #undef W_GET
@@ -1498,6 +1517,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_pf(ChainArgs a) {
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
     }
 #undef CH_REUSE
 #undef CH_LD
@@ -1542,7 +1562,10 @@ __global__ __launch_bounds__(ONEX ? CH_BS + 64 : CH_BS) void k_mgs_chain_small(C
             }
             const double h2 = onex_sum_comm(epoch++, a.gran, G, bid, a.err, smd);
             if (writer) a.hdev[a.hnext] = sqrt(fabs(h2));
-            if (bid == 0 && a.hpin != nullptr) __syncthreads();          // (the copy at the end, by the working waves)
+            if (bid == 0 && a.hpin != nullptr) {
+                __syncthreads();          // (the copy at the end, by the working waves)
+                if (a.donepin != nullptr) __syncthreads();          // (... and the barrier of CH_SIGNAL_DONE)
+            }
             return;
         }
     }
@@ -1650,6 +1673,7 @@ __global__ __launch_bounds__(ONEX ? CH_BS + 64 : CH_BS) void k_mgs_chain_small(C
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
     }
 #undef CH_OK
 }

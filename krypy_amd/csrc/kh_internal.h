@@ -99,6 +99,15 @@ struct kh_ctx_s {
     unsigned long long* chain_xcc = nullptr;   // per-XCD result granules + leader stamps of the grid-wide sums
     int* chain_err = nullptr;        // device error word
     int* chain_err_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    // completion tags: the last kernel of a chained step writes done_seq[slot] to the slot's pinned word behind the H
+    // column and the host polls it - an event record between two launches costs 2.8 us of queue time
+    // (tools/probe/gap_probe.hip); steps whose last kernel does not write the tag keep the event
+    int* done_pin[KH_NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    int done_seq[KH_NSLOT] = {0, 0, 0, 0};
+    bool wait_tag[KH_NSLOT] = {false, false, false, false};
+    int done_counter = 0;
+    int tag_wait = 1;       // KRYPY_AMD_TAG_WAIT=0: events for every step
+    int64_t n_tag_waits = 0;
     unsigned chain_epoch = 1;
     int chain_debug = 0;
     int roctx = 0;          // KRYPY_AMD_ROCTX=1: roctx ranges around the entry points of the hot loop

@@ -630,6 +630,14 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     a.hpin = hpin;
     a.hcount = hcount;
     a.errpin = ctx->chain_err_pin[slot];
+    // completion tag (kh_internal.h): whichever chain-family kernel this call ends up launching writes it
+    a.donepin = (hpin != nullptr && ctx->tag_wait) ? ctx->done_pin[slot] : nullptr;
+    a.done_tag = 0;
+    if (a.donepin != nullptr) {
+        ctx->done_counter = (ctx->done_counter == 0x7fffffff) ? 1 : ctx->done_counter + 1;
+        a.done_tag = ctx->done_counter;
+        ctx->done_seq[slot] = a.done_tag;
+    }
 #ifdef KH_CHAIN_TRACE
     a.trace = ctx->chain_trace;
 #endif
@@ -718,7 +726,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                                       ctx->stream));
             ctx->mr_taken = job.on ? 1 : 0;     // (the MINRES job - if any - went along)
-            return 1;
+            { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
         }
         (void)hipGetLastError();             // e.g. the dynamic LDS was refused: the general chain kernel below
         if (!presub) a.bprev = nullptr;
@@ -752,7 +760,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             if (hpin == nullptr)
                 KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                                       ctx->stream));
-            return 1;
+            { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
         }
         (void)hipGetLastError();
     }
@@ -785,7 +793,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             if (hpin == nullptr)
                 KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                                       ctx->stream));
-            return 1;
+            { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
         }
         (void)hipGetLastError();
     }
@@ -839,7 +847,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     if (hpin == nullptr)      // (otherwise workgroup 0 has written the error word to the pinned slot itself)
         KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
                               ctx->stream));
-    return 1;
+    { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
 }
 
 // ---- register-resident panel Gram-Schmidt (k_cgs_dots / k_cgs_update, chain.h) -----------------
@@ -1019,6 +1027,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
     for (int s = 0; s < KH_NSLOT; ++s) {
         KH_HIP(hipHostMalloc(&ctx->chain_err_pin[s], sizeof(int), hipHostMallocDefault));
         *ctx->chain_err_pin[s] = 0;
+        KH_HIP(hipHostMalloc(&ctx->done_pin[s], sizeof(int), hipHostMallocCoherent));          // (fine-grained: the tag is visible when it is written)
+        *ctx->done_pin[s] = 0;
     }
     {
         const char* e = getenv("KRYPY_AMD_MGS_CHAIN");
@@ -1030,6 +1040,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_lds = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_PF");
         ctx->chain_pf = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_TAG_WAIT");
+        ctx->tag_wait = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_SMALL");
         ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
@@ -1069,8 +1081,10 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipFree(ctx->chain_xcc);
     (void)hipFree(ctx->onex_ticket);
     (void)hipFree(ctx->chain_err);
-    for (int s = 0; s < KH_NSLOT; ++s)
+    for (int s = 0; s < KH_NSLOT; ++s) {
         if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
+        if (ctx->done_pin[s]) (void)hipHostFree(ctx->done_pin[s]);
+    }
     (void)hipFree(ctx->part);
     (void)hipFree(ctx->scal);
     (void)hipHostFree(ctx->hpin);
@@ -1135,6 +1149,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
+    else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
@@ -1158,6 +1173,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_onex")) *value = ctx->chain_onex;
     else if (!strcmp(key, "n_chain_onex")) *value = ctx->n_chain_onex;
     else if (!strcmp(key, "chain_small")) *value = ctx->chain_small;
+    else if (!strcmp(key, "tag_wait")) *value = ctx->tag_wait;
+    else if (!strcmp(key, "n_tag_waits")) *value = ctx->n_tag_waits;
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
@@ -1915,6 +1932,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     KH_TRY(check_vec(W, wcol, Md ? 2 : 1, "kh_arnoldi_step(W)"));
     KH_ARG(W->n == V->n, "kh_arnoldi_step: W length");
     const int64_t n = V->n;
+    ctx->wait_tag[slot] = false;
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 1;
@@ -2131,8 +2149,12 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         }
         KH_HIP(hipGetLastError());
     }
-    // (the last kernel of the step - chain or scale-store - has written the H column to the pinned slot)
-    KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+    // (the last kernel of the step - chain or scale-store - has written the H column to the pinned slot; the chain
+    // kernels also write a completion tag there: no event then, kh_arnoldi_step_end polls the tag)
+    if (!(chained && ctx->wait_tag[slot])) {
+        ctx->wait_tag[slot] = false;
+        KH_HIP(hipEventRecord(ctx->hev[slot], ctx->stream));
+    }
     return 0;
 }
 
@@ -2142,7 +2164,21 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
     KH_ARG(slot >= 0 && slot < KH_NSLOT && count >= 0 && count <= ctx->hcap,
            "kh_arnoldi_step_end: slot %d / count %lld", slot, (long long)count);
     KH_ARG(ctx->hev[slot] != nullptr, "kh_arnoldi_step_end: no step was begun");
-    KH_HIP(hipEventSynchronize(ctx->hev[slot]));
+    if (ctx->wait_tag[slot]) {
+        // the step's chain kernel writes its tag behind the H column (CH_SIGNAL_DONE).  Should the tag never show up
+        // the stream running empty says the same thing later.
+        volatile int* tagp = ctx->done_pin[slot];
+        const int want = ctx->done_seq[slot];
+        for (unsigned spins = 1; *tagp != want; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 0x3fffu) == 0 && hipStreamQuery(ctx->stream) == hipSuccess) break;
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        ctx->wait_tag[slot] = false;
+        ctx->n_tag_waits += 1;
+    } else {
+        KH_HIP(hipEventSynchronize(ctx->hev[slot]));
+    }
     if (*ctx->chain_err_pin[slot] != 0) {
         // The grid-wide reduction of the chain kernel timed out (its workgroups were not co-resident: a shared
         // or partially masked GPU).  Column k+1 of the basis and this H column are garbage, columns 0..k are

@@ -246,6 +246,7 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
         for (int i = tid; i < a.hcount; i += CH_BS)
             a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
     }
 #undef W_PUT
 #undef W_GET

@@ -753,6 +753,7 @@ int kh_zarnoldi_step_begin_md(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_
     KH_ARG(proj == nullptr || (proj->cplx && proj->W->n == V->n && A != nullptr),
            "kh_zarnoldi_step_begin: a complex projector of length N and the operator are needed");
     KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1) + pd)));
+    ctx->wait_tag[slot] = false;
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 2;

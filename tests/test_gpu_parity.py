@@ -707,6 +707,47 @@ def test_column_ring_kernel_for_short_vectors(hip, n):
         assert np.linalg.norm(res[1, "prologue"][0] - st.H) < 1e-11 * np.linalg.norm(st.H)
 
 
+def test_completion_tags_replace_the_per_step_event(hip):
+    """The last kernel of a chained Arnoldi step writes a completion tag behind the H column in pinned memory and
+    kh_arnoldi_step_end polls it; steps whose last kernel does not write one (link kernels, panel Gram-Schmidt) keep
+    their event.  Same H columns either way (bit for bit), with look-ahead (several steps in flight), through a faked
+    timeout (the re-run step waits for its event) and for a whole solve."""
+    from krypy_amd import _hip, linsys
+
+    A = ref.laplace2d(300, 200)
+    n = A.shape[0]
+    v = np.random.default_rng(8).standard_normal(n)
+    m = 12
+    res = {}
+    for tag in (1, 0):
+        ctx = _hip.Context(0)
+        ctx.set("tag_wait", tag)
+        Ad = ctx.csr(A)
+        V, W = ctx.alloc(n, m + 2), ctx.alloc(n, 2)
+        V.upload(0, v / np.linalg.norm(v))
+        H = np.zeros((m + 2, m + 1))
+        w0 = ctx.get("n_tag_waits")
+        ctx.arnoldi_step_begin(Ad, None, V, None, W, 0, 0, 0, 1, 0, 0.0, 0)
+        for k in range(m):                     # step k + 1 is in flight while step k is collected
+            if k == 6:
+                ctx.set("chain_fault", 1)
+            ctx.arnoldi_step_begin(Ad, None, V, None, W, 0, k + 1, 0, 1, 1 if k == 9 else 0, 0.0, (k + 1) % 4)
+            H[: k + 2, k] = ctx.arnoldi_step_end(k % 4, k + 2)
+            if ctx.get("chain") == 0:
+                ctx.set("chain", 1)
+        H[: m + 2, m] = ctx.arnoldi_step_end(m % 4, m + 2)
+        waits = ctx.get("n_tag_waits") - w0
+        assert (waits >= m - 3) if tag else (waits == 0), (tag, waits)
+        res[tag] = (H, V.download())
+        ctx.close()
+    # (the step behind the faked timeout is re-run on the link kernels, the one after it consumed its garbage and is
+    # re-run too: same launches in both runs)
+    assert np.array_equal(res[1][0], res[0][0])
+    assert np.array_equal(res[1][1], res[0][1])
+    Hm, Vm = res[1]
+    assert np.linalg.norm(A.dot(Vm[:, : m + 1]) - Vm.dot(Hm)) < 1e-12 * np.linalg.norm(Hm)
+
+
 def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
     """kh_gmres_cycle (Arnoldi steps with look-ahead on the device, Givens QR and the residual recurrence on the host
     in C: linsys.py:951-997 in one call) against the per-step Python loop (KRYPY_AMD_GMRES_CYCLE=0): same iteration
