@@ -647,9 +647,9 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
                 if G2 is not None:
                     R1, R2 = rot(G2, R1, R2)
                 G1 = G2
-                g = utils.Givens(numpy.array([[R2], [R3]]))
-                G2 = (_pyscalar(g.c), _pyscalar(g.s))
-                R2 = _pyscalar(g.r)
+                gc, gs, gr = utils.givens_scalars(R2, R3)
+                G2 = (_pyscalar(gc), _pyscalar(gs))
+                R2 = _pyscalar(gr)
                 y = list(rot(G2, y[0], y[1]))
                 # z = (V_k - R0*W0 - R1*W1)/R2 ; W = [W1, z] ; yk += y[0]*z   (linsys.py:844-846)
                 # (deferred: the next Lanczos launch carries the update in the shadow of its last pass; whoever reads
@@ -755,8 +755,8 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
                 t0, t1 = col[i], col[i + 1]
                 col[i] = c * t0 + s * t1
                 col[i + 1] = -s.conjugate() * t0 + c * t1
-            g = utils.Givens(numpy.array([[col[k]], [col[k + 1]]]))
-            c, s = _pyscalar(g.c), _pyscalar(g.s)
+            gc, gs, _ = utils.givens_scalars(col[k], col[k + 1])
+            c, s = _pyscalar(gc), _pyscalar(gs)
             cs.append((c, s))
             t0, t1 = col[k], col[k + 1]
             col[k] = c * t0 + s * t1

@@ -480,6 +480,22 @@ class Givens(object):
         return numpy.dot(self.G, x)
 
 
+def givens_scalars(a, b):
+    """``(c, s, r)`` of ``Givens(numpy.array([[a], [b]]))`` for two Python scalars, without the arrays: the same BLAS
+    call on the same values and the same expression for ``r`` - the same bits - in 0.4 instead of 10 microseconds.  (The
+    MINRES loop at short vectors is host-bound: an iteration is one 18 us launch.)"""
+    if isinstance(a, complex) or isinstance(b, complex):
+        a = complex(a)          # (what the (2, 1) array would have made of the pair)
+        b = complex(b)
+    if a.imag == 0 and b.imag == 0:
+        a = a.real
+        b = b.real
+        c, s = blas.drotg(a, b)
+    else:
+        c, s = blas.zrotg(a, b)
+    return c, s, c * a + s * b
+
+
 # ----------------------------------------------------------------------------------------
 # linear operators (utils.py:1365-1602)
 # ----------------------------------------------------------------------------------------

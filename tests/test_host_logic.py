@@ -278,3 +278,35 @@ def test_committed_bench_line_fractions_are_fractions():
     assert r["traffic"] is None or (r["traffic"] == r["bytes_per_launch"] and r["traffic"] >= r["compulsory_bytes_per_launch"])
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s"
+
+
+def test_givens_scalars_equal_the_givens_class():
+    """utils.givens_scalars is what the MINRES / GMRES loops call per iteration (the (2, 1)-array constructor of
+    utils.Givens costs 10 us, an iteration at short vectors is one 18 us launch): the same BLAS call on the same values -
+    bit for bit for real pairs (zero pairs and complex dtypes with zero imaginary parts included); for complex pairs
+    zrotg hands back c with an uninitialised imaginary part (denormal garbage that differs from call to call in the
+    reference as well), everything else is identical."""
+    import numpy as np
+    from krypy_amd import utils
+
+    rng = np.random.default_rng(0)
+    for t in range(3000):
+        kind = t % 6
+        a, b = float(rng.standard_normal()), float(rng.standard_normal())
+        if kind == 1:
+            a, b = complex(a, rng.standard_normal()), complex(b, rng.standard_normal())
+        elif kind == 2:
+            b = complex(b, rng.standard_normal())
+        elif kind == 3:
+            a, b = complex(a, 0.0), complex(b, 0.0)
+        elif kind == 4:
+            b = 0.0
+        elif kind == 5:
+            a, b = 0.0, (0.0 if t % 12 == 5 else b)
+        g = utils.Givens(np.array([[a], [b]]))
+        c, s, r = utils.givens_scalars(a, b)
+        if kind in (1, 2):
+            assert complex(g.c).real == complex(c).real and complex(g.s) == complex(s)
+            assert abs(complex(g.r) - complex(r)) < 1e-300
+        else:
+            assert type(c) is type(g.c) and (g.c, g.s, g.r) == (c, s, r), (a, b)
