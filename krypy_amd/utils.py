@@ -1320,8 +1320,9 @@ class Arnoldi(object):
         if self.ortho == "lanczos":
             start = k
             if k > 0:
-                H[k - 1, k] = H[k, k - 1]
-                h_km1 = float(numpy.real(H[k, k - 1]))
+                hv = H[k, k - 1]
+                H[k - 1, k] = hv
+                h_km1 = float(hv.real)
         if self._fused:
             if self._lookahead:
                 last = min(k + self._lookahead, self.maxiter - 1)
@@ -1353,8 +1354,11 @@ class Arnoldi(object):
             if self.ortho == "lanczos" and hcol.dtype.kind == "c":
                 hcol = hcol.real       # alpha = real(alpha), utils.py:1024-1027
             off = self._base          # (window: the column arrives in window coordinates)
-            H[start: k + 1, k] += hcol[start - off: k + 1 - off]
-            hn = float(numpy.real(hcol[k + 1 - off]))
+            if start == k:            # (Lanczos: one entry - no slices; an iteration at short vectors is one 18 us launch)
+                H[k, k] += hcol[k - off]
+            else:
+                H[start: k + 1, k] += hcol[start - off: k + 1 - off]
+            hn = float(hcol[k + 1 - off].real)
         elif self.ortho == "house":
             hn = self._advance_house(k)
         elif self._BV is not None:
