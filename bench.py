@@ -386,6 +386,23 @@ def _run():
                             "ms_per_cycle": d2 / args.steps * 1e3,
                             "final_relres": float(s2.resnorms[-1])}
 
+    # the reference-order solver on a GENERAL CSR operator (the CSR-stream SpMV kernel + the chain kernel: what a matrix
+    # that is not a stencil gets), and with the banded SpMV as a launch of its own (no operator in the chain's prologue)
+    if not sharded and args.other_modes and ortho == "mgs" and hasattr(ctx, "set"):
+        for label, key in (("mgs, general CSR SpMV kernel + chain kernel (spmv_dia = 0, as KRYPY_AMD_SPMV_DIA=0)", "spmv_dia"),
+                           ("mgs, banded SpMV launch + chain kernel (chain_spmv = 0, as KRYPY_AMD_CHAIN_SPMV=0)", "chain_spmv")):
+            barrier()
+            ctx.set(key, 0)
+            try:
+                t1 = time.perf_counter()
+                s2 = run_cycles(args.steps, x0, ortho="mgs")
+                ctx.sync()
+                d2 = time.perf_counter() - t1
+            finally:
+                ctx.set(key, 1)
+            others[label] = {"iterations_per_s": (len(s2.resnorms) - 1) / d2, "ms_per_cycle": d2 / args.steps * 1e3,
+                             "final_relres": float(s2.resnorms[-1])}
+
     # ---- roofline of the dominant kernel, timed live with HIP events on the library stream ----
     nloc = ls.N
     roof = None
@@ -399,7 +416,7 @@ def _run():
         # bench.py cannot collect counters itself): attached only if the file carries the stamp of the kernel
         # sources that have just been timed, otherwise `traffic` stays null and the byte model is used
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-        roof, extra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS, traffic_files=tfiles)
+        roof, extra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS, traffic_files=tfiles, m=m)
     except Exception as exc:   # never lose the headline number to the instrumentation
         extra = {"roofline_error": repr(exc)}
 

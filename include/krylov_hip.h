@@ -269,6 +269,7 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
 #define KH_CG_NONPOSITIVE_PAP 2   /* Re <p, Ap> <= 0: not a positive definite operator in this inner product */
 #define KH_CG_NONFINITE_RHO 4     /* <r, z> is inf / nan */
 #define KH_CG_NEGATIVE_RHO 8      /* <r, z> < 0: the preconditioner is not positive definite */
+#define KH_CG_STEP_CLAMPED 16     /* rho / <p, Ap> is not finite although both are (a zero divisor): the device took NO step */
 int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol,
                kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first,
                double omega, double rho, double* out);
@@ -340,6 +341,13 @@ int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec
  * reduction alone), 8 register-resident panel GS over 16 columns (k_cgs_dots + k_reduce_partials +
  * k_cgs_update).  V needs >= 17 columns, W 2 columns. */
 int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double* avg_ms);
+/* The solver's own launch sequence (what Gmres._solve / kh_gmres_cycle enqueue, utils.py:954-1048 once per k):
+ * `reps` times the Arnoldi steps k = 0 .. m-1 on V (>= m+1 columns, column 0 a unit vector), one step of look-ahead,
+ * columns fetched in order.  avg_step_ms = HIP-event time / (reps * m).  With a banded operator and vectors that
+ * fit the register file each step is ONE launch of the fused chain kernel: its average duration over k+1 = 1 .. m
+ * Gram-Schmidt links is the `roofline.avg_launch_ms` of bench.py. */
+int kh_bench_arnoldi(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t m, int gs_mode, int reps,
+                     double* avg_step_ms);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ K_GS_LINK, K_MULTIDOT16, K_MULTIAXPY16, K_AXPY_NRM, K_SCALE_STORE, K_CHAIN, K_CG
 K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
-_SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h")
+_SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h", "chain_blk.h",
+            "chain_blk.hip")
 
 
 def source_stamp():
@@ -65,8 +66,9 @@ def chain_reread_fraction(n, ncu, lds=True):
     return 0, 1.0
 
 
-def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
-    """Returns (roofline dict of the dominant kernel, extra dict with the other kernels)."""
+def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
+    """Returns (roofline dict of the dominant kernel, extra dict with the other kernels).  ``m``: the restart length
+    of the timed solver (the solver's own launches are timed over k = 0 .. m-1)."""
     n = ls.N
     ncol = 18
     V = ctx.alloc(n, ncol)
@@ -80,6 +82,9 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
     def run(which, name, compulsory, moved_model, survey=None):
         ctx.bench_kernel(which, V, W, 5)             # warm-up
         ms = ctx.bench_kernel(which, V, W, reps)
+        return run_ms(ms, name, compulsory, moved_model, survey)
+
+    def run_ms(ms, name, compulsory, moved_model, survey=None):
         # compulsory: what must cross the HBM interface; request model: every byte the kernel asks the L2 for (an
         # UPPER bound on its HBM traffic - re-reads served by L2 / Infinity Cache are in it); PMC traffic, where a
         # stamped profile exists, is attached to the dominant kernel below
@@ -137,6 +142,41 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
         del ms_probe
     except Exception as exc:   # not eligible (w larger than the register file, multi-GPU)
         kernels["k_mgs_chain"] = {"unavailable": repr(exc)}
+    # ---- the solver's OWN launches: Arnoldi steps k = 0 .. m-1 as Gmres._solve enqueues them ----
+    solver = None
+    solver_name = None
+    Amat0 = ls.A._device_matrix() if hasattr(ls.A, "_device_matrix") else None
+    if (chain is not None and ortho in ("mgs",) and Amat0 is not None and Amat0.kind == "csr"
+            and hasattr(ctx, "bench_arnoldi")):
+        try:
+            c0 = ctx.counters()
+            Vm = ctx.alloc(n, m + 1)
+            v0 = rng.standard_normal(n)
+            Vm.upload(0, v0 / numpy.linalg.norm(v0))
+            ctx.bench_arnoldi(Amat0, Vm, W, m, 0, 1)             # warm-up
+            c1 = ctx.counters()
+            ms = ctx.bench_arnoldi(Amat0, Vm, W, m, 0, 3)
+            c2 = ctx.counters()
+            nd = Amat0.diagonals
+            fused = nd and (c2.get("chain_fused", 0) - c1.get("chain_fused", 0)) == 3 * m
+            one_launch = (c2.get("chain", 0) - c1.get("chain", 0)) == 3 * m
+            if one_launch:
+                # every datum once: the operator (diagonal-major copy, or the CSR arrays + w written and read back when
+                # the step is SpMV + chain), columns 0..k, v_{k+1} out - averaged over k = 0 .. m-1
+                op = 8.0 * nd * n if fused else (12.0 * Amat0.nnz + 4.0 * (n + 1) + 8.0 * n + 16.0 * n)
+                comp = op + 8.0 * n * (m + 1) / 2.0 + 8.0 * n
+                r2 = chain_reread_fraction(n, int(info.get("compute_units", 256)), True)[0]
+                solver_name = ("k_mgs_chain_lds<%d,false,false,%d>: the solver's Arnoldi steps k = 0..%d, one launch each "
+                               "(operator in the prologue, k+1 Gram-Schmidt links)" % (r2, nd, m - 1)) if fused else \
+                              ("SpMV + k_mgs_chain_lds<%d>: the solver's Arnoldi steps k = 0..%d" % (r2, m - 1))
+                solver = run_ms(ms, solver_name, comp, comp + 8.0 * n * (m + 1) / 2.0 * rr,
+                                (8.0 * nd * n if fused else op) + 16.0 * n * (m + 1) / 2.0 + 8.0 * n)
+                solver["fused_operator"] = bool(fused)
+                solver["links_per_launch_avg"] = (m + 1) / 2.0
+                solver["us_per_link"] = ms * 1e3 / ((m + 1) / 2.0)
+            del Vm
+        except Exception as exc:
+            kernels["solver_arnoldi_steps"] = {"unavailable": repr(exc)}
     cgs = None
     try:
         # register-resident panel GS: 16 columns read for the dots, again for the update (the basis does not fit
@@ -203,19 +243,20 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
         k = {"avg_ms": d["avg_ms"] + a["avg_ms"], "compulsory_bytes": d["compulsory_bytes"] + a["compulsory_bytes"],
              "moved_bytes_model": d["moved_bytes_model"] + a["moved_bytes_model"]}
         name, traffic_keys = "k_multidot<16>+k_multiaxpy<16>", ()
+    elif solver is not None:
+        k, name, traffic_keys = solver, solver_name, ("k_mgs_chain_solver",)
     elif chain is not None:
         k, name, traffic_keys = chain, chain_name, ("k_mgs_chain",)
     else:
         k, name, traffic_keys = kernels["k_gs_link<A_PART,T_DOT>"], "k_gs_link<A_PART,T_DOT>", ()
     ms = k["avg_ms"]
     comp = k["compulsory_bytes"]
-    # without PMC numbers for exactly this source tree the only bytes known to cross the HBM interface are the
-    # compulsory ones: a lower bound on the traffic, so no fraction below can exceed 1 (the kernel's own
-    # request model - every byte it asks L2 for - stays in `kernels` as moved_bytes_model, an upper bound)
-    moved, source = comp, ("compulsory bytes (lower bound on the HBM traffic: no profiles/*_traffic.json carries the "
-                           "stamp of these kernel sources)")
+    # `bytes_per_launch` = the ALGORITHMIC (compulsory) bytes of a launch - every datum once - and `frac` the
+    # fraction of the peak they are moved at.  `traffic` = what the memory fabric was asked for, from the PMC passes
+    # of this same command, attached only when the profile carries the stamp of the kernel sources that have just
+    # been timed; traffic_over_bytes > 1 is re-read traffic (the second use of a column that missed LDS / L2).
     stamp = source_stamp()
-    traffic = None
+    traffic, traffic_file = None, None
     for fn in sorted(traffic_files or [], reverse=True):
         try:
             import json
@@ -228,31 +269,45 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None):
                 continue
             traffic = sum(tj[key]["hbm_read_bytes_per_launch"] + tj[key]["hbm_write_bytes_per_launch"]
                           for key in traffic_keys)
-            moved, source = traffic, "rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE), " + os.path.basename(fn)
+            traffic_file = os.path.basename(fn)
             break
         except Exception:
             continue
-    ach = _gbs(moved, ms)
-    if traffic is not None:
-        k["hbm_bytes_pmc"] = traffic
-        k["frac_pmc"] = ach / peak_gbs
+    ach = _gbs(comp, ms)
     roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": peak_gbs, "unit": "GB/s",
             "frac": ach / peak_gbs, "traffic": traffic, "avg_launch_ms": ms,
-            "bytes_per_launch": moved, "bytes_source": source,
-            "compulsory_bytes_per_launch": comp, "frac_compulsory": _gbs(comp, ms) / peak_gbs,
+            "bytes_per_launch": comp,
+            "bytes_source": "compulsory (algorithmic) bytes: every basis column once (8 N each), the operator's arrays once, "
+                            "v_{k+1} out - SURVEY 8(d)'s per-unit figures with the column's second use NOT charged to HBM",
             "source_stamp": stamp}
+    if traffic is not None:
+        roof["traffic_over_bytes"] = traffic / comp
+        roof["traffic_gbs"] = _gbs(traffic, ms)
+        roof["frac_traffic"] = _gbs(traffic, ms) / peak_gbs
+        roof["traffic_source"] = ("rocprofv3 PMC, separate passes: 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 "
+                                  "correction), " + traffic_file + "; these counters sit in front of the Infinity "
+                                  "Cache, so this is memory-FABRIC traffic - an upper bound on what reached HBM")
+        k["fabric_bytes_pmc"] = traffic
+        k["frac_pmc"] = _gbs(traffic, ms) / peak_gbs
+    else:
+        roof["traffic_source"] = ("null: no profiles/*_traffic.json carries the stamp of these kernel sources "
+                                  "(tools/profile.sh + tools/summarize_prof.py produce it)")
     if attainable:
         roof["attainable_gbs"] = attainable
         roof["frac_of_attainable"] = ach / attainable
-        roof["frac_compulsory_of_attainable"] = _gbs(comp, ms) / attainable
     if "survey_8d_bytes" in k:
         roof["survey_8d_side_number"] = {
             "bytes_per_launch": k["survey_8d_bytes"], "gbs": _gbs(k["survey_8d_bytes"], ms),
             "note": "SURVEY 8(d) charges 16 N per basis column (read for the projection, read again for the "
                     "update); the kernel serves part of the second use from LDS / registers / L2, so this rate "
                     "is NOT an HBM rate and is not compared with the peak"}
-    if chain is not None and k is chain:
+    if solver is not None and k is solver:
+        roof["note"] = ("avg_launch_ms = HIP-event time of 3 x %d Arnoldi steps (kh_bench_arnoldi: the launches Gmres._solve "
+                        "enqueues, k+1 = 1..%d links each, %.1f on average) / %d; frac = bytes_per_launch / avg_launch_ms / "
+                        "peak.  The 64-link micro-launch of the same kernel without the operator (FND = 0) is in "
+                        "`kernels`." % (m, m, (m + 1) / 2.0, 3 * m))
+    elif chain is not None and k is chain:
         roof["note"] = ("64-link launches that load w (FND = 0 instantiation); the solver's own launches are the same "
                         "kernel with w = A v_k computed in the prologue and k+1 links each.  frac = bytes_per_launch / "
-                        "avg_launch_ms / peak; frac_compulsory counts every column once.")
+                        "avg_launch_ms / peak with every column counted once.")
     return roof, extra

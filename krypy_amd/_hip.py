@@ -31,6 +31,7 @@ _INT = ctypes.c_int
 
 # sanity word of the fused CG step (KH_CG_* of include/krylov_hip.h)
 CG_NONFINITE_PAP, CG_NONPOSITIVE_PAP, CG_NONFINITE_RHO, CG_NEGATIVE_RHO = 1, 2, 4, 8
+CG_STEP_CLAMPED = 16
 # stop reasons of kh_gmres_cycle (KH_CYCLE_* of the header)
 CYCLE_LIMIT, CYCLE_TOL, CYCLE_CHECK = 0, 1, 2
 
@@ -104,6 +105,7 @@ _SIGNATURES = {
     "kh_cg_step": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _INT, _D, _D,
                    _c_double_p],
     "kh_bench_kernel": [_H, _INT, _H, _H, _INT, _c_double_p],
+    "kh_bench_arnoldi": [_H, _H, _H, _H, _I64, _INT, _INT, _c_double_p],
     # complex (c128) side: vectors are real blocks of length 2N (interleaved re, im)
     "kh_zcsr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
                        ctypes.POINTER(_H)],
@@ -772,6 +774,8 @@ class Context(object):
         for a in (H, R, cs, y, resn):
             if a.dtype != numpy.float64 or not a.flags.c_contiguous:
                 raise BackendError("gmres_cycle: C-ordered float64 arrays needed")
+        if H.ndim != 2 or R.ndim != 2 or H.shape[0] < k_stop + 1 or R.shape[0] < k_stop + 1:
+            raise BackendError("gmres_cycle: H and R need k_stop + 1 = %d rows" % (k_stop + 1))
         enq_ = ctypes.c_int64(int(enq))
         h2_ = _D(float(h2))
         kd = ctypes.c_int64(0)
@@ -826,6 +830,13 @@ class Context(object):
         ms = _D(0.0)
         _check(self._lib, self._lib.kh_bench_kernel(self._h, which, V.handle, W.handle, reps,
                                                     ctypes.byref(ms)), "kh_bench_kernel")
+        return ms.value
+
+    def bench_arnoldi(self, A, V, W, m, gs_mode, reps):
+        """Average duration (ms) of one Arnoldi step over ``reps`` sequences k = 0 .. m-1 (``kh_bench_arnoldi``)."""
+        ms = _D(0.0)
+        _check(self._lib, self._lib.kh_bench_arnoldi(self._h, A.handle, V.handle, W.handle, int(m), int(gs_mode),
+                                                     int(reps), ctypes.byref(ms)), "kh_bench_arnoldi")
         return ms.value
 
 

@@ -442,7 +442,7 @@ __device__ __forceinline__ unsigned long long ld_l2(const unsigned long long* p)
 }
 
 // how many workgroups of a launch land on each XCD (kh_ctx_create checks the deal once)
-__global__ void k_onex_probe(unsigned* count) {
+static __global__ void k_onex_probe(unsigned* count) {
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     if (threadIdx.x == 0) atomicAdd(count + (v & 0xfu), 1u);
@@ -631,7 +631,7 @@ struct ChainShape {
 #ifndef KH_RIF
 #define KH_RIF 3          // rows of the fused operator in flight - 1 (a mask: 1 = two rows, 3 = four)
 #endif
-template <int R2, int FND, class Put>
+template <int R2, int FND, int RIF = KH_RIF, class Put>
 __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, Put&& put) {
     // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
     // separate multiply and add, empty slots skipped): the 80 MB of w are never written nor read.
@@ -673,7 +673,7 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
             s1 = (av[d].y != 0.0) ? s1 + p1 : s1;
         }
         put(r, s0, s1);         // (row r of w: a register, or - long shapes - this lane's LDS entry)
-        if ((r & KH_RIF) == KH_RIF) asm volatile("" : "+v"(fb) : : "memory");   // four rows of loads in flight (with the running index of rounds 1-2: one 1023 it/s, two 1028-1037, four 1018-1030; with the constant distances: two 1087-1089, four 1093-1095 on one box)
+        if ((r & RIF) == RIF) asm volatile("" : "+v"(fb) : : "memory");   // four rows of loads in flight (with the running index of rounds 1-2: one 1023 it/s, two 1028-1037, four 1018-1030; with the constant distances: two 1087-1089, four 1093-1095 on one box)
     }
 }
 

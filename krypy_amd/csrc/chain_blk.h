@@ -1,0 +1,476 @@
+// Blocked reference-order modified Gram-Schmidt for vectors whose COLUMNS fit the register file:
+// ONE grid-wide sum per block of BC basis columns instead of one per column.
+//
+// The reference's loop (utils.py:1012-1029) is   for j: alpha_j = <v_j, w_j>;  w_{j+1} = w_j - alpha_j v_j .
+// For a block of BC consecutive columns v_0 .. v_{BC-1} (link order) and w = the vector as the block finds it,
+//
+//     c_l      = <v_l, w>                         all BC of them against the NOT YET UPDATED w
+//     G_{m,l}  = <v_m, v_l>,  m < l               the block's strict upper Gram matrix
+//     alpha_l  = c_l - sum_{m<l} alpha_m G_{m,l}  ( = <v_l, w - sum_{m<l} alpha_m v_m> = the reference's alpha_l )
+//     w       -= alpha_0 v_0;  w -= alpha_1 v_1; ...   (the reference's updates, in its order, multiply then subtract)
+//
+// is the SAME recurrence in exact arithmetic: the coefficient of link l is taken against the vector the reference
+// takes it against, only the inner product with the already subtracted part is formed from the Gram entries instead
+// of from the updated vector.  Rounding differs by O(eps |alpha_m| |G_{m,l}|) per term, G being the basis'
+// orthogonality defect - 1e-16 ... 1e-10 in a GMRES cycle -, i.e. far below the rounding of the dot products
+// themselves (the low-synchronisation MGS of Swirydowicz et al. rests on the same identity).  c and G travel in one
+// grid-wide sum of NV = BC + BC (BC - 1) / 2 values (BC = 4: 10); nothing about the basis is remembered between
+// launches - the Gram entries are recomputed from the resident columns each time (a few hundred FMAs per lane), so
+// there is no table that could go stale when a block is recycled, grown or written by another entry point.
+//
+// Shape: the short-vector geometry of k_mgs_chain_small (4 rows of 16 B per lane, 512 working lanes per workgroup),
+// a ring of NSLOT blocks of BC whole columns in registers (the loads of block i + NSLOT are issued when block i has
+// been used: they are in flight across the sum of block i + 1), and a NINTH wave per workgroup that owns no rows and
+// does all the communication (vector-memory results return to a wave in order: a poll issued by a wave that has
+// requested columns ahead waits for those columns first).  The eight working waves leave their wave partials in LDS
+// and wait at two LDS-only barriers; the communication wave publishes the workgroup's NV partials as tagged 8-byte
+// granules (chain.h), gathers everybody's - all workgroups of the one XCD (ONEX), or the XCD leaders over the fabric
+// with the result handed on through the XCD's L2 - adds them in a fixed order (every workgroup: the same bits) and
+// puts the totals into LDS.
+#pragma once
+#include "chain.h"
+
+namespace kh {
+
+constexpr int BLK_BC = 4;                     // basis columns per block
+constexpr int BLK_NSLOT = 2;                  // blocks of columns in registers
+constexpr int BLK_NVMAX = 8;                  // values per sum (the block's BC coefficients; the norm + BC - 1 table entries)
+constexpr int BLK_NVS = 16;                   // granule PAIRS reserved per workgroup and parity (256 B records)
+#ifndef BLK_NPRE_FND
+#define BLK_NPRE_FND 1
+#define BLK_RIF 1
+#endif
+constexpr int BLK_TABCOLS = 4096;             // basis columns the Gram table has rows for (BLK_BC entries each)
+constexpr int BLK_GS = 16;                    // workgroups per group of the two-level exchange
+constexpr int BLK_NG2 = CH_GMAX / BLK_GS;     // groups at most
+
+template <int BC>
+struct BlkShape {
+    static constexpr int NG = BC * (BC - 1) / 2;      // strict upper Gram entries of a block
+    static constexpr int NT = BC + NG;                // what the working waves read from LDS per block: coefficients + entries
+    static_assert(BC <= BLK_NVMAX && NT <= 64, "one communication wave handles a block's values");
+};
+
+struct BlkBufs {
+    unsigned long long* gran;     // [2 parities][CH_GMAX][BLK_NVS][2] granules: the workgroups' partial sums
+    unsigned long long* gran2;    // [2 parities][BLK_NG2][BLK_NVS][2] granules: the groups' partial sums (write-through)
+    unsigned long long* res;      // [16 XCDs][2 parities][BLK_NVS][2] the totals, handed on inside an XCD through its L2
+    double* gtab;                 // [BLK_TABCOLS][BC] Gram table of the current Arnoldi sequence: row j = <v_m, v_j>, m in j's block
+};
+
+// ---- the communication wave's side of a sum -------------------------------------------------------------------
+// Gather the NV values of `count` records (BLK_NVS granule pairs each, tagged with this epoch) starting at `rec` and add
+// them in a fixed order: lane = q * NV + v takes value v of the records p * NGRP + q, p = 0, 1, ... (ascending), the NGRP
+// lane groups meet in LDS and lane v adds them in ascending q.  All loads of a sweep are issued back to back; a sweep
+// that finds a tag of an older epoch is repeated as a whole (guide, Guideline 16 R2).  count <= PMAX * NGRP.
+template <int NV, int PMAX>
+__device__ __forceinline__ double blk_gather(const unsigned long long* rec, unsigned epoch, int count, int* err,
+                                             double* smq, bool l2) {
+    constexpr int NGRP = 64 / NV;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / NV, v = lane - q * NV;
+    const bool mine = lane < NGRP * NV;
+    const unsigned long long* e0 = rec + ((unsigned)q * BLK_NVS + (unsigned)v) * 2u;
+    unsigned lo[PMAX], hi[PMAX];
+    unsigned spins = 0;
+    while (true) {
+        bool ok = true;
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
+            lo[p] = 0u;
+            hi[p] = 0u;
+            if (mine && p * NGRP + q < count) {
+                const unsigned long long* e = e0 + (unsigned)(p * NGRP * BLK_NVS * 2);
+                const unsigned long long x0 = ld_agent(e), x1 = ld_agent(e + 1);
+                lo[p] = (unsigned)x0;
+                hi[p] = (unsigned)x1;
+                ok = ok && (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+            }
+        }
+        if (__all(ok)) break;
+        if ((++spins & 255u) == 0) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            if (spins > (1u << 20)) {
+                __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        if (!l2) __builtin_amdgcn_s_sleep(1);
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) {
+        const double d = __longlong_as_double((long long)(((unsigned long long)hi[p] << 32) | lo[p]));
+        acc += (mine && p * NGRP + q < count) ? d : 0.0;
+    }
+    if constexpr (NV == 1) {
+        return wave_sum_dpp(acc);
+    } else {
+        if (mine) smq[q * NV + v] = acc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its own LDS writes are in order)
+        double t = 0.0;
+        if (lane < NV) {
+            t = smq[lane];
+#pragma unroll
+            for (int qq = 1; qq < NGRP; ++qq) t += smq[qq * NV + lane];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        return t;               // lanes 0 .. NV-1: the total of value `lane`
+    }
+}
+
+// granule pair {epoch | low word}, {epoch | high word} of one double
+__device__ __forceinline__ void blk_put(unsigned long long* e, unsigned epoch, double x, bool plain) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    if (plain) {                                       // plain stores stay in this XCD's L2
+        volatile unsigned long long* ev = e;
+        ev[0] = tag | (bits & 0xffffffffull);
+        ev[1] = tag | (bits >> 32);
+    } else {                                           // write-through: visible on every XCD
+        st_agent(e, tag | (bits & 0xffffffffull));
+        st_agent(e + 1, tag | (bits >> 32));
+    }
+}
+
+// LDS of the sums: wave partials [NV][8], totals [NV], lane groups of the gather [64]
+struct BlkSm {
+    double part[BLK_NVMAX * (CH_BS / 64)];
+    double tot[BlkShape<BLK_BC>::NT];
+    double q[64];
+};
+
+// One grid-wide sum of NV values, communication wave.  Returns (lanes 0 .. NV-1) the totals, which are also in
+// sm.tot for the working waves once the second barrier has been passed.
+//   ONEX        every workgroup runs on the one XCD: partials published with plain stores, EVERY communication wave
+//               gathers all G <= 32 records from the L2
+//   otherwise   partials published write-through; up to FLAT workgroups: the XCD leaders gather all records over the
+//               fabric; more: the communication wave of workgroup j first adds the records of group j (BLK_GS
+//               workgroups) and publishes the group's sums, the leaders gather the <= 16 group records - two short
+//               sweeps (<= 3 loads of 16 B per lane each) instead of one of 40 per lane.  The leader leaves the totals
+//               in its XCD's L2 (plain stores), everybody else polls them there.
+// The order of the additions is a function of the workgroup numbers alone: every workgroup gets the same bits, run
+// after run, wherever the workgroups were placed.
+template <int NV, bool ONEX>
+__device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf, int G, int bid, int* err, BlkSm& sm,
+                                               const GridRole role, bool skip = false, int nv_all = NV,
+                                               double extra = 0.0) {
+    // (lanes NV .. nv_all-1 put `extra` - the block's Gram entries from the table - behind the totals)
+    constexpr int NW = CH_BS / 64;
+    constexpr int NGRP = 64 / NV;
+#ifndef BLK_PFLAT
+#define BLK_PFLAT 6
+#endif
+    constexpr int PFLAT = (NV == 1) ? (CH_GMAX / 2 + 63) / 64 : BLK_PFLAT;        // passes of a flat sweep
+    constexpr int P2 = (BLK_GS + NGRP - 1) / NGRP;                       // passes over one group / over the groups
+    const int lane = threadIdx.x & 63;
+    ch_lds_barrier();                                  // A: the working waves' partials are in LDS
+    unsigned long long* slot = bf.gran + (size_t)(epoch & 1u) * ((size_t)CH_GMAX * BLK_NVS * 2);
+    if (lane < NV && !skip) {
+        double s = sm.part[lane * NW];
+#pragma unroll
+        for (int i = 1; i < NW; ++i) s += sm.part[lane * NW + i];
+        blk_put(slot + ((size_t)bid * BLK_NVS + lane) * 2, epoch, s, ONEX);
+    }
+    double t;
+    if (skip) {                                        // measurement: no exchange, the workgroup's own partial sums
+        t = 0.0;
+        if (lane < NV) {
+            t = sm.part[lane * NW];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) t += sm.part[lane * NW + i];
+        }
+    } else if constexpr (ONEX) {
+        t = blk_gather<NV, PFLAT>(slot, epoch, G, err, sm.q, true);
+    } else {
+        const bool flat = G <= PFLAT * NGRP;
+        unsigned long long* slot2 = bf.gran2 + (size_t)(epoch & 1u) * ((size_t)BLK_NG2 * BLK_NVS * 2);
+        const int ng2 = (G + BLK_GS - 1) / BLK_GS;
+        if (!flat && bid < ng2) {                      // this workgroup adds up group `bid`
+            const int cnt = (G - bid * BLK_GS) < BLK_GS ? (G - bid * BLK_GS) : BLK_GS;
+            const double g = blk_gather<NV, P2>(slot + (size_t)bid * BLK_GS * BLK_NVS * 2, epoch, cnt, err, sm.q, false);
+            if (lane < NV) blk_put(slot2 + ((size_t)bid * BLK_NVS + lane) * 2, epoch, g, false);
+        }
+        unsigned long long* res = bf.res + ((size_t)role.xcc * 2 + (epoch & 1u)) * (BLK_NVS * 2);
+        if (role.leader) {
+            t = flat ? blk_gather<NV, PFLAT>(slot, epoch, G, err, sm.q, false)
+                     : blk_gather<NV, P2>(slot2, epoch, ng2, err, sm.q, false);
+            if (lane < NV) blk_put(res + 2 * lane, epoch, t, true);
+        } else {
+            unsigned long long x0 = 0, x1 = 0;
+            unsigned spins = 0;
+            while (true) {
+                bool ok = true;
+                if (lane < NV) {
+                    x0 = ld_agent(res + 2 * lane);
+                    x1 = ld_agent(res + 2 * lane + 1);
+                    ok = (unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if ((++spins & 1023u) == 0) {
+                    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+                    if (spins > (1u << 22)) {
+                        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                }
+            }
+            t = __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
+        }
+    }
+    if (lane < NV) sm.tot[lane] = t;
+    else if (lane < nv_all) sm.tot[lane] = extra;
+    ch_lds_barrier();                                  // B: the totals are in LDS
+    return t;
+}
+
+// ... and the working waves' side: wave partials into LDS, two LDS-only barriers, the totals are in sm.tot
+template <int NV>
+__device__ __forceinline__ void blk_sum_work(const double (&val)[NV], BlkSm& sm) {
+    constexpr int NW = CH_BS / 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const double ws = wave_sum_dpp(val[v]);
+        if (lane == 0) sm.part[v * NW + wid] = ws;
+    }
+    ch_lds_barrier();          // A
+    ch_lds_barrier();          // B
+}
+
+// alpha_l = c_l - sum_{m<l} alpha_m G_{m,l} (fixed order; tot = [c_0 .. c_{BC-1}, G_01, G_02, G_12, G_03, ...]:
+// the Gram entries of column l sit behind those of column l - 1)
+template <int BC>
+__device__ __forceinline__ void blk_alphas(const double* tot, int nvalid, double (&alpha)[BC]) {
+    int gi = BC;
+#pragma unroll
+    for (int l = 0; l < BC; ++l) {
+        double a = tot[l];
+#pragma unroll
+        for (int m = 0; m < l; ++m) {
+            const double pr = alpha[m] * tot[gi + m];
+            a = a - pr;
+        }
+        gi += l;
+        alpha[l] = (l < nvalid) ? a : 0.0;
+    }
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void blk_unroll(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        blk_unroll<N, I + 1>(f);
+    }
+}
+
+template <int R2, int BC, int NSLOT, bool MASKED, int FND, bool ONEX, int DBG = 0>
+__global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBufs bf) {
+    // DBG: the measurement instantiations (tools/blk_prof.py): 1 = no exchange between workgroups, 2 = no column stream,
+    // 3 = both; the product's kernels (DBG = 0) know a.debug = 4 only (tests: a faked timeout)
+    constexpr bool dbg_noex = (DBG & 1) != 0;
+    constexpr bool dbg_nost = (DBG & 2) != 0;
+    static_assert(FND == 0 || !MASKED, "the fused operator exists for padded blocks");
+    static_assert(BC == BLK_BC, "the Gram table has BLK_BC entries per column");
+    constexpr int NT = BlkShape<BC>::NT;
+    __shared__ BlkSm sm;
+    __shared__ int slead;
+    const int tid = threadIdx.x;
+    int G = gridDim.x;
+    int bid = blockIdx.x;
+    GridRole role;
+    if constexpr (ONEX) {
+        if (!onex_enter(a, &slead, bid, G, role)) return;
+    } else {
+        role = grid_role(a.xcc_leader, a.epoch0, &slead);
+    }
+    unsigned epoch = a.epoch0;
+    const int total = a.ncol;                               // links (one sweep, columns 0 .. ncol-1: blocks are aligned)
+    const int nblk = (total + BC - 1) / BC;
+    const int nlast = total - (nblk - 1) * BC;              // links of the last block
+    if (tid >= CH_BS) {
+        // ---- the communication wave: the sums, the H entries and the Gram table; no rows ----
+        const int lane = tid - CH_BS;
+        const bool writer = bid == 0 && lane == 0;
+        // lane BC + e holds Gram entry e of a block: (l, m) = (1,0) (2,0) (2,1) (3,0) (3,1) (3,2) ...
+        int gl = 1, gm = 0;
+        {
+            int e = lane - BC;
+            for (int l = 1; l < BC; ++l)
+                if (e >= 0 && e < l) { gl = l; gm = e; e = -1; } else if (e >= 0) e -= l;
+        }
+        for (int ib = 0; ib < nblk; ++ib) {
+            double gval = 0.0;                              // requested before the sum: it arrives under it
+            if (lane >= BC && lane < NT && ib * BC + gl < total)
+                gval = __hip_atomic_load(bf.gtab + (size_t)(ib * BC + gl) * BC + gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex, NT, gval);
+            if (writer) {
+                double alpha[BC];
+                const int nvalid = total - ib * BC;
+                blk_alphas<BC>(sm.tot, nvalid, alpha);
+#pragma unroll
+                for (int l = 0; l < BC; ++l) {
+                    const int j = ib * BC + l;
+                    if (j < total) a.hdev[a.col0 + j] = (a.debug == 4) ? alpha[l] * 0.5 : alpha[l];   // (what the working waves subtract)
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (sm.tot has been read before the next sum rewrites it)
+        }
+        // the norm, and <v_m, w> for the columns m of the last block: row k+1 of the table when v_{k+1} joins that block
+        const double tf = blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex);
+        const double h = sqrt(fabs(sm.tot[0]));
+        if (writer) a.hdev[a.hnext] = h;
+        if (bid == 0 && lane >= 1 && lane < BC && (total % BC) != 0 && lane - 1 < nlast)
+            bf.gtab[(size_t)total * BC + (lane - 1)] = tf / h;
+        if (bid == 0 && a.hpin != nullptr) {
+            __threadfence();                                      // the H entries, for the working waves' copy below
+            __syncthreads();
+            if (a.donepin != nullptr) __syncthreads();            // (... and the barrier of CH_SIGNAL_DONE)
+        }
+        return;
+    }
+    const int64_t first = (int64_t)bid * a.chunk2 + tid;
+    const int64_t left = a.n2 - first;
+    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
+#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+    // (the column's address is a wave-uniform base + this lane's 32-bit byte offset)
+#define CH_COL(j) (reinterpret_cast<const char*>(a.V + (a.col0 + ((j) < total ? (j) : total - 1)) * a.ld))
+#define CH_ROW(c, r) (*reinterpret_cast<const double2*>((c) + (size_t)(r) * (CH_BS * sizeof(double2)) + boff))
+    const unsigned boff = (unsigned)first * (unsigned)sizeof(double2);
+    double2 ring[NSLOT][BC][R2];
+    double2 w[R2];
+    // w first, then the first NSLOT blocks.  The ORDER of the requests matters to the compiler's wait counts (vector-memory
+    // results return in order, a wait names how many of the newest requests may still be outstanding): with w requested
+    // last every use of w in the loop would wait for everything requested before it - all column blocks in flight.
+    if constexpr (FND > 0) {
+        chain_apply_banded<R2, FND, BLK_RIF>(a, first, [&](int r, double s0, double s1) { w[r] = make_double2(s0, s1); });
+    } else {
+        const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
+            w[r].x = CH_OK(r) ? v.x : 0.0;
+            w[r].y = CH_OK(r) ? v.y : 0.0;
+        }
+    }
+    CH_ISSUE_FENCE();
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+#pragma unroll
+        for (int l = 0; l < BC; ++l) {
+            const char* __restrict__ c = CH_COL(s * BC + l);
+#pragma unroll
+            for (int r = 0; r < R2; ++r) ring[s][l][r] = CH_ROW(c, r);
+        }
+    }
+    CH_ISSUE_FENCE();
+    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
+    // one block: coefficients, sum, update, request of the block NSLOT blocks ahead into the freed slot S
+    auto block = [&](const int i, auto slot_c) {
+        constexpr int S = decltype(slot_c)::value;
+        const int nvalid = total - i * BC;           // links of this block (>= BC except in the last one)
+        double val[BC];
+        // the block's coefficients against the not yet updated w
+#pragma unroll
+        for (int l = 0; l < BC; ++l) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                double2 v = ring[S][l][r];
+                if (MASKED && !CH_OK(r)) v = make_double2(0.0, 0.0);
+                ring[S][l][r] = v;
+                acc0 = fma(v.x, w[r].x, acc0);
+                acc1 = fma(v.y, w[r].y, acc1);
+            }
+            val[l] = (l < nvalid) ? acc0 + acc1 : 0.0;
+        }
+        blk_sum_work<BC>(val, sm);
+        double alpha[BC];
+        blk_alphas<BC>(sm.tot, nvalid, alpha);
+#pragma unroll
+        for (int l = 0; l < BC; ++l) {
+            const double al = (a.debug == 4) ? alpha[l] * 0.5 : alpha[l];      // ... a faked timeout leaves garbage behind
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {          // (one rounding per entry: this kernel is not the bit-for-bit one)
+                w[r].x = CH_OK(r) ? fma(-al, ring[S][l][r].x, w[r].x) : 0.0;
+                w[r].y = CH_OK(r) ? fma(-al, ring[S][l][r].y, w[r].y) : 0.0;
+            }
+        }
+        // the slot is free: the block NSLOT blocks ahead - or, at the end of the chain, this block again (the last
+        // block's columns are wanted once more, for the new column's row of the Gram table)
+        if constexpr (!dbg_nost) {
+            const int nxt = (i + NSLOT < nblk) ? i + NSLOT : i;
+#pragma unroll
+            for (int l = 0; l < BC; ++l) {
+                const char* __restrict__ c = CH_COL(nxt * BC + l);
+#pragma unroll
+                for (int r = 0; r < R2; ++r) ring[S][l][r] = CH_ROW(c, r);
+            }
+        }
+        CH_ISSUE_FENCE();
+    };
+    // The steady-state loop has NO conditional inside: a block that may or may not request columns leaves the compiler's
+    // wait counts at "everything" on the back edge (s_waitcnt vmcnt(0) in front of every block: no column would ever be
+    // in flight across a sum).  The last nblk % NSLOT blocks run behind the loop.
+    int ib = 0;
+    for (; ib + NSLOT <= nblk; ib += NSLOT) {
+        blk_unroll<NSLOT>([&](auto sc) { block(ib + decltype(sc)::value, sc); });
+    }
+    blk_unroll<NSLOT - 1>([&](auto sc) {
+        if (ib + decltype(sc)::value < nblk) block(ib + decltype(sc)::value, sc);
+    });
+#undef CH_ROW
+#undef CH_COL
+    double nv[BC];
+    {
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            acc = fma(w[r].x, w[r].x, acc);
+            acc = fma(w[r].y, w[r].y, acc);
+        }
+        nv[0] = acc;
+        // <v_m, w> for the first BC - 1 columns of the last block (requested again), which sits in slot (nblk - 1) % NSLOT
+        const int sl = (nblk - 1) % NSLOT;
+#pragma unroll
+        for (int m = 0; m < BC - 1; ++m) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int r = 0; r < R2; ++r) {
+                double2 v = ring[0][m][r];
+#pragma unroll
+                for (int s2 = 1; s2 < NSLOT; ++s2) {
+                    v.x = (sl == s2) ? ring[s2][m][r].x : v.x;
+                    v.y = (sl == s2) ? ring[s2][m][r].y : v.y;
+                }
+                if (MASKED && !CH_OK(r)) v = make_double2(0.0, 0.0);
+                acc0 = fma(v.x, w[r].x, acc0);
+                acc1 = fma(v.y, w[r].y, acc1);
+            }
+            nv[1 + m] = (m < nlast) ? acc0 + acc1 : 0.0;
+        }
+    }
+    blk_sum_work<BC>(nv, sm);
+    const double h = sqrt(fabs(sm.tot[0]));
+    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        if (r * CH_BS < rem) {
+            double2 o;
+            o.x = w[r].x / h;
+            o.y = w[r].y / h;
+            st_nt2(vn2 + (int64_t)r * CH_BS, o);
+        }
+    }
+    if (bid == 0 && a.hpin != nullptr) {
+        __syncthreads();          // the H entries were written by the communication wave of this workgroup
+        for (int i = tid; i < a.hcount; i += CH_BS)
+            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        CH_SIGNAL_DONE(a);
+    }
+#undef CH_OK
+}
+
+}  // namespace kh

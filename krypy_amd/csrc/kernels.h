@@ -256,7 +256,7 @@ __global__ __launch_bounds__(BS) void k_multidot(int64_t n, ColPtrs cols,
 
 // out[c] (op)= fixed-order sum of part[c*pstride + 0..nb); one workgroup per column.
 // mode 0: out = s, 1: out += s, 2: out = sqrt(|s|)
-__global__ __launch_bounds__(BS) void k_reduce_partials(const double* __restrict__ part, int nb,
+static __global__ __launch_bounds__(BS) void k_reduce_partials(const double* __restrict__ part, int nb,
                                                         int pstride, double* __restrict__ out,
                                                         int mode) {
     __shared__ double sm[8];
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(BS) void k_multiaxpy(int64_t n, ColPtrs cols,
 }
 
 // z = alpha*x + beta*y  (numpy order: (alpha*x) + (beta*y); alpha==1 / beta==1 skip the multiply)
-__global__ __launch_bounds__(BS) void k_waxpby(int64_t n, double* z, double alpha,
+static __global__ __launch_bounds__(BS) void k_waxpby(int64_t n, double* z, double alpha,
                                                const double* x, double beta,
                                                const double* y) {
     const int64_t stride = (int64_t)gridDim.x * BS;
@@ -358,13 +358,13 @@ __global__ __launch_bounds__(BS) void k_waxpby(int64_t n, double* z, double alph
     }
 }
 
-__global__ __launch_bounds__(BS) void k_vdiv(int64_t n, double* __restrict__ z,
+static __global__ __launch_bounds__(BS) void k_vdiv(int64_t n, double* __restrict__ z,
                                              const double* __restrict__ x, double s) {
     const int64_t stride = (int64_t)gridDim.x * BS;
     for (int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x; i < n; i += stride) st_nt(z + i, x[i] / s);
 }
 
-__global__ __launch_bounds__(BS) void k_diag_apply(int64_t n, const double* __restrict__ d,
+static __global__ __launch_bounds__(BS) void k_diag_apply(int64_t n, const double* __restrict__ d,
                                                    const double* __restrict__ x,
                                                    double* __restrict__ y) {
     const int64_t stride = (int64_t)gridDim.x * BS;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(BS) void k_diag_apply(int64_t n, const double* __re
 // MINRES vector recurrences (linsys.py:844-846), one pass:
 //   z = (v - r0*w0 - r1*w1)/r2 ;  w0 <- z (the slot that held W0 becomes the new W1) ; yk += y0*z
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS) void k_minres_update(int64_t n, const double* __restrict__ v,
+static __global__ __launch_bounds__(BS) void k_minres_update(int64_t n, const double* __restrict__ v,
                                                       double* __restrict__ w0,
                                                       const double* __restrict__ w1, double r0,
                                                       double r1, double r2, double y0,
@@ -638,7 +638,7 @@ __host__ __device__ __forceinline__ int dia_virtual_col(int c, int nloc, int npr
     return c < nloc ? c : (c < nloc + nprev ? c - nloc - nprev : c - nprev);
 }
 
-__global__ __launch_bounds__(BS) void k_dia_fill(const int32_t* __restrict__ indptr,
+static __global__ __launch_bounds__(BS) void k_dia_fill(const int32_t* __restrict__ indptr,
                                                  const int32_t* __restrict__ indices,
                                                  const double* __restrict__ data, int64_t n_rows,
                                                  int nprev, DiaOffs o, double* __restrict__ dia,
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(BS) void k_spmm_dia(DiaOffs o, const double* __rest
 // One wave64 per row: lanes stride the row with double2 loads, x stays in L2 (256 KB).
 // HBM-bound (0.25 flop/B); MFMA cannot help a single right-hand side.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_cols,
+static __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_cols,
                                                    const double* __restrict__ a, int64_t lda,
                                                    const double* __restrict__ x,
                                                    double* __restrict__ y) {
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(BS) void k_gemm_dense_mfma(int64_t n_rows, int64_t 
 // Attainable-bandwidth probes for bench.py ("measure the attainable ceiling on the box with
 // a device triad/copy kernel"): plain 16-byte grid-stride streams, non-temporal loads, no reuse.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BS) void k_stream_copy(int64_t n2, const double2* __restrict__ src,
+static __global__ __launch_bounds__(BS) void k_stream_copy(int64_t n2, const double2* __restrict__ src,
                                                     double2* __restrict__ dst) {
     const int64_t stride = (int64_t)gridDim.x * BS;
     int64_t i = (int64_t)blockIdx.x * BS + threadIdx.x;
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(BS) void k_stream_copy(int64_t n2, const double2* _
     for (; i < n2; i += stride) dst[i] = ld_nt2(src + i);
 }
 
-__global__ __launch_bounds__(BS) void k_stream_triad(int64_t n2, const double2* __restrict__ b,
+static __global__ __launch_bounds__(BS) void k_stream_triad(int64_t n2, const double2* __restrict__ b,
                                                      const double2* __restrict__ c, double s,
                                                      double2* __restrict__ a) {
     const int64_t stride = (int64_t)gridDim.x * BS;
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(BS) void k_stream_triad(int64_t n2, const double2* 
     }
 }
 
-__global__ __launch_bounds__(BS) void k_stream_read(int64_t n2, const double2* __restrict__ src,
+static __global__ __launch_bounds__(BS) void k_stream_read(int64_t n2, const double2* __restrict__ src,
                                                     double* __restrict__ part_out) {
     __shared__ double sm[8];
     const int64_t stride = (int64_t)gridDim.x * BS;
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(BS) void k_probe_read(int64_t n2, const double2* __
 
 // y = M x for a tiny dense row-major M (d x d, d <= 1024) held on the device: the projector's
 // R^{-1} Q^H and WR^H factors.  One workgroup, one row per thread, sequential sums (deterministic).
-__global__ __launch_bounds__(BS) void k_small_matvec(int d, const double* __restrict__ M,
+static __global__ __launch_bounds__(BS) void k_small_matvec(int d, const double* __restrict__ M,
                                                      const double* __restrict__ x,
                                                      double* __restrict__ y) {
     for (int i = threadIdx.x; i < d; i += BS) {

@@ -14,6 +14,8 @@ constexpr int MAXC = 16;         // widest column panel one multidot / multiaxpy
 constexpr int NB_MAX = 4096;     // upper bound of the reduction grid
 constexpr int SCAL_CAP = 8192;   // device scalar slots (panel coefficients, norms)
 #define KH_NSLOT 4               // Arnoldi steps that may be in flight (H-column slots)
+#define KH_CHAIN_REARM_STEPS 100  // clean per-column steps after which a timed-out chain family is tried again
+#define KH_CHAIN_MAX_RECOVERIES 3
 
 extern thread_local std::string g_err;
 
@@ -71,6 +73,16 @@ struct kh_ctx_s {
     int chain_enabled = 1;
     int64_t n_chain = 0, n_chain_lds = 0, n_chain_fused = 0, n_cgs_reg = 0;   // launch counters (kh_ctx_counters)
     int64_t n_chain_recovered = 0;   // Arnoldi steps re-run on the link kernels after a chain timeout
+    // A timed-out chain launch switches the chain family off (chain_enabled = 0) and the step is re-run on the
+    // per-column kernels.  A timeout is a transient of a shared GPU, so the switch is not for life: after
+    // KH_CHAIN_REARM_STEPS clean steps on the per-column kernels, or when a new basis starts (k == 0), the configured
+    // value comes back.  The third recovery in one context leaves it off and says so once on stderr.
+    int chain_configured = 1;        // what KRYPY_AMD_MGS_CHAIN / kh_ctx_set("chain") asked for
+    int chain_recoveries = 0;        // timeouts recovered in this context (kh_ctx_get "chain_recoveries")
+    int chain_clean_steps = 0;       // steps begun on the per-column kernels since the last timeout
+    int chain_in_recovery = 0;       // kh_arnoldi_step_end is re-running a step: no re-arming from inside it
+    int64_t n_chain_rearmed = 0;     // times the chain family was switched on again (kh_ctx_get "n_chain_rearmed")
+    int64_t chain_refused_n = -1;    // vector length whose chain launch the runtime refused (occupancy): that shape only
     int64_t n_spmm = 0;     // panel applications of a CSR operator that streamed the matrix once
     int chain_spmv = 1;     // banded operators: w = A v_k in the chain kernel's prologue (KRYPY_AMD_CHAIN_SPMV)
     int chain_pf = 1;       // ... and keep HBM busy through the update phase (k_mgs_chain_pf; KRYPY_AMD_CHAIN_PF)
@@ -79,6 +91,13 @@ struct kh_ctx_s {
     int64_t n_chain_onex = 0;
     int chain_small = 1;    // short vectors without a preconditioner: the column-ring kernel k_mgs_chain_small (KRYPY_AMD_CHAIN_SMALL)
     int64_t n_chain_small = 0;
+    // ... and its blocked form: one grid-wide sum per block of 4 columns (chain_blk.h; KRYPY_AMD_CHAIN_BLK)
+    int chain_blk = 1;
+    int64_t n_chain_blk = 0;
+    unsigned long long* blk_gran = nullptr;   // granules + per-XCD totals of the blocked kernel's sums + its Gram table (chain_blk.hip)
+    const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...
+    int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
+    int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
     unsigned* onex_ticket = nullptr;   // 256 rotating ticket words
     int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)
@@ -196,4 +215,16 @@ int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream
 int comm_halo_exchange_panel(kh_ctx ctx, kh_mat A, const double* X, int64_t ldx, int64_t ncols, hipStream_t stream);
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
+// chain_blk.hip
+struct ChainArgs;
+hipError_t chain_blk_launch(kh_ctx ctx, int r2, int G, bool onex, bool padded, int fnd, ChainArgs& a, const void* V, int* nsums);
+double* chain_blk_table(kh_ctx ctx);
+bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd);
+constexpr int KH_BLK_BC = 4;          // (= BLK_BC of chain_blk.h) columns per block, entries per row of the Gram table
+// an entry point writes to block v: the Gram table of an Arnoldi sequence on it (chain_blk.hip) is no longer vouched for
+static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
+    if (ctx->blk_V == v) ctx->blk_next = -1;
+}
+hipError_t chain_blk_reset(kh_ctx ctx);
+void chain_blk_free(kh_ctx ctx);
 }  // namespace kh

@@ -14,6 +14,10 @@
 #include "lanczos.h"
 #include <stdlib.h>
 
+extern "C" {
+static int dot_panel_dev(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* w, double* out_dev, int rmode);
+}
+
 namespace kh {
 
 thread_local std::string g_err;
@@ -557,6 +561,13 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     return ld == 0 ? 32 : ld;
 }
 
+#define KH_BLK_MIN_LINKS 8     // Gram-Schmidt links from which the blocked kernel (chain_blk.h) takes a step of short vectors
+// true when the step goes to the blocked kernel (which has no operator prologue yet)
+static inline bool blk_takes_step(kh_ctx ctx, const ChainArgs& a, int r2) {
+    return ctx->chain_blk && r2 == 4 && !a.presub && a.sweeps == 1 && a.col0 == 0 && a.ncol >= KH_BLK_MIN_LINKS &&
+           a.ncol + 2 <= 4096 && !kh_multi(ctx);
+}
+
 // returns 1 if the chain was launched, 0 if this step is not eligible (caller uses the link
 // kernels), negative on error
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
@@ -570,6 +581,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     if (!ctx->chain_enabled || kh_multi(ctx)) return 0;
     if (cplx && (dg != nullptr || P != nullptr)) return 0;
     const int64_t n = V->n;
+    if (n == ctx->chain_refused_n) return 0;
     const int64_t n2 = (n + 1) >> 1;
     int r2 = 0, G = 0;
     if (!chain_geometry(ctx, n, &r2, &G)) return 0;
@@ -599,6 +611,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
         KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
+        if (ctx->blk_gran != nullptr) {
+            KH_HIP(chain_blk_reset(ctx));
+            KH_HIP(hipStreamSynchronize(ctx->stream));
+        }
         ctx->chain_epoch = 1;
     }
     ChainArgs a;
@@ -663,6 +679,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
+        // long chains of short vectors: the blocked kernel (chain_blk.h) takes w from the SpMV launch - one sum per four
+        // links is worth more than the launch the fused prologue saves
+        if (small_shape && blk_takes_step(ctx, a, r2)) return 0;
         a.dia = Afuse->dia;
         a.dia_ld = Afuse->dia_ld;
         a.xk = xk;
@@ -734,7 +753,8 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // short vectors (4 ... 32 workgroups of 4 / 8 rows per lane): a link is its grid-wide sum - all working
     // workgroups on ONE XCD, where the sum is an L2 round trip (chain.h, ONEX)
     // short vectors, no preconditioner, real data: the column-ring kernel (one read per column, several links of look-ahead)
-    if (ctx->chain_small && r2 <= 8 && B == V && dg == nullptr && !cplx && (a.debug == 0 || a.debug == 4) &&
+    const bool blk_debug = (a.debug >= 1 && a.debug <= 3) && !fused && blk_takes_step(ctx, a, r2);   // measurement modes of the blocked kernel
+    if (ctx->chain_small && r2 <= 8 && B == V && dg == nullptr && !cplx && (a.debug == 0 || a.debug == 4 || blk_debug) &&
         !(fused && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1)) {
         if (want_onex) {
             const unsigned slot_ = (unsigned)(ctx->n_chain_onex & 255);
@@ -742,6 +762,40 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             a.onex_target = 0u;
             a.onex_ticket = ctx->onex_ticket + slot_;
             a.onex_clear = ctx->onex_ticket + ((slot_ + 128u) & 255u);
+        }
+        // a long chain: the blocked form - one grid-wide sum per FOUR columns (chain_blk.h)
+        if (!fused && blk_takes_step(ctx, a, r2) && chain_blk_shape_ok(r2, G, a, 0)) {
+            int nsums = 0;
+            // the Gram table: valid when this is the next step of the sequence that owns it; otherwise (a sequence's
+            // first blocked step, a block grown / recycled / written by another entry point since) its rows are
+            // rebuilt from the basis - one panel product per column, once
+            if (!(ctx->blk_V == V && ctx->blk_next == k)) {
+                double* gt = chain_blk_table(ctx);
+                if (gt == nullptr) return fail(KH_ERR_NOMEM, "chain_blk: no memory for the Gram table");
+                for (int64_t j = 1; j <= k; ++j) {
+                    const int64_t b0 = (j / KH_BLK_BC) * KH_BLK_BC;
+                    if (j > b0) KH_TRY(::dot_panel_dev(ctx, V, b0, j - b0, V->col(j), gt + j * KH_BLK_BC, 0));
+                }
+                ctx->blk_V = V;
+                ctx->blk_next = k;
+                ctx->n_blk_rebuild += 1;
+            }
+            e = chain_blk_launch(ctx, r2, G, want_onex, padded, 0, a, V, &nsums);
+            if (e == hipSuccess) {
+                if (a.debug == 4) ctx->chain_fault = 0;
+                ctx->n_chain += 1;
+                ctx->n_chain_small += 1;
+                ctx->n_chain_blk += 1;
+                ctx->n_chain_onex += want_onex ? 1 : 0;
+                ctx->n_chain_fused += fused ? 1 : 0;
+                ctx->n_chain_lds += 1;
+                ctx->chain_epoch += (unsigned)nsums;
+                if (hpin == nullptr)
+                    KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
+                                          ctx->stream));
+                { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
+            }
+            (void)hipGetLastError();
         }
 #define KH_SM(R, X)                                                                                          \
     (fused ? (a.offs.nd == 5 ? launch_chain_small<R, false, 5, X>(ctx, G, a) : launch_chain_small<R, false, 7, X>(ctx, G, a)) \
@@ -833,9 +887,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 #undef KH_CHAIN_LDS
 #undef KH_CHAIN_PLAIN
     if (e != hipSuccess) {
-        // e.g. hipErrorCooperativeLaunchTooLarge: not all workgroups can be co-resident
+        // e.g. hipErrorCooperativeLaunchTooLarge: not all workgroups can be co-resident.  A property of this shape
+        // on this device, not of the context: vectors of this length take the per-column kernels from now on
         (void)hipGetLastError();
-        ctx->chain_enabled = 0;
+        ctx->chain_refused_n = n;
         return 0;
     }
     if (a.debug == 4) ctx->chain_fault = 0;
@@ -1034,6 +1089,7 @@ int kh_ctx_create(int device, kh_ctx* out) {
         const char* e = getenv("KRYPY_AMD_MGS_CHAIN");
         ctx->chain_enabled = (e == nullptr) ? 1 : atoi(e);
         if (ctx->ncu > CH_GMAX) ctx->chain_enabled = 0;
+        ctx->chain_configured = ctx->chain_enabled;
         e = getenv("KRYPY_AMD_CHAIN_SPMV");
         ctx->chain_spmv = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_LDS");
@@ -1044,6 +1100,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->tag_wait = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_SMALL");
         ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_BLK");
+        ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
         if (ctx->chain_onex) {
@@ -1080,6 +1138,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipFree(ctx->chain_gran);
     (void)hipFree(ctx->chain_xcc);
     (void)hipFree(ctx->onex_ticket);
+    chain_blk_free(ctx);
     (void)hipFree(ctx->chain_err);
     for (int s = 0; s < KH_NSLOT; ++s) {
         if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
@@ -1139,7 +1198,12 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile) {
 int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     KH_ARG(ctx != nullptr && key != nullptr, "kh_ctx_set: NULL");
     if (!strcmp(key, "spmv_dia")) ctx->spmv_dia = value != 0;
-    else if (!strcmp(key, "chain")) ctx->chain_enabled = (value != 0 && ctx->ncu <= CH_GMAX);
+    else if (!strcmp(key, "chain")) {
+        ctx->chain_enabled = ctx->chain_configured = (value != 0 && ctx->ncu <= CH_GMAX);
+        ctx->chain_recoveries = 0;          // (an explicit setting starts the count again)
+        ctx->chain_clean_steps = 0;
+        ctx->chain_refused_n = -1;
+    }
     else if (!strcmp(key, "chain_lds")) ctx->chain_lds = value != 0;
     else if (!strcmp(key, "chain_pf")) ctx->chain_pf = (int)value;
     else if (!strcmp(key, "chain_spmv")) ctx->chain_spmv = value != 0;
@@ -1149,6 +1213,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
+    else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
@@ -1159,6 +1224,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     KH_ARG(ctx != nullptr && key != nullptr && value != nullptr, "kh_ctx_get: NULL");
     if (!strcmp(key, "spmv_dia")) *value = ctx->spmv_dia;
     else if (!strcmp(key, "chain")) *value = ctx->chain_enabled;
+    else if (!strcmp(key, "chain_recoveries")) *value = ctx->chain_recoveries;
+    else if (!strcmp(key, "n_chain_rearmed")) *value = ctx->n_chain_rearmed;
     else if (!strcmp(key, "chain_lds")) *value = ctx->chain_lds;
     else if (!strcmp(key, "chain_pf")) *value = ctx->chain_pf;
     else if (!strcmp(key, "n_chain_pf")) *value = ctx->n_chain_pf;
@@ -1173,6 +1240,9 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_onex")) *value = ctx->chain_onex;
     else if (!strcmp(key, "n_chain_onex")) *value = ctx->n_chain_onex;
     else if (!strcmp(key, "chain_small")) *value = ctx->chain_small;
+    else if (!strcmp(key, "chain_blk")) *value = ctx->chain_blk;
+    else if (!strcmp(key, "n_chain_blk")) *value = ctx->n_chain_blk;
+    else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "tag_wait")) *value = ctx->tag_wait;
     else if (!strcmp(key, "n_tag_waits")) *value = ctx->n_tag_waits;
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
@@ -1226,8 +1296,9 @@ int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out) {
 // a freed handle must not be dereferenced by the recovery of a chain timeout (kh_arnoldi_step_end re-runs the step
 // from the slot's record): forget every record that names it
 static void forget_steps(kh_ctx ctx, const void* handle) {
+    if (ctx->blk_V == handle) { ctx->blk_V = nullptr; ctx->blk_next = -1; }
     if (ctx->mr_pending.on && (ctx->mr_pending.V == handle || ctx->mr_pending.W == handle || ctx->mr_pending.YK == handle))
-        ctx->mr_pending.on = 0;          // (a deferred MINRES update whose owner went away: nobody will read its result)
+        ctx->mr_pending.on = 0;          // (kh_vec_free has run the update already; a matrix / projector is never named)
     for (int s = 0; s < KH_NSLOT; ++s) {
         kh_step_s& st = ctx->step[s];
         if (st.kind != 0 && (st.A == handle || st.Md == handle || st.proj == handle || st.V == handle ||
@@ -1236,8 +1307,17 @@ static void forget_steps(kh_ctx ctx, const void* handle) {
     }
 }
 
+static int minres_flush(kh_ctx ctx);
+
 int kh_vec_free(kh_vec v) {
     if (!v) return 0;
+    // A deferred MINRES update that names this block runs NOW: the basis of an unwindowed MINRES grows by moving to a
+    // new block (utils.Arnoldi._grow) while the previous iteration's update still points at the old one - dropping the
+    // job would leave W and yk one recurrence step short.
+    {
+        const auto& j = v->ctx->mr_pending;
+        if (j.on && (j.V == v || j.W == v || j.YK == v)) (void)minres_flush(v->ctx);
+    }
     (void)hipStreamSynchronize(v->ctx->stream);
     forget_steps(v->ctx, v);
     (void)hipFree(v->d);
@@ -1255,6 +1335,7 @@ int kh_vec_shape(kh_vec v, int64_t* n, int64_t* ncols, int64_t* ld) {
 
 int kh_vec_upload(kh_vec v, int64_t col0, int64_t ncols, const double* host, int64_t host_ld) {
     KH_TRY(check_vec(v, col0, ncols, "kh_vec_upload"));
+    chain_blk_touch(v->ctx, v);
     if (ncols == 0 || v->n == 0) return 0;
     KH_ARG(host != nullptr && host_ld >= v->n, "kh_vec_upload: bad host buffer");
     KH_HIP(hipMemcpy2DAsync(v->col(col0), v->ld * sizeof(double), host, host_ld * sizeof(double),
@@ -1275,6 +1356,7 @@ int kh_vec_download(kh_vec v, int64_t col0, int64_t ncols, double* host, int64_t
 
 int kh_vec_zero(kh_vec v, int64_t col0, int64_t ncols) {
     KH_TRY(check_vec(v, col0, ncols, "kh_vec_zero"));
+    chain_blk_touch(v->ctx, v);
     if (ncols == 0) return 0;
     KH_HIP(hipMemsetAsync(v->col(col0), 0, sizeof(double) * v->ld * ncols, v->ctx->stream));
     return 0;
@@ -1282,6 +1364,7 @@ int kh_vec_zero(kh_vec v, int64_t col0, int64_t ncols) {
 
 int kh_vec_copy(kh_vec dst, int64_t dcol, kh_vec src, int64_t scol, int64_t ncols) {
     KH_TRY(check_vec(dst, dcol, ncols, "kh_vec_copy(dst)"));
+    chain_blk_touch(dst->ctx, dst);
     KH_TRY(check_vec(src, scol, ncols, "kh_vec_copy(src)"));
     KH_ARG(dst->n == src->n, "kh_vec_copy: length mismatch %lld vs %lld", (long long)dst->n,
            (long long)src->n);
@@ -1321,6 +1404,7 @@ int kh_vec_get(kh_vec v, int64_t col, int64_t i0, int64_t count, double* out) {
 
 int kh_vec_set(kh_vec v, int64_t col, int64_t i0, int64_t count, const double* in) {
     KH_TRY(check_range(v, col, i0, count, "kh_vec_set"));
+    chain_blk_touch(v->ctx, v);
     if (count == 0) return 0;
     KH_ARG(in != nullptr, "kh_vec_set: NULL");
     KH_HIP(hipMemcpyAsync(v->col(col) + i0, in, sizeof(double) * count, hipMemcpyHostToDevice, v->ctx->stream));
@@ -1330,6 +1414,7 @@ int kh_vec_set(kh_vec v, int64_t col, int64_t i0, int64_t count, const double* i
 
 int kh_vec_zero_range(kh_vec v, int64_t col, int64_t i0, int64_t count) {
     KH_TRY(check_range(v, col, i0, count, "kh_vec_zero_range"));
+    chain_blk_touch(v->ctx, v);
     if (count == 0) return 0;
     KH_HIP(hipMemsetAsync(v->col(col) + i0, 0, sizeof(double) * count, v->ctx->stream));
     return 0;
@@ -1648,6 +1733,7 @@ int kh_mat_diagonals(kh_mat A) { return (A != nullptr && A->dia != nullptr) ? A-
 
 int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols) {
     KH_ARG(ctx && A, "kh_apply: NULL handle");
+    if (Y != nullptr) chain_blk_touch(ctx, Y);
     KH_TRY(check_vec(X, xcol, ncols, "kh_apply(X)"));
     KH_TRY(check_vec(Y, ycol, ncols, "kh_apply(Y)"));
     if (A->kind >= KH_MAT_ZCSR) return zapply_cols(ctx, A, X, xcol, Y, ycol, ncols);
@@ -1801,6 +1887,7 @@ int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y
 int kh_axpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W,
                   int64_t wcol) {
     KH_ARG(ctx && (h || ncols == 0), "kh_axpy_panel: NULL");
+    if (W != nullptr) chain_blk_touch(ctx, W);
     KH_TRY(check_vec(V, j0, ncols, "kh_axpy_panel(V)"));
     KH_TRY(check_vec(W, wcol, 1, "kh_axpy_panel(W)"));
     KH_ARG(V->n == W->n, "kh_axpy_panel: length mismatch");
@@ -1819,6 +1906,7 @@ int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int
     KH_TRY(check_vec(Y, y0, nc, "kh_gemm_nn(Y)"));
     KH_ARG(X->n == Y->n, "kh_gemm_nn: length mismatch");
     KH_ARG(X != Y, "kh_gemm_nn: X and Y must be different blocks");
+    chain_blk_touch(ctx, Y);
     constexpr int64_t KMAX = 1024;      // coefficients staged per pass (SC_COEF region of the device scalars)
     std::vector<double> coef((size_t)std::max<int64_t>(std::min(k, KMAX), 1));
     double* dev = ctx->scal + SC_COEF;
@@ -1864,6 +1952,7 @@ int kh_nrm2(kh_ctx ctx, kh_vec W, int64_t wcol, double* out) {
 int kh_waxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, double alpha, kh_vec X, int64_t xcol, double beta,
               kh_vec Y, int64_t ycol) {
     KH_ARG(ctx, "kh_waxpby: NULL ctx");
+    if (Z != nullptr) chain_blk_touch(ctx, Z);
     KH_TRY(check_vec(Z, zcol, 1, "kh_waxpby(Z)"));
     KH_TRY(check_vec(X, xcol, 1, "kh_waxpby(X)"));
     KH_TRY(check_vec(Y, ycol, 1, "kh_waxpby(Y)"));
@@ -1877,6 +1966,7 @@ int kh_waxpby(kh_ctx ctx, kh_vec Z, int64_t zcol, double alpha, kh_vec X, int64_
 
 int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s) {
     KH_ARG(ctx, "kh_vdiv: NULL ctx");
+    if (Z != nullptr) chain_blk_touch(ctx, Z);
     KH_TRY(check_vec(Z, zcol, 1, "kh_vdiv(Z)"));
     KH_TRY(check_vec(X, xcol, 1, "kh_vdiv(X)"));
     KH_ARG(Z->n == X->n, "kh_vdiv: length mismatch");
@@ -1884,6 +1974,32 @@ int kh_vdiv(kh_ctx ctx, kh_vec Z, int64_t zcol, kh_vec X, int64_t xcol, double s
                        Z->col(zcol), X->col(xcol), s);
     KH_HIP(hipGetLastError());
     return 0;
+}
+
+// Called when an Arnoldi step is begun: bring the chain family back after a recovered timeout (kh_internal.h).
+static inline void chain_rearm(kh_ctx ctx, int64_t k) {
+    if (ctx->chain_enabled || !ctx->chain_configured || ctx->chain_in_recovery || ctx->chain_recoveries == 0 ||
+        ctx->chain_recoveries >= KH_CHAIN_MAX_RECOVERIES)
+        return;
+    for (int s = 0; s < KH_NSLOT; ++s)      // steps that still wait to be re-run read the per-column path's state
+        if (*ctx->chain_err_pin[s] != 0) return;
+    if (k == 0 || ++ctx->chain_clean_steps >= KH_CHAIN_REARM_STEPS) {
+        ctx->chain_enabled = 1;
+        ctx->chain_clean_steps = 0;
+        ctx->n_chain_rearmed += 1;
+    }
+}
+
+// what a timeout does to the context (kh_arnoldi_step_end, kh_zarnoldi_step)
+static inline void chain_switch_off(kh_ctx ctx) {
+    ctx->chain_enabled = 0;
+    ctx->blk_next = -1;              // (the faulted launch may have left a garbage row in the Gram table)
+    ctx->chain_clean_steps = 0;
+    ctx->chain_recoveries += 1;
+    if (ctx->chain_recoveries == KH_CHAIN_MAX_RECOVERIES)
+        fprintf(stderr, "krylov_hip: the grid-wide sum of the register-resident Gram-Schmidt kernels timed out %d times in "
+                        "this context (a GPU shared with other work?); they stay off, the per-column kernels take over\n",
+                KH_CHAIN_MAX_RECOVERIES);
 }
 
 // A step begun while its predecessor (same basis, step k-1) is marked "timed out, to be re-run" would
@@ -1933,6 +2049,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     KH_ARG(W->n == V->n, "kh_arnoldi_step: W length");
     const int64_t n = V->n;
     ctx->wait_tag[slot] = false;
+    chain_rearm(ctx, k);
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 1;
@@ -1975,7 +2092,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     if (A != nullptr) {
         KH_ARG(A->n_rows == n, "kh_arnoldi_step: operator rows %lld != %lld", (long long)A->n_rows,
                (long long)n);
-        if (want_chain && proj == nullptr && A->kind == KH_MAT_CSR && A->dia != nullptr) {
+        if (want_chain && proj == nullptr && A->kind == KH_MAT_CSR && A->dia != nullptr && ctx->spmv_dia) {
             // banded operator: the chain kernel computes w = A v_k in its prologue (no SpMV launch, w
             // never touches HBM); returns 0 when that instantiation does not apply
             // a deferred MINRES update of an earlier iteration rides along when the step runs as the three-pass
@@ -2170,8 +2287,17 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         volatile int* tagp = ctx->done_pin[slot];
         const int want = ctx->done_seq[slot];
         for (unsigned spins = 1; *tagp != want; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
-            if ((spins & 0x3fffu) == 0 && hipStreamQuery(ctx->stream) == hipSuccess) break;
+#endif
+            if ((spins & 0x3fffu) == 0) {
+                const hipError_t q = hipStreamQuery(ctx->stream);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) {          // a sticky launch / device error: the tag will never come
+                    ctx->wait_tag[slot] = false;
+                    KH_HIP(q);
+                }
+            }
         }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         ctx->wait_tag[slot] = false;
@@ -2186,7 +2312,7 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         // Steps begun after it (look-ahead) consumed the garbage; each of them reports the error in its own
         // slot and is recovered in turn when the host asks for it, in order.
         *ctx->chain_err_pin[slot] = 0;
-        ctx->chain_enabled = 0;
+        if (ctx->chain_enabled) chain_switch_off(ctx);      // (look-ahead steps that saw the same timeout do not count again)
         ctx->n_chain_recovered += 1;
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
@@ -2195,6 +2321,11 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
                 ctx->step[s2].V == ctx->step[slot].V && ctx->step[s2].k > ctx->step[slot].k)
                 *ctx->chain_err_pin[s2] = 1;
         const kh_step_s st = ctx->step[slot];
+        struct InRecovery {
+            kh_ctx c;
+            explicit InRecovery(kh_ctx c_) : c(c_) { c->chain_in_recovery += 1; }
+            ~InRecovery() { c->chain_in_recovery -= 1; }
+        } in_recovery_(ctx);
         if (st.kind == 1)
             KH_TRY(kh_arnoldi_step_begin(ctx, st.A, st.proj, st.Md, st.V, st.P, st.W, st.wcol, st.k, st.start, st.sweeps,
                                          st.gs_mode, st.h_km1[0], slot));
@@ -2411,10 +2542,13 @@ int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, i
 // sanity word of a fused CG step (KH_CG_* bits of the header): the step length never visits the host, so a divisor
 // that is not a positive finite number (an operator that is not positive definite - or a fault) is reported with
 // the scalars; k_cg_update leaves yk and r untouched when the step length is not finite
-static inline int cg_sanity(double d, double rho_new) {
+static inline int cg_sanity(double d, double rho_new, double rho) {
     int f = 0;
     if (!std::isfinite(d)) f |= KH_CG_NONFINITE_PAP;
     else if (!(d > 0.0)) f |= KH_CG_NONPOSITIVE_PAP;
+    // the device clamps a step length that is not finite to "no step" (k_cg_update): a zero (or tiny) divisor under
+    // a finite rho is neither what the reference does nor an ordinary indefinite operator - the host is told
+    if (std::isfinite(d) && std::isfinite(rho) && !std::isfinite(rho / d)) f |= KH_CG_STEP_CLAMPED;
     if (!std::isfinite(rho_new)) f |= KH_CG_NONFINITE_RHO;
     else if (rho_new < 0.0) f |= KH_CG_NEGATIVE_RHO;
     return f;
@@ -2462,7 +2596,7 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
     KH_HIP(hipGetLastError());
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
     KH_TRY(fetch_scalars(ctx, tmp, 2, out));
-    out[2] = (double)cg_sanity(out[0], out[1]);
+    out[2] = (double)cg_sanity(out[0], out[1], rho);
     return 0;
 }
 
@@ -2583,6 +2717,34 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
                 if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
                 break;
             }
+            case 20:
+            case 21:
+            case 22:
+            case 23: {
+                // the blocked chain (chain_blk.h) over 64 columns, one sweep, Gram entries from the table (steady state
+                // of a sequence; the table's content does not matter for the time); 21 / 22 / 23: without the exchange
+                // between workgroups / without the column stream / without both
+                KH_ARG(V->ncols >= 66, "kh_bench_kernel: the blocked chain needs 66 basis columns");
+                ctx->chain_debug = which - 20;
+                ctx->blk_V = V;
+                ctx->blk_next = 63;
+                const int64_t nb0 = ctx->n_chain_blk;
+                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 63, 0, 1, false, 0.0, nullptr,
+                                         ctx->hslot_dev[0], 0);
+                ctx->chain_debug = 0;
+                ctx->blk_next = -1;
+                if (rc != 1 || ctx->n_chain_blk == nb0) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: blocked chain kernel not eligible");
+                break;
+            }
+            case 24: {     // ... and the per-column kernel on the same 64 columns
+                const int keep = ctx->chain_blk;
+                ctx->chain_blk = 0;
+                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 63, 0, 1, false, 0.0, nullptr,
+                                         ctx->hslot_dev[0], 0);
+                ctx->chain_blk = keep;
+                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
+                break;
+            }
             case 8: {
                 // register-resident panel GS over 16 columns: k_cgs_dots + reduce + k_cgs_update
                 int cnt = 0;
@@ -2633,6 +2795,36 @@ int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double*
     float ms = 0.f;
     KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / reps;
+    return 0;
+}
+
+// The solver's own launch sequence, timed: `reps` times the Arnoldi steps k = 0 .. m-1 on basis V (column 0 = the
+// caller's unit vector), begun with one step of look-ahead and fetched in order exactly like kh_gmres_cycle does -
+// without the Givens bookkeeping.  avg_step_ms = HIP-event time / (reps * m): with a banded operator and w in
+// registers that is the average duration of ONE launch of the fused chain kernel over k+1 = 1 .. m links.
+int kh_bench_arnoldi(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t m, int gs_mode, int reps, double* avg_step_ms) {
+    KH_ARG(ctx && A && V && W && avg_step_ms, "kh_bench_arnoldi: NULL");
+    KH_ARG(m >= 1 && V->ncols >= m + 1 && reps >= 1, "kh_bench_arnoldi: need m + 1 = %lld basis columns, have %lld",
+           (long long)(m + 1), (long long)V->ncols);
+    std::vector<double> col((size_t)m + 2);
+    KH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    for (int r = 0; r < reps; ++r) {
+        int64_t enq = 0;
+        for (int64_t k = 0; k < m; ++k) {
+            const int64_t last = std::min<int64_t>(k + 1, m - 1);
+            while (enq <= last) {
+                KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, nullptr, V, nullptr, W, 0, enq, 0, 1, gs_mode, 0.0,
+                                             (int)(enq % KH_NSLOT)));
+                ++enq;
+            }
+            KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), k + 2, col.data()));
+        }
+    }
+    KH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    KH_HIP(hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_step_ms = (double)ms / ((double)reps * (double)m);
     return 0;
 }
 

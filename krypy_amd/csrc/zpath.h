@@ -732,7 +732,7 @@ int kh_zarnoldi_step(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol, int
     KH_TRY(zfetch(ctx, hdev, 2 * (k + 2), hcol_out));
     if (*ctx->chain_err_pin[0] != 0) {
         *ctx->chain_err_pin[0] = 0;
-        ctx->chain_enabled = 0;
+        chain_switch_off(ctx);
         (void)hipMemsetAsync(ctx->chain_err, 0, sizeof(int), ctx->stream);
         return fail(KH_ERR_HIP, "grid-wide reduction of the complex MGS chain kernel timed out; the chain "
                                 "path is now disabled for this context");
@@ -754,6 +754,7 @@ int kh_zarnoldi_step_begin_md(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_
            "kh_zarnoldi_step_begin: a complex projector of length N and the operator are needed");
     KH_TRY(ensure_hcap(ctx, 2 * (std::max<int64_t>(k + 2, V->ncols + 1) + pd)));
     ctx->wait_tag[slot] = false;
+    chain_rearm(ctx, k);
     {
         kh_step_s& st = ctx->step[slot];
         st.kind = 2;
@@ -848,7 +849,7 @@ int kh_zcg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec
     KH_HIP(hipGetLastError());
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
     KH_TRY(fetch_scalars(ctx, tmp, 4, out));
-    out[4] = (double)(cg_sanity(out[0], out[1]) | ((std::isfinite(out[2]) && std::isfinite(out[3])) ? 0 : KH_CG_NONFINITE_PAP));
+    out[4] = (double)(cg_sanity(out[0], out[1], rho) | ((std::isfinite(out[2]) && std::isfinite(out[3])) ? 0 : KH_CG_NONFINITE_PAP));
     return 0;
 }
 

@@ -484,7 +484,7 @@ class Cg(_KrylovSolver):
                     0 if M_id else self._MMlrk.col, k == 0, float(omega) if k > 0 else 0.0,
                     float(rhos[-1]))
                 trace.append((k, float(rhos[-1]), den, pAp, rho_new, flags))
-                if flags & (_hip.CG_NONFINITE_PAP | _hip.CG_NONFINITE_RHO) and numpy.isfinite(rhos[-1]):
+                if flags & (_hip.CG_NONFINITE_PAP | _hip.CG_NONFINITE_RHO | _hip.CG_STEP_CLAMPED) and numpy.isfinite(rhos[-1]):
                     # finite data in, inf / nan out: nothing to iterate on (yk and r were left as they were)
                     self.xk = self._get_xk(yk)
                     raise _hip.BackendError(
@@ -504,7 +504,7 @@ class Cg(_KrylovSolver):
                     f"Iter {k}: abs(alpha.imag) = {abs(alpha.imag)} > 1e-12. "
                     "Is your operator self-adjoint in the provided inner product?")
             # (one_call: the step length the device took, real part of the same quotient)
-            alpha = float(rhos[-1]) / den if one_call else float(numpy.real(alpha))
+            alpha = float(numpy.float64(rhos[-1]) / numpy.float64(den)) if one_call else float(numpy.real(alpha))
 
             if self.store_arnoldi:
                 if k > 0:
@@ -807,9 +807,18 @@ class Gmres(_ArnoldiBasisMixin, _KrylovSolver):
         for sl in range(4):
             ar._claim(sl)
         bnorm = self.linear_system.MMlb_norm
-        k_done, enq, h2, why = ctx.gmres_cycle(
-            ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, k_stop, k_last, ar._sweeps, ar._gs_mode, max(ar._enq, k0),
-            float(self.tol), float(bnorm), ar.H, self.R, cyc["cs"], cyc["y"], ar._h2, cyc["resn"])
+        try:
+            k_done, enq, h2, why = ctx.gmres_cycle(
+                ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, k_stop, k_last, ar._sweeps, ar._gs_mode, max(ar._enq, k0),
+                float(self.tol), float(bnorm), ar.H, self.R, cyc["cs"], cyc["y"], ar._h2, cyc["resn"])
+        except BaseException:
+            # a failed launch / recovery inside the C loop: steps may have been begun that this object knows nothing
+            # of.  Nothing of them is used (the error propagates); the slots go back so that another basis of the
+            # context does not wait for an owner that will never fetch them.
+            ar._enq = ar.iter
+            for sl in range(4):
+                ar._release(sl)
+            raise
         ar._enq, ar._h2 = enq, h2
         in_flight = {j % 4 for j in range(k_done, enq)}       # (their slots stay claimed until advance() / _settle())
         for sl in range(4):

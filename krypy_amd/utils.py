@@ -1218,6 +1218,8 @@ class Arnoldi(object):
             return
         cols = min(self.maxiter + 1, max(need, 2 * self._cols))
         done = self.iter + 1
+        # a deferred MINRES recurrence update of the previous iteration still names a column of the old block
+        self._ctx.minres_flush()
         for name in ("_V", "_P", "_BV"):
             old = getattr(self, name)
             if old is None:

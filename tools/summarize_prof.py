@@ -61,6 +61,11 @@ def main(src, dst):
             if d:
                 lines.append("Kernel-trace average of the last %d `%s` launches (bench.py's micro-launches): "
                              "**%.1f us**." % (len(d), label, sum(x[0] for x in d) / len(d) / 1e3))
+        d = q(tdb, "select end - start from kernels where name like '%k_mgs_chain%' and name not like '%, 0>%'")
+        if d:
+            lines.append("Kernel-trace average of all %d launches of the fused-operator chain kernel (the solver's Arnoldi "
+                         "steps; bench.py's `roofline.avg_launch_ms` averages the same launches plus step k = 0 and the "
+                         "queue gaps): **%.1f us**." % (len(d), sum(x[0] for x in d) / len(d) / 1e3))
         lines.append("")
     except Exception as exc:  # pragma: no cover
         lines += ["(micro-launch durations unavailable: %r)" % exc, ""]
@@ -105,6 +110,18 @@ def main(src, dst):
                            "launches_averaged": len(f),
                            "note": "last %d launches of the run = bench.py's kh_bench_kernel launches; "
                                    "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
+        # the solver's own instantiation of the chain kernel (operator in the prologue: a template argument FND > 0),
+        # every launch of the run - whole cycles k = 1 .. m-1 of the solver and of kh_bench_arnoldi alike
+        cond = "name like '%k_mgs_chain%' and name not like '%, 0>%'"
+        f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + cond)
+        w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and " + cond)
+        if f and w:
+            rd = 2 * sum(x[0] for x in f) / len(f) * 1024
+            wr = sum(x[0] for x in w) / len(w) * 1024
+            tj["k_mgs_chain_solver"] = {
+                "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "launches_averaged": len(f),
+                "note": "all %d launches of the fused-operator chain kernel in the run (Arnoldi steps k >= 1 of whole "
+                        "GMRES cycles); FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
     except Exception as exc:  # pragma: no cover
         tj = {"error": repr(exc)}
     if tj and "error" not in tj:
