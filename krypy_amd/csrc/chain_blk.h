@@ -36,10 +36,6 @@ constexpr int BLK_BC = 4;                     // basis columns per block
 constexpr int BLK_NSLOT = 2;                  // blocks of columns in registers
 constexpr int BLK_NVMAX = 8;                  // values per sum (the block's BC coefficients; the norm + BC - 1 table entries)
 constexpr int BLK_NVS = 16;                   // granule PAIRS reserved per workgroup and parity (256 B records)
-#ifndef BLK_NPRE_FND
-#define BLK_NPRE_FND 1
-#define BLK_RIF 1
-#endif
 constexpr int BLK_TABCOLS = 4096;             // basis columns the Gram table has rows for (BLK_BC entries each)
 constexpr int BLK_GS = 16;                    // workgroups per group of the two-level exchange
 constexpr int BLK_NG2 = CH_GMAX / BLK_GS;     // groups at most
@@ -344,7 +340,12 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
     // results return in order, a wait names how many of the newest requests may still be outstanding): with w requested
     // last every use of w in the loop would wait for everything requested before it - all column blocks in flight.
     if constexpr (FND > 0) {
-        chain_apply_banded<R2, FND, BLK_RIF>(a, first, [&](int r, double s0, double s1) { w[r] = make_double2(s0, s1); });
+        chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { w[r] = make_double2(s0, s1); });
+        // w is COMPUTED before the first column is requested: the fence below orders memory operations only, and the
+        // compiler otherwise sinks the operator's arithmetic behind the columns' loads - the operator's 160 registers of
+        // loaded values live next to the ring's 128
+#pragma unroll
+        for (int r = 0; r < R2; ++r) asm volatile("" : "+v"(w[r].x), "+v"(w[r].y) : : "memory");
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll

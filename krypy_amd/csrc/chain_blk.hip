@@ -52,7 +52,8 @@ double* chain_blk_table(kh_ctx ctx) {
 
 // can the blocked kernel take this step at all (shape only; the table is the caller's business)?
 bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd) {
-    return r2 == 4 && !a.presub && a.sweeps == 1 && a.col0 == 0 && fnd == 0 && G <= CH_GMAX / 2 && a.ncol + 2 <= BLK_TABCOLS;
+    return r2 == 4 && !a.presub && a.sweeps == 1 && a.col0 == 0 && (fnd == 0 || fnd == 5 || fnd == 7) && G <= CH_GMAX / 2 &&
+           a.ncol + 2 <= BLK_TABCOLS;
 }
 
 // One Arnoldi step k = ncol - 1 of basis block V (columns 0 .. k, one sweep) on the blocked kernel.  r2: rows of 16 B per
@@ -73,9 +74,11 @@ hipError_t chain_blk_launch(kh_ctx ctx, int r2, int G, bool onex, bool padded, i
     const int64_t k = a.ncol - 1;
     *nsums = (a.ncol + BLK_BC - 1) / BLK_BC + 1;
     hipError_t e;
-#define KH_BLK(X) launch_blk<4, false, 0, X>(ctx, G, a, bf)
+#define KH_BLK(X)                                                 \
+    (fnd == 5 ? launch_blk<4, false, 5, X>(ctx, G, a, bf)         \
+              : (fnd == 7 ? launch_blk<4, false, 7, X>(ctx, G, a, bf) : launch_blk<4, false, 0, X>(ctx, G, a, bf)))
     if (a.debug >= 1 && a.debug <= 3) {        // measurement (kh_bench_kernel 21 .. 23): padded blocks, spread over the chip
-        if (onex || !padded) return hipErrorInvalidValue;
+        if (onex || !padded || fnd != 0) return hipErrorInvalidValue;
         e = a.debug == 1 ? launch_blk<4, false, 0, false, 1>(ctx, G, a, bf)
                          : (a.debug == 2 ? launch_blk<4, false, 0, false, 2>(ctx, G, a, bf)
                                          : launch_blk<4, false, 0, false, 3>(ctx, G, a, bf));

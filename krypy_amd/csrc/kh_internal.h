@@ -93,6 +93,9 @@ struct kh_ctx_s {
     int64_t n_chain_small = 0;
     // ... and its blocked form: one grid-wide sum per block of 4 columns (chain_blk.h; KRYPY_AMD_CHAIN_BLK)
     int chain_blk = 1;
+    int64_t blk_onex_maxn = 100000;   // vectors longer than this run the blocked kernel spread over the chip, not on one XCD: the
+                                      // one XCD's memory port is the bound from there on (16.6k vs 14.6k it/s at 62,500 rows, 13.4k either way at
+                                      // 10^5, 12.0k vs 13.1k at 129,600; KRYPY_AMD_BLK_ONEX_MAXN)
     int64_t n_chain_blk = 0;
     unsigned long long* blk_gran = nullptr;   // granules + per-XCD totals of the blocked kernel's sums + its Gram table (chain_blk.hip)
     const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...

@@ -594,7 +594,11 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         // (the column-ring kernel with 8 rows per lane - 1.3e5 < N <= 2.6e5 - is faster spread over the chip with 4:
         // a one-XCD link moves the whole column through one XCD's port; 7,240 vs 6,770 it/s at N = 2.5e5)
         const bool ring_kernel = ctx->chain_small && B == V && dg == nullptr && !cplx;
-        if (chain_geometry(ctx, n, &r2x, &Gx, true) && !(ring_kernel && r2x == 8 && r2 == 4)) {
+        // (... and the blocked kernel - four times fewer sums - is bound by the one XCD's memory port from
+        // ctx->blk_onex_maxn rows on: it then spreads over the chip as well)
+        const bool blk_long = ctx->chain_blk && ring_kernel && !presub && sweeps == 1 && start == 0 &&
+                              k + 1 >= KH_BLK_MIN_LINKS && r2 == 4 && n > ctx->blk_onex_maxn;
+        if (chain_geometry(ctx, n, &r2x, &Gx, true) && !(ring_kernel && r2x == 8 && r2 == 4) && !blk_long) {
             r2 = r2x;
             G = Gx;
             want_onex = true;
@@ -679,9 +683,6 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
-        // long chains of short vectors: the blocked kernel (chain_blk.h) takes w from the SpMV launch - one sum per four
-        // links is worth more than the launch the fused prologue saves
-        if (small_shape && blk_takes_step(ctx, a, r2)) return 0;
         a.dia = Afuse->dia;
         a.dia_ld = Afuse->dia_ld;
         a.xk = xk;
@@ -753,7 +754,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     // short vectors (4 ... 32 workgroups of 4 / 8 rows per lane): a link is its grid-wide sum - all working
     // workgroups on ONE XCD, where the sum is an L2 round trip (chain.h, ONEX)
     // short vectors, no preconditioner, real data: the column-ring kernel (one read per column, several links of look-ahead)
-    const bool blk_debug = (a.debug >= 1 && a.debug <= 3) && !fused && blk_takes_step(ctx, a, r2);   // measurement modes of the blocked kernel
+    const bool blk_debug = (a.debug >= 1 && a.debug <= 3) && !fused && padded && blk_takes_step(ctx, a, r2);   // measurement modes of the blocked kernel
     if (ctx->chain_small && r2 <= 8 && B == V && dg == nullptr && !cplx && (a.debug == 0 || a.debug == 4 || blk_debug) &&
         !(fused && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1)) {
         if (want_onex) {
@@ -764,7 +765,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             a.onex_clear = ctx->onex_ticket + ((slot_ + 128u) & 255u);
         }
         // a long chain: the blocked form - one grid-wide sum per FOUR columns (chain_blk.h)
-        if (!fused && blk_takes_step(ctx, a, r2) && chain_blk_shape_ok(r2, G, a, 0)) {
+        if (blk_takes_step(ctx, a, r2) && padded && chain_blk_shape_ok(r2, G, a, fused ? a.offs.nd : 0)) {
             int nsums = 0;
             // the Gram table: valid when this is the next step of the sequence that owns it; otherwise (a sequence's
             // first blocked step, a block grown / recycled / written by another entry point since) its rows are
@@ -780,7 +781,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 ctx->blk_next = k;
                 ctx->n_blk_rebuild += 1;
             }
-            e = chain_blk_launch(ctx, r2, G, want_onex, padded, 0, a, V, &nsums);
+            e = chain_blk_launch(ctx, r2, G, want_onex, padded, fused ? a.offs.nd : 0, a, V, &nsums);
             if (e == hipSuccess) {
                 if (a.debug == 4) ctx->chain_fault = 0;
                 ctx->n_chain += 1;
@@ -1102,6 +1103,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK");
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_BLK_ONEX_MAXN");
+        if (e != nullptr) ctx->blk_onex_maxn = atoll(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
         if (ctx->chain_onex) {
@@ -1214,6 +1217,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
+    else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
