@@ -15,9 +15,10 @@ Inputs (CSR matrix, b) are resident in HBM before the timed region starts.
 
 value = K*100 iterations / wall time (max over ranks, barrier + device sync on both sides).
 For N > 1 the matrix rows and all vectors are sharded in contiguous slabs (one process per
-GPU, launched with torch.distributed.run); halo exchange + dot-product all-reduces go through
-RCCL inside libkrylov_hip.so; torch.distributed (gloo) is used only to hand the ncclUniqueId
-to the ranks and for the timing barrier.  Total work is fixed -> "scaling": "strong".
+GPU, launched with torch.distributed.run or any launcher that sets RANK / WORLD_SIZE / MASTER_*); halo
+exchange + dot-product all-reduces go through RCCL inside libkrylov_hip.so; the ncclUniqueId reaches the
+ranks, and the timing barrier / max-over-ranks run, over krypy_amd.dist.TcpRendezvous (plain sockets: no
+PyTorch on the host side).  Total work is fixed -> "scaling": "strong".
 
 Extra objects on the JSON line:
   roofline     the dominant kernel (Gram-Schmidt link / panel kernels), timed live with HIP
@@ -247,7 +248,7 @@ def main():
     os.dup2(2, 1)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 def _run():
@@ -266,10 +267,8 @@ def _run():
         os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
     dist = None
     if sharded:
-        import torch.distributed as dist  # plumbing only: unique-id broadcast + barrier
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from krypy_amd.dist import TcpRendezvous      # plumbing only: unique-id broadcast, barrier, max over ranks
+        dist = TcpRendezvous(rank, world)
 
     import krypy_amd
     from krypy_amd import _hip, linsys, utils
@@ -288,9 +287,8 @@ def _run():
         ortho = "cgs" if sharded else "mgs"
     if sharded:
         from krypy_amd import dist as kdist
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
+        uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
+        ctx.comm_init(rank, world, uid)
         # contiguous slabs of grid rows (y index): every shard holds whole x-lines
         cuts = [(ny * p) // world for p in range(world + 1)]
         Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
@@ -343,10 +341,7 @@ def _run():
     dt = time.perf_counter() - t0
     cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        dt = dist.allreduce_max(dt)
     n_iters = len(sol.resnorms) - 1
     assert n_iters == args.steps * m, (n_iters, args.steps, m)
     its = n_iters / dt
@@ -467,10 +462,8 @@ def _run_config5(args):
         os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
     dist = None
     if sharded:
-        import torch.distributed as dist  # plumbing only: unique-id broadcast + barrier
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from krypy_amd.dist import TcpRendezvous      # plumbing only: unique-id broadcast, barrier, max over ranks
+        dist = TcpRendezvous(rank, world)
     from krypy_amd import _hip, deflation, linsys, utils
 
     if not os.path.exists(_hip.library_path()):
@@ -491,9 +484,8 @@ def _run_config5(args):
     b_rng = np.random.default_rng(0)
     if sharded:
         from krypy_amd import dist as kdist
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(rank, world, uid[0])
+        uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
+        ctx.comm_init(rank, world, uid)
         cuts = [(nz * p) // world for p in range(world + 1)]          # whole planes per rank
         z0, z1 = cuts[rank], cuts[rank + 1]
         Aloc = laplace3d(nx, ny, nz, z0, z1)
@@ -544,10 +536,7 @@ def _run_config5(args):
     dt = time.perf_counter() - t0
     cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
     if dist is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+        dt = dist.allreduce_max(dt)
     assert n_iters == args.steps * m, (n_iters, args.steps, m)
     its = n_iters / dt
     nloc = ls.N

@@ -1,5 +1,5 @@
 // Blocked reference-order modified Gram-Schmidt for vectors whose COLUMNS fit the register file:
-// ONE grid-wide sum per block of BC basis columns instead of one per column.
+// ONE grid-wide sum per block of BC = 4 basis columns instead of one per column.
 //
 // The reference's loop (utils.py:1012-1029) is   for j: alpha_j = <v_j, w_j>;  w_{j+1} = w_j - alpha_j v_j .
 // For a block of BC consecutive columns v_0 .. v_{BC-1} (link order) and w = the vector as the block finds it,
@@ -7,26 +7,38 @@
 //     c_l      = <v_l, w>                         all BC of them against the NOT YET UPDATED w
 //     G_{m,l}  = <v_m, v_l>,  m < l               the block's strict upper Gram matrix
 //     alpha_l  = c_l - sum_{m<l} alpha_m G_{m,l}  ( = <v_l, w - sum_{m<l} alpha_m v_m> = the reference's alpha_l )
-//     w       -= alpha_0 v_0;  w -= alpha_1 v_1; ...   (the reference's updates, in its order, multiply then subtract)
+//     w       -= alpha_0 v_0;  w -= alpha_1 v_1; ...   (the reference's updates in its order)
 //
 // is the SAME recurrence in exact arithmetic: the coefficient of link l is taken against the vector the reference
 // takes it against, only the inner product with the already subtracted part is formed from the Gram entries instead
 // of from the updated vector.  Rounding differs by O(eps |alpha_m| |G_{m,l}|) per term, G being the basis'
 // orthogonality defect - 1e-16 ... 1e-10 in a GMRES cycle -, i.e. far below the rounding of the dot products
-// themselves (the low-synchronisation MGS of Swirydowicz et al. rests on the same identity).  c and G travel in one
-// grid-wide sum of NV = BC + BC (BC - 1) / 2 values (BC = 4: 10); nothing about the basis is remembered between
-// launches - the Gram entries are recomputed from the resident columns each time (a few hundred FMAs per lane), so
-// there is no table that could go stale when a block is recycled, grown or written by another entry point.
+// themselves (the low-synchronisation MGS of Swirydowicz et al. rests on the same identity).  This kernel is therefore
+// NOT one of the bit-for-bit ones (it also fuses the update's multiply and subtract); it is held to north_star's 1e-10
+// against the per-column kernels and the CPU oracle (tests/test_gpu_blocked.py).
 //
-// Shape: the short-vector geometry of k_mgs_chain_small (4 rows of 16 B per lane, 512 working lanes per workgroup),
-// a ring of NSLOT blocks of BC whole columns in registers (the loads of block i + NSLOT are issued when block i has
-// been used: they are in flight across the sum of block i + 1), and a NINTH wave per workgroup that owns no rows and
-// does all the communication (vector-memory results return to a wave in order: a poll issued by a wave that has
-// requested columns ahead waits for those columns first).  The eight working waves leave their wave partials in LDS
-// and wait at two LDS-only barriers; the communication wave publishes the workgroup's NV partials as tagged 8-byte
-// granules (chain.h), gathers everybody's - all workgroups of the one XCD (ONEX), or the XCD leaders over the fabric
-// with the result handed on through the XCD's L2 - adds them in a fixed order (every workgroup: the same bits) and
-// puts the totals into LDS.
+// The Gram entries are a property of the basis: row j of a small device table holds <v_m, v_j> for the columns m < j of
+// j's block.  The launch of step k computes row k + 1 while it still holds the last block and the final w (BC - 1 more
+// values in the sum that carries ||w||^2; G = <v_m, w> / h) and reads the rows of columns <= k.  The table belongs to ONE
+// Arnoldi sequence (ctx->blk_V, ctx->blk_next: this basis block, the next step); a step that is not the next one of that
+// sequence - another basis, a block recycled / grown / written to through any other entry point since (chain_blk_touch) -
+// rebuilds the rows from the basis first (one panel product per column, krylov_hip.hip), so a stale table cannot be used.
+// (A stateless form - the block's six Gram entries computed from the resident columns in every launch, ten values per
+// sum - was built first: its arithmetic, 900 instructions per block and wave, cost what the saved sums gained.)
+//
+// Shape: the short-vector geometry of k_mgs_chain_small (4 rows of 16 B per lane, 512 working lanes per workgroup), a
+// ring of NSLOT = 2 blocks of BC whole columns in registers (the loads of block i + 2 are issued when block i has been
+// used), and a NINTH wave per workgroup that owns no rows and does all the communication.  The eight working waves
+// leave their wave partials in LDS and wait at two LDS-only barriers; the communication wave publishes the workgroup's
+// partials as tagged 8-byte granules (chain.h), gathers everybody's - every workgroup itself when all run on one XCD
+// (ONEX, L2 hits), otherwise group by group (the wave of workgroup j adds group j's 16 records) and then the XCD leaders
+// the groups, the totals handed on through the XCD's L2 - adds them in an order that depends on the workgroup numbers
+// only (every workgroup: the same bits, run after run) and puts the totals and the block's Gram entries into LDS.
+//
+// What bounds it (tools/blk_prof.py, profiles/r04_blk_*.log): a poll of the communication wave waits in the compute
+// unit's memory queue behind whatever the working waves have requested, so on every compute unit the exchange of block
+// i and the stream of block i + 1 take turns whatever the code does - a block costs stream + exchange + arithmetic
+// (N = 10^6: 4.0 + 3.2 + 2.0 us per four links = 2.3 us per link against 3.2 for the per-column kernel).
 #pragma once
 #include "chain.h"
 

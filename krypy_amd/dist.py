@@ -20,12 +20,149 @@ Usage (every rank)::
     ls = LinearSystem(op, b_local)                         #         global column indices
     RestartedGmres(ls, maxiter=100, max_restarts=R, ortho="cgs2")
 """
+import os
+import socket
+import struct
+import time
+
 import numpy
 import scipy.sparse
 
 from . import _hip, utils
 
-__all__ = ["slab_cuts", "localize_columns", "ShardedCSROperator"]
+__all__ = ["slab_cuts", "localize_columns", "ShardedCSROperator", "TcpRendezvous"]
+
+
+class TcpRendezvous(object):
+    """What a launcher of one process per GPU needs besides RCCL itself: hand rank 0's ``ncclUniqueId`` to the other
+    ranks, a barrier, and the maximum of one double over the ranks (the timing contract of ``bench.py``).  Plain TCP
+    sockets in a star around rank 0 - no PyTorch, no MPI on the host side (north_star).  The environment is the one
+    ``python -m torch.distributed.run`` (or any other launcher) provides: ``MASTER_ADDR`` and ``MASTER_PORT``; the
+    port itself belongs to the launcher's own store, so rank 0 listens on the first free one of the eight ports
+    behind it and the others find it there (a handshake word tells a foreign listener from rank 0).  Everything that
+    moves data between GPUs - halo exchange, all-reduces - runs inside ``libkrylov_hip.so`` over RCCL."""
+
+    MAGIC = b"krypy_amd.rdv.1\0"
+
+    def __init__(self, rank, world, addr=None, port=None, timeout=600.0):
+        self.rank, self.world = int(rank), int(world)
+        self._peers = []          # rank 0: sockets of ranks 1 .. world-1 (by rank); others: [socket to rank 0]
+        if self.world <= 1:
+            return
+        addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+        base = int(port if port is not None else os.environ.get("MASTER_PORT", "29511"))
+        ports = [base + 1 + i for i in range(8)]
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = None
+            for p in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr if addr not in ("localhost",) else "127.0.0.1", p))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError("TcpRendezvous: no free port in %s on %s" % (ports, addr))
+            srv.listen(self.world)
+            got = {}
+            while len(got) < self.world - 1:
+                srv.settimeout(max(1.0, deadline - time.time()))
+                c, _ = srv.accept()
+                c.settimeout(30.0)
+                try:
+                    hello = self._recv_exact(c, len(self.MAGIC) + 8)
+                except (OSError, RuntimeError):
+                    c.close()
+                    continue
+                r, w = struct.unpack("<ii", hello[len(self.MAGIC):])
+                if hello[: len(self.MAGIC)] != self.MAGIC or w != self.world or not (0 < r < self.world) or r in got:
+                    c.close()
+                    continue
+                c.sendall(self.MAGIC)
+                c.settimeout(None)
+                c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                got[r] = c
+            srv.close()
+            self._peers = [got[r] for r in range(1, self.world)]
+        else:
+            sock = None
+            while sock is None:
+                for p in ports:
+                    try:
+                        c = socket.create_connection((addr, p), timeout=2.0)
+                        c.sendall(self.MAGIC + struct.pack("<ii", self.rank, self.world))
+                        if self._recv_exact(c, len(self.MAGIC)) == self.MAGIC:
+                            c.settimeout(None)
+                            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            sock = c
+                            break
+                        c.close()
+                    except (OSError, RuntimeError):
+                        pass
+                if sock is None:
+                    if time.time() > deadline:
+                        raise RuntimeError("TcpRendezvous: rank %d found no rank 0 at %s:%s" % (self.rank, addr, ports))
+                    time.sleep(0.05)
+            self._peers = [sock]
+
+    @staticmethod
+    def _recv_exact(sock, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = sock.recv(n - len(buf))
+            if not chunk:
+                raise RuntimeError("TcpRendezvous: peer closed the connection")
+            buf += chunk
+        return buf
+
+    def _send(self, sock, payload):
+        sock.sendall(struct.pack("<I", len(payload)) + payload)
+
+    def _recv(self, sock):
+        (n,) = struct.unpack("<I", self._recv_exact(sock, 4))
+        return self._recv_exact(sock, n)
+
+    def broadcast_bytes(self, data):
+        """``data`` of rank 0 on every rank."""
+        if self.world <= 1:
+            return data
+        if self.rank == 0:
+            for s in self._peers:
+                self._send(s, bytes(data))
+            return data
+        return self._recv(self._peers[0])
+
+    def _reduce(self, x, fn):
+        if self.world <= 1:
+            return x
+        if self.rank == 0:
+            vals = [x] + [struct.unpack("<d", self._recv(s))[0] for s in self._peers]
+            out = fn(vals)
+            for s in self._peers:
+                self._send(s, struct.pack("<d", out))
+            return out
+        self._send(self._peers[0], struct.pack("<d", float(x)))
+        return struct.unpack("<d", self._recv(self._peers[0]))[0]
+
+    def allreduce_max(self, x):
+        """max over the ranks of one double (every rank gets it)."""
+        return self._reduce(float(x), max)
+
+    def barrier(self):
+        self._reduce(0.0, max)
+
+    def close(self):
+        for s in self._peers:
+            try:
+                s.close()
+            except OSError:
+                pass
+        self._peers = []
+
+    destroy_process_group = close        # (the name the launcher-side code knew the torch.distributed module by)
 
 
 def slab_cuts(n, nranks, align=1):

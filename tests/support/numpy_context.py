@@ -145,6 +145,12 @@ class NumpyContext(object):
     def comm_init(self, rank, nranks, unique_id):
         assert len(unique_id) == 128 and unique_id.startswith(b"gloo-test-double"), "every rank must get rank 0's id"
         self.rank, self.nranks = rank, nranks
+        if nranks > 1:
+            # the double's "RCCL" is torch.distributed's gloo group; a launcher that does not use torch itself
+            # (bench.py: krypy_amd.dist.TcpRendezvous) has not created one
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                dist.init_process_group("gloo", rank=rank, world_size=nranks)
         self._comm = GlooComm(rank, nranks) if nranks > 1 else None
 
     # allocation

@@ -383,3 +383,40 @@ def test_slab_cuts_and_localize():
     assert np.array_equal(Al.dot(xl), A[12:24].dot(x))
     Al, nrp, nrn = kdist.localize_columns(A[0:12], 0, 36)
     assert (nrp, nrn) == (0, 6)
+
+
+def _rdv_worker(rank, world, port, q):
+    try:
+        from krypy_amd.dist import TcpRendezvous
+        r = TcpRendezvous(rank, world, addr="127.0.0.1", port=port, timeout=120.0)
+        uid = r.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+        r.barrier()
+        m = r.allreduce_max(10.0 + rank)
+        m2 = r.allreduce_max(-float(rank))
+        r.barrier()
+        r.close()
+        q.put((rank, "ok", (uid, m, m2)))
+    except BaseException:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_tcp_rendezvous_broadcast_barrier_max(world):
+    """krypy_amd.dist.TcpRendezvous is all the launcher-side plumbing bench.py needs for N > 1 (the ncclUniqueId to
+    every rank, a barrier, the max over ranks of the elapsed time) - plain sockets, no torch.distributed."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rdv_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = {}
+    for _ in range(world):
+        rank, status, payload = q.get(timeout=300)
+        assert status == "ok", payload
+        outs[rank] = payload
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        uid, m, m2 = outs[r]
+        assert uid == bytes(range(128)) and m == 10.0 + world - 1 and m2 == 0.0
