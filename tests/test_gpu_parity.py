@@ -1128,3 +1128,41 @@ def test_solve_fuzz_random_solves_against_the_oracle(hip):
     for seed in range(16):
         solve_fuzz.one_solve(seed)
         solve_fuzz.one_solve_extra(seed)        # complex CG / MINRES / GMRES (oracle/krylov_ref_c.py), deflated GMRES
+
+
+@pytest.mark.parametrize("kind,n", [("band", 400_000), ("ragged", 150_000)])
+def test_general_csr_operators_of_the_bench_tool(hip, kind, n):
+    """The two non-stencil operators tools/bench_configs.py times at N = 5e6 / 2e6 (about nine entries per row at random
+    places in a band; 3 ... 40 entries per row), here at a size the oracle handles in seconds: no banded copy, the
+    CSR-stream kernel bit-identical to scipy's csr_matvec (utils.py:1593-1594), and a GMRES(40) cycle - SpMV launch +
+    chain kernel, w through HBM - against the CPU oracle at 1e-10."""
+    import importlib.util
+    import os
+    from krypy_amd import linsys, utils
+
+    spec = importlib.util.spec_from_file_location(
+        "bench_configs", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bench_configs.py"))
+    bc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bc)
+    A = bc.general_csr(kind, n)
+    b = np.random.default_rng(0).standard_normal(n)
+    Ad = hip.csr(A)
+    assert Ad.diagonals == 0
+    X, Y = hip.upload(b), hip.alloc(n, 1)
+    hip.apply(Ad, X, 0, Y, 0, 1)
+    assert np.array_equal(Y.download()[:, 0], A.dot(b))
+    f0 = hip.counters()["chain_fused"]
+    try:
+        sol = linsys.Gmres(linsys.LinearSystem(A, b), maxiter=40, tol=1e-30)
+    except utils.ConvergenceError as e:
+        sol = e.solver
+    assert hip.counters()["chain_fused"] == f0          # (nothing to fuse: the operator is not banded)
+    want = ref.gmres(A, b, tol=1e-30, maxiter=40)
+    res, wres = np.array(sol.resnorms), np.array(want.resnorms)
+    assert len(res) == len(wres) == 41
+    # (these systems are diagonally dominant: the residual reaches rounding level within the 40 steps, where its
+    # digits are noise in the oracle too - the history is compared down to 1e-6 of the right-hand side)
+    live = wres > 1e-6
+    assert live.sum() >= 5
+    assert np.max(np.abs(res[live] - wres[live]) / wres[live]) < 1e-10
+    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-10 * np.linalg.norm(want.xk)

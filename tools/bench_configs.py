@@ -100,6 +100,66 @@ def config5(ctx, nx=200, m=100, d=16, nz=None, ortho="mgs"):
                 plain_relres=float(s0.resnorms[-1]), deflated_relres=float(s1.resnorms[-1]))
 
 
+def general_csr(kind, n, seed=11):
+    """Two operators that are NOT stencils (no diagonal structure: the CSR-stream kernel, a separate SpMV launch and w
+    through HBM in every Arnoldi step - what `MatrixLinearOperator._dot`, utils.py:1593-1594, gets for any other matrix):
+      band    about nine entries per row at random places within +-899 of the diagonal (the pattern of
+              tests/test_gpu_halo_loopback._stencil("random")), plus 16 I
+      ragged  3 ... 40 entries per row (uniform) at random places within +-20000 of the diagonal, plus 64 I"""
+    r = np.random.default_rng(seed)
+    if kind == "band":
+        rows = np.repeat(np.arange(n, dtype=np.int64), 8)
+        cols = np.clip(rows + r.integers(-899, 900, rows.size), 0, n - 1)
+        shift = 16.0
+    else:
+        lens = r.integers(3, 41, n)
+        rows = np.repeat(np.arange(n, dtype=np.int64), lens)
+        cols = np.clip(rows + r.integers(-20000, 20001, rows.size), 0, n - 1)
+        shift = 64.0
+    A = (sp.coo_matrix((r.standard_normal(rows.size), (rows, cols)), shape=(n, n)) + shift * sp.identity(n)).tocsr()
+    A.sum_duplicates()
+    A.sort_indices()
+    return A
+
+
+def config_csr(ctx, kind, n):
+    A = general_csr(kind, n)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+    Ad = ctx.csr(A)
+    assert Ad.diagonals == 0, "meant to be a general CSR operator"
+    X, Y = ctx.upload(b), ctx.alloc(N, 1)
+    for _ in range(3):
+        ctx.apply(Ad, X, 0, Y, 0, 1)
+    ctx.timer_start()
+    reps = 50
+    for _ in range(reps):
+        ctx.apply(Ad, X, 0, Y, 0, 1)
+    ms = ctx.timer_stop() / reps
+    same = bool(np.array_equal(Y.download()[:, 0], A.dot(b)))
+    nbytes = 12.0 * A.nnz + 4.0 * (N + 1) + 16.0 * N
+    ls = linsys.LinearSystem(A, b)
+
+    def run(ncyc):
+        try:
+            return linsys.RestartedGmres(ls, maxiter=100, max_restarts=ncyc - 1, tol=1e-30)
+        except utils.ConvergenceError as e:
+            return e.solver
+    run(1)
+    ctx.sync()
+    t0 = time.perf_counter()
+    s = run(4)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    n_it = len(s.resnorms) - 1
+    lens = np.diff(A.indptr)
+    return dict(config="general CSR '%s': N=%d, nnz=%d (%d ... %d per row, mean %.1f), GMRES(100) mgs" % (
+                    kind, N, A.nnz, lens.min(), lens.max(), lens.mean()),
+                spmv_us=ms * 1e3, spmv_algorithmic_bytes=nbytes, spmv_gbs=nbytes / ms / 1e6, spmv_frac_of_8TBs=nbytes / ms / 1e6 / 8000.0,
+                spmv_bit_identical_to_scipy=same, iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+                chain_launches=ctx.counters()["chain"], chain_fused=ctx.counters()["chain_fused"])
+
+
 if __name__ == "__main__":
     ctx = _hip.get_context()
     which = sys.argv[1:] or ["3", "4", "5"]
@@ -107,5 +167,7 @@ if __name__ == "__main__":
         fn = {"3": config3, "4": config4, "5": config5,
               # the per-GPU share of config 5 at its stated size: a 500 x 500 x 50 slab, 12.5 M rows (beyond the
               # register file: 48 rows per lane, eight of them in LDS), reference-order MGS and the panel form
-              "5s": lambda c: config5(c, nx=500, nz=50), "5sc": lambda c: config5(c, nx=500, nz=50, ortho="cgs")}[w]
+              "5s": lambda c: config5(c, nx=500, nz=50), "5sc": lambda c: config5(c, nx=500, nz=50, ortho="cgs"),
+              # operators that are not stencils: the CSR-stream SpMV kernel + chain kernel (N = 5e6 / 2e6)
+              "band": lambda c: config_csr(c, "band", 5_000_000), "ragged": lambda c: config_csr(c, "ragged", 2_000_000)}[w]
         print(json.dumps(fn(ctx)), flush=True)
