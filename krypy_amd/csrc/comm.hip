@@ -70,6 +70,7 @@ namespace kh {
 
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
     if (ctx->comm == nullptr || count == 0) return 0;   // a 1-rank communicator still goes through RCCL
+    ctx->n_allreduce += 1;
     KH_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                              ctx->stream));
     return 0;

@@ -150,6 +150,7 @@ struct kh_ctx_s {
     int64_t n_spmv_split = 0;
     int halo_loopback = 0;          // tests: a 1-rank communicator exchanges its halo with itself (periodic slab)
     int64_t n_halo_exchange = 0;    // grouped ncclSend / ncclRecv exchanges issued
+    int64_t n_allreduce = 0;        // ncclAllReduce calls issued (kh_ctx_get "n_allreduce")
     double* commbuf = nullptr;  // device staging for host all-reduces
 };
 

@@ -1252,6 +1252,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
+    else if (!strcmp(key, "n_allreduce")) *value = ctx->n_allreduce;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
     return 0;
