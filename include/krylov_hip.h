@@ -230,6 +230,27 @@ int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W
                    double* R, int64_t ldr, double* cs, double* y, double* h2_io, double* resn, int64_t* k_done,
                    int* reason);
 
+/* The Givens rotation the C host loops (kh_gmres_cycle, kh_minres_cycle) generate: by default the reference BLAS formula;
+ * a caller whose own per-step loop uses its BLAS library's drotg (krypy/utils.py:426-427 through scipy.linalg.blas)
+ * hands that function over - Fortran convention drotg(a, b, c, s), a and b overwritten - and gets the same bits from
+ * both loops.  NULL restores the built-in formula. */
+int kh_ctx_set_rotg(kh_ctx ctx, void (*drotg)(double* a, double* b, double* c, double* s));
+
+/* A run of MINRES iterations in ONE call (krypy/linsys.py:791-853): Lanczos steps k0 .. k_stop-1 with look-ahead on the
+ * device (kh_arnoldi_step_begin / _end, slots k mod 4; the basis may be a sliding WINDOW whose column 0 is logical
+ * column `base`), and on the host in C what the reference does between two steps: the symmetric fill H[k-1,k] = H[k,k-1],
+ * the new column through the two remembered Givens rotations and its own, the rotated right-hand side, and the vector
+ * recurrences z = (v_k - R0 W0 - R1 W1)/R2; W <- [W1, z]; yk += y0 z as a DEFERRED update (kh_minres_update_deferred:
+ * the next Lanczos launch carries it; call kh_minres_flush before yk is read).  H is (ldh >= k_stop) row-major like the
+ * reference's array and receives the three entries of each recorded column.  st[0..3] = the two remembered rotations
+ * (c, s) older first, st[4] = how many of them exist (0, 1, 2), st[5..6] = the rotated right-hand side (y[0], y[1]);
+ * *wslot_io = the column of Wm that holds W0; *h2_io the running squared Frobenius norm of H; *enq_io as for
+ * kh_gmres_cycle.  resn[k] = |y[k+1]| of every recorded step.  Stop reasons and *k_done as for kh_gmres_cycle. */
+int kh_minres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
+                    int64_t k_last, int64_t base, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
+                    kh_vec Wm, int* wslot_io, kh_vec YK, int64_t ycol, double* st, double* h2_io, double* resn,
+                    int64_t* k_done, int* reason);
+
 /* r = b - A x fused with its squared norm: R[:, rcol] = B[:, bcol] - A X[:, xcol]; *nrm = ||r||_2
  * (LinearSystem.get_residual linsys.py:156-160 for M = Ml = identity) */
 int kh_residual(kh_ctx ctx, kh_mat A, kh_vec B, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,

@@ -98,6 +98,10 @@ _SIGNATURES = {
     "kh_gmres_cycle": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _INT, _INT, _c_int64_p, _D, _D, _c_double_p, _I64,
                        _c_double_p, _I64, _c_double_p, _c_double_p, _c_double_p, _c_double_p, _c_int64_p,
                        ctypes.POINTER(ctypes.c_int)],
+    "kh_ctx_set_rotg": [_H, ctypes.c_void_p],
+    "kh_minres_cycle": [_H, _H, _H, _H, _H, _H, _I64, _I64, _I64, _I64, _c_int64_p, _D, _D, _c_double_p, _I64, _H,
+                        ctypes.POINTER(ctypes.c_int), _H, _I64, _c_double_p, _c_double_p, _c_double_p, _c_int64_p,
+                        ctypes.POINTER(ctypes.c_int)],
     "kh_minres_update": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_minres_update_deferred": [_H, _H, _I64, _H, _INT, _D, _D, _D, _D, _H, _I64],
     "kh_minres_flush": [_H],
@@ -352,6 +356,21 @@ class DeviceVectors(object):
                                                               count * self._w), "kh_vec_zero_range")
 
 
+def _blas_drotg_address():
+    """Address of the Fortran ``drotg`` behind ``scipy.linalg.blas.drotg`` (f2py keeps it in a capsule), or None."""
+    try:
+        from scipy.linalg import blas
+        cap = blas.drotg._cpointer
+        api = ctypes.pythonapi
+        api.PyCapsule_GetName.restype = ctypes.c_char_p
+        api.PyCapsule_GetName.argtypes = [ctypes.py_object]
+        api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+        api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+        return api.PyCapsule_GetPointer(cap, api.PyCapsule_GetName(cap)) or None
+    except Exception:
+        return None
+
+
 class Context(object):
     """One GPU, one HIP stream (``kh_ctx``).  Not thread-safe, like the reference."""
 
@@ -371,6 +390,12 @@ class Context(object):
         self.device = device
         self.rank, self.nranks = 0, 1
         self._pool, self._pool_bytes = {}, 0
+        # the C host loops (kh_gmres_cycle, kh_minres_cycle) generate their Givens rotations with the SAME BLAS drotg the
+        # per-step loops of the host layer call (utils.givens_scalars -> scipy.linalg.blas.drotg): its address goes
+        # across the ABI once.  Without it they use the reference BLAS formula (last-bit differences).
+        fn = _blas_drotg_address()
+        if fn:
+            _check(self._lib, self._lib.kh_ctx_set_rotg(self._h, fn), "kh_ctx_set_rotg")
 
     def close(self):
         if self._alive:
@@ -786,6 +811,31 @@ class Context(object):
             _dptr(R), R.shape[1], _dptr(cs), _dptr(y), ctypes.byref(h2_), _dptr(resn), ctypes.byref(kd),
             ctypes.byref(why)), "kh_gmres_cycle")
         return kd.value, enq_.value, h2_.value, why.value
+
+    def minres_cycle(self, A, Md, V, P, W, k0, k_stop, k_last, base, enq, tol, bnorm, H, Wm, wslot, YK, ycol, st, h2,
+                     resn):
+        """Iterations ``k0 .. k_stop-1`` of MINRES in one call (``kh_minres_cycle``): Lanczos steps with look-ahead on
+        the device, the QR update with the two remembered rotations and the deferred vector recurrences in C.  ``H``:
+        the C-ordered float64 Lanczos matrix of the solver, ``st`` (7 doubles: rotations, their count, rotated
+        right-hand side) and ``resn``: float64 1-D arrays, updated in place.  Returns
+        ``(k_done, enq, h2, wslot, reason)``."""
+        for a in (H, st, resn):
+            if a.dtype != numpy.float64 or not a.flags.c_contiguous:
+                raise BackendError("minres_cycle: C-ordered float64 arrays needed")
+        if H.ndim != 2 or H.shape[0] < k_stop + 1 or st.size < 7 or resn.size < k_stop:
+            raise BackendError("minres_cycle: H needs k_stop + 1 = %d rows, st 7 entries, resn k_stop" % (k_stop + 1))
+        _same_dtype("minres_cycle", V, W, Wm, YK)
+        enq_ = ctypes.c_int64(int(enq))
+        h2_ = _D(float(h2))
+        kd = ctypes.c_int64(0)
+        why = ctypes.c_int(0)
+        ws = ctypes.c_int(int(wslot))
+        _check(self._lib, self._lib.kh_minres_cycle(
+            self._h, A.handle, Md.handle if Md is not None else None, V.handle, P.handle if P is not None else None,
+            W.handle, k0, k_stop, k_last, base, ctypes.byref(enq_), float(tol), float(bnorm), _dptr(H), H.shape[1],
+            Wm.handle, ctypes.byref(ws), YK.handle, ycol, _dptr(st), ctypes.byref(h2_), _dptr(resn), ctypes.byref(kd),
+            ctypes.byref(why)), "kh_minres_cycle")
+        return kd.value, enq_.value, h2_.value, ws.value, why.value
 
     def minres_flush(self):
         """Run a deferred MINRES update now (``kh_minres_flush``)."""

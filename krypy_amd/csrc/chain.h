@@ -677,14 +677,15 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
     }
 }
 
-// WL > 0: the vector is longer than the register file can hold (more than 40 rows per lane, N > 10.48 M on
+// WL > 0 (with FND > 0 the operator's rows beyond the registers are put into the LDS entries directly: instantiated for
+// 48 rows and 7 / 5 diagonals - config 5's slab; at 56 rows the unrolled prologue spills 163 registers):
+// the vector is longer than the register file can hold (more than 40 rows per lane, N > 10.48 M on
 // 256 CUs): the last WL rows of w live in LDS (8 KB per row and workgroup, each lane touches only its own
 // entries: no barrier), the first R2 - WL in registers as ever.  R2 = 48 / 56 (WL = 8 / 16) take N to
 // 12.58 M / 14.68 M per GPU with the same single launch per Arnoldi step and the same arithmetic.
 template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0, bool ONEX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
-    static_assert(WL == 0 || FND == 0, "the fused operator writes registers only");
     constexpr int RW = R2 - WL;                   // rows of w in registers
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
 #define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
@@ -763,7 +764,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
             // issue the next batch: v_j rows of batch b+1, or the first rows of b_j
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : b2;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i)
+                ring[(b + 1) & 1][i] = (WL > 0 && b + 1 == NB) ? ld_nt2(nx + (int64_t)i * CH_BS) : nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
@@ -819,8 +821,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? b2 + (int64_t)(b + 1) * PB * CH_BS : vn;
+            // long shapes (WL > 0: a 100 MB column, both of whose reads come from memory): the second read is the last
+            // use - non-temporal, it then streams from the Infinity Cache, where the first (normal) read left it, at
+            // 8.5 instead of 7.6 TB/s of requested bytes (tools/probe/reread_probe.hip: 22.6 vs 25.3 us per link)
 #pragma unroll
-            for (int i = 0; i < PB; ++i) ring[(b + 1) & 1][i] = nx[(int64_t)i * CH_BS];
+            for (int i = 0; i < PB; ++i)
+                ring[(b + 1) & 1][i] = (WL > 0 && b + 1 < NB) ? ld_nt2(nx + (int64_t)i * CH_BS) : nx[(int64_t)i * CH_BS];
             CH_ISSUE_FENCE();
 #pragma unroll
             for (int i = 0; i < PB; ++i) {

@@ -44,8 +44,14 @@
 
 namespace kh {
 
-constexpr int BLK_BC = 4;                     // basis columns per block
-constexpr int BLK_NSLOT = 2;                  // blocks of columns in registers
+#ifndef KH_BLK_BC_CFG
+#define KH_BLK_BC_CFG 4                       // (kh_internal.h has the same default: the Gram table's row length)
+#endif
+#ifndef KH_BLK_NSLOT_CFG
+#define KH_BLK_NSLOT_CFG 2
+#endif
+constexpr int BLK_BC = KH_BLK_BC_CFG;         // basis columns per block
+constexpr int BLK_NSLOT = KH_BLK_NSLOT_CFG;   // blocks of columns in registers
 constexpr int BLK_NVMAX = 8;                  // values per sum (the block's BC coefficients; the norm + BC - 1 table entries)
 constexpr int BLK_NVS = 16;                   // granule PAIRS reserved per workgroup and parity (256 B records)
 constexpr int BLK_TABCOLS = 4096;             // basis columns the Gram table has rows for (BLK_BC entries each)

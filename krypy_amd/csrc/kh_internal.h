@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "krylov_hip.h"
 
@@ -102,6 +103,9 @@ struct kh_ctx_s {
     int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
     int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
+    int64_t n_minres_cycle_steps = 0;   // MINRES iterations recorded by kh_minres_cycle
+    void (*rotg)(double*, double*, double*, double*) = nullptr;   // the host layer's BLAS drotg (kh_ctx_set_rotg), or NULL
+    std::vector<double> cyc_col;        // H-column scratch of the C host loops
     unsigned* onex_ticket = nullptr;   // 256 rotating ticket words
     int lanczos_fused = 1;  // steps with one Gram-Schmidt link: the three-pass kernel of lanczos.h (KRYPY_AMD_LANCZOS_FUSED)
     int64_t n_lanczos_fused = 0;
@@ -224,7 +228,10 @@ struct ChainArgs;
 hipError_t chain_blk_launch(kh_ctx ctx, int r2, int G, bool onex, bool padded, int fnd, ChainArgs& a, const void* V, int* nsums);
 double* chain_blk_table(kh_ctx ctx);
 bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd);
-constexpr int KH_BLK_BC = 4;          // (= BLK_BC of chain_blk.h) columns per block, entries per row of the Gram table
+#ifndef KH_BLK_BC_CFG
+#define KH_BLK_BC_CFG 4
+#endif
+constexpr int KH_BLK_BC = KH_BLK_BC_CFG;   // (= BLK_BC of chain_blk.h) columns per block, entries per row of the Gram table
 // an entry point writes to block v: the Gram table of an Arnoldi sequence on it (chain_blk.hip) is no longer vouched for
 static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
     if (ctx->blk_V == v) ctx->blk_next = -1;

@@ -679,7 +679,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         const bool lz_shape = ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr) &&
                               (r2 == 4 || r2 == 8);
         const bool small_shape = ctx->chain_small && r2 <= 8 && B == V && dg == nullptr;
-        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 40) || want_onex || lz_shape || small_shape) && xk != nullptr &&
+        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 48) || want_onex || lz_shape || small_shape) && xk != nullptr &&
                 Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                 Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
         if (!fused) return 0;
@@ -711,7 +711,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     const bool use_pf = use_lds && ctx->chain_pf && (r2 <= 24 || (ctx->chain_pf == 2 && r2 <= 40));   // (2: measurement)
 #define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
     // a step with ONE Gram-Schmidt link (Lanczos / MINRES, the first Arnoldi step): three passes instead of six
-    if (fused && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
+    if (fused && r2 <= 40 && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
         if (!presub) {                 // no previous column: subtract 0 * (some valid column)
             a.bprev = B->col(k);
             a.h_km1 = 0.0;
@@ -859,7 +859,8 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     (use_lds ? (use_pf ? launch_chain_pf<R, false, false, D>(ctx, G, a) : launch_chain_lds<R, false, false, D>(ctx, G, a)) \
              : launch_chain<R, false, false, D>(ctx, G, a))
             if (r2 < 16) return 0;       // (4 / 8 rows: only the Lanczos and the one-XCD kernels have the prologue)
-            if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
+            if (r2 == 48) e = (a.offs.nd == 5) ? launch_chain<48, false, false, 5, 8>(ctx, G, a) : launch_chain<48, false, false, 7, 8>(ctx, G, a);
+            else if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
             else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
             else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);
             else e = (a.offs.nd == 5) ? KH_FUSED(16, 5) : KH_FUSED(16, 7);
@@ -1251,6 +1252,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_tag_waits")) *value = ctx->n_tag_waits;
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
+    else if (!strcmp(key, "n_minres_cycle_steps")) *value = ctx->n_minres_cycle_steps;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_allreduce")) *value = ctx->n_allreduce;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
@@ -2369,6 +2371,23 @@ static inline void host_drotg(double a, double b, double* c, double* s) {
     *s = b / r;
 }
 
+// the rotation of a C host loop: the caller's own BLAS drotg when it has handed one over (kh_ctx_set_rotg: the same bits
+// as the per-step loop of the host layer), the reference formula otherwise
+static inline void ctx_rotg(kh_ctx ctx, double a, double b, double* c, double* s) {
+    if (ctx->rotg != nullptr) {
+        double a_ = a, b_ = b;
+        ctx->rotg(&a_, &b_, c, s);
+    } else {
+        host_drotg(a, b, c, s);
+    }
+}
+
+int kh_ctx_set_rotg(kh_ctx ctx, void (*drotg)(double*, double*, double*, double*)) {
+    KH_ARG(ctx != nullptr, "kh_ctx_set_rotg: NULL context");
+    ctx->rotg = drotg;
+    return 0;
+}
+
 int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
                    int64_t k_last, int sweeps, int gs_mode, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
                    double* R, int64_t ldr, double* cs, double* y, double* h2_io, double* resn, int64_t* k_done,
@@ -2412,7 +2431,7 @@ int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W
             col[(size_t)i + 1] = -s * t0 + c * t1;
         }
         double c, s;
-        host_drotg(col[(size_t)k], col[(size_t)k + 1], &c, &s);
+        ctx_rotg(ctx, col[(size_t)k], col[(size_t)k + 1], &c, &s);
         cs[2 * k] = c;
         cs[2 * k + 1] = s;
         {
@@ -2510,6 +2529,109 @@ int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, doubl
     hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, V->col(k),
                        Wk->col(slot), Wk->col(1 - slot), r0, r1, r2, y0, YK->col(ycol));
     KH_HIP(hipGetLastError());
+    return 0;
+}
+
+// A run of MINRES iterations in one call (krypy/linsys.py:791-853; the header has the contract)
+int kh_minres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
+                    int64_t k_last, int64_t base, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
+                    kh_vec Wm, int* wslot_io, kh_vec YK, int64_t ycol, double* st, double* h2_io, double* resn,
+                    int64_t* k_done, int* reason) {
+    KH_ARG(ctx && A && V && W && enq_io && H && Wm && wslot_io && YK && st && h2_io && resn && k_done && reason,
+           "kh_minres_cycle: NULL");
+    KH_ARG(base >= 0 && k0 >= base && k0 <= k_stop && k_stop <= k_last + 1 && k_last + 2 - base <= V->ncols,
+           "kh_minres_cycle: steps [%lld, %lld), last %lld, window base %lld, %lld basis columns", (long long)k0,
+           (long long)k_stop, (long long)k_last, (long long)base, (long long)V->ncols);
+    KH_ARG(k0 == 0 || k0 - 1 >= base, "kh_minres_cycle: column k0 - 1 is not in the window");
+    KH_ARG(*enq_io >= k0 && *enq_io <= k0 + KH_NSLOT - 1, "kh_minres_cycle: %lld steps in flight", (long long)(*enq_io - k0));
+    KH_ARG(ldh >= k_stop, "kh_minres_cycle: leading dimension of H");
+    KH_ARG(*wslot_io == 0 || *wslot_io == 1, "kh_minres_cycle: W slot");
+    KH_ARG(Wm->ncols >= 2 && Wm->n == V->n && YK->n == V->n, "kh_minres_cycle: W / yk shape");
+    RoctxScope range_(ctx, "kh_minres_cycle");
+    int64_t enq = *enq_io;
+    double h2 = *h2_io;
+    int wslot = *wslot_io;
+    // st: the two remembered rotations (older first), how many of them exist, the rotated right-hand side
+    double g1c = st[0], g1s = st[1], g2c = st[2], g2s = st[3];
+    int nrot = (int)st[4];
+    double y0 = st[5], y1 = st[6];
+    *reason = KH_CYCLE_LIMIT;
+    int64_t k = k0;
+    for (; k < k_stop; ++k) {
+        // look-ahead (utils.Arnoldi._begin): a Lanczos step takes H[e, e-1] from the host when its predecessor has been
+        // fetched, from the predecessor's device-side H column (NaN) when it is still in flight
+        const int64_t last = std::min<int64_t>(k + 1, k_last);
+        while (enq <= last) {
+            const int64_t e = enq;
+            double h_km1 = 0.0;
+            if (e > 0) h_km1 = (e <= k) ? H[e * ldh + (e - 1)] : std::nan("");
+            KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, 0, e - base, e > 0 ? e - base : 0, 1, KH_GS_MGS, h_km1,
+                                         (int)(e % KH_NSLOT)));
+            ++enq;
+        }
+        // the step's column arrives in window coordinates: only its last two entries are this step's
+        const int64_t kp = k - base;
+        std::vector<double>& colv = ctx->cyc_col;
+        if ((int64_t)colv.size() < kp + 2) colv.resize((size_t)(kp + 2) + 64);
+        KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), kp + 2, colv.data()));
+        const double alpha = colv[(size_t)kp], hn = colv[(size_t)kp + 1];
+        const double hkm = (k > 0) ? H[k * ldh + (k - 1)] : 0.0;       // H[k-1, k] = H[k, k-1]  (utils.py:1000-1003)
+        // invariance pre-test (utils.py:1035-1039 through the Frobenius norm); a step that does not clear it is not
+        // recorded: it stays in its slot and the caller's Arnoldi.advance decides it with the exact 2-norm
+        const double c2 = (k > 0 ? hkm * hkm : 0.0) + alpha * alpha + hn * hn;
+        const double fro = std::sqrt(h2 + c2);
+        if (!(fro > 0.0) || !(hn / fro > 1e-14) || !std::isfinite(fro)) {
+            *reason = KH_CYCLE_CHECK;
+            break;
+        }
+        h2 += c2;
+        if (k > 0) H[(k - 1) * ldh + k] = hkm;
+        H[k * ldh + k] += alpha;
+        H[(k + 1) * ldh + k] = hn;
+        // QR update of the Lanczos matrix with the two remembered rotations (linsys.py:826-841), the expressions of
+        // the host layer's loop term for term
+        double R0 = 0.0, R1 = (k > 0) ? hkm : 0.0;
+        if (nrot >= 2) {
+            const double u = R0, v = R1;
+            R0 = g1c * u + g1s * v;
+            R1 = -g1s * u + g1c * v;
+        }
+        double R2 = H[k * ldh + k];
+        const double R3 = hn;
+        if (nrot >= 1) {
+            const double u = R1, v = R2;
+            R1 = g2c * u + g2s * v;
+            R2 = -g2s * u + g2c * v;
+        }
+        g1c = g2c; g1s = g2s;
+        double c, s;
+        ctx_rotg(ctx, R2, R3, &c, &s);
+        g2c = c; g2s = s;
+        nrot = nrot < 2 ? nrot + 1 : 2;
+        R2 = c * R2 + s * R3;
+        {
+            const double u = y0, v = y1;
+            y0 = c * u + s * v;
+            y1 = -s * u + c * v;
+        }
+        // z = (v_k - R0 W0 - R1 W1) / R2;  W <- [W1, z];  yk += y0 z   (linsys.py:844-846), carried by the next launch
+        KH_TRY(kh_minres_update_deferred(ctx, V, kp, Wm, wslot, R0, R1, R2, y0, YK, ycol));
+        wslot = 1 - wslot;
+        y0 = y1;
+        y1 = 0.0;
+        resn[k] = std::fabs(y0);
+        if (!(resn[k] / bnorm > tol)) {      // the caller's own test, linsys.py:476
+            ++k;
+            *reason = KH_CYCLE_TOL;
+            break;
+        }
+    }
+    st[0] = g1c; st[1] = g1s; st[2] = g2c; st[3] = g2s; st[4] = (double)nrot; st[5] = y0; st[6] = y1;
+    *wslot_io = wslot;
+    *k_done = k;
+    *enq_io = enq;
+    *h2_io = h2;
+    ctx->n_minres_cycle_steps += k - k0;
     return 0;
 }
 

@@ -632,9 +632,29 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
         def rot(G, u, v):      # [[c, s], [-conj(s), c]] (utils.py:430)
             return G[0] * u + G[1] * v, -G[1].conjugate() * u + G[0] * v
 
+        # runs of iterations in ONE C call each (kh_minres_cycle: Lanczos steps with look-ahead on the device, the
+        # rotations and the deferred recurrence updates in C instead of in this interpreter - at N <= 10^5 the loop
+        # below is what shows between two 18 us launches); the call stops after the step that reaches the tolerance,
+        # at a possible invariant subspace, when the basis window is full and before the last iteration - those take
+        # the per-step path below
+        cyc = self._cycle_state()
         try:      # (whatever ends the loop - an exception included - a deferred update must not outlive W and yk)
             while (self.resnorms[-1] > self.tol and self.lanczos.iter < self.lanczos.maxiter
                    and not self.lanczos.invariant):
+                if cyc is not None and self.lanczos.iter + 1 < self.lanczos.maxiter:
+                    st = cyc["st"]
+                    st[0:2] = G1 if G1 is not None else (0.0, 0.0)
+                    st[2:4] = G2 if G2 is not None else (0.0, 0.0)
+                    st[4] = (G1 is not None) + (G2 is not None)
+                    st[5:7] = y
+                    got = self._run_cycle(cyc, W, slot, yk)
+                    if got is not None:
+                        slot = got
+                        n = int(st[4])
+                        G2 = (float(st[2]), float(st[3])) if n >= 1 else None
+                        G1 = (float(st[0]), float(st[1])) if n >= 2 else None
+                        y = [float(st[5]), float(st[6])]
+                        continue
                 k = self.iter = self.lanczos.iter
                 self.lanczos.advance()
                 H = self.lanczos.H
@@ -663,6 +683,64 @@ class Minres(_ArnoldiBasisMixin, _KrylovSolver):
             ctx.minres_flush()
         if not _is_set(self, "xk"):      # (reading self.xk would download it)
             self.xk = self._get_xk(yk)
+
+    def _cycle_state(self):
+        """Scratch of the C cycle, or None when this solve is not eligible: real data, Euclidean inner product, the
+        fused Lanczos step on a plain device matrix (Jacobi M allowed), nothing but the residual recurrence to record
+        per iteration."""
+        ar = self.lanczos
+        ctx = self._ctx
+        if (os.environ.get("KRYPY_AMD_MINRES_CYCLE", "1") == "0" or not hasattr(ctx, "minres_cycle")
+                or not (ar._fused and ar._lookahead == 1 and ar._Amat is not None and ar._proj is None)
+                or ar._cplx or ar.H.dtype != numpy.float64 or ar.ortho != "lanczos" or ar._BV is not None
+                or (ar._Md is not None and ar._Md.kind != "diag")
+                or self.explicit_residual or self.linear_system.exact_solution is not None
+                or type(self)._finalize_iteration is not _KrylovSolver._finalize_iteration      # (a subclass watches every step)
+                or ar.maxiter < 3 or not ar.H.flags.c_contiguous):
+            return None
+        return dict(st=numpy.zeros(8), resn=numpy.zeros(ar.maxiter))
+
+    def _run_cycle(self, cyc, W, slot, yk):
+        """One kh_minres_cycle call from the current iteration on; returns the new W slot when at least one iteration
+        was recorded (the caller re-tests its loop condition), None otherwise."""
+        ar = self.lanczos
+        ctx = self._ctx
+        k0 = ar.iter
+        m = ar.maxiter
+        # steps up to k_last can be begun in the columns the basis (or its sliding window) has now; beyond that
+        # Arnoldi.advance slides the window / grows the blocks and the next call takes over again
+        k_last = min(m - 1, ar._base + ar._cols - 2)
+        k_stop = min(m - 1, k_last)
+        if k_stop <= k0 or ar._enq > k_last + 1 or (k0 > 0 and k0 - 1 < ar._base):
+            return None
+        for sl in range(4):
+            ar._claim(sl)
+        bnorm = self.linear_system.MMlb_norm
+        try:
+            k_done, enq, h2, slot, why = ctx.minres_cycle(
+                ar._Amat, ar._Md, ar._V, ar._P, ar._W, k0, k_stop, k_last, ar._base, max(ar._enq, k0), float(self.tol),
+                float(bnorm), ar.H, W, slot, yk.block, yk.col, cyc["st"], ar._h2, cyc["resn"])
+        except BaseException:
+            ar._enq = ar.iter       # (as Gmres._run_cycle: nothing of the steps begun in C is used, the slots go back)
+            for sl in range(4):
+                ar._release(sl)
+            raise
+        ar._enq, ar._h2 = enq, h2
+        in_flight = {j % 4 for j in range(k_done, enq)}       # (their slots stay claimed until advance() / _settle())
+        for sl in range(4):
+            if sl not in in_flight:
+                ar._release(sl)
+        if k_done == k0:
+            return None                                 # (an invariance check is due: the per-step path takes it)
+        ar.iter = k_done
+        last_plain = k_done if why != _hip.CYCLE_TOL else k_done - 1
+        for i in range(k0, last_plain):                 # plain appends (linsys.py:476-477)
+            self.resnorms.append(float(cyc["resn"][i]) / bnorm)
+        self.iter = k_done - 1
+        self.xk = None
+        if why == _hip.CYCLE_TOL:
+            self._finalize_iteration(yk, float(cyc["resn"][k_done - 1]))
+        return slot
 
     def _get_xk(self, yk):
         self._ctx.minres_flush()         # a deferred recurrence update may still be waiting for its launch

@@ -360,6 +360,64 @@ class NumpyContext(object):
         Wk.a[:, slot] = z
         YK.a[:, ycol] = YK.a[:, ycol] + y0 * z
 
+    def minres_cycle(self, A, Md, V, P, W, k0, k_stop, k_last, base, enq, tol, bnorm, H, Wm, wslot, YK, ycol, st, h2,
+                     resn):
+        """Semantics of kh_minres_cycle (include/krylov_hip.h): Lanczos steps with one step of look-ahead through the
+        four slots, the QR update with the two remembered rotations, the recurrence update, stop reasons."""
+        from scipy.linalg import blas
+        self._count("minres_cycle")
+        if not (base >= 0 and k0 >= base and k0 <= k_stop <= k_last + 1 and k_last + 2 - base <= V.ncols):
+            raise BackendError("minres_cycle: step range")
+        g1, g2, nrot, y0, y1 = (st[0], st[1]), (st[2], st[3]), int(st[4]), float(st[5]), float(st[6])
+        reason, k = 0, k0
+        while k < k_stop:
+            last = min(k + 1, k_last)
+            while enq <= last:
+                e = enq
+                h_km1 = 0.0
+                if e > 0:
+                    h_km1 = float(H[e, e - 1]) if e <= k else float("nan")
+                self.arnoldi_step_begin(A, Md, V, P, W, 0, e - base, e - base if e > 0 else 0, 1, 0, h_km1, e % 4)
+                enq += 1
+            kp = k - base
+            col = self.arnoldi_step_end(k % 4, kp + 2)
+            alpha, hn = float(col[kp]), float(col[kp + 1])
+            hkm = float(H[k, k - 1]) if k > 0 else 0.0
+            c2 = (hkm * hkm if k > 0 else 0.0) + alpha * alpha + hn * hn
+            fro = np.sqrt(h2 + c2)
+            if not (fro > 0.0) or not (hn / fro > 1e-14) or not np.isfinite(fro):
+                reason = 2
+                break
+            h2 += c2
+            if k > 0:
+                H[k - 1, k] = hkm
+            H[k, k] += alpha
+            H[k + 1, k] = hn
+            R0, R1 = 0.0, (hkm if k > 0 else 0.0)
+            if nrot >= 2:
+                R0, R1 = g1[0] * R0 + g1[1] * R1, -g1[1] * R0 + g1[0] * R1
+            R2, R3 = float(H[k, k]), hn
+            if nrot >= 1:
+                R1, R2 = g2[0] * R1 + g2[1] * R2, -g2[1] * R1 + g2[0] * R2
+            g1 = g2
+            c, s = blas.drotg(R2, R3)
+            c, s = float(c), float(s)
+            g2 = (c, s)
+            nrot = min(nrot + 1, 2)
+            R2 = c * R2 + s * R3
+            y0, y1 = c * y0 + s * y1, -s * y0 + c * y1
+            self.minres_update(V, kp, Wm, wslot, R0, R1, R2, y0, YK, ycol, defer=True)
+            wslot = 1 - wslot
+            y0, y1 = y1, 0.0
+            resn[k] = abs(y0)
+            if not (resn[k] / bnorm > tol):
+                k += 1
+                reason = 1
+                break
+            k += 1
+        st[0:2], st[2:4], st[4], st[5], st[6] = g1, g2, nrot, y0, y1
+        return k, enq, h2, wslot, reason
+
     def cg_update(self, alpha, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Md, Z, zcol):
         self._count("cg_update")
         cplx = _same("cg_update", Pd, AP, YK, R)

@@ -250,6 +250,43 @@ def test_solve_fuzz_host_layer_against_the_oracle(cpu_double):
         solve_fuzz.one_solve_extra(seed, max_n=20_000)
 
 
+def test_minres_cycle_bookkeeping_equals_the_per_step_loop(cpu_double, monkeypatch):
+    """Minres._run_cycle (a run of iterations through Context.minres_cycle - on the GPU kh_minres_cycle, here the NumPy
+    restatement of its contract) against the per-step loop: every observable equal - residual history, Lanczos matrix,
+    iterate, iteration counters - through window slides (150 steps, 66 columns), Jacobi, a stored basis, maxiter = 2 and 3
+    (no room for the call), convergence inside a call."""
+    import numpy as np
+    import scipy.sparse as sp
+    from krypy_amd import linsys, utils
+    from oracle.inputs import lap2d_system
+
+    A, b = lap2d_system(24, rhs="rng1")
+    M = sp.diags(1.0 / A.diagonal()).tocsr()
+
+    def run(**kw):
+        ls = linsys.LinearSystem(A, b, M=kw.pop("M", None), self_adjoint=True)
+        try:
+            return linsys.Minres(ls, **kw)
+        except utils.ConvergenceError as e:
+            return e.solver
+
+    for kw, min_calls in ((dict(tol=1e-10, maxiter=400), 1), (dict(tol=1e-10, maxiter=400, M=M), 1),
+                          (dict(tol=1e-30, maxiter=150), 3), (dict(tol=1e-8, maxiter=300, store_arnoldi=True), 1),
+                          (dict(tol=1e-30, maxiter=2), 0), (dict(tol=1e-30, maxiter=3), 1)):
+        n0 = cpu_double.calls.get("minres_cycle", 0)
+        s1 = run(**dict(kw))
+        calls = cpu_double.calls.get("minres_cycle", 0) - n0
+        monkeypatch.setenv("KRYPY_AMD_MINRES_CYCLE", "0")
+        s0 = run(**dict(kw))
+        assert cpu_double.calls.get("minres_cycle", 0) - n0 == calls
+        monkeypatch.delenv("KRYPY_AMD_MINRES_CYCLE")
+        assert calls >= min_calls, (kw, calls)
+        assert s1.resnorms == s0.resnorms and s1.iter == s0.iter and s1.lanczos.iter == s0.lanczos.iter, kw
+        k = s1.lanczos.iter
+        assert np.array_equal(s1.lanczos.H[: k + 2, : k + 1], s0.lanczos.H[: k + 2, : k + 1]), kw
+        assert np.array_equal(s1.xk, s0.xk), kw
+
+
 def test_committed_bench_line_fractions_are_fractions():
     """profiles/r02_bench.json (a bench.py line from the MI355X): no roofline fraction above 1, each one a single
     division of numbers in the same object, the traffic from a stamped PMC profile, the contract's fields present."""
