@@ -381,6 +381,26 @@ def _run():
                             "ms_per_cycle": d2 / args.steps * 1e3,
                             "final_relres": float(s2.resnorms[-1])}
 
+    # sharded runs: the reference order next to the panel form.  On N ranks ortho='mgs' takes all k + 1 coefficients of a
+    # step from one pass and ONE all-reduce (Gram-table correction, krylov_hip.hip: try_lowsync_mgs) - two all-reduces per
+    # step like 'cgs', the reference's recurrence in exact arithmetic; all-reduces per Arnoldi step are counted
+    if sharded and args.other_modes and hasattr(ctx, "get"):
+        for mode in [t for t in ("cgs", "mgs") if t != ortho]:
+            barrier()
+            a0 = ctx.get("n_allreduce")
+            t1 = time.perf_counter()
+            s2 = run_cycles(args.steps, x0, ortho=mode)
+            ctx.sync()
+            d2 = time.perf_counter() - t1
+            n2 = max(len(s2.resnorms) - 1, 1)
+            others[mode] = {"iterations_per_s": (len(s2.resnorms) - 1) / d2, "ms_per_cycle": d2 / args.steps * 1e3,
+                            "final_relres": float(s2.resnorms[-1]),
+                            "allreduces_per_iteration": (ctx.get("n_allreduce") - a0) / float(n2)}
+            try:
+                orth[mode] = basis_orthogonality(mode)
+            except Exception as exc:
+                orth[mode] = repr(exc)
+
     # the reference-order solver on a GENERAL CSR operator (the CSR-stream SpMV kernel + the chain kernel: what a matrix
     # that is not a stencil gets), and with the banded SpMV as a launch of its own (no operator in the chain's prologue)
     if not sharded and args.other_modes and ortho == "mgs" and hasattr(ctx, "set"):

@@ -1726,6 +1726,8 @@ struct CgsArgs {
     double* mw;            // update: D w
     int reverse;           // update: walk the columns last to first (see k_cgs_update)
     int nt_cols;           // dots: non-temporal column loads (a panel far larger than the Infinity Cache)
+    const double* x2;      // dots, X2 instantiations: a second right-hand side (v_k: the new row of the Gram table) ...
+    double* part2;         // ... and where its wave partials go: [ncol][pstride]
 };
 
 // WL > 0: as in k_mgs_chain, the last WL rows of w live in LDS (shards / vectors beyond 10.48 M rows per GPU)
@@ -1739,10 +1741,15 @@ struct CgsArgs {
 // CPLX: every double2 is one complex number: <v, w> = conj(v) w as two sums per column (partials of column t in
 // rows 2t (re) and 2t+1 (im) of `part`, so the reduction leaves (re, im) pairs), the update multiplies by a complex
 // coefficient (NumPy's product: (ac - bd, ad + bc)); the norm is that of the real view either way.
-template <int R2, bool MASKED, bool NTC, int WL = 0, bool CPLX = false>
+// X2 (round 4; real data, short shards: R2 <= 16): the same pass also forms <v_j, x> for a second vector x whose rows sit
+// in LDS behind the rows of w - x = v_k, the newest basis vector: its inner products with the older columns are the new
+// row of the Gram table the one-reduction form of reference-order Gram-Schmidt corrects its coefficients with
+// (krylov_hip.hip: try_lowsync_mgs).  One more read of one column per step, no second pass over the basis.
+template <int R2, bool MASKED, bool NTC, int WL = 0, bool CPLX = false, bool X2 = false>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
+    static_assert(!X2 || (!CPLX && WL == 0 && R2 <= 16), "second right-hand side: real data, all of w in registers, x fits LDS");
     constexpr int RW = R2 - WL;
-    extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
+    extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS] rows of w, then (X2) [R2][CH_BS] rows of x
     constexpr int PB = CgsShape<R2>::PB;
     constexpr int NB = CgsShape<R2>::NB;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1764,6 +1771,18 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
             if ((r + 1) % 8 == 0) CH_ISSUE_FENCE();
         }
     }
+    double2* const xl = wl + (size_t)WL * CH_BS;      // (X2) this lane's rows of x: own entries only, no barrier
+    if constexpr (X2) {
+        const double2* __restrict__ x2 = reinterpret_cast<const double2*>(a.x2) + first;
+#pragma unroll
+        for (int r = 0; r < R2; ++r) {
+            const double2 v = x2[(int64_t)r * CH_BS];
+            double2 t;
+            t.x = CH_OK(r) ? v.x : 0.0;
+            t.y = CH_OK(r) ? v.y : 0.0;
+            xl[r * CH_BS + tid] = t;
+        }
+    }
     {
         const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.Vb + a.col0 * a.ld) + first;
 #pragma unroll
@@ -1779,6 +1798,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         const double2* __restrict__ vn =
             reinterpret_cast<const double2*>(a.Vb + (a.col0 + (t + 1 < a.ncol ? t + 1 : t)) * a.ld) + first;
         double acc0 = 0.0, acc1 = 0.0, aci0 = 0.0, aci1 = 0.0;
+        double acx0 = 0.0, acx1 = 0.0;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const double2* __restrict__ nx = (b + 1 < NB) ? v2 + (int64_t)(b + 1) * PB * CH_BS : vn;
@@ -1797,7 +1817,16 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
                     aci0 = fma(v.x, wr.y, aci0);
                     aci1 = fma(v.y, wr.x, aci1);
                 }
+                if constexpr (X2) {
+                    const double2 xr = xl[(b * PB + i) * CH_BS + tid];
+                    acx0 = fma(v.x, xr.x, acx0);
+                    acx1 = fma(v.y, xr.y, acx1);
+                }
             }
+        }
+        if constexpr (X2) {
+            const double sx = wave_sum(acx0 + acx1);
+            if (lane == 0) a.part2[(int64_t)t * a.pstride + slot] = sx;
         }
         const double s = wave_sum(acc0 + acc1);
         if (CPLX) {
@@ -1936,5 +1965,46 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_update(CgsArgs a) {
 }
 #undef CGS_W_PUT
 #undef CGS_W_GET
+
+// ---- reference-order Gram-Schmidt with ONE reduction per step (round 4; N > 1 ranks) -------------------------------
+// The reference's loop (utils.py:1012-1029):  alpha_j = <v_j, w_j>,  w_{j+1} = w_j - alpha_j v_j.  Since
+// w_j = w - sum_{m<j} alpha_m v_m,
+//     alpha_j = c_j - sum_{m<j} alpha_m G_{m,j},    c = V^T w (against the NOT YET UPDATED w),  G_{m,j} = <v_m, v_j>,
+// i.e. (I + U^T) alpha = c with U the strict upper triangle of the basis' Gram matrix - the SAME coefficients in exact
+// arithmetic, with all k+1 inner products in ONE pass (one all-reduce on N ranks instead of k+1).  In floating point it
+// differs from the loop by O(eps |alpha| |G|), G being the basis' orthogonality defect (the blocked kernel of
+// chain_blk.h rests on the same identity, block by block; Swirydowicz et al.'s low-synchronisation MGS on its
+// compact-WY form).  It is NOT classical Gram-Schmidt: the correction keeps the coefficients those of the sequential
+// loop however far the basis has drifted from orthogonality.
+// k_lowsync_solve: one workgroup.  cg = the reduced sums of the step's dots pass, [c_0 .. c_k | g_0 .. g_{k-1}] with
+// g_m = <v_m, v_k> (the new column k of the table; gt[m * LDG + j] = G_{m,j}, m < j).  Forward substitution in the
+// order of the reference's loop (alpha_m times G_{m,j} subtracted from c_j for m = 0, 1, ...: the order of its updates);
+// the triangle of the table is staged in LDS.  Writes alpha to coef (the update pass' coefficients) and to the H column.
+constexpr int LS_MAXCOL = 128;      // basis columns the one-reduction form handles (a GMRES(100) cycle; more: the per-column path)
+static __global__ __launch_bounds__(LS_MAXCOL) void k_lowsync_solve(int k, const double* __restrict__ cg, double* __restrict__ gt,
+                                                                  double* __restrict__ coef, double* __restrict__ hcol) {
+    extern __shared__ double ls_sm[];                 // [k rows m][k + 1 columns j] + 2 broadcast slots
+    const int tid = threadIdx.x;
+    const int ld = k + 1;
+    double* bc = ls_sm + (size_t)k * ld;
+    if (tid < k) gt[(size_t)tid * LS_MAXCOL + k] = cg[k + 1 + tid];            // column k of the table: <v_m, v_k>
+    for (int m = 0; m < k; ++m)
+        for (int j = m + 1 + tid; j <= k; j += LS_MAXCOL)
+            ls_sm[(size_t)m * ld + j] = (j == k) ? cg[k + 1 + m] : gt[(size_t)m * LS_MAXCOL + j];
+    double c = (tid <= k) ? cg[tid] : 0.0;
+    __syncthreads();
+    for (int m = 0; m < k; ++m) {
+        if (tid == m) bc[m & 1] = c;
+        __syncthreads();
+        if (tid > m && tid <= k) {
+            const double pr = bc[m & 1] * ls_sm[(size_t)m * ld + tid];
+            c = c - pr;
+        }
+    }
+    if (tid <= k) {
+        coef[tid] = c;
+        hcol[tid] = c;
+    }
+}
 
 }  // namespace kh

@@ -102,6 +102,17 @@ struct kh_ctx_s {
     const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...
     int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
     int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
+    // reference-order Gram-Schmidt with one reduction per step on N ranks (krylov_hip.hip: try_lowsync_mgs; KRYPY_AMD_MGS_LOWSYNC)
+    int mgs_lowsync = 1;
+    double* ls_tab = nullptr;        // [LS_MAXCOL][LS_MAXCOL] Gram table of the current Arnoldi sequence: [m][j] = <v_m, v_j>, m < j
+    const void* ls_V = nullptr;      // the basis block whose sequence owns the table ...
+    int64_t ls_next = -1;            // ... and the step that finds columns 0 .. k-1 of it valid
+    int64_t n_lowsync = 0, n_ls_rebuild = 0;
+    // the deflation projector with the vector in registers, one launch (proj_reg.h; KRYPY_AMD_PROJ_REG)
+    int proj_reg = 1;
+    unsigned long long* proj_gran = nullptr;   // granules, per-XCD totals and leader stamps of its 16-value sums
+    unsigned proj_epoch = 1;
+    int64_t n_proj_reg = 0;
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
     int64_t n_minres_cycle_steps = 0;   // MINRES iterations recorded by kh_minres_cycle
     void (*rotg)(double*, double*, double*, double*) = nullptr;   // the host layer's BLAS drotg (kh_ctx_set_rotg), or NULL
@@ -235,7 +246,11 @@ constexpr int KH_BLK_BC = KH_BLK_BC_CFG;   // (= BLK_BC of chain_blk.h) columns 
 // an entry point writes to block v: the Gram table of an Arnoldi sequence on it (chain_blk.hip) is no longer vouched for
 static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
     if (ctx->blk_V == v) ctx->blk_next = -1;
+    if (ctx->ls_V == v) ctx->ls_next = -1;       // (the one-reduction form's table, krylov_hip.hip: same rule)
 }
 hipError_t chain_blk_reset(kh_ctx ctx);
 void chain_blk_free(kh_ctx ctx);
+// proj_reg.hip
+int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G, double* ya_dev);
+void proj_reg_free(kh_ctx ctx);
 }  // namespace kh

@@ -79,6 +79,7 @@ constexpr int SLOT_PING = MAXC, SLOT_PONG = MAXC + 1, SLOT_NRM = MAXC + 2;
 // device scalar layout inside ctx->scal
 constexpr int SC_TMP = 6144;     // scratch scalars (dot0 of the fused SpMV, norms, ...)
 constexpr int SC_COEF = 6400;    // panel coefficients for axpy_panel / gemm_nn (<= 1024)
+constexpr int SC_LS = 7424;      // [c | g] of the one-reduction Gram-Schmidt (2 * LS_MAXCOL)
 
 // H-column slots: up to NSLOT Arnoldi steps can be in flight on the stream (the host processes
 // step k's column while steps k+1.. already run), each with its own device column, pinned copy
@@ -1021,6 +1022,119 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
     return 1;
 }
 
+// ---- reference-order Gram-Schmidt with one reduction per step (chain.h: k_cgs_dots<..., X2>, k_lowsync_solve) -----
+template <int R2, bool MASKED>
+static hipError_t launch_dots_x2(kh_ctx ctx, int G, CgsArgs& a) {
+    constexpr size_t lds = (size_t)R2 * CH_BS * sizeof(double2);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, false, 0, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_cgs_dots<R2, MASKED, false, 0, false, true>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+static __global__ void k_ls_put_column(double* gt, int j, const double* vals) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < j) gt[(size_t)m * LS_MAXCOL + j] = vals[m];
+}
+
+// One Arnoldi step's reference-order Gram-Schmidt on N ranks (or a 1-rank communicator in forced mode) with ONE
+// all-reduce for the k + 1 coefficients: dots pass with w register-resident (all columns against the un-updated w, and
+// against v_k for the new column of the Gram table), reduce, all-reduce of 2 k + 1 values, forward substitution on the
+// device, update pass.  Returns 1 when done (norm partials in SLOT_NRM, *nrm_count of them), 0 when not eligible.
+// The Gram table (ctx->ls_tab) belongs to ONE Arnoldi sequence, like the blocked kernel's: (ls_V, ls_next) name the
+// basis block and the step that finds columns 0 .. k-1 of it valid; any other step rebuilds them from the basis first.
+static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
+    if (!ctx->mgs_lowsync || !ctx->chain_configured || k + 1 > LS_MAXCOL) return false;
+    const int64_t n = V->n;
+    int r2 = 0, G = 0;
+    if (!chain_geometry(ctx, n, &r2, &G) || r2 > 16) return false;      // (the second right-hand side lives in LDS: 16 rows of 8 KB)
+    if ((n & 1) && (V->ld <= n || wld <= n)) return false;
+    return true;
+}
+
+static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t k, bool multi, double* hdev, double* coef,
+                           int* nrm_count) {
+    if (!lowsync_eligible(ctx, V, wld, k)) return 0;
+    const int64_t n = V->n;
+    int r2 = 0, G = 0;
+    chain_geometry(ctx, n, &r2, &G);
+    const int64_t n2 = (n + 1) >> 1;
+    const int64_t chunk2 = (int64_t)r2 * CH_BS;
+    const int64_t need_ld = (int64_t)G * chunk2 * 2;
+    const bool padded = V->ld >= need_ld && wld >= need_ld;
+    if (ctx->cgs_part == nullptr)
+        KH_HIP(hipMalloc(&ctx->cgs_part, sizeof(double) * (size_t)2 * CGS_MAXCOL * CGS_PSTRIDE));
+    if (ctx->ls_tab == nullptr) {
+        KH_HIP(hipMalloc(&ctx->ls_tab, sizeof(double) * (size_t)LS_MAXCOL * LS_MAXCOL));
+        KH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lowsync_solve), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(double) * ((size_t)LS_MAXCOL * LS_MAXCOL + 2))));
+    }
+    const int ncol = (int)(k + 1);
+    const int nwave = G * (CH_BS / 64);
+    if (!(ctx->ls_V == V && ctx->ls_next == k)) {
+        // columns 1 .. k-1 of the table from the basis (a sequence that did not start here: a grown / recycled block, a
+        // step re-run after a timeout): one panel product per column, once
+        for (int64_t j = 1; j < k; ++j) {
+            KH_TRY(::dot_panel_dev(ctx, V, 0, j, V->col(j), coef, 0));
+            if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, j));
+            hipLaunchKernelGGL(k_ls_put_column, dim3((unsigned)((j + 127) / 128)), dim3(128), 0, ctx->stream, ctx->ls_tab, (int)j, coef);
+        }
+        KH_HIP(hipGetLastError());
+        ctx->ls_V = V;
+        ctx->n_ls_rebuild += 1;
+    }
+    ctx->ls_next = -1;
+    CgsArgs a;
+    a.n2 = n2;
+    a.chunk2 = chunk2;
+    a.Vb = V->d;
+    a.ld = V->ld;
+    a.col0 = 0;
+    a.ncol = ncol;
+    a.w = w;
+    a.coef = nullptr;
+    a.part = ctx->cgs_part;
+    a.pstride = CGS_PSTRIDE;
+    a.dg = nullptr;
+    a.mw = nullptr;
+    a.reverse = 1;
+    a.nt_cols = 0;
+    a.x2 = V->col(k);
+    a.part2 = ctx->cgs_part + (size_t)ncol * CGS_PSTRIDE;
+    hipError_t e;
+#define KH_DX2(R) (padded ? launch_dots_x2<R, false>(ctx, G, a) : launch_dots_x2<R, true>(ctx, G, a))
+    e = (r2 == 4) ? KH_DX2(4) : (r2 == 8 ? KH_DX2(8) : KH_DX2(16));
+#undef KH_DX2
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    // [c_0 .. c_k | g_0 .. g_{k-1}]: one reduction launch, ONE all-reduce
+    double* cg = ctx->scal + SC_LS;
+    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(2 * ncol - 1)), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
+                       CGS_PSTRIDE, cg, 0);
+    KH_HIP(hipGetLastError());
+    if (multi) KH_TRY(comm_allreduce_dev(ctx, cg, 2 * ncol - 1));
+    hipLaunchKernelGGL(k_lowsync_solve, dim3(1), dim3(LS_MAXCOL), sizeof(double) * ((size_t)k * (k + 1) + 2), ctx->stream, (int)k, cg,
+                       ctx->ls_tab, coef, hdev);
+    KH_HIP(hipGetLastError());
+    a.coef = coef;
+    a.part = part_slot(ctx, SLOT_NRM);
+#define KH_UPD(R) (padded ? launch_cgs<R, false, 0>(ctx, G, a, true) : launch_cgs<R, true, 0>(ctx, G, a, true))
+    KH_HIP((r2 == 4) ? KH_UPD(4) : (r2 == 8 ? KH_UPD(8) : KH_UPD(16)));
+#undef KH_UPD
+    *nrm_count = nwave;
+    ctx->ls_V = V;
+    ctx->ls_next = k + 1;
+    ctx->n_lowsync += 1;
+    return 1;
+}
+
 static inline int grid_lin(kh_ctx ctx, int64_t n) {
     int64_t need = (n + BS - 1) / BS;
     if (need < 1) need = 1;
@@ -1104,6 +1218,10 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK");
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_PROJ_REG");
+        ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_MGS_LOWSYNC");
+        ctx->mgs_lowsync = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK_ONEX_MAXN");
         if (e != nullptr) ctx->blk_onex_maxn = atoll(e);
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
@@ -1143,6 +1261,8 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipFree(ctx->chain_xcc);
     (void)hipFree(ctx->onex_ticket);
     chain_blk_free(ctx);
+    proj_reg_free(ctx);
+    if (ctx->ls_tab != nullptr) (void)hipFree(ctx->ls_tab);
     (void)hipFree(ctx->chain_err);
     for (int s = 0; s < KH_NSLOT; ++s) {
         if (ctx->chain_err_pin[s]) (void)hipHostFree(ctx->chain_err_pin[s]);
@@ -1218,6 +1338,8 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
+    else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
+    else if (!strcmp(key, "proj_reg")) ctx->proj_reg = value != 0;
     else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
@@ -1253,6 +1375,11 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_minres_cycle_steps")) *value = ctx->n_minres_cycle_steps;
+    else if (!strcmp(key, "mgs_lowsync")) *value = ctx->mgs_lowsync;
+    else if (!strcmp(key, "proj_reg")) *value = ctx->proj_reg;
+    else if (!strcmp(key, "n_proj_reg")) *value = ctx->n_proj_reg;
+    else if (!strcmp(key, "n_lowsync")) *value = ctx->n_lowsync;
+    else if (!strcmp(key, "n_ls_rebuild")) *value = ctx->n_ls_rebuild;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_allreduce")) *value = ctx->n_allreduce;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
@@ -1304,6 +1431,7 @@ int kh_vec_alloc(kh_ctx ctx, int64_t n, int64_t ncols, kh_vec* out) {
 // from the slot's record): forget every record that names it
 static void forget_steps(kh_ctx ctx, const void* handle) {
     if (ctx->blk_V == handle) { ctx->blk_V = nullptr; ctx->blk_next = -1; }
+    if (ctx->ls_V == handle) { ctx->ls_V = nullptr; ctx->ls_next = -1; }
     if (ctx->mr_pending.on && (ctx->mr_pending.V == handle || ctx->mr_pending.W == handle || ctx->mr_pending.YK == handle))
         ctx->mr_pending.on = 0;          // (kh_vec_free has run the update already; a matrix / projector is never named)
     for (int s = 0; s < KH_NSLOT; ++s) {
@@ -1847,8 +1975,16 @@ static int dot_panel_dev(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const 
 
 // ---- deflation projector on the device ---------------------------------------------------------
 // z = complement projection of z (in place); ya_dev (d doubles on the device) gets <Y, z_in>
-static int proj_apply_dev(kh_ctx ctx, kh_proj p, double* z, double* ya_dev) {
+static int proj_apply_dev(kh_ctx ctx, kh_proj p, double* z, double* ya_dev, int64_t zld = 0) {
     const int d = (int)p->d;
+    // long vectors on one GPU: both sweeps in ONE launch with z in registers (proj_reg.h)
+    if (zld > 0) {
+        int r2 = 0, G = 0;
+        if (chain_geometry(ctx, p->W->n, &r2, &G)) {
+            const int rc = proj_reg_apply(ctx, p, z, zld, r2, G, ya_dev);
+            if (rc != 0) return rc < 0 ? rc : 0;
+        }
+    }
     for (int it = 0; it < p->iterations; ++it) {
         KH_TRY(dot_panel_dev(ctx, p->W, 0, d, z, p->c0, 0));
         if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, d));
@@ -2087,8 +2223,11 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     int cr2 = 0, cg = 0;
     const bool want_chain = (gs_mode == KH_GS_MGS && ctx->chain_enabled && !kh_multi(ctx) && !md_mat &&
                              chain_geometry(ctx, n, &cr2, &cg));
+    // N ranks, reference order: all coefficients of the step from one pass and ONE all-reduce (try_lowsync_mgs below)
+    const bool want_lowsync = (kh_multi(ctx) && gs_mode == KH_GS_MGS && sweeps == 1 && start == 0 && !presub && Md == nullptr &&
+                               lowsync_eligible(ctx, V, W->ld, k));
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
-                            A->nblk > 0 && !want_chain && proj == nullptr);
+                            A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync);
     // the H column accumulates over sweeps, so it starts from zero - except under the chain kernel, whose
     // first sweep assigns (one memset launch and its queue bubble less per step)
     // (nor under the single-sweep register-resident panel kernels, which write the entries directly)
@@ -2136,7 +2275,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         else
             KH_TRY(apply_one(ctx, A, V->col(k), w, EPI_NONE, nullptr, nullptr, 0));
         // deflated solvers: w <- (I - P) w, and <U, A v_k> behind the H column (deflation.py:135-143)
-        if (proj != nullptr) KH_TRY(proj_apply_dev(ctx, proj, w, hdev + (k + 2)));
+        if (proj != nullptr) KH_TRY(proj_apply_dev(ctx, proj, w, hdev + (k + 2), W->ld));
     }
 
     double* nrm_part = part_slot(ctx, SLOT_NRM);
@@ -2151,8 +2290,16 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
             KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
         }
     }
+    bool lowsync = false;
+    if (!chained && want_lowsync) {
+        const int rc = try_lowsync_mgs(ctx, V, w, W->ld, k, multi, hdev, ctx->scal + SC_COEF, &nrm_count);
+        if (rc < 0) return rc;
+        lowsync = (rc == 1);
+    }
     if (chained) {
         // the whole Gram-Schmidt chain, the norm and the normalised store ran in one launch
+    } else if (lowsync) {
+        // all k + 1 coefficients from one pass and one all-reduce (try_lowsync_mgs); the norm follows below
     } else if (gs_mode == KH_GS_MGS) {
         // column visiting order of all sweeps
         const int64_t ncol = k - start + 1;
@@ -2781,7 +2928,7 @@ int kh_proj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_v
     if (!(A == Z && acol == zcol))
         KH_HIP(hipMemcpyAsync(Z->col(zcol), A->col(acol), sizeof(double) * A->n, hipMemcpyDeviceToDevice,
                               ctx->stream));
-    KH_TRY(proj_apply_dev(ctx, p, Z->col(zcol), ya_out ? p->ya : nullptr));
+    KH_TRY(proj_apply_dev(ctx, p, Z->col(zcol), ya_out ? p->ya : nullptr, Z->ld));
     if (ya_out) return fetch_scalars(ctx, p->ya, p->d, ya_out);
     return 0;
 }

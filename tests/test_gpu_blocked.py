@@ -114,3 +114,168 @@ def test_gram_table_is_rebuilt_when_the_basis_is_touched(hip):
     for V, H in ((V1, H1), (V2, H2)):
         assert np.linalg.norm(H - H0) < 1e-10 * np.linalg.norm(H0)
         assert np.linalg.norm(V - V0) < 1e-9
+
+
+@pytest.fixture
+def forced_ctx(hip):
+    """A context with a 1-rank RCCL communicator in forced multi-rank mode: every inner product goes through the partial
+    sums -> device scalar -> ncclAllReduce path the ranks of a node take, the chain kernels are off."""
+    import os
+    from krypy_amd import _hip
+
+    os.environ["KRYPY_AMD_FORCE_MULTI"] = "1"
+    try:
+        ctx = _hip.Context(0)
+        ctx.comm_init(0, 1, ctx.comm_unique_id())
+    finally:
+        del os.environ["KRYPY_AMD_FORCE_MULTI"]
+    old = _hip._install_context_for_testing(ctx)
+    yield ctx
+    _hip._install_context_for_testing(old)
+    ctx.close()
+
+
+@pytest.mark.parametrize("nx,ny", [(90, 90), (301, 211), (1200, 1000), (2000, 1500)])
+def test_one_reduction_reference_order_gram_schmidt(forced_ctx, nx, ny):
+    """ortho='mgs' on the multi-rank path (round 4): all k + 1 coefficients of a step from ONE pass over the local basis
+    and ONE all-reduce - alpha = (I + U^T)^{-1} V^T w with the strict upper Gram table U carried by the sequence, the
+    reference's loop (utils.py:1012-1029) in exact arithmetic - instead of k + 1 dependent all-reduces.  30 Arnoldi
+    steps against the CPU oracle's MGS and against the per-column path of the same context at 1e-10 (H) / 1e-9 (basis);
+    two all-reduces per step whatever k; 8,100 rows (4 rows per lane, padded), 63,511 (odd), 1.2 M (8 rows per lane),
+    3 M (16 rows: the largest shape whose second right-hand side fits LDS); the table is rebuilt from the basis when the
+    block is not the one the sequence has been writing (a basis grown on demand)."""
+    from krypy_amd import utils
+
+    ctx = forced_ctx
+    A = ref.laplace2d(nx, ny)
+    n = A.shape[0]
+    v = np.random.default_rng(5).standard_normal((n, 1))
+    m = 30
+    st = ref.arnoldi_init(A, v[:, 0], m, ortho="mgs")
+    for _ in range(m):
+        ref.arnoldi_step(st)
+    out = {}
+    for low in (1, 0):
+        ctx.set("mgs_lowsync", low)
+        try:
+            ar = utils.Arnoldi(utils.get_linearoperator(A.shape, A), v, maxiter=m, ortho="mgs")
+            a0, l0 = ctx.get("n_allreduce"), ctx.get("n_lowsync")
+            for _ in range(m):
+                ar.advance()
+            ar._settle()
+            out[low] = dict(H=np.array(ar.H), V=ar.V, allred=ctx.get("n_allreduce") - a0, steps=ctx.get("n_lowsync") - l0)
+            del ar
+        finally:
+            ctx.set("mgs_lowsync", 1)
+    a, c = out[1], out[0]
+    assert a["steps"] == m and c["steps"] == 0, (a["steps"], c["steps"])
+    assert a["allred"] == 2 * m, a["allred"]                                  # the coefficients, the norm
+    assert c["allred"] == sum(k + 2 for k in range(m)), c["allred"]           # one per link, the norm
+    hn = np.linalg.norm(st.H)
+    assert np.linalg.norm(a["H"] - st.H) < 1e-10 * hn and np.linalg.norm(c["H"] - st.H) < 1e-10 * hn
+    assert np.linalg.norm(a["H"] - c["H"]) < 1e-11 * hn
+    assert np.max(np.abs(a["V"] - st.V)) < 1e-9 and np.max(np.abs(a["V"] - c["V"])) < 1e-9
+    G = a["V"].T.dot(a["V"]) - np.eye(m + 1)
+    Gc = c["V"].T.dot(c["V"]) - np.eye(m + 1)
+    assert np.linalg.norm(G) <= 2.0 * np.linalg.norm(Gc) + 1e-13, (np.linalg.norm(G), np.linalg.norm(Gc))
+
+
+def test_one_reduction_gram_schmidt_whole_solves(forced_ctx, monkeypatch):
+    """Whole solves through the one-reduction path against the CPU oracle: a restarted GMRES (every cycle a new basis:
+    the table starts over), a GMRES whose basis grows on demand (a new block mid-sequence: the table is rebuilt from the
+    basis), GMRES(100) cycles at 1.25 M rows - the shard one of eight ranks holds of the benchmark problem - with the
+    orthogonality of the basis next to the per-column path's."""
+    from krypy_amd import linsys, utils
+    from oracle.inputs import lap2d_system
+
+    ctx = forced_ctx
+    A, b = lap2d_system(64, rhs="rng1")
+    l0 = ctx.get("n_lowsync")
+    try:
+        sol = linsys.RestartedGmres(linsys.LinearSystem(A, b), maxiter=30, max_restarts=60, tol=1e-9)
+    except utils.ConvergenceError as e:
+        sol = e.solver
+    want = ref.restarted_gmres(A, b, maxiter=30, max_restarts=60, tol=1e-9)
+    assert ctx.get("n_lowsync") - l0 >= 30
+    assert len(sol.resnorms) == len(want.resnorms)
+    r, wr = np.array(sol.resnorms), np.array(want.resnorms)
+    assert np.max(np.abs(r[:31] - wr[:31]) / wr[:31]) < 1e-10          # the first cycle closed-loop; open loop beyond (SURVEY 0)
+    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-8 * np.linalg.norm(want.xk)
+    # a basis that grows on demand: the new block is not the one the table belongs to
+    monkeypatch.setattr(utils.Arnoldi, "_max_initial_cols", 8)
+    r0 = ctx.get("n_ls_rebuild")
+    try:
+        sol = linsys.Gmres(linsys.LinearSystem(A, b), maxiter=60, tol=1e-9)
+    except utils.ConvergenceError as e:
+        sol = e.solver
+    monkeypatch.undo()
+    want = ref.gmres(A, b, maxiter=60, tol=1e-9)
+    assert ctx.get("n_ls_rebuild") - r0 >= 3
+    r, wr = np.array(sol.resnorms), np.array(want.resnorms)
+    assert len(r) == len(wr) and np.max(np.abs(r[:-1] - wr[:-1]) / wr[:-1]) < 1e-10
+    assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-10 * np.linalg.norm(want.xk)
+    # the 1/8 shard of the benchmark problem: one cycle both ways
+    A2 = ref.laplace2d(4000, 313)
+    b2 = np.random.default_rng(0).standard_normal(A2.shape[0])
+    out = {}
+    for low in (1, 0):
+        ctx.set("mgs_lowsync", low)
+        try:
+            try:
+                s = linsys.Gmres(linsys.LinearSystem(A2, b2), maxiter=100, tol=1e-14, store_arnoldi=True)
+            except utils.ConvergenceError as e:
+                s = e.solver
+            Vb = s.arnoldi._V
+            G = ctx.gemm_tn(Vb, 0, 101, Vb, 0, 101)
+            out[low] = (np.array(s.resnorms), float(np.linalg.norm(G - np.eye(101))))
+            del s, Vb
+        finally:
+            ctx.set("mgs_lowsync", 1)
+    assert np.max(np.abs(out[1][0] - out[0][0]) / out[0][0]) < 1e-10
+    assert out[1][1] <= 2.0 * out[0][1] + 1e-13, (out[1][1], out[0][1])
+
+
+@pytest.mark.parametrize("n,d", [(3_000_000, 16), (5_000_001, 7), (8_000_000, 16), (10_200_000, 16), (12_500_000, 16),
+                                 (14_000_000, 3)])
+def test_projector_with_the_vector_in_registers(hip, n, d):
+    """Projection.apply_complement (utils.py:604-627) as ONE launch with z register-resident (proj_reg.h: both sweeps, a
+    grid-wide sum of d values each, T c on every workgroup) against the four-launch form and against NumPy: z and
+    <Y, z_in> at 1e-13 of their norms.  16 ... 56 rows per lane (the last two shapes keep rows of z in LDS), d = 16 and
+    ragged d, T and WRH given or identity."""
+    rng = np.random.default_rng(n % 1000 + d)
+    Wh = np.empty((n, d), order="F")
+    Vh = np.empty((n, d), order="F")
+    for j in range(d):
+        Wh[:, j] = rng.standard_normal(n) / np.sqrt(n)
+        Vh[:, j] = rng.standard_normal(n) / np.sqrt(n)
+    a = rng.standard_normal(n)
+    ident = d == 7
+    T = None if ident else rng.standard_normal((d, d))
+    WRH = None if ident else rng.standard_normal((d, d))
+    Wd, Vd = hip.upload(Wh), hip.upload(Vh)
+    pj = hip.proj_create(Wd, Vd, d, T, WRH, 2)
+    A = hip.upload(a)
+    out = {}
+    for reg in (1, 0):
+        hip.set("proj_reg", reg)
+        try:
+            Z = hip.alloc(n, 1)
+            c0 = hip.get("n_proj_reg")
+            ya = hip.proj_apply_complement(pj, A, 0, Z, 0, want_ya=True)
+            out[reg] = (Z.download()[:, 0], np.array(ya), hip.get("n_proj_reg") - c0)
+            del Z
+        finally:
+            hip.set("proj_reg", 1)
+    assert out[1][2] == 1 and out[0][2] == 0, (out[1][2], out[0][2])
+    z = a.copy()
+    ya_want = None
+    for it in range(2):
+        c = Wh.T.dot(z)
+        if it == 0:
+            ya_want = c if WRH is None else WRH.dot(c)
+        z = z - Vh.dot(c if T is None else T.dot(c))
+    zn = np.linalg.norm(z)
+    for reg in (1, 0):
+        assert np.linalg.norm(out[reg][0] - z) < 1e-13 * zn * max(1.0, np.linalg.norm(T) if T is not None else 1.0), reg
+        assert np.linalg.norm(out[reg][1] - ya_want) < 1e-13 * max(np.linalg.norm(ya_want), 1.0), reg
+    assert np.linalg.norm(out[1][0] - out[0][0]) < 1e-13 * zn * max(1.0, np.linalg.norm(T) if T is not None else 1.0)

@@ -223,7 +223,8 @@ def test_gmres_on_a_periodic_slab_through_the_exchange(loop_ctx):
 def test_all_reduces_per_arnoldi_step_are_counted(loop_ctx):
     """What the ranks of a node would issue per Arnoldi step (kh_ctx_get "n_allreduce", counted on the forced multi-rank
     path of a 1-rank communicator): the panel form two ncclAllReduce calls - the coefficient panel, the norm -, the
-    reference order k + 2 (one per Gram-Schmidt link and the norm)."""
+    reference order two as well since round 4 (all coefficients from one pass, corrected with the Gram table:
+    tests/test_gpu_blocked.py), k + 2 (one per Gram-Schmidt link and the norm) with that form switched off."""
     from krypy_amd import _hip, utils
 
     old = _hip._install_context_for_testing(loop_ctx)
@@ -232,14 +233,17 @@ def test_all_reduces_per_arnoldi_step_are_counted(loop_ctx):
         A = ref.laplace2d(200, 150)
         v = np.random.default_rng(2).standard_normal((A.shape[0], 1))
         per_step = {}
-        for ortho in ("cgs", "mgs"):
-            ar = utils.Arnoldi(utils.get_linearoperator(A.shape, A), v, maxiter=20, ortho=ortho)
+        for ortho in ("cgs", "mgs", "mgs per column"):
+            loop_ctx.set("mgs_lowsync", 0 if ortho == "mgs per column" else 1)
+            ar = utils.Arnoldi(utils.get_linearoperator(A.shape, A), v, maxiter=20, ortho=ortho.split()[0])
             n0 = loop_ctx.get("n_allreduce")
             for _ in range(20):
                 ar.advance()
             ar._settle()
             per_step[ortho] = (loop_ctx.get("n_allreduce") - n0) / 20.0
+        loop_ctx.set("mgs_lowsync", 1)
         assert abs(per_step["cgs"] - 2.0) < 0.2, per_step
-        assert abs(per_step["mgs"] - (sum(k + 2 for k in range(20)) / 20.0)) < 1.5, per_step
+        assert abs(per_step["mgs"] - 2.0) < 0.2, per_step
+        assert abs(per_step["mgs per column"] - (sum(k + 2 for k in range(20)) / 20.0)) < 1.5, per_step
     finally:
         _hip._install_context_for_testing(old)

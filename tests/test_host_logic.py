@@ -317,6 +317,36 @@ def test_committed_bench_line_fractions_are_fractions():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s"
 
 
+def test_round4_bench_line_says_what_was_measured():
+    """profiles/r04_bench.json (round 4's bench.py line from the MI355X; the round-3 verdict's item 2): `bytes_per_launch`
+    is the ALGORITHMIC figure (every basis column once, the operator's arrays once, v_{k+1} out), `frac` is that figure
+    over the HIP-event launch time over the peak, `traffic` is the PMC fabric traffic of the same launches (never less
+    than the algorithmic bytes) with `traffic_over_bytes` beside it, the kernel timed is the SOLVER's instantiation
+    (operator in the prologue), and the general-CSR / separate-SpMV rates of the reference order are on the line."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r04_bench.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "iterations/s" and d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9 / r["peak"]) < 1e-12
+    assert 0.0 < r["frac"] <= 1.0
+    assert "prologue" in r["kernel"] and "k_mgs_chain_lds<40,false,false,5>" in r["kernel"]
+    assert r["traffic"] is not None and r["traffic"] >= r["bytes_per_launch"]
+    assert abs(r["traffic_over_bytes"] - r["traffic"] / r["bytes_per_launch"]) < 1e-12
+    assert 0.0 < r["frac_traffic"] <= 1.0 and "fabric" in r["traffic_source"].lower()
+    assert "hbm_bytes_pmc" not in json.dumps(d)
+    modes = d["other_modes"]
+    assert any("spmv_dia = 0" in k for k in modes) and any("chain_spmv = 0" in k for k in modes)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "iterations/s"
+
+
 def test_givens_scalars_equal_the_givens_class():
     """utils.givens_scalars is what the MINRES / GMRES loops call per iteration (the (2, 1)-array constructor of
     utils.Givens costs 10 us, an iteration at short vectors is one 18 us launch): the same BLAS call on the same values -
