@@ -11,6 +11,19 @@ from oracle import krylov_ref as ref
 pytestmark = pytest.mark.gpu
 
 
+def _report(name, **vals):
+    """The measured deviations of a full-size comparison, one line per test: printed (pytest -s) and, when
+    KRYPY_AMD_PARITY_LOG names a file, appended there (profiles/r04_fullsize_parity.log comes from such a run)."""
+    import os
+    line = "PARITY %s: %s" % (name, ", ".join("%s = %.3e" % (k, float(v)) if isinstance(v, (float, np.floating)) else
+                                                "%s = %s" % (k, v) for k, v in vals.items()))
+    print(line)
+    path = os.environ.get("KRYPY_AMD_PARITY_LOG")
+    if path:
+        with open(path, "a") as fh:
+            fh.write(line + "\n")
+
+
 def test_config2_whole_cycle_against_the_oracle_at_full_size(hip):
     """BASELINE.json config 2 at its stated size, the instantiation bench.py times (GMRES(100) through
     linsys.Gmres: operator fused into the prologue of the 40-rows-per-lane chain kernel): ONE whole restart
@@ -49,6 +62,10 @@ def test_config2_whole_cycle_against_the_oracle_at_full_size(hip):
         lim.restore_original_limits()
     assert len(res) == len(want.resnorms) == 101
     wres = np.array(want.resnorms)
+    _report("config 2, one GMRES(100) cycle at N = 1e7 vs the oracle (bar 1e-10)",
+            resnorms_max_rel=np.max(np.abs(res - wres) / wres), H_rel_fro=np.linalg.norm(H - want.H) / np.linalg.norm(want.H),
+            xk_norm_rel=abs(xn - np.linalg.norm(want.xk)) / np.linalg.norm(want.xk),
+            v101_abs=np.linalg.norm(vlast - want.V[:, 100]))
     assert np.max(np.abs(res - wres) / wres) < 1e-10
     for k in (0, 25, 50, 99):
         assert np.linalg.norm(H[: k + 2, k] - want.H[: k + 2, k]) < 1e-10 * np.linalg.norm(want.H[: k + 2, k]), k
@@ -135,6 +152,9 @@ def test_config3_against_the_oracle_at_full_size(hip):
     assert len(res) == len(want["resnorms"]) == steps + 1
     # (the last entry is the explicitly computed residual the failing solve ends with; the recurrence's are compared)
     dev = np.max(np.abs(res[:-1] - want["resnorms"][:-1]) / want["resnorms"][:-1])
+    _report("config 3, 60 MINRES + Jacobi steps at N = 1e7 vs the oracle", resnorms_max_rel=dev, bar_resnorms=ptol(sens, "resnorms"),
+            H_rel_fro=np.linalg.norm(H - want["H"]) / np.linalg.norm(want["H"]), bar_H=ptol(sens, "H"),
+            xk_norm_rel=abs(xn - want["xnorm"][0]) / want["xnorm"][0], bar_xnorm=ptol(sens, "xnorm"))
     assert dev < ptol(sens, "resnorms"), (dev, sens)
     assert np.linalg.norm(H - want["H"]) < ptol(sens, "H") * np.linalg.norm(want["H"])
     assert abs(xn - want["xnorm"][0]) < ptol(sens, "xnorm") * want["xnorm"][0]
@@ -183,6 +203,10 @@ def test_config4_against_the_oracle_at_full_size(hip):
         xsens = max(xsens, float(np.linalg.norm(other.xk - want.xk) / np.linalg.norm(want.xk)))
     print("oracle's own movement under other summation orders: resnorms %.1e, xk %.1e" % (sens, xsens))
     assert sens < 1e-8
+    _report("config 4, the whole CG solve at n = 32768 vs the oracle", resnorms_max_rel=np.max(np.abs(got - wres) / wres),
+            bar=max(1e-10, 30.0 * sens), first_ten_max_rel=np.max(np.abs(got[:10] - wres[:10]) / wres[:10]),
+            xk_rel=np.linalg.norm(sol.xk[:, 0] - want.xk) / np.linalg.norm(want.xk), bar_xk=max(1e-10, 30.0 * xsens),
+            iterations=len(got) - 1)
     # thirty times the oracle's own movement (the factor tools/solve_fuzz.py uses), never below 1e-10; the first ten
     # iterations - residuals well above the rounding floor - at 1e-10 flat
     assert np.max(np.abs(got - wres) / wres) < max(1e-10, 30.0 * sens)
@@ -232,17 +256,18 @@ def test_config5_shape_deflated_gmres_single_gpu(hip):
 def test_config5_flow_against_the_oracle(hip):
     """Config 5's flow - plain GMRES(60), the 16 Ritz vectors of smallest magnitude harvested on the device,
     DeflatedGmres(60) with them (recycling/linsys.py:51-103, deflation.py:93-163) - iterate for iterate against the
-    CPU oracle (gmres -> ritz_vectors_smallest -> deflated_gmres) on a 100^3 grid (N = 10^6: long enough for the
+    CPU oracle (gmres -> ritz_vectors_smallest -> deflated_gmres) on a 130^3 grid (N = 2.2 * 10^6: long enough for the
     fused step, the device projector and the SpMM of the set-up to run as they do at full size, short enough for the
     oracle).  The deflated solve depends on span(U) only; tolerances from the oracle's own movement when the Ritz
     vectors are perturbed by one rounding error per entry."""
     import bench
     from krypy_amd import deflation, linsys, utils
 
-    A = bench.laplace3d(100, 100, 100)
+    A = bench.laplace3d(130, 130, 130)       # (2.2 M rows: 16 rows per lane - the one-launch projector of proj_reg.h serves it)
     N = A.shape[0]
     b = np.random.default_rng(0).standard_normal(N)
     m, d = 60, 16
+    pr0 = hip.get("n_proj_reg")
     ls = linsys.LinearSystem(A, b, self_adjoint=True)
 
     def run(U):
@@ -268,6 +293,10 @@ def test_config5_flow_against_the_oracle(hip):
     sens = float(np.max(np.abs(w1p[:-1] - w1[:-1]) / w1[:-1]))
     print("deflated history: deviation %.2e, oracle's own movement %.2e" % (np.max(np.abs(r1[:-1] - w1[:-1]) / w1[:-1]), sens))
     assert len(r1) == len(w1)
+    assert hip.get("n_proj_reg") - pr0 >= m - 1          # every deflated step projected with the vector in registers
+    _report("config 5 flow (GMRES -> Ritz vectors on the device -> DeflatedGmres) at N = 2.2e6 vs the oracle",
+            plain_resnorms_max_rel=np.max(np.abs(r0[:-1] - w0[:-1]) / w0[:-1]),
+            deflated_resnorms_max_rel=np.max(np.abs(r1[:-1] - w1[:-1]) / w1[:-1]), bar_deflated=max(1e-10, 30.0 * sens))
     assert np.max(np.abs(r1[:-1] - w1[:-1]) / w1[:-1]) < max(1e-10, 30.0 * sens)          # (measured: 2e-12)
     assert r1[-1] < r0[-1]
     # the same subspace: the oracle's Ritz vectors lie in the span of the device's

@@ -1,0 +1,45 @@
+#!/bin/bash
+# Round-4 evidence on one MI355X box (through gpurun): tools/r04_evidence.sh <tests|bench|configs|small>
+# Everything lands under gpurun_out/ev/; the summaries that are judged are copied to profiles/ by hand afterwards.
+set -u
+WHAT=${1:-bench}
+export TMPDIR=/tmp
+mkdir -p gpurun_out/ev
+case $WHAT in
+tests)
+  rm -f gpurun_out/ev/fullsize_parity.log
+  KRYPY_AMD_PARITY_LOG=$PWD/gpurun_out/ev/fullsize_parity.log python -m pytest tests -m gpu -q > gpurun_out/ev/gputest.log 2>&1
+  tail -4 gpurun_out/ev/gputest.log
+  python __graft_entry__.py smoke > gpurun_out/ev/smoke.log 2>&1; tail -1 gpurun_out/ev/smoke.log
+  cat gpurun_out/ev/fullsize_parity.log
+  ;;
+bench)
+  # kernel trace + PMC passes of the bench command, for the reference order (the default) and the panel form
+  bash tools/profile.sh r04_mgs --ortho mgs --other-modes none > gpurun_out/ev/profile_mgs.log 2>&1
+  python tools/summarize_prof.py gpurun_out/prof_r04_mgs profiles/r04_bench_mgs_chain.md
+  bash tools/profile.sh r04_cgs --ortho cgs --other-modes none > gpurun_out/ev/profile_cgs.log 2>&1
+  python tools/summarize_prof.py gpurun_out/prof_r04_cgs profiles/r04_bench_cgs.md
+  cp profiles/r04_bench_mgs_chain.md profiles/r04_bench_mgs_chain_traffic.json profiles/r04_bench_cgs.md profiles/r04_bench_cgs_traffic.json gpurun_out/ev/ 2>/dev/null
+  rm -rf gpurun_out/prof_r04_mgs/trace gpurun_out/prof_r04_mgs/pmc_* gpurun_out/prof_r04_cgs/trace gpurun_out/prof_r04_cgs/pmc_*
+  # the line itself (the traffic files just written carry the stamp of these sources)
+  python bench.py > gpurun_out/ev/r04_bench.json 2> gpurun_out/ev/r04_bench.err
+  tail -c 400 gpurun_out/ev/r04_bench.json
+  ;;
+configs)
+  for c in 3 4 5 5s; do bash tools/profile_config.sh $c > gpurun_out/ev/profile_cfg$c.log 2>&1; cp gpurun_out/prof_cfg$c/summary.md gpurun_out/ev/r04_config$c.md; done
+  for c in 3 4 5 5s band ragged; do python tools/bench_configs.py $c 2>/dev/null | tail -1; done > gpurun_out/ev/r04_configs.jsonl
+  cat gpurun_out/ev/r04_configs.jsonl | cut -c1-300
+  ;;
+small)
+  python tools/blk_bench.py 100 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/blk_bench.log; cat gpurun_out/ev/blk_bench.log
+  python tools/small_bench.py 64 100 200 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/small_bench.log; cat gpurun_out/ev/small_bench.log
+  python tools/proj_bench.py 2>/dev/null | grep "N =" > gpurun_out/ev/proj_bench.log; cat gpurun_out/ev/proj_bench.log
+  for ny in 1250 625 313; do for o in cgs mgs; do python bench.py --force-sharded --nx 4000 --ny $ny --ortho $o --no-roofline --steps 10 --other-modes none 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000 x $ny ($o): %.0f it/s' % d['value'])"; done; done | tee gpurun_out/ev/shards.log
+  KRYPY_AMD_MGS_LOWSYNC=0 python bench.py --force-sharded --nx 4000 --ny 313 --ortho mgs --no-roofline --steps 3 --other-modes none 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000 x 313 (mgs, one all-reduce per link): %.0f it/s' % d['value'])" | tee -a gpurun_out/ev/shards.log
+  python tools/complex_bench.py 2>/dev/null | tail -3 | tee gpurun_out/ev/complex.log
+  ;;
+esac
