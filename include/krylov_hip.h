@@ -142,7 +142,9 @@ int kh_mat_free(kh_mat A);
  * 0 when the CSR kernel serves.  Same results bit for bit either way. */
 int kh_mat_diagonals(kh_mat A);
 /* Y[:, ycol:ycol+nc] = A * X[:, xcol:xcol+nc].  CSR rows are summed left to right in storage
- * order with separate multiply and add, i.e. bit-identical to scipy's csr_matvec(s). */
+ * order with separate multiply and add, i.e. bit-identical to scipy's csr_matvec(s) - for every row that fits the
+ * kernel's LDS tile (2048 entries; kh_ctx_tune).  A longer row gets a workgroup of its own that adds its products as a
+ * fixed tree: the same sum to rounding (tested at 1e-12), not the same bits. */
 int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t ycol, int64_t ncols);
 
 /* ---- inner products, norms, updates (utils.inner/norm utils.py:160-238) ------------- */

@@ -1179,6 +1179,7 @@ def test_abi_fuzz_random_calls_against_numpy(hip):
         total += abi_fuzz.step_round(hip, dbl, seed, 200_000)
         total += abi_fuzz.shard_round(hip, seed)      # block-row shards with hand-written ghost entries, bit for bit
         total += abi_fuzz.cycle_round(hip, dbl, seed)  # kh_gmres_cycle against step-by-step + NumPy Givens, deferred MINRES update
+        total += abi_fuzz.minres_cycle_round(hip, dbl, seed)   # kh_minres_cycle against the NumPy restatement of its contract
     assert total > 1000
 
 

@@ -335,6 +335,74 @@ def cycle_round(ctx, dbl, seed):
     return checks
 
 
+def minres_cycle_round(ctx, dbl, seed):
+    """kh_minres_cycle (a run of MINRES iterations in one C call, krypy/linsys.py:791-853) against the NumPy restatement of
+    its contract (tests/support/numpy_context.py: the per-step entries of the double + the rotations in NumPy): recorded
+    steps and stop reason, the three entries per column of the Lanczos matrix, rotations / rotated right-hand side, the
+    residual recurrence, and - after a flush - the direction vectors and the iterate; with and without Jacobi, in two
+    calls (the second continues where the first stopped)."""
+    if not hasattr(ctx, "minres_cycle"):
+        return 0
+    rng = np.random.default_rng(170_000 + seed)
+    n = int(rng.integers(30, 60_000))
+    m = int(rng.integers(4, 24))
+    offs = sorted({1} | {int(o) for o in rng.integers(2, min(n - 1, 300) + 1, size=2)})
+    diags = [rng.standard_normal(n) + 6.0] + [rng.standard_normal(n - o) for o in offs]
+    A = sp.diags(diags + diags[1:], [0] + offs + [-o for o in offs], shape=(n, n), format="csr")
+    with_m = bool(rng.integers(0, 2))
+    d = rng.uniform(0.5, 2.0, n)
+    v = rng.standard_normal(n)
+    tol, bnorm = float(10.0 ** rng.uniform(-12, -2)), float(rng.uniform(0.5, 2.0))
+    nrm = np.sqrt(np.dot(v, d * v)) if with_m else np.linalg.norm(v)
+    split = int(rng.integers(1, m - 1))
+    out = []
+    for c in (ctx, dbl):
+        V, W = c.alloc(n, m + 1), c.alloc(n, 2)
+        P = c.alloc(n, m + 1) if with_m else None
+        Md = c.diag(d) if with_m else None
+        if with_m:
+            P.upload(0, (v / nrm).reshape(-1, 1))
+            V.upload(0, (d * v / nrm).reshape(-1, 1))
+        else:
+            V.upload(0, (v / nrm).reshape(-1, 1))
+        Wm, YK = c.alloc(n, 2), c.alloc(n, 1)
+        H, st, resn = np.zeros((m + 1, m)), np.zeros(8), np.zeros(m)
+        st[5] = nrm
+        Ad = c.csr(A)
+        k, enq, h2, slot, why = c.minres_cycle(Ad, Md, V, P, W, 0, split, m - 1, 0, 0, tol, bnorm, H, Wm, 0, YK, 0, st, 0.0, resn)
+        first = (k, why)
+        if why == 0 and k == split:
+            k, enq, h2, slot, why = c.minres_cycle(Ad, Md, V, P, W, k, m - 1, m - 1, 0, enq, tol, bnorm, H, Wm, slot, YK, 0, st,
+                                                   h2, resn)
+        for j in range(k, enq):            # speculative steps: fetched and dropped
+            c.arnoldi_step_end(j % 4, j + 2)
+        c.minres_flush()
+        out.append(dict(first=first, k=k, why=why, slot=slot, h2=h2, H=H.copy(), st=st.copy(), resn=resn.copy(),
+                        W=Wm.download(), yk=YK.download(), V=V.download(0, k + 1)))
+    g, w = out
+    checks = 0
+
+    def expect(name, got, want, rtol=1e-9):
+        nonlocal checks
+        checks += 1
+        got, want = np.asarray(got, dtype=float), np.asarray(want, dtype=float)
+        scale = max(1.0, float(np.max(np.abs(want)))) if want.size else 1.0
+        if got.shape != want.shape or not np.allclose(got, want, rtol=rtol, atol=rtol * scale):
+            raise AssertionError("seed %d (n=%d, m=%d%s): minres_cycle %s deviates" % (seed, n, m, ", Jacobi" if with_m else "", name))
+
+    expect("steps / stop reasons / W slot", [g["first"][0], g["first"][1], g["k"], g["why"], g["slot"]],
+           [w["first"][0], w["first"][1], w["k"], w["why"], w["slot"]], rtol=0.0)
+    kk = w["k"]
+    expect("Lanczos matrix", g["H"][:, :kk], w["H"][:, :kk])
+    expect("rotations, right-hand side", g["st"][:7], w["st"][:7])
+    expect("residual recurrence", g["resn"][:kk], w["resn"][:kk])
+    expect("running Frobenius norm", g["h2"], w["h2"])
+    expect("basis", g["V"], w["V"])
+    expect("direction vectors", g["W"], w["W"], rtol=1e-8)
+    expect("iterate", g["yk"], w["yk"], rtol=1e-8)
+    return checks
+
+
 def shard_round(ctx, seed):
     """Block-row shards on one device: a random banded / scattered matrix cut into random uneven slabs, ghost
     entries written by hand (kh_mat_set_ghost) instead of the halo exchange - every slab must reproduce its rows of
@@ -404,4 +472,5 @@ if __name__ == "__main__":
         total += step_round(ctx, dbl, seed, max_n)
         total += shard_round(ctx, seed)
         total += cycle_round(ctx, dbl, seed)
+        total += minres_cycle_round(ctx, dbl, seed)
     print("abi_fuzz: %d rounds, %d comparisons, all within tolerance" % (rounds, total))
