@@ -297,6 +297,19 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
                kh_vec YK, int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first,
                double omega, double rho, double* out);
 
+/* A run of CG iterations in ONE call (krypy/linsys.py:622-690): iterations k0 .. k_stop-1 of kh_cg_step with what the
+ * reference does between two of them on the host in C - omega = rho_k / rho_{k-1}, rho_{k+1} = (sqrt |<r, z>|)^2 as the
+ * caller forms it, the convergence test.  rhos[i] = rho after i iterations (in: rhos[k0] and, for k0 > 0, rhos[k0 - 1];
+ * out: rhos[k0 + 1 ..]); trace receives six doubles per iteration: rho, d, <p, Ap>, <r, z>, the KH_CG_* sanity word,
+ * sqrt(|<r, z>|).  (rho_{k+1} is libm's pow(sqrt |<r, z>|, 2.0), which is what `norm ** 2` on a NumPy scalar evaluates.)
+ * Stops  KH_CYCLE_TOL    after the iteration whose sqrt(|<r, z>|) / bnorm <= tol (recorded; the caller finalises it),
+ *        KH_CYCLE_CHECK  at an iteration that returned non-finite scalars from finite input (NOT recorded; yk and r are
+ *                        as before it, the caller raises with the trace),
+ *        KH_CYCLE_LIMIT  at k_stop.        *k_done = iterations recorded (counted from 0). */
+int kh_cg_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK, int64_t ycol,
+                kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int64_t k0, int64_t k_stop, double tol, double bnorm,
+                double* rhos, double* trace, int64_t* k_done, int* reason);
+
 /* ---- complex (c128) twin of the hot path ------------------------------------------------- */
 /* KryPy's kernels are dtype-generic NumPy (H/V are allocated with the common dtype of A, v, M:
  * utils.py:893-905, complex inner products are X^H Y: utils.py:183).  A complex N-vector block is

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "kh_cg_update": [_H, _D, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _H, _I64, _c_double_p],
     "kh_cg_step": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _INT, _D, _D,
                    _c_double_p],
+    "kh_cg_cycle": [_H, _H, _H, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _H, _I64, _I64, _I64, _D, _D, _c_double_p,
+                    _c_double_p, _c_int64_p, ctypes.POINTER(ctypes.c_int)],
     "kh_bench_kernel": [_H, _INT, _H, _H, _INT, _c_double_p],
     "kh_bench_arnoldi": [_H, _H, _H, _H, _I64, _INT, _INT, _c_double_p],
     # complex (c128) side: vectors are real blocks of length 2N (interleaved re, im)
@@ -854,6 +856,25 @@ class Context(object):
             ctypes.byref(out)), "kh_cg_update")
         return out.value
 
+
+    def cg_cycle(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, k0, k_stop, tol, bnorm, rhos, trace):
+        """Iterations ``k0 .. k_stop-1`` of CG in one call (``kh_cg_cycle``; real data): ``rhos`` (float64, at least
+        ``k_stop + 1`` entries, ``rhos[i]`` = rho after i iterations) and ``trace`` (six doubles per iteration) are
+        updated in place.  Returns ``(k_done, reason)``."""
+        for a in (rhos, trace):
+            if a.dtype != numpy.float64 or not a.flags.c_contiguous:
+                raise BackendError("cg_cycle: C-ordered float64 arrays needed")
+        if rhos.size < k_stop + 1 or trace.size < 6 * k_stop:
+            raise BackendError("cg_cycle: rhos needs k_stop + 1 entries, trace 6 k_stop")
+        if _same_dtype("cg_cycle", Pd, AP, YK, R):
+            raise BackendError("cg_cycle: real blocks expected")
+        kd = ctypes.c_int64(0)
+        why = ctypes.c_int(0)
+        _check(self._lib, self._lib.kh_cg_cycle(
+            self._h, A.handle, Md.handle if Md is not None else None, Pd.handle, pcol, AP.handle, apcol, YK.handle, ycol,
+            R.handle, rcol, Z.handle if Z is not None else None, zcol, k0, k_stop, float(tol), float(bnorm), _dptr(rhos),
+            _dptr(trace), ctypes.byref(kd), ctypes.byref(why)), "kh_cg_cycle")
+        return kd.value, why.value
 
     def cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first, omega, rho):
         """One CG iteration in one call; returns ``(d, rho_new, <p, Ap>, flags)`` (``flags``: the ``KH_CG_*`` sanity

@@ -115,6 +115,7 @@ struct kh_ctx_s {
     int64_t n_proj_reg = 0;
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
     int64_t n_minres_cycle_steps = 0;   // MINRES iterations recorded by kh_minres_cycle
+    int64_t n_cg_cycle_steps = 0;       // CG iterations recorded by kh_cg_cycle
     void (*rotg)(double*, double*, double*, double*) = nullptr;   // the host layer's BLAS drotg (kh_ctx_set_rotg), or NULL
     std::vector<double> cyc_col;        // H-column scratch of the C host loops
     unsigned* onex_ticket = nullptr;   // 256 rotating ticket words

@@ -1375,6 +1375,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;
     else if (!strcmp(key, "n_cycle_steps")) *value = ctx->n_cycle_steps;
     else if (!strcmp(key, "n_minres_cycle_steps")) *value = ctx->n_minres_cycle_steps;
+    else if (!strcmp(key, "n_cg_cycle_steps")) *value = ctx->n_cg_cycle_steps;
     else if (!strcmp(key, "mgs_lowsync")) *value = ctx->mgs_lowsync;
     else if (!strcmp(key, "proj_reg")) *value = ctx->proj_reg;
     else if (!strcmp(key, "n_proj_reg")) *value = ctx->n_proj_reg;
@@ -2871,6 +2872,45 @@ int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec 
     if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
     KH_TRY(fetch_scalars(ctx, tmp, 2, out));
     out[2] = (double)cg_sanity(out[0], out[1], rho);
+    return 0;
+}
+
+// A run of CG iterations in one call (krypy/linsys.py:622-690; the header has the contract)
+int kh_cg_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK, int64_t ycol,
+                kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int64_t k0, int64_t k_stop, double tol, double bnorm,
+                double* rhos, double* trace, int64_t* k_done, int* reason) {
+    KH_ARG(ctx && A && rhos && trace && k_done && reason, "kh_cg_cycle: NULL");
+    KH_ARG(k0 >= 0 && k0 <= k_stop, "kh_cg_cycle: iterations [%lld, %lld)", (long long)k0, (long long)k_stop);
+    RoctxScope range_(ctx, "kh_cg_cycle");
+    *reason = KH_CYCLE_LIMIT;
+    int64_t k = k0;
+    for (; k < k_stop; ++k) {
+        const double rho = rhos[k];
+        const double omega = (k > 0) ? rho / rhos[k - 1] : 0.0;          // p = z + rhos[-1] / rhos[-2] p  (linsys.py:627)
+        double out[3];
+        KH_TRY(kh_cg_step(ctx, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, k == 0, omega, rho, out));
+        double* t = trace + 6 * k;
+        t[0] = rho; t[1] = out[0]; t[2] = out[0]; t[3] = out[1]; t[4] = out[2]; t[5] = 0.0;
+        const int flags = (int)out[2];
+        if ((flags & (KH_CG_NONFINITE_PAP | KH_CG_NONFINITE_RHO | KH_CG_STEP_CLAMPED)) && std::isfinite(rho)) {
+            *reason = KH_CYCLE_CHECK;            // finite data in, inf / nan out: the caller raises with the trace
+            break;
+        }
+        // ||M Ml r_k|| in the M^-1 norm, then rho AS THE CALLER FORMS IT: `MMlrk_norm ** 2` on a NumPy scalar is libm's
+        // pow(x, 2.0), which is not always the correctly rounded x * x - the call goes through a volatile pointer so that
+        // the compiler does not replace it by the multiplication
+        static double (*volatile libm_pow)(double, double) = &pow;
+        const double nrm = std::sqrt(std::fabs(out[1]));
+        t[5] = nrm;
+        rhos[k + 1] = libm_pow(nrm, 2.0);
+        if (!(nrm / bnorm > tol)) {              // the caller's own test, linsys.py:476: that iteration is the caller's to finalise
+            ++k;
+            *reason = KH_CYCLE_TOL;
+            break;
+        }
+    }
+    *k_done = k;
+    ctx->n_cg_cycle_steps += k - k0;
     return 0;
 }
 

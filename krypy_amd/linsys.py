@@ -472,8 +472,51 @@ class Cg(_KrylovSolver):
         # carries for diagnosis when the fused step is in use (the step length never visits the host there)
         self.cg_trace = trace = collections.deque(maxlen=16)
 
+        # runs of iterations in ONE C call each (kh_cg_cycle: the fused step with omega, rho and the convergence test
+        # formed in C instead of in this interpreter); the call stops after the iteration that reaches the tolerance
+        # (finalised below like any other: iterate, explicit residual), at non-finite scalars and before the last iteration
+        cyc = None
+        if (one_call and not cplx and not self.store_arnoldi and not self.explicit_residual
+                and ls.exact_solution is None and hasattr(ctx, "cg_cycle") and self.maxiter >= 3
+                and type(self)._finalize_iteration is _KrylovSolver._finalize_iteration
+                and os.environ.get("KRYPY_AMD_CG_CYCLE", "1") != "0"):
+            cyc = dict(rhos=numpy.zeros(self.maxiter + 1), trace=numpy.zeros(6 * self.maxiter))
+        bnorm = ls.MMlb_norm
+
         while self.resnorms[-1] > self.tol and self.iter < self.maxiter:
             k = self.iter
+            if cyc is not None and k + 1 < self.maxiter:
+                cr, ct = cyc["rhos"], cyc["trace"]
+                cr[k] = rhos[-1]
+                if k > 0:
+                    cr[k - 1] = rhos[-2]
+                k_done, why = ctx.cg_cycle(
+                    Amat, None if M_id else Md, p.block, p.col, Ap.block, Ap.col, yk.block, yk.col,
+                    self._Mlrk.block, self._Mlrk.col, None if M_id else self._MMlrk.block,
+                    0 if M_id else self._MMlrk.col, k, self.maxiter - 1, float(self.tol), float(bnorm), cr, ct)
+                for i in range(k, k_done + (1 if why == _hip.CYCLE_CHECK else 0)):
+                    trace.append((i, float(ct[6 * i]), float(ct[6 * i + 1]), float(ct[6 * i + 2]), float(ct[6 * i + 3]),
+                                  int(ct[6 * i + 4])))
+                if why == _hip.CYCLE_CHECK:
+                    self.iter = k_done
+                    self.xk = self._get_xk(yk)
+                    raise _hip.BackendError(
+                        "Cg: the fused step %d returned non-finite scalars (flags %d); last steps "
+                        "(k, rho, d, <p,Ap>, rho_new, flags): %s" % (k_done, int(ct[6 * k_done + 4]), list(trace)))
+                if k_done > k:
+                    last_plain = k_done if why != _hip.CYCLE_TOL else k_done - 1
+                    for i in range(k, k_done):
+                        rhos.append(float(cr[i + 1]))
+                    for i in range(k, last_plain):          # plain appends (linsys.py:476-477)
+                        self.resnorms.append(numpy.float64(ct[6 * i + 5]) / bnorm)
+                    self.xk = None
+                    if why == _hip.CYCLE_TOL:
+                        self.iter = k_done - 1
+                        rkn = self._finalize_iteration(yk, numpy.float64(ct[6 * (k_done - 1) + 5]))
+                        if rkn is not None:
+                            rhos[-1] = rkn ** 2
+                    self.iter = k_done
+                    continue
             if k > 0:
                 # p = MMlrk + rhos[-1]/rhos[-2] * p   (linsys.py:627)
                 omega = rhos[-1] / rhos[-2]

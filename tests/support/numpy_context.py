@@ -488,6 +488,35 @@ def _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, first
 NumpyContext.cg_step = _cg_step
 
 
+def _cg_cycle(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, k0, k_stop, tol, bnorm, rhos, trace):
+    """Semantics of kh_cg_cycle (include/krylov_hip.h): iterations of the fused step with omega, rho and the convergence
+    test formed here; real data."""
+    self._count("cg_cycle")
+    if _same("cg_cycle", Pd, AP, YK, R):
+        raise BackendError("cg_cycle: real blocks expected")
+    reason, k = 0, k0
+    while k < k_stop:
+        rho = float(rhos[k])
+        omega = rho / float(rhos[k - 1]) if k > 0 else 0.0
+        den, rho_new, pap, flags = _cg_step(self, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, k == 0, omega, rho)
+        trace[6 * k: 6 * k + 6] = (rho, den, pap, rho_new, flags, 0.0)
+        if (flags & (1 | 4 | 16)) and np.isfinite(rho):
+            reason = 2
+            break
+        nrm = np.sqrt(abs(rho_new))
+        trace[6 * k + 5] = nrm
+        rhos[k + 1] = nrm ** 2          # (a NumPy scalar: libm's pow, as in Cg._solve)
+        if not (nrm / bnorm > tol):
+            k += 1
+            reason = 1
+            break
+        k += 1
+    return k, reason
+
+
+NumpyContext.cg_cycle = _cg_cycle
+
+
 class GlooComm(object):
     """torch.distributed (gloo, CPU) stand-in for the RCCL calls of libkrylov_hip: sum
     all-reduce of small panels and the nearest-neighbour halo exchange.  world_size-2 tests only."""

@@ -840,6 +840,44 @@ def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
     assert np.max(np.abs(np.array(bad.resnorms[:-1]) - np.array(good.resnorms[:-1])) / np.array(good.resnorms[:-1])) < 1e-9
 
 
+def test_cg_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
+    """kh_cg_cycle (iterations of the fused CG step with omega, rho and the convergence test formed in C: linsys.py:622-690
+    in one call) against the per-step Python loop (KRYPY_AMD_CG_CYCLE=0): the same residual history, rhos and trace BIT FOR
+    BIT, the same iterate - sparse and dense operators, Jacobi, an exhausted maxiter, short and long vectors."""
+    from oracle.inputs import dense_spd_system
+
+    A, b = lap2d_system(70, rhs="rng1")
+    M = sp.diags(1.0 / A.diagonal()).tocsr()
+    A2, b2 = lap2d_system(700, rhs="rng1")
+    Ad, bd = dense_spd_system(512)
+    hpd = dict(self_adjoint=True, positive_definite=True)
+    cases = [("sparse", lambda: linsys.Cg(linsys.LinearSystem(A, b, **hpd), tol=1e-10, maxiter=600)),
+             ("jacobi", lambda: linsys.Cg(linsys.LinearSystem(A, b, M=M, **hpd), tol=1e-10, maxiter=600)),
+             ("long", lambda: linsys.Cg(linsys.LinearSystem(A2, b2, **hpd), tol=1e-30, maxiter=120)),
+             ("dense", lambda: linsys.Cg(linsys.LinearSystem(Ad, bd, **hpd), tol=1e-9, maxiter=200)),
+             ("maxiter", lambda: linsys.Cg(linsys.LinearSystem(A, b, **hpd), tol=1e-13, maxiter=30))]
+
+    def run(make):
+        try:
+            return make()
+        except utils.ConvergenceError as e:
+            return e.solver
+
+    for name, make in cases:
+        c0 = hip.get("n_cg_cycle_steps")
+        s1 = run(make)
+        used = hip.get("n_cg_cycle_steps") - c0
+        monkeypatch.setenv("KRYPY_AMD_CG_CYCLE", "0")
+        c1 = hip.get("n_cg_cycle_steps")
+        s0 = run(make)
+        assert hip.get("n_cg_cycle_steps") == c1
+        monkeypatch.delenv("KRYPY_AMD_CG_CYCLE")
+        assert used > 0, name
+        assert s1.resnorms == s0.resnorms and s1.rhos == s0.rhos and s1.iter == s0.iter, name
+        assert list(s1.cg_trace) == list(s0.cg_trace), name
+        assert np.array_equal(s1.xk, s0.xk), name
+
+
 def test_minres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
     """kh_minres_cycle (Lanczos steps with look-ahead on the device; the symmetric fill, the QR update with the two
     remembered rotations, the rotated right-hand side and the deferred recurrence updates on the host in C:

@@ -287,6 +287,41 @@ def test_minres_cycle_bookkeeping_equals_the_per_step_loop(cpu_double, monkeypat
         assert np.array_equal(s1.xk, s0.xk), kw
 
 
+def test_cg_cycle_bookkeeping_equals_the_per_step_loop(cpu_double, monkeypatch):
+    """Cg._solve through Context.cg_cycle (on the GPU kh_cg_cycle, here the NumPy restatement of its contract) against the
+    per-step loop: residual history, rhos, the trace of the last sixteen steps, iterate and counters equal - converging
+    solves with and without Jacobi, an exhausted maxiter, maxiter = 2 (no room for the call) and 3, the default
+    tolerance."""
+    import numpy as np
+    import scipy.sparse as sp
+    from krypy_amd import linsys, utils
+    from oracle.inputs import lap2d_system
+
+    A, b = lap2d_system(24, rhs="rng1")
+    M = sp.diags(1.0 / A.diagonal()).tocsr()
+
+    def run(**kw):
+        ls = linsys.LinearSystem(A, b, M=kw.pop("M", None), self_adjoint=True, positive_definite=True)
+        try:
+            return linsys.Cg(ls, **kw)
+        except utils.ConvergenceError as e:
+            return e.solver
+
+    for kw, min_calls in ((dict(tol=1e-10, maxiter=400), 1), (dict(tol=1e-10, maxiter=400, M=M), 1), (dict(tol=1e-30, maxiter=40), 1),
+                          (dict(tol=1e-30, maxiter=3), 1), (dict(tol=1e-30, maxiter=2), 0), (dict(tol=1e-3), 1)):
+        n0 = cpu_double.calls.get("cg_cycle", 0)
+        s1 = run(**dict(kw))
+        calls = cpu_double.calls.get("cg_cycle", 0) - n0
+        monkeypatch.setenv("KRYPY_AMD_CG_CYCLE", "0")
+        s0 = run(**dict(kw))
+        assert cpu_double.calls.get("cg_cycle", 0) - n0 == calls
+        monkeypatch.delenv("KRYPY_AMD_CG_CYCLE")
+        assert calls >= min_calls, (kw, calls)
+        assert s1.resnorms == s0.resnorms and s1.rhos == s0.rhos and s1.iter == s0.iter, kw
+        assert list(s1.cg_trace) == list(s0.cg_trace), kw
+        assert np.array_equal(s1.xk, s0.xk), kw
+
+
 def test_committed_bench_line_fractions_are_fractions():
     """profiles/r02_bench.json (a bench.py line from the MI355X): no roofline fraction above 1, each one a single
     division of numbers in the same object, the traffic from a stamped PMC profile, the contract's fields present."""

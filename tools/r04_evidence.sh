@@ -42,4 +42,12 @@ import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000 x 313 (mgs, one all-reduce per link): %.0f it/s' % d['value'])" | tee -a gpurun_out/ev/shards.log
   python tools/complex_bench.py 2>/dev/null | tail -3 | tee gpurun_out/ev/complex.log
   ;;
+fuzz)
+  # randomised layers on the final tree: every C entry against NumPy (kh_minres_cycle included), whole solves against the oracle,
+  # a soak of solves of every kind, the one-XCD launches
+  python tools/abi_fuzz.py 500 > gpurun_out/ev/abi_fuzz.log 2>&1; tail -1 gpurun_out/ev/abi_fuzz.log
+  python tools/solve_fuzz.py 150 > gpurun_out/ev/solve_fuzz.log 2>&1; tail -1 gpurun_out/ev/solve_fuzz.log
+  python tools/soak.py 30 > gpurun_out/ev/soak.log 2>&1; tail -3 gpurun_out/ev/soak.log
+  timeout 400 python tools/onex_soak.py > gpurun_out/ev/onex_soak.log 2>&1; tail -2 gpurun_out/ev/onex_soak.log
+  ;;
 esac
