@@ -631,6 +631,40 @@ struct ChainShape {
 #ifndef KH_RIF
 #define KH_RIF 3          // rows of the fused operator in flight - 1 (a mask: 1 = two rows, 3 = four)
 #endif
+// The same for a complex operator (round 4): one double2 row of w is ONE complex row, the diagonal-major copy holds
+// (re, im) pairs (zpath.h: k_zdia_fill), x_k is read as double2; products by NumPy's formula and sums from (0, 0) in
+// ascending offset order, empty slots skipped - exactly what k_zspmv_stream does entry by entry: the same bits.
+template <int R2, int FND, class Put>
+__device__ __forceinline__ void chain_apply_banded_z(const ChainArgs& a, int64_t first, Put&& put) {
+    const double2* __restrict__ xk = reinterpret_cast<const double2*>(a.xk);
+    const double2* __restrict__ dia = reinterpret_cast<const double2*>(a.dia);
+    const int64_t last = a.n_last;           // last complex row
+    int64_t fb = first;
+#pragma unroll
+    for (int r = 0; r < R2; ++r) {
+        const int64_t row = fb + (int64_t)r * CH_BS;
+        double2 av[FND], xv[FND];
+#pragma unroll
+        for (int d = 0; d < FND; ++d) {
+            av[d] = ld_nt2(dia + (int64_t)d * a.dia_ld + row);
+            int64_t c = row + a.offs.off[d];
+            c = c < 0 ? 0 : (c > last ? last : c);
+            xv[d] = xk[c];
+        }
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int d = 0; d < FND; ++d) {
+            const double px = av[d].x * xv[d].x - av[d].y * xv[d].y;
+            const double py = av[d].x * xv[d].y + av[d].y * xv[d].x;
+            const bool on = (av[d].x != 0.0) || (av[d].y != 0.0);
+            sx = on ? sx + px : sx;
+            sy = on ? sy + py : sy;
+        }
+        put(r, sx, sy);
+        if ((r & 1) == 1) asm volatile("" : "+v"(fb) : : "memory");      // two rows of loads in flight
+    }
+}
+
 template <int R2, int FND, int RIF = KH_RIF, class Put>
 __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t first, Put&& put) {
     // w = A x_k for this lane's rows, exactly as k_spmv_dia computes them (ascending offsets,
@@ -685,7 +719,7 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
 // 12.58 M / 14.68 M per GPU with the same single launch per Arnoldi step and the same arithmetic.
 template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0, bool ONEX = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
-    static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
+    static_assert(FND == 0 || !MASKED, "the fused operator exists for the padded kernels");
     constexpr int RW = R2 - WL;                   // rows of w in registers
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
 #define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
@@ -715,7 +749,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
     double2 w[RW];
     double2 ring[2][PB];
-    if constexpr (FND > 0) {
+    if constexpr (FND > 0 && CPLX) {
+        chain_apply_banded_z<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
+    } else if constexpr (FND > 0) {
         chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
@@ -964,7 +1000,7 @@ struct ChainShapeLds {
 
 template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
-    static_assert(FND == 0 || (!MASKED && !CPLX), "the fused operator exists for the padded real kernel");
+    static_assert(FND == 0 || !MASKED, "the fused operator exists for the padded kernels");
     constexpr int PB = ChainShapeLds<R2, CPLX>::PB;
     constexpr int NB = ChainShapeLds<R2, CPLX>::NB;
     constexpr int LB = ChainShapeLds<R2, CPLX>::LB;
@@ -995,7 +1031,9 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
 #define CH_LD(ptr, reuse) ((reuse) ? *(ptr) : ld_nt2(ptr))
     double2 w[RW];
     double2 ring[2][PB];
-    if constexpr (FND > 0) {
+    if constexpr (FND > 0 && CPLX) {
+        chain_apply_banded_z<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
+    } else if constexpr (FND > 0) {
         chain_apply_banded<R2, FND>(a, first, [&](int r, double s0, double s1) { W_PUT(r, make_double2(s0, s1)); });
     } else {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
@@ -1741,13 +1779,15 @@ struct CgsArgs {
 // CPLX: every double2 is one complex number: <v, w> = conj(v) w as two sums per column (partials of column t in
 // rows 2t (re) and 2t+1 (im) of `part`, so the reduction leaves (re, im) pairs), the update multiplies by a complex
 // coefficient (NumPy's product: (ac - bd, ad + bc)); the norm is that of the real view either way.
-// X2 (round 4; real data, short shards: R2 <= 16): the same pass also forms <v_j, x> for a second vector x whose rows sit
-// in LDS behind the rows of w - x = v_k, the newest basis vector: its inner products with the older columns are the new
+// X2 (round 4; real data, shards up to R2 = 24 rows per lane): the same pass also forms <v_j, x> for a second vector x whose
+// rows sit in LDS behind the rows of w (sixteen of them; the other eight, at 24 rows per lane, in registers; at 32 rows the
+// kernel spills 102 registers and is not instantiated) - x = v_k, the newest basis vector: its inner products with the older columns are the new
 // row of the Gram table the one-reduction form of reference-order Gram-Schmidt corrects its coefficients with
 // (krylov_hip.hip: try_lowsync_mgs).  One more read of one column per step, no second pass over the basis.
 template <int R2, bool MASKED, bool NTC, int WL = 0, bool CPLX = false, bool X2 = false>
 __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
-    static_assert(!X2 || (!CPLX && WL == 0 && R2 <= 16), "second right-hand side: real data, all of w in registers, x fits LDS");
+    static_assert(!X2 || (!CPLX && WL == 0 && R2 <= 24), "second right-hand side: real data, all of w in registers, x fits LDS + registers");
+    constexpr int XR = (X2 && R2 > 16) ? R2 - 16 : 0;      // rows of x in registers (24 rows per lane: LDS takes sixteen)
     constexpr int RW = R2 - WL;
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS] rows of w, then (X2) [R2][CH_BS] rows of x
     constexpr int PB = CgsShape<R2>::PB;
@@ -1772,6 +1812,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         }
     }
     double2* const xl = wl + (size_t)WL * CH_BS;      // (X2) this lane's rows of x: own entries only, no barrier
+    double2 xr[XR > 0 ? XR : 1];
+#define CGS_X_GET(r) (((r) < XR) ? xr[((r) < XR) ? (r) : 0] : xl[((r) - XR) * CH_BS + tid])
     if constexpr (X2) {
         const double2* __restrict__ x2 = reinterpret_cast<const double2*>(a.x2) + first;
 #pragma unroll
@@ -1780,7 +1822,8 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
             double2 t;
             t.x = CH_OK(r) ? v.x : 0.0;
             t.y = CH_OK(r) ? v.y : 0.0;
-            xl[r * CH_BS + tid] = t;
+            if (r < XR) xr[(r < XR) ? r : 0] = t;
+            else xl[(r - XR) * CH_BS + tid] = t;
         }
     }
     {
@@ -1818,9 +1861,9 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
                     aci1 = fma(v.y, wr.x, aci1);
                 }
                 if constexpr (X2) {
-                    const double2 xr = xl[(b * PB + i) * CH_BS + tid];
-                    acx0 = fma(v.x, xr.x, acx0);
-                    acx1 = fma(v.y, xr.y, acx1);
+                    const double2 xv = CGS_X_GET(b * PB + i);
+                    acx0 = fma(v.x, xv.x, acx0);
+                    acx1 = fma(v.y, xv.y, acx1);
                 }
             }
         }
@@ -1849,6 +1892,7 @@ __global__ __launch_bounds__(CH_BS) void k_cgs_dots(CgsArgs a) {
         }
         if (t < a.ncol) column(std::integral_constant<int, 0>{}, t);
     }
+#undef CGS_X_GET
 #undef CH_OK
 }
 

@@ -197,6 +197,10 @@ struct kh_mat_s {
     int64_t dia_ld = 0;
     int dia_nd = 0, dia_nblk = 0, dia_rpt = 0;
     int dia_off[32] = {0};
+    // the same for a complex CSR operator (round 4): zdia[d][i] as (re, im) pairs, leading dimension in complex entries;
+    // dia_nd / dia_off describe it; used by the complex chain kernels' prologue (the stand-alone SpMV stays CSR-stream)
+    double* zdia = nullptr;
+    int64_t zdia_ld = 0;
     // dense
     double* a = nullptr;
     int64_t lda = 0;

@@ -680,14 +680,22 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         const bool lz_shape = ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr) &&
                               (r2 == 4 || r2 == 8);
         const bool small_shape = ctx->chain_small && r2 <= 8 && B == V && dg == nullptr;
-        fused = ctx->chain_spmv && padded && !cplx && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 48) || want_onex || lz_shape || small_shape) && xk != nullptr &&
-                Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
-                Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
+        if (cplx) {
+            // complex banded operator (zpath.h: zdia, leading dimension and rows counted in complex entries): the padded
+            // chain kernels with 16 ... 40 rows per lane, spread over the chip
+            fused = ctx->chain_spmv && padded && ((a.debug & 3) == 0) && r2 >= 16 && r2 <= 40 && !want_onex && !presub && xk != nullptr &&
+                    Afuse->kind == KH_MAT_ZCSR && Afuse->zdia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
+                    2 * Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && 2 * Afuse->zdia_ld >= need_ld;
+        } else {
+            fused = ctx->chain_spmv && padded && ((a.debug & 3) == 0) && ((r2 >= 16 && r2 <= 48) || want_onex || lz_shape || small_shape) && xk != nullptr &&
+                    Afuse->kind == KH_MAT_CSR && Afuse->dia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
+                    Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && Afuse->dia_ld >= need_ld;
+        }
         if (!fused) return 0;
-        a.dia = Afuse->dia;
-        a.dia_ld = Afuse->dia_ld;
+        a.dia = cplx ? Afuse->zdia : Afuse->dia;
+        a.dia_ld = cplx ? Afuse->zdia_ld : Afuse->dia_ld;
         a.xk = xk;
-        a.n_last = n - 1;
+        a.n_last = cplx ? Afuse->n_rows - 1 : n - 1;
         a.offs.nd = Afuse->dia_nd;
         for (int d = 0; d < KH_DIA_MAX; ++d) a.offs.off[d] = d < Afuse->dia_nd ? Afuse->dia_off[d] : 0;
     } else {
@@ -712,7 +720,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     const bool use_pf = use_lds && ctx->chain_pf && (r2 <= 24 || (ctx->chain_pf == 2 && r2 <= 40));   // (2: measurement)
 #define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
     // a step with ONE Gram-Schmidt link (Lanczos / MINRES, the first Arnoldi step): three passes instead of six
-    if (fused && r2 <= 40 && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
+    if (fused && !cplx && r2 <= 40 && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
         if (!presub) {                 // no previous column: subtract 0 * (some valid column)
             a.bprev = B->col(k);
             a.h_km1 = 0.0;
@@ -859,13 +867,26 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
 #define KH_FUSED(R, D)                                                                                   \
     (use_lds ? (use_pf ? launch_chain_pf<R, false, false, D>(ctx, G, a) : launch_chain_lds<R, false, false, D>(ctx, G, a)) \
              : launch_chain<R, false, false, D>(ctx, G, a))
+#define KH_FUSED_Z(R, D) (use_lds ? launch_chain_lds<R, false, true, D>(ctx, G, a) : launch_chain<R, false, true, D>(ctx, G, a))
             if (r2 < 16) return 0;       // (4 / 8 rows: only the Lanczos and the one-XCD kernels have the prologue)
+            if (cplx) {
+                if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED_Z(40, 5) : KH_FUSED_Z(40, 7);
+                else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED_Z(32, 5) : KH_FUSED_Z(32, 7);
+                else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED_Z(24, 5) : KH_FUSED_Z(24, 7);
+                else e = (a.offs.nd == 5) ? KH_FUSED_Z(16, 5) : KH_FUSED_Z(16, 7);
+                if (e != hipSuccess) {
+                    (void)hipGetLastError();
+                    return 0;
+                }
+                break;
+            }
             if (r2 == 48) e = (a.offs.nd == 5) ? launch_chain<48, false, false, 5, 8>(ctx, G, a) : launch_chain<48, false, false, 7, 8>(ctx, G, a);
             else if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
             else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
             else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);
             else e = (a.offs.nd == 5) ? KH_FUSED(16, 5) : KH_FUSED(16, 7);
 #undef KH_FUSED
+#undef KH_FUSED_Z
             if (e != hipSuccess) {       // the caller falls back to SpMV + the ordinary chain
                 (void)hipGetLastError();
                 return 0;
@@ -1025,7 +1046,7 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
 // ---- reference-order Gram-Schmidt with one reduction per step (chain.h: k_cgs_dots<..., X2>, k_lowsync_solve) -----
 template <int R2, bool MASKED>
 static hipError_t launch_dots_x2(kh_ctx ctx, int G, CgsArgs& a) {
-    constexpr size_t lds = (size_t)R2 * CH_BS * sizeof(double2);
+    constexpr size_t lds = (size_t)(R2 < 16 ? R2 : 16) * CH_BS * sizeof(double2);      // (the rows of x beyond sixteen: registers)
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_cgs_dots<R2, MASKED, false, 0, false, true>),
@@ -1052,7 +1073,8 @@ static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
     if (!ctx->mgs_lowsync || !ctx->chain_configured || k + 1 > LS_MAXCOL) return false;
     const int64_t n = V->n;
     int r2 = 0, G = 0;
-    if (!chain_geometry(ctx, n, &r2, &G) || r2 > 16) return false;      // (the second right-hand side lives in LDS: 16 rows of 8 KB)
+    if (!chain_geometry(ctx, n, &r2, &G) || r2 > 24) return false;      // (the second right-hand side: 16 rows of 8 KB in LDS, 8 more in registers;
+                                                                        //  at 32 rows per lane the dots kernel spills 102 registers)
     if ((n & 1) && (V->ld <= n || wld <= n)) return false;
     return true;
 }
@@ -1108,7 +1130,7 @@ static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t
     a.part2 = ctx->cgs_part + (size_t)ncol * CGS_PSTRIDE;
     hipError_t e;
 #define KH_DX2(R) (padded ? launch_dots_x2<R, false>(ctx, G, a) : launch_dots_x2<R, true>(ctx, G, a))
-    e = (r2 == 4) ? KH_DX2(4) : (r2 == 8 ? KH_DX2(8) : KH_DX2(16));
+    e = (r2 == 4) ? KH_DX2(4) : (r2 == 8 ? KH_DX2(8) : (r2 == 16 ? KH_DX2(16) : KH_DX2(24)));
 #undef KH_DX2
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1126,7 +1148,7 @@ static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t
     a.coef = coef;
     a.part = part_slot(ctx, SLOT_NRM);
 #define KH_UPD(R) (padded ? launch_cgs<R, false, 0>(ctx, G, a, true) : launch_cgs<R, true, 0>(ctx, G, a, true))
-    KH_HIP((r2 == 4) ? KH_UPD(4) : (r2 == 8 ? KH_UPD(8) : KH_UPD(16)));
+    KH_HIP((r2 == 4) ? KH_UPD(4) : (r2 == 8 ? KH_UPD(8) : (r2 == 16 ? KH_UPD(16) : KH_UPD(24))));
 #undef KH_UPD
     *nrm_count = nwave;
     ctx->ls_V = V;
@@ -1586,7 +1608,8 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
 // 12 B per CSR entry).  One pass over the host arrays; gives up at the first violation.
 static bool detect_dia(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
                        const int32_t* indices, const double* data, std::vector<int>& offs,
-                       int64_t nprev = 0, int64_t nnext = 0) {
+                       int64_t nprev = 0, int64_t nnext = 0, int cw = 1) {
+    // cw = 2: complex data, (re, im) pairs - a stored zero is an entry whose two parts are zero
     // nprev / nnext: ghost columns of a block-row shard, taken as the rows before / after the slab
     offs.clear();
     if (n_rows + nprev + nnext != n_cols || n_rows < 2 || nnz == 0 || data == nullptr) return false;
@@ -1597,7 +1620,7 @@ static bool detect_dia(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_
         int prev = 0;
         for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
             const int c = dia_virtual_col(indices[p], (int)n_rows, (int)nprev);
-            if ((p > indptr[r] && c <= prev) || data[p] == 0.0) return false;
+            if ((p > indptr[r] && c <= prev) || (data[p * cw] == 0.0 && (cw == 1 || data[p * cw + 1] == 0.0))) return false;
             prev = c;
             const int off = c - (int)r;
             int d = 0;
@@ -1857,6 +1880,7 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->rowblk);
     (void)hipFree(A->part);
     (void)hipFree(A->dia);
+    (void)hipFree(A->zdia);
     (void)hipFree(A->a);
     (void)hipFree(A->diag);
     (void)hipFree(A->ghost);

@@ -173,6 +173,20 @@ __global__ __launch_bounds__(BS) void k_zdiag_apply(int64_t n, const double2* __
     }
 }
 
+// diagonal-major copy of a banded complex CSR operator: zdia[d * ld + i] = A[i, i + off[d]] ((0, 0) where the row has no entry)
+static __global__ __launch_bounds__(BS) void k_zdia_fill(const int32_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                        const double2* __restrict__ data, int64_t n_rows, DiaOffs o,
+                                                        double2* __restrict__ zdia, int64_t ld) {
+    const int64_t r = (int64_t)blockIdx.x * BS + threadIdx.x;
+    if (r >= n_rows) return;
+    for (int p = indptr[r]; p < indptr[r + 1]; ++p) {
+        const int off = indices[p] - (int)r;
+        int d = 0;
+        while (d < o.nd - 1 && o.off[d] != off) ++d;
+        zdia[(int64_t)d * ld + r] = data[p];
+    }
+}
+
 // complex CSR-stream SpMV: products parked in LDS as double2, rows summed left to right
 template <int ITEMS>
 __global__ __launch_bounds__(BS) void k_zspmv_stream(const int32_t* __restrict__ indptr,
@@ -477,6 +491,32 @@ int kh_zcsr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, cons
         KH_HIP(hipMemcpy(A->data, data, sizeof(double) * 2 * nnz, hipMemcpyHostToDevice));
     }
     KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+    // a banded complex operator (a shifted stencil matrix) gets a diagonal-major copy like the real ones: the complex chain
+    // kernels compute w = A v_k from it in their prologue (chain.h, CPLX + FND); kh_apply keeps the CSR-stream kernel
+    if (n_rows == n_cols && nnz > 0 && ctx->spmv_dia && ctx->chain_spmv) {
+        std::vector<int> offs;
+        if (detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs, 0, 0, 2) && (offs.size() == 5 || offs.size() == 7)) {
+            const int64_t ld = std::max<int64_t>(padded_ld(ctx, 2 * n_rows) / 2, ((n_rows + 31) / 32) * 32);
+            double* zd = nullptr;
+            if (hipMalloc(&zd, sizeof(double) * 2 * (size_t)ld * offs.size()) == hipSuccess) {
+                KH_HIP(hipMemsetAsync(zd, 0, sizeof(double) * 2 * (size_t)ld * offs.size(), ctx->stream));
+                DiaOffs o;
+                o.nd = (int)offs.size();
+                for (int d = 0; d < KH_DIA_MAX; ++d) o.off[d] = d < o.nd ? offs[d] : 0;
+                hipLaunchKernelGGL(k_zdia_fill, dim3((unsigned)((n_rows + BS - 1) / BS)), dim3(BS), 0, ctx->stream, A->indptr,
+                                   A->indices, reinterpret_cast<const double2*>(A->data), n_rows, o,
+                                   reinterpret_cast<double2*>(zd), ld);
+                KH_HIP(hipGetLastError());
+                KH_HIP(hipStreamSynchronize(ctx->stream));
+                A->zdia = zd;
+                A->zdia_ld = ld;
+                A->dia_nd = o.nd;
+                for (int d = 0; d < o.nd; ++d) A->dia_off[d] = offs[d];
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
     *out = A;
     return 0;
 }
@@ -649,6 +689,15 @@ static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol,
     KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * 2 * (k + 2), ctx->stream));
     if (A != nullptr) {
         KH_ARG(A->kind >= KH_MAT_ZCSR && A->n_rows == n, "kh_zarnoldi_step: complex operator of matching size needed");
+        // a banded complex operator, reference-order Gram-Schmidt, no projector / preconditioner / Lanczos pre-subtraction:
+        // the chain kernel computes w = A v_k in its prologue (no SpMV launch, w never written to memory)
+        if (gs_mode == KH_GS_MGS && Md == nullptr && proj == nullptr && A->kind == KH_MAT_ZCSR && A->zdia != nullptr &&
+            !(start > 0 && start == k)) {
+            const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, false, 0.0, nullptr, hdev,
+                                     slot, true, nullptr, 0, A, V->col(k));
+            if (rc < 0) return rc;
+            if (rc == 1) return 0;
+        }
         KH_TRY(zapply_one(ctx, A, V->col(k), W->col(wcol)));
         // deflated solvers: w <- (I - P) w, and <U, A v_k> behind the H column (deflation.py:135-143)
         if (proj != nullptr) KH_TRY(zproj_apply_dev(ctx, proj, w, hdev + 2 * (k + 2)));

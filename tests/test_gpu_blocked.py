@@ -135,14 +135,15 @@ def forced_ctx(hip):
     ctx.close()
 
 
-@pytest.mark.parametrize("nx,ny", [(90, 90), (301, 211), (1200, 1000), (2000, 1500)])
+@pytest.mark.parametrize("nx,ny", [(90, 90), (301, 211), (1200, 1000), (2000, 1500), (2500, 2001)])
 def test_one_reduction_reference_order_gram_schmidt(forced_ctx, nx, ny):
     """ortho='mgs' on the multi-rank path (round 4): all k + 1 coefficients of a step from ONE pass over the local basis
     and ONE all-reduce - alpha = (I + U^T)^{-1} V^T w with the strict upper Gram table U carried by the sequence, the
     reference's loop (utils.py:1012-1029) in exact arithmetic - instead of k + 1 dependent all-reduces.  30 Arnoldi
     steps against the CPU oracle's MGS and against the per-column path of the same context at 1e-10 (H) / 1e-9 (basis);
     two all-reduces per step whatever k; 8,100 rows (4 rows per lane, padded), 63,511 (odd), 1.2 M (8 rows per lane),
-    3 M (16 rows: the largest shape whose second right-hand side fits LDS); the table is rebuilt from the basis when the
+    3 M (16 rows: the second right-hand side fills LDS), 5 M (24 rows: eight of its rows in registers - a rank's share of the
+    benchmark problem on two GPUs); the table is rebuilt from the basis when the
     block is not the one the sequence has been writing (a basis grown on demand)."""
     from krypy_amd import utils
 

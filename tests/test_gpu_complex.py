@@ -347,3 +347,44 @@ def test_complex_shard_with_ghost_columns_and_rccl_path(hip):
     finally:
         _hip._install_context_for_testing(old)
         ctx.close()
+
+
+@pytest.mark.parametrize("shape", [("lap2d", 1300, 1000), ("lap2d", 1700, 1500), ("lap2d", 2200, 1800), ("lap2d", 2500, 2000),
+                                   ("lap3d", 120, 0)])
+def test_complex_operator_fused_into_the_chain_prologue(hip, shape):
+    """A banded COMPLEX operator (a shifted stencil matrix) + long vectors (round 4): the complex chain kernels compute
+    w = A v_k in their prologue from a diagonal-major copy of (re, im) pairs instead of reading what k_zspmv_stream wrote -
+    NumPy's product formula, sums from (0, 0) in storage order, empty slots skipped: H and the basis must come out bit for
+    bit as with the SpMV launch (16 ... 40 rows per lane, 5 and 7 diagonals, single and double sweeps), and the Arnoldi
+    relation must hold against SciPy's product."""
+    from oracle import krylov_ref as ref
+
+    kind, a, b_ = shape
+    L = ref.laplace2d(a, b_) if kind == "lap2d" else ref.laplace3d(a).tocsr()
+    n = L.shape[0]
+    A = (L.astype(complex) + sp.diags(1j * np.linspace(0.1, 1.0, n))).tocsr()
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    m = 6
+    out = []
+    Ad = hip.csr(A, dtype=complex)
+    for fused in (1, 0):
+        hip.set("chain_spmv", fused)
+        try:
+            before = hip.counters()
+            V, W = hip.alloc(n, m + 1, dtype=complex), hip.alloc(n, 2, dtype=complex)
+            V.upload(0, (v / np.linalg.norm(v)).reshape(-1, 1))
+            H = np.zeros((m + 1, m), dtype=complex)
+            for k in range(m):
+                hcol = hip.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 4 else 1, 0, 0.0)
+                H[: k + 2, k] = hcol[: k + 2]
+            c = hip.counters()
+            assert c["chain"] - before["chain"] == m, c
+            assert c["chain_fused"] - before["chain_fused"] == (m if fused else 0), (fused, c)
+            out.append((H, V.download()))
+            del V, W
+        finally:
+            hip.set("chain_spmv", 1)
+    (Hf, Vf), (Hs, Vs) = out
+    assert np.array_equal(Hf, Hs) and np.array_equal(Vf, Vs)
+    assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
