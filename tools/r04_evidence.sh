@@ -42,6 +42,18 @@ import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000 x 313 (mgs, one all-reduce per link): %.0f it/s' % d['value'])" | tee -a gpurun_out/ev/shards.log
   python tools/complex_bench.py 2>/dev/null | tail -3 | tee gpurun_out/ev/complex.log
   ;;
+fallback)
+  # the fallback paths are tested paths: the parity / complex / blocked / loopback files under the switches that take the round's
+  # kernels away (failures there must be tests that ASSERT the switched-off kernel ran, nothing else)
+  F="tests/test_gpu_parity.py tests/test_gpu_complex.py tests/test_gpu_blocked.py tests/test_gpu_halo_loopback.py"
+  : > gpurun_out/ev/fallback.log
+  run() { echo "## $1" >> gpurun_out/ev/fallback.log; env $1 python -m pytest $F -q 2>&1 | grep -E "^FAILED|passed|failed" >> gpurun_out/ev/fallback.log; echo >> gpurun_out/ev/fallback.log; }
+  run "KRYPY_AMD_TEST_FORCE_MULTI=1"
+  run "KRYPY_AMD_MGS_CHAIN=0"
+  run "KRYPY_AMD_CHAIN_BLK=0 KRYPY_AMD_MGS_LOWSYNC=0 KRYPY_AMD_PROJ_REG=0 KRYPY_AMD_MINRES_CYCLE=0 KRYPY_AMD_CG_CYCLE=0 KRYPY_AMD_GMRES_CYCLE=0"
+  run "KRYPY_AMD_CHAIN_SPMV=0 KRYPY_AMD_SPMV_DIA=0 KRYPY_AMD_CHAIN_LDS=0"
+  cat gpurun_out/ev/fallback.log
+  ;;
 fuzz)
   # randomised layers on the final tree: every C entry against NumPy (kh_minres_cycle included), whole solves against the oracle,
   # a soak of solves of every kind, the one-XCD launches
