@@ -316,7 +316,9 @@ int kh_cg_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec
  * a REAL kh_vec of length 2N (interleaved re, im), allocated / copied / zeroed / normed / scaled
  * by a real with the entry points above; the entry points below are what is genuinely complex.
  * Complex scalars cross the ABI as (re, im) pairs of doubles. */
-/* complex operators; kh_apply dispatches on the handle (X, Y are 2N-real views) */
+/* complex operators; kh_apply dispatches on the handle (X, Y are 2N-real views).  A square complex CSR operator whose
+ * entries sit on 5 or 7 well-filled diagonals (a shifted stencil matrix) also gets a diagonal-major copy of (re, im) pairs:
+ * the complex Arnoldi / Lanczos step then forms w = A v_k inside its Gram-Schmidt kernel - same bits as the SpMV launch. */
 int kh_zcsr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* indptr,
                    const int32_t* indices, const double* data_re_im, kh_mat* out);
 int kh_zdense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a_re_im, int64_t lda,

@@ -683,7 +683,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         if (cplx) {
             // complex banded operator (zpath.h: zdia, leading dimension and rows counted in complex entries): the padded
             // chain kernels with 16 ... 40 rows per lane, spread over the chip
-            fused = ctx->chain_spmv && padded && ((a.debug & 3) == 0) && r2 >= 16 && r2 <= 40 && !want_onex && !presub && xk != nullptr &&
+            fused = ctx->chain_spmv && padded && ((a.debug & 3) == 0) && r2 >= 16 && r2 <= 40 && !want_onex && xk != nullptr &&
                     Afuse->kind == KH_MAT_ZCSR && Afuse->zdia != nullptr && (Afuse->dia_nd == 5 || Afuse->dia_nd == 7) &&
                     2 * Afuse->n_rows == n && Afuse->nrecv_prev + Afuse->nrecv_next == 0 && 2 * Afuse->zdia_ld >= need_ld;
         } else {

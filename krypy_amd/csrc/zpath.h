@@ -691,10 +691,13 @@ static int zstep_enqueue(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t wcol,
         KH_ARG(A->kind >= KH_MAT_ZCSR && A->n_rows == n, "kh_zarnoldi_step: complex operator of matching size needed");
         // a banded complex operator, reference-order Gram-Schmidt, no projector / preconditioner / Lanczos pre-subtraction:
         // the chain kernel computes w = A v_k in its prologue (no SpMV launch, w never written to memory)
+        // (a Lanczos step too: its pre-subtraction w -= H[k,k-1] v_{k-1} has a REAL coefficient - the norm of the previous
+        // step - and runs inside the kernel like the real one's; a coefficient with an imaginary part takes the launches)
+        const bool lz = (start > 0 && start == k);
         if (gs_mode == KH_GS_MGS && Md == nullptr && proj == nullptr && A->kind == KH_MAT_ZCSR && A->zdia != nullptr &&
-            !(start > 0 && start == k)) {
-            const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, false, 0.0, nullptr, hdev,
-                                     slot, true, nullptr, 0, A, V->col(k));
+            (!lz || h_km1_dev != nullptr || h_km1[1] == 0.0)) {
+            const int rc = try_chain(ctx, V, V, W->col(wcol), W->ld, nullptr, nullptr, k, start, sweeps, lz, lz ? h_km1[0] : 0.0,
+                                     lz ? h_km1_dev : nullptr, hdev, slot, true, nullptr, 0, A, V->col(k));
             if (rc < 0) return rc;
             if (rc == 1) return 0;
         }

@@ -388,3 +388,46 @@ def test_complex_operator_fused_into_the_chain_prologue(hip, shape):
     (Hf, Vf), (Hs, Vs) = out
     assert np.array_equal(Hf, Hs) and np.array_equal(Vf, Vs)
     assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
+
+
+@pytest.mark.parametrize("nx,ny", [(1300, 1000), (2500, 2000)])
+def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
+    """A complex HERMITIAN banded operator (D^H L D with a diagonal of phases D): the Lanczos step of complex MINRES -
+    operator, pre-subtraction of H[k,k-1] v_{k-1} (a real coefficient), one Gram-Schmidt link, norm, store - is ONE launch
+    of the complex chain kernel with the operator in its prologue; H and the basis bit for bit as with the separate
+    SpMV / axpy launches, H real-tridiagonal to rounding, the Lanczos relation against SciPy's product."""
+    from oracle import krylov_ref as ref
+
+    L = ref.laplace2d(nx, ny)
+    n = L.shape[0]
+    rng = np.random.default_rng(7)
+    ph = sp.diags(np.exp(1j * rng.uniform(0, 2 * np.pi, n)))
+    A = (ph.conj() @ L.astype(complex) @ ph).tocsr()
+    A.sort_indices()
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    m = 6
+    Ad = hip.csr(A, dtype=complex)
+    out = []
+    for fused in (1, 0):
+        hip.set("chain_spmv", fused)
+        try:
+            before = hip.counters()
+            V, W = hip.alloc(n, m + 1, dtype=complex), hip.alloc(n, 2, dtype=complex)
+            V.upload(0, (v / np.linalg.norm(v)).reshape(-1, 1))
+            H = np.zeros((m + 1, m), dtype=complex)
+            for k in range(m):
+                hk = H[k, k - 1] if k > 0 else 0.0
+                hcol = hip.arnoldi_step(Ad, None, V, None, W, 0, k, k, 1, 0, hk)
+                H[k: k + 2, k] = hcol[k: k + 2]
+                if k > 0:
+                    H[k - 1, k] = H[k, k - 1]
+            c = hip.counters()
+            assert c["chain_fused"] - before["chain_fused"] == (m if fused else 0), (fused, c)
+            out.append((H, V.download()))
+            del V, W
+        finally:
+            hip.set("chain_spmv", 1)
+    (Hf, Vf), (Hs, Vs) = out
+    assert np.array_equal(Hf, Hs) and np.array_equal(Vf, Vs)
+    assert np.max(np.abs(Hf.imag)) < 1e-12
+    assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-10 * np.linalg.norm(Hf)

@@ -21,6 +21,26 @@ A = (A + sp.diags(1j * np.linspace(0.1, 1.0, N))).tocsr()
 rng = np.random.default_rng(0)
 b = rng.standard_normal(N) + 1j * rng.standard_normal(N)
 ls = linsys.LinearSystem(A, b)
+if "minres" in sys.argv[1:]:
+    # complex Hermitian MINRES (krypy/linsys.py:791-853 on c128 data): the Laplacian between two diagonals of phases, 150 steps
+    sys.argv.remove("minres")
+    ph = sp.diags(np.exp(1j * rng.uniform(0, 2 * np.pi, N)))
+    Ah = (ph.conj() @ bench.laplace2d(NX, NY).astype(complex) @ ph).tocsr()
+    Ah.sort_indices()
+    lsh = linsys.LinearSystem(Ah, b, self_adjoint=True)
+    for it in range(2):
+        ctx.sync()
+        t0 = time.perf_counter()
+        try:
+            s = linsys.Minres(lsh, maxiter=150, tol=1e-30)
+        except utils.ConvergenceError as e:
+            s = e.solver
+        ctx.sync()
+        dt = time.perf_counter() - t0
+    print(json.dumps({"config": "complex Hermitian MINRES, N=%d, 150 steps" % N, "iterations_per_s": (len(s.resnorms) - 1) / dt,
+                      "relres": float(s.resnorms[-1])}))
+    if not sys.argv[1:]:
+        sys.exit(0)
 for ortho in (sys.argv[1:] or ["mgs", "cgs"]):
     for it in range(2):
         ctx.sync()

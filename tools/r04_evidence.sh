@@ -40,7 +40,7 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000
   KRYPY_AMD_MGS_LOWSYNC=0 python bench.py --force-sharded --nx 4000 --ny 313 --ortho mgs --no-roofline --steps 3 --other-modes none 2>/dev/null | python -c "
 import json,sys
 d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('shard 4000 x 313 (mgs, one all-reduce per link): %.0f it/s' % d['value'])" | tee -a gpurun_out/ev/shards.log
-  python tools/complex_bench.py 2>/dev/null | tail -3 | tee gpurun_out/ev/complex.log
+  python tools/complex_bench.py minres mgs cgs 2>/dev/null | tail -3 | tee gpurun_out/ev/complex.log
   ;;
 fallback)
   # the fallback paths are tested paths: the parity / complex / blocked / loopback files under the switches that take the round's
