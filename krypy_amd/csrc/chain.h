@@ -2032,9 +2032,13 @@ static __global__ __launch_bounds__(LS_MAXCOL) void k_lowsync_solve(int k, const
     const int ld = k + 1;
     double* bc = ls_sm + (size_t)k * ld;
     if (tid < k) gt[(size_t)tid * LS_MAXCOL + k] = cg[k + 1 + tid];            // column k of the table: <v_m, v_k>
-    for (int m = 0; m < k; ++m)
-        for (int j = m + 1 + tid; j <= k; j += LS_MAXCOL)
-            ls_sm[(size_t)m * ld + j] = (j == k) ? cg[k + 1 + m] : gt[(size_t)m * LS_MAXCOL + j];
+    // (the whole k x (k + 1) rectangle in one flat loop of independent loads: the entries at and below the diagonal are
+    // never read; a row-by-row loop over the triangle waited for memory k times)
+#pragma unroll 4
+    for (int e = tid; e < k * ld; e += LS_MAXCOL) {
+        const int m = e / ld, j = e - m * ld;
+        ls_sm[e] = (j == k) ? cg[k + 1 + m] : gt[(size_t)m * LS_MAXCOL + j];
+    }
     double c = (tid <= k) ? cg[tid] : 0.0;
     __syncthreads();
     for (int m = 0; m < k; ++m) {

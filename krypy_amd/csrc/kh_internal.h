@@ -113,6 +113,8 @@ struct kh_ctx_s {
     unsigned long long* proj_gran = nullptr;   // granules, per-XCD totals and leader stamps of its 16-value sums
     unsigned proj_epoch = 1;
     int64_t n_proj_reg = 0;
+    int proj_panel = 1;              // ... or, on N ranks, its passes through the register-resident panel kernels (KRYPY_AMD_PROJ_PANEL)
+    int64_t n_proj_panel = 0;        // sweeps that took them
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
     int64_t n_minres_cycle_steps = 0;   // MINRES iterations recorded by kh_minres_cycle
     int64_t n_cg_cycle_steps = 0;       // CG iterations recorded by kh_cg_cycle

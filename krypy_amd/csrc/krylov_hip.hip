@@ -1043,6 +1043,51 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
     return 1;
 }
 
+// One pass of the register-resident panel kernels over columns 0 .. ncol-1 of block X with w in registers: the dots pass
+// (wave partials of <x_j, w> into ctx->cgs_part, *nwave of them per column) or the update pass (w -= sum_j coef[j] x_j).
+// What try_cgs_reg does for an Arnoldi step, for callers with their own coefficients in between - the deflation projector
+// on N ranks.  Returns 1 when launched, 0 when this shape is not served.
+static int cgs_panel_pass(kh_ctx ctx, kh_vec X, int ncol, double* w, int64_t wld, const double* coef, bool update, int* nwave) {
+    if (!ctx->chain_enabled || ncol < 1 || ncol > CGS_MAXCOL) return 0;
+    const int64_t n = X->n;
+    int r2 = 0, G = 0;
+    // (measured, d = 16, two sweeps: 12.5 M rows - 48 rows per lane - 1075 against 1111 us for the chunked kernels; 8 M rows -
+    // 32 rows per lane - 764 against 737: the long shapes only)
+    if (!chain_geometry(ctx, n, &r2, &G) || r2 < 40) return 0;
+    if ((n & 1) && (X->ld <= n || wld <= n)) return 0;
+    const int64_t chunk2 = (int64_t)r2 * CH_BS;
+    const int64_t need_ld = (int64_t)G * chunk2 * 2;
+    const bool padded = X->ld >= need_ld && wld >= need_ld;
+    if (ctx->cgs_part == nullptr)
+        KH_HIP(hipMalloc(&ctx->cgs_part, sizeof(double) * (size_t)2 * CGS_MAXCOL * CGS_PSTRIDE));
+    CgsArgs a;
+    a.n2 = (n + 1) >> 1;
+    a.chunk2 = chunk2;
+    a.Vb = X->d;
+    a.ld = X->ld;
+    a.col0 = 0;
+    a.ncol = ncol;
+    a.w = w;
+    a.coef = coef;
+    a.part = update ? part_slot(ctx, SLOT_NRM) : ctx->cgs_part;
+    a.pstride = CGS_PSTRIDE;
+    a.dg = nullptr;
+    a.mw = nullptr;
+    a.reverse = 0;
+    a.nt_cols = ((double)ncol * (double)n * 8.0 > 0.75e9) ? 1 : 0;
+    a.x2 = nullptr;
+    a.part2 = nullptr;
+#define KH_PP_L(R, WL) (padded ? launch_cgs<R, false, WL>(ctx, G, a, update) : launch_cgs<R, true, WL>(ctx, G, a, update))
+    const hipError_t e = r2 == 40 ? KH_PP_L(40, 0) : r2 == 48 ? KH_PP_L(48, 8) : KH_PP_L(56, 16);
+#undef KH_PP_L
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    *nwave = G * (CH_BS / 64);
+    return 1;
+}
+
 // ---- reference-order Gram-Schmidt with one reduction per step (chain.h: k_cgs_dots<..., X2>, k_lowsync_solve) -----
 template <int R2, bool MASKED>
 static hipError_t launch_dots_x2(kh_ctx ctx, int G, CgsArgs& a) {
@@ -1242,6 +1287,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");
         ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_PROJ_PANEL");
+        ctx->proj_panel = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_MGS_LOWSYNC");
         ctx->mgs_lowsync = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK_ONEX_MAXN");
@@ -1362,6 +1409,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
     else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
     else if (!strcmp(key, "proj_reg")) ctx->proj_reg = value != 0;
+    else if (!strcmp(key, "proj_panel")) ctx->proj_panel = value != 0;
     else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
@@ -1401,6 +1449,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "mgs_lowsync")) *value = ctx->mgs_lowsync;
     else if (!strcmp(key, "proj_reg")) *value = ctx->proj_reg;
     else if (!strcmp(key, "n_proj_reg")) *value = ctx->n_proj_reg;
+    else if (!strcmp(key, "proj_panel")) *value = ctx->proj_panel;
+    else if (!strcmp(key, "n_proj_panel")) *value = ctx->n_proj_panel;
     else if (!strcmp(key, "n_lowsync")) *value = ctx->n_lowsync;
     else if (!strcmp(key, "n_ls_rebuild")) *value = ctx->n_ls_rebuild;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
@@ -2011,13 +2061,27 @@ static int proj_apply_dev(kh_ctx ctx, kh_proj p, double* z, double* ya_dev, int6
         }
     }
     for (int it = 0; it < p->iterations; ++it) {
-        KH_TRY(dot_panel_dev(ctx, p->W, 0, d, z, p->c0, 0));
+        // long vectors (N ranks, or one GPU without the one-launch form): the passes over W and V through the
+        // register-resident panel kernels - the same launches and bytes as the chunked kernels, at their streaming rate
+        int nwave = 0;
+        const bool panel = zld > 0 && ctx->proj_panel && p->W->ld == p->V->ld;
+        const int rc_d = panel ? cgs_panel_pass(ctx, p->W, d, z, zld, nullptr, false, &nwave) : 0;
+        if (rc_d < 0) return rc_d;
+        if (rc_d == 1) {
+            hipLaunchKernelGGL(k_reduce_partials, dim3(d), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave, CGS_PSTRIDE, p->c0, 0);
+            KH_HIP(hipGetLastError());
+        } else {
+            KH_TRY(dot_panel_dev(ctx, p->W, 0, d, z, p->c0, 0));
+        }
         if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, d));
         if (it == 0 && ya_dev != nullptr)
             hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->WRH, p->c0, ya_dev);
         hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->T, p->c0, p->c1);
         KH_HIP(hipGetLastError());
-        KH_TRY(multiaxpy_cols(ctx, p->V, 0, d, p->c1, 1.0, 1.0, z, T_NONE, nullptr, nullptr));
+        const int rc_u = panel ? cgs_panel_pass(ctx, p->V, d, z, zld, p->c1, true, &nwave) : 0;
+        if (rc_u < 0) return rc_u;
+        if (rc_u == 0) KH_TRY(multiaxpy_cols(ctx, p->V, 0, d, p->c1, 1.0, 1.0, z, T_NONE, nullptr, nullptr));
+        if (rc_u == 1) ctx->n_proj_panel += 1;
     }
     return 0;
 }

@@ -257,17 +257,22 @@ def test_projector_with_the_vector_in_registers(hip, n, d):
     pj = hip.proj_create(Wd, Vd, d, T, WRH, 2)
     A = hip.upload(a)
     out = {}
-    for reg in (1, 0):
-        hip.set("proj_reg", reg)
+    # 1: one launch, z in registers; 0: the passes over W and V through the register-resident panel kernels (what N ranks
+    # run, with the all-reduce in between); 2: the chunked kernels (k_multidot<16> / k_multiaxpy<16>)
+    for reg in (1, 0, 2):
+        hip.set("proj_reg", 1 if reg == 1 else 0)
+        hip.set("proj_panel", 0 if reg == 2 else 1)
         try:
             Z = hip.alloc(n, 1)
-            c0 = hip.get("n_proj_reg")
+            c0, p0 = hip.get("n_proj_reg"), hip.get("n_proj_panel")
             ya = hip.proj_apply_complement(pj, A, 0, Z, 0, want_ya=True)
-            out[reg] = (Z.download()[:, 0], np.array(ya), hip.get("n_proj_reg") - c0)
+            out[reg] = (Z.download()[:, 0], np.array(ya), hip.get("n_proj_reg") - c0, hip.get("n_proj_panel") - p0)
             del Z
         finally:
             hip.set("proj_reg", 1)
-    assert out[1][2] == 1 and out[0][2] == 0, (out[1][2], out[0][2])
+            hip.set("proj_panel", 1)
+    assert out[1][2] == 1 and out[0][2] == 0 and out[2][2] == 0, (out[1][2], out[0][2], out[2][2])
+    assert out[1][3] == 0 and out[0][3] == (2 if n > 8_400_000 else 0) and out[2][3] == 0, (out[1][3], out[0][3], out[2][3])      # (40 rows per lane and more)
     z = a.copy()
     ya_want = None
     for it in range(2):
@@ -276,7 +281,7 @@ def test_projector_with_the_vector_in_registers(hip, n, d):
             ya_want = c if WRH is None else WRH.dot(c)
         z = z - Vh.dot(c if T is None else T.dot(c))
     zn = np.linalg.norm(z)
-    for reg in (1, 0):
+    for reg in (1, 0, 2):
         assert np.linalg.norm(out[reg][0] - z) < 1e-13 * zn * max(1.0, np.linalg.norm(T) if T is not None else 1.0), reg
         assert np.linalg.norm(out[reg][1] - ya_want) < 1e-13 * max(np.linalg.norm(ya_want), 1.0), reg
     assert np.linalg.norm(out[1][0] - out[0][0]) < 1e-13 * zn * max(1.0, np.linalg.norm(T) if T is not None else 1.0)

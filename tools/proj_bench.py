@@ -25,8 +25,9 @@ def main(sizes):
         pj = ctx.proj_create(Wd, Vd, d, rng.standard_normal((d, d)) * 0.1, None, 2)
         A, Z = ctx.upload(rng.standard_normal(n)), ctx.alloc(n, 1)
         out = []
-        for reg in (1, 0):
-            ctx.set("proj_reg", reg)
+        for reg in (1, 0, 2):
+            ctx.set("proj_reg", 1 if reg == 1 else 0)
+            ctx.set("proj_panel", 0 if reg == 2 else 1)
             ctx.proj_apply_complement(pj, A, 0, Z, 0, want_ya=True)
             best = 1e30
             for _ in range(3):
@@ -34,10 +35,11 @@ def main(sizes):
                 for _ in range(20):
                     ctx.proj_apply_complement(pj, Z, 0, Z, 0)
                 best = min(best, ctx.timer_stop() / 20)
-            nbytes = (528.0 if reg else 560.0) * n
-            out.append("%s %.1f us (%.2f TB/s on %d N bytes)" % ("one launch" if reg else "four launches per sweep", best * 1e3,
-                                                                  nbytes / (best * 1e-3) / 1e12, 528 if reg else 560))
+            nbytes = (528.0 if reg == 1 else 560.0) * n
+            label = {1: "one launch", 0: "four launches per sweep, panel kernels (the N-rank form)", 2: "four launches per sweep, chunked kernels"}[reg]
+            out.append("%s %.1f us (%.2f TB/s on %d N bytes)" % (label, best * 1e3, nbytes / (best * 1e-3) / 1e12, 528 if reg == 1 else 560))
         ctx.set("proj_reg", 1)
+        ctx.set("proj_panel", 1)
         print("N = %9d: %s" % (n, "; ".join(out)), flush=True)
         del Wd, Vd, A, Z, pj
 
