@@ -108,6 +108,9 @@ struct kh_ctx_s {
     const void* ls_V = nullptr;      // the basis block whose sequence owns the table ...
     int64_t ls_next = -1;            // ... and the step that finds columns 0 .. k-1 of it valid
     int64_t n_lowsync = 0, n_ls_rebuild = 0;
+    // N ranks: (local slab length, longest slab of the run) pairs announced by the host layer - the form is chosen for the longest
+    int64_t ls_rows_local[4] = {-1, -1, -1, -1}, ls_rows_max[4] = {0, 0, 0, 0};
+    int ls_rows_n = 0;
     // the deflation projector with the vector in registers, one launch (proj_reg.h; KRYPY_AMD_PROJ_REG)
     int proj_reg = 1;
     unsigned long long* proj_gran = nullptr;   // granules, per-XCD totals and leader stamps of its 16-value sums

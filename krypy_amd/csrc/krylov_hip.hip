@@ -1118,6 +1118,17 @@ static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
     if (!ctx->mgs_lowsync || !ctx->chain_configured || k + 1 > LS_MAXCOL) return false;
     const int64_t n = V->n;
     int r2 = 0, G = 0;
+    // N ranks: this choice changes the PATTERN of all-reduces (one of 2 k + 1 values against k + 1 of one value), so every
+    // rank must make it alike whatever the length of its own slab: it is made for the longest slab of the run, which the
+    // host layer has announced for vectors of this local length (krypy_amd/dist.py: kh_ctx_set "lowsync_rows"); without
+    // that announcement the per-link path - the same on every rank - is taken
+    if (ctx->nranks > 1) {
+        int64_t nmax = 0;
+        for (int i = 0; i < 4; ++i)
+            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        int r2m = 0, Gm = 0;
+        if (nmax < n || !chain_geometry(ctx, nmax, &r2m, &Gm) || r2m > 24) return false;
+    }
     if (!chain_geometry(ctx, n, &r2, &G) || r2 > 24) return false;      // (the second right-hand side: 16 rows of 8 KB in LDS, 8 more in registers;
                                                                         //  at 32 rows per lane the dots kernel spills 102 registers)
     if ((n & 1) && (V->ld <= n || wld <= n)) return false;
@@ -1408,6 +1419,15 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
     else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
+    else if (!strcmp(key, "lowsync_rows")) {        // (local slab length << 32) | longest slab of the run
+        const int64_t loc = value >> 32, mx = value & 0xffffffffll;
+        int slot = ctx->ls_rows_n % 4;
+        for (int i = 0; i < 4; ++i)
+            if (ctx->ls_rows_local[i] == loc) slot = i;
+        if (ctx->ls_rows_local[slot] != loc) ctx->ls_rows_n += 1;
+        ctx->ls_rows_local[slot] = loc;
+        ctx->ls_rows_max[slot] = mx;
+    }
     else if (!strcmp(key, "proj_reg")) ctx->proj_reg = value != 0;
     else if (!strcmp(key, "proj_panel")) ctx->proj_panel = value != 0;
     else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;

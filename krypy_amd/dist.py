@@ -211,12 +211,17 @@ class ShardedCSROperator(utils.LinearOperator):
         nloc = A_local.shape[0]
         # every rank learns its neighbours' halo widths: what rank p receives from p-1 is what
         # p-1 has to send "next", and vice versa
-        table = numpy.zeros(2 * ctx.nranks)
-        table[2 * ctx.rank] = nrp
-        table[2 * ctx.rank + 1] = nrn
+        table = numpy.zeros(3 * ctx.nranks)
+        table[3 * ctx.rank] = nrp
+        table[3 * ctx.rank + 1] = nrn
+        table[3 * ctx.rank + 2] = nloc
         table = ctx.allreduce_host(table)
-        nsend_prev = int(table[2 * (ctx.rank - 1) + 1]) if ctx.rank > 0 else 0
-        nsend_next = int(table[2 * (ctx.rank + 1)]) if ctx.rank + 1 < ctx.nranks else 0
+        nsend_prev = int(table[3 * (ctx.rank - 1) + 1]) if ctx.rank > 0 else 0
+        nsend_next = int(table[3 * (ctx.rank + 1)]) if ctx.rank + 1 < ctx.nranks else 0
+        # the LONGEST slab of the run: kernel choices that change the pattern of all-reduces (the one-reduction form of
+        # reference-order Gram-Schmidt) must come out the same on every rank, so they are made for that length
+        if hasattr(ctx, "set") and ctx.nranks > 1:
+            ctx.set("lowsync_rows", (int(nloc) << 32) | int(table[2::3].max()))
         if nsend_prev > nloc or nsend_next > nloc:
             raise utils.ArgumentError("halo wider than the local slab: use fewer ranks")
         self._A_local = A_local
