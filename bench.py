@@ -384,7 +384,10 @@ def _run():
     # sharded runs: the reference order next to the panel form.  On N ranks ortho='mgs' takes all k + 1 coefficients of a
     # step from one pass and ONE all-reduce (Gram-table correction, krylov_hip.hip: try_lowsync_mgs) - two all-reduces per
     # step like 'cgs', the reference's recurrence in exact arithmetic; all-reduces per Arnoldi step are counted
-    if sharded and args.other_modes and hasattr(ctx, "get"):
+    # (on one rank in forced mode by default; on a real N-rank run only with KRYPY_AMD_BENCH_SHARDED_EXTRAS=1 - the one-reduction form
+    # has run through a 1-rank communicator only, and an untimed extra must not be able to cost the run its line)
+    if (sharded and args.other_modes and hasattr(ctx, "get")
+            and (world == 1 or os.environ.get("KRYPY_AMD_BENCH_SHARDED_EXTRAS", "0") == "1")):
         for mode in [t for t in ("cgs", "mgs") if t != ortho]:
             barrier()
             a0 = ctx.get("n_allreduce")
