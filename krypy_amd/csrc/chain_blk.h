@@ -17,28 +17,43 @@
 // NOT one of the bit-for-bit ones (it also fuses the update's multiply and subtract); it is held to north_star's 1e-10
 // against the per-column kernels and the CPU oracle (tests/test_gpu_blocked.py).
 //
-// The Gram entries are a property of the basis: row j of a small device table holds <v_m, v_j> for the columns m < j of
-// j's block.  The launch of step k computes row k + 1 while it still holds the last block and the final w (BC - 1 more
-// values in the sum that carries ||w||^2; G = <v_m, w> / h) and reads the rows of columns <= k.  The table belongs to ONE
-// Arnoldi sequence (ctx->blk_V, ctx->blk_next: this basis block, the next step); a step that is not the next one of that
-// sequence - another basis, a block recycled / grown / written to through any other entry point since (chain_blk_touch) -
-// rebuilds the rows from the basis first (one panel product per column, krylov_hip.hip), so a stale table cannot be used.
+// The Gram entries are a property of the basis: row j of a small device table holds <v_m, v_j> for the BC columns m of the block
+// BEFORE j's and for the columns m < j of j's own block.  The launch of step k computes row k + 1 while it still holds the last
+// two blocks and the final w (2 BC - 1 more values in the sum that carries ||w||^2; G = <v_m, w> / h) and reads the rows of
+// columns <= k.  The table belongs to ONE Arnoldi sequence (ctx->blk_V, ctx->blk_next: this basis block, the next step); a step
+// that is not the next one of that sequence - another basis, a block recycled / grown / written to through any other entry
+// point since (chain_blk_touch) - rebuilds the rows from the basis first (two panel products per column, krylov_hip.hip), so a
+// stale table cannot be used.
 // (A stateless form - the block's six Gram entries computed from the resident columns in every launch, ten values per
 // sum - was built first: its arithmetic, 900 instructions per block and wave, cost what the saved sums gained.)
 //
-// Shape: the short-vector geometry of k_mgs_chain_small (4 rows of 16 B per lane, 512 working lanes per workgroup), a
-// ring of NSLOT = 2 blocks of BC whole columns in registers (the loads of block i + 2 are issued when block i has been
-// used), and a NINTH wave per workgroup that owns no rows and does all the communication.  The eight working waves
-// leave their wave partials in LDS and wait at two LDS-only barriers; the communication wave publishes the workgroup's
-// partials as tagged 8-byte granules (chain.h), gathers everybody's - every workgroup itself when all run on one XCD
-// (ONEX, L2 hits), otherwise group by group (the wave of workgroup j adds group j's 16 records) and then the XCD leaders
-// the groups, the totals handed on through the XCD's L2 - adds them in an order that depends on the workgroup numbers
-// only (every workgroup: the same bits, run after run) and puts the totals and the block's Gram entries into LDS.
+// ONE BLOCK AHEAD.  The c_l of block i + 1 are taken while block i's sums are exchanged, i.e. against a w that block i has not
+// updated yet; blk_alphas corrects for block i's coefficients with the entries between the two blocks exactly as it does for
+// the earlier columns of the own block (the same identity, BC more terms).  A block is then
+//     partial sums of block i -> LDS | barrier A | request block i + 1, its dots | barrier B | w -= block i
+// and what runs between the barriers - the stream of the next block and its dots - runs UNDER the exchange.
 //
-// What bounds it (tools/blk_prof.py, profiles/r04_blk_*.log): a poll of the communication wave waits in the compute
-// unit's memory queue behind whatever the working waves have requested, so on every compute unit the exchange of block
-// i and the stream of block i + 1 take turns whatever the code does - a block costs stream + exchange + arithmetic
-// (N = 10^6: 4.0 + 3.2 + 2.0 us per four links = 2.3 us per link against 3.2 for the per-column kernel).
+// Shape: the short-vector geometry of k_mgs_chain_small (4 rows of 16 B per lane, 512 working lanes per workgroup), two blocks
+// of BC whole columns in registers (the block being subtracted and the block whose dots run), and a NINTH wave per workgroup
+// that owns no rows and does all the communication.  The eight working waves leave their wave partials in LDS and wait at two
+// LDS-only barriers; the communication wave publishes the workgroup's partials as tagged 8-byte granules (chain.h), gathers
+// everybody's - every workgroup itself when all run on one XCD (ONEX, L2 hits), otherwise group by group (the wave of
+// workgroup j adds group j's 32 records) and then the XCD leaders the groups, the totals handed on through the XCD's L2 -,
+// adds them in an order that depends on the workgroup numbers only (every workgroup: the same bits, run after run), forms
+// the block's coefficients (blk_alphas) and leaves them in LDS.
+//
+// What bounds it, and the two things that made the exchange and the stream overlap (tools/blk_prof.py, blk_bench.py;
+// profiles/r04_blk_*.log).  A request of the communication wave waits in the compute unit's memory queue behind whatever the
+// working waves have requested.  (1) Requests issued BEFORE the sum kept the publication of the partial sums waiting for the
+// whole stream - stream and exchange took turns (first form of this round: stream 4.0 + exchange 3.2 + arithmetic 2.0 us per
+// block at N = 10^6).  The working waves now request the next block a moment AFTER barrier A (BLK_REQ_SLEEP), behind the
+// publication.  (2) The gathers still queued behind the stream on the compute units that do them.  Spread over the chip, the
+// launch therefore has EIGHT workgroups WITHOUT rows in front of the ones with rows (BlkBufs::nx): they come to the leader
+// election first and they are the workgroups 0 .. 7 that add up the groups, so both levels of the gather run on compute
+// units that carry no stream; a workgroup with rows only publishes (early) and polls its XCD's L2 for the totals (late,
+// behind its stream - which the dots need anyway).  N = 10^6: 7.5k -> 8.1k it/s of GMRES(100), 2.5 * 10^5: 11.4k -> 12.0k,
+// 10^5: 12.7k -> 13.9k (now spread over the chip: ctx->blk_onex_maxn), 10^4: 16.9k -> 17.7k; either measure alone gains
+// nothing (7.1k-7.6k at 10^6).
 #pragma once
 #include "chain.h"
 
@@ -55,21 +70,36 @@ constexpr int BLK_NSLOT = KH_BLK_NSLOT_CFG;   // blocks of columns in registers
 constexpr int BLK_NVMAX = 8;                  // values per sum (the block's BC coefficients; the norm + BC - 1 table entries)
 constexpr int BLK_NVS = 16;                   // granule PAIRS reserved per workgroup and parity (256 B records)
 constexpr int BLK_TABCOLS = 4096;             // basis columns the Gram table has rows for (BLK_BC entries each)
-constexpr int BLK_GS = 16;                    // workgroups per group of the two-level exchange
+#ifndef BLK_GS_CFG
+#define BLK_GS_CFG 32
+#endif
+constexpr int BLK_GS = BLK_GS_CFG;            // workgroups per group of the two-level exchange (32: the groups of a full chip are
+                                              // added up by the first EIGHT workgroups - the ones without rows, see BlkBufs::nx)
 constexpr int BLK_NG2 = CH_GMAX / BLK_GS;     // groups at most
 
+#ifndef BLK_REQ_SLEEP
+#define BLK_REQ_SLEEP 8                       // s_sleep units (64 clocks) between barrier A and the working waves' requests of the
+#endif                                        // next block: the publication of the partial sums goes out first (spread over the chip)
+#ifndef BLK_REQ_SLEEP_ONEX
+#define BLK_REQ_SLEEP_ONEX 16                 // ... on one XCD
+#endif
+constexpr int BLK_TW = 2 * BLK_BC;            // entries per row of the Gram table: BC of the previous block, < BC of the own
 template <int BC>
 struct BlkShape {
     static constexpr int NG = BC * (BC - 1) / 2;      // strict upper Gram entries of a block
-    static constexpr int NT = BC + NG;                // what the working waves read from LDS per block: coefficients + entries
-    static_assert(BC <= BLK_NVMAX && NT <= 64, "one communication wave handles a block's values");
+    static constexpr int NX = BC * BC;                // entries between a block and the block before it
+    static constexpr int NT = BC + NG + NX;           // what the working waves read from LDS per block: coefficients + entries
+    static_assert(2 * BC <= BLK_NVMAX && NT <= 64, "one communication wave handles a block's values");
 };
 
 struct BlkBufs {
     unsigned long long* gran;     // [2 parities][CH_GMAX][BLK_NVS][2] granules: the workgroups' partial sums
     unsigned long long* gran2;    // [2 parities][BLK_NG2][BLK_NVS][2] granules: the groups' partial sums (write-through)
     unsigned long long* res;      // [16 XCDs][2 parities][BLK_NVS][2] the totals, handed on inside an XCD through its L2
-    double* gtab;                 // [BLK_TABCOLS][BC] Gram table of the current Arnoldi sequence: row j = <v_m, v_j>, m in j's block
+    double* gtab;                 // [BLK_TABCOLS][BLK_TW] Gram table of the current Arnoldi sequence: row j = <v_m, v_j> for the BC
+                                  // columns m of the block before j's (entries 0 .. BC-1) and the columns m < j of j's block (BC ..)
+    int nx;                       // the first nx workgroups own NO rows: their compute units carry no column stream, so the sums
+                                  // they gather (the groups', the XCD leaders') do not queue behind one (0: everybody has rows)
 };
 
 // ---- the communication wave's side of a sum -------------------------------------------------------------------
@@ -152,6 +182,7 @@ struct BlkSm {
     double part[BLK_NVMAX * (CH_BS / 64)];
     double tot[BlkShape<BLK_BC>::NT];
     double q[64];
+    double al[BLK_BC];            // the block's coefficients, formed by the communication wave for everybody
 };
 
 // One grid-wide sum of NV values, communication wave.  Returns (lanes 0 .. NV-1) the totals, which are also in
@@ -168,7 +199,7 @@ struct BlkSm {
 template <int NV, bool ONEX>
 __device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf, int G, int bid, int* err, BlkSm& sm,
                                                const GridRole role, bool skip = false, int nv_all = NV,
-                                               double extra = 0.0) {
+                                               double extra = 0.0, bool barrier_b = true) {
     // (lanes NV .. nv_all-1 put `extra` - the block's Gram entries from the table - behind the totals)
     constexpr int NW = CH_BS / 64;
     constexpr int NGRP = 64 / NV;
@@ -234,7 +265,8 @@ __device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf
     }
     if (lane < NV) sm.tot[lane] = t;
     else if (lane < nv_all) sm.tot[lane] = extra;
-    ch_lds_barrier();                                  // B: the totals are in LDS
+    if (barrier_b) ch_lds_barrier();                   // B: the totals are in LDS
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (the caller reads them first: one wave, its LDS writes are in order)
     return t;
 }
 
@@ -254,12 +286,23 @@ __device__ __forceinline__ void blk_sum_work(const double (&val)[NV], BlkSm& sm)
 
 // alpha_l = c_l - sum_{m<l} alpha_m G_{m,l} (fixed order; tot = [c_0 .. c_{BC-1}, G_01, G_02, G_12, G_03, ...]:
 // the Gram entries of column l sit behind those of column l - 1)
+// ONE BLOCK AHEAD (round 4, second form): the c_l of a block are taken against the w that the block BEFORE it has not yet
+// updated either - the dots of block i + 1 run while block i's sums are exchanged -, so the coefficients of the previous block
+// (aprev) are corrected for as well:  alpha_l = c_l - sum_{m in previous block} aprev_m X_{m,l} - sum_{m<l} alpha_m G_{m,l};
+// tot = [c_0 .. c_{BC-1} | G_01, G_02, G_12, ... | X_{0,0} .. X_{BC-1,0}, X_{0,1} ...] (X_{m,l}: entry m of column l's table row).
+// The order of the subtractions is that of the reference's loop: earlier columns first.
 template <int BC>
-__device__ __forceinline__ void blk_alphas(const double* tot, int nvalid, double (&alpha)[BC]) {
+__device__ __forceinline__ void blk_alphas(const double* tot, int nvalid, const double (&aprev)[BC], double (&alpha)[BC]) {
+    constexpr int NG = BlkShape<BC>::NG;
     int gi = BC;
 #pragma unroll
     for (int l = 0; l < BC; ++l) {
         double a = tot[l];
+#pragma unroll
+        for (int m = 0; m < BC; ++m) {
+            const double pr = aprev[m] * tot[BC + NG + l * BC + m];
+            a = a - pr;
+        }
 #pragma unroll
         for (int m = 0; m < l; ++m) {
             const double pr = alpha[m] * tot[gi + m];
@@ -294,15 +337,24 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
     int G = gridDim.x;
     int bid = blockIdx.x;
     GridRole role;
+    int nx = 0;
     if constexpr (ONEX) {
         if (!onex_enter(a, &slead, bid, G, role)) return;
     } else {
+        nx = bf.nx;
+        // (the workgroups with rows come to the leader election late: the first arrival of an XCD leads it, and the
+        // leaders should be workgroups without a column stream.  Who leads changes nothing in the sums' bits.)
+        if (nx > 0 && bid >= nx) __builtin_amdgcn_s_sleep(48);
         role = grid_role(a.xcc_leader, a.epoch0, &slead);
     }
+    const bool rowless = bid < nx;
     unsigned epoch = a.epoch0;
     const int total = a.ncol;                               // links (one sweep, columns 0 .. ncol-1: blocks are aligned)
     const int nblk = (total + BC - 1) / BC;
-    const int nlast = total - (nblk - 1) * BC;              // links of the last block
+    // (chain_blk_shape_ok: at least NSLOT blocks.  Told to the compiler: for the path around the steady-state loop it
+    // parks the whole ring in scratch memory in front of the loop.)
+    __builtin_assume(total > BC * (NSLOT - 1));
+    __builtin_assume(nblk >= NSLOT);
     if (tid >= CH_BS) {
         // ---- the communication wave: the sums, the H entries and the Gram table; no rows ----
         const int lane = tid - CH_BS;
@@ -314,29 +366,46 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
             for (int l = 1; l < BC; ++l)
                 if (e >= 0 && e < l) { gl = l; gm = e; e = -1; } else if (e >= 0) e -= l;
         }
+        double aprev[BC];
+#pragma unroll
+        for (int l = 0; l < BC; ++l) aprev[l] = 0.0;
+        constexpr int NG_ = BlkShape<BC>::NG;
         for (int ib = 0; ib < nblk; ++ib) {
             double gval = 0.0;                              // requested before the sum: it arrives under it
-            if (lane >= BC && lane < NT && ib * BC + gl < total)
-                gval = __hip_atomic_load(bf.gtab + (size_t)(ib * BC + gl) * BC + gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex, NT, gval);
-            if (writer) {
+            if (lane >= BC && lane < BC + NG_ && ib * BC + gl < total)
+                gval = __hip_atomic_load(bf.gtab + (size_t)(ib * BC + gl) * BLK_TW + BC + gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane >= BC + NG_ && lane < NT && ib > 0) {      // X_{m,l}: lane BC + NG + l * BC + m
+                const int x = lane - (BC + NG_), l = x / BC, m = x - l * BC;
+                if (ib * BC + l < total)
+                    gval = __hip_atomic_load(bf.gtab + (size_t)(ib * BC + l) * BLK_TW + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            (void)blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex, NT, gval, false);
+            {
                 double alpha[BC];
                 const int nvalid = total - ib * BC;
-                blk_alphas<BC>(sm.tot, nvalid, alpha);
+                blk_alphas<BC>(sm.tot, nvalid, aprev, alpha);
 #pragma unroll
                 for (int l = 0; l < BC; ++l) {
                     const int j = ib * BC + l;
-                    if (j < total) a.hdev[a.col0 + j] = (a.debug == 4) ? alpha[l] * 0.5 : alpha[l];   // (what the working waves subtract)
+                    const double al = (a.debug == 4) ? alpha[l] * 0.5 : alpha[l];      // ... a faked timeout leaves garbage behind
+                    if (writer && j < total) a.hdev[a.col0 + j] = al;                  // (what the working waves subtract)
+                    if (lane == 0) sm.al[l] = al;
+                    aprev[l] = alpha[l];
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (sm.tot has been read before the next sum rewrites it)
+            ch_lds_barrier();                                     // B: the block's coefficients are in LDS
         }
-        // the norm, and <v_m, w> for the columns m of the last block: row k+1 of the table when v_{k+1} joins that block
-        const double tf = blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex);
+        // the norm, and <v_m, w> for the columns of the new column's row of the table: lanes 1 .. BC the block before the new
+        // column's, lanes BC + 1 .. 2 BC - 1 the earlier columns of its own block
+        const double tf = blk_sum_comm<2 * BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex);
         const double h = sqrt(fabs(sm.tot[0]));
         if (writer) a.hdev[a.hnext] = h;
-        if (bid == 0 && lane >= 1 && lane < BC && (total % BC) != 0 && lane - 1 < nlast)
-            bf.gtab[(size_t)total * BC + (lane - 1)] = tf / h;
+        {
+            const int pnew = total % BC, bnew = total / BC;      // the new column: position in its block, its block
+            const int e = lane - 1;                              // table entry this lane's value belongs to
+            const bool ok = (e >= 0 && e < BC) ? (bnew >= 1) : (e >= BC && e < BC + pnew);
+            if (bid == 0 && ok && e < BLK_TW) bf.gtab[(size_t)total * BLK_TW + e] = tf / h;
+        }
         if (bid == 0 && a.hpin != nullptr) {
             __threadfence();                                      // the H entries, for the working waves' copy below
             __syncthreads();
@@ -344,7 +413,27 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
         }
         return;
     }
-    const int64_t first = (int64_t)bid * a.chunk2 + tid;
+    // bid == 0 hands the H entries to the host when the chain is done (after the communication wave has written them)
+    auto finish = [&]() __attribute__((always_inline)) {
+        if (bid == 0 && a.hpin != nullptr) {
+            __syncthreads();          // the H entries were written by the communication wave of this workgroup
+            for (int i = tid; i < a.hcount; i += CH_BS)
+                a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            CH_SIGNAL_DONE(a);
+        }
+    };
+    if (rowless) {
+        // no rows: partial sums of zero, and the barriers of the nblk + 1 sums
+        for (int i = tid; i < BLK_NVMAX * (CH_BS / 64); i += CH_BS) sm.part[i] = 0.0;
+        for (int s_ = 0; s_ <= nblk; ++s_) {
+            ch_lds_barrier();
+            ch_lds_barrier();
+        }
+        finish();
+        return;
+    }
+    const int64_t first = (int64_t)(bid - nx) * a.chunk2 + tid;
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
 #define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
@@ -374,8 +463,10 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
         }
     }
     CH_ISSUE_FENCE();
+    // block 0 (block 1 is requested inside block 0's sum, like every other block; the measurement form without the column
+    // stream fills both slots here)
 #pragma unroll
-    for (int s = 0; s < NSLOT; ++s) {
+    for (int s = 0; s < (dbg_nost ? NSLOT : 1); ++s) {
 #pragma unroll
         for (int l = 0; l < BC; ++l) {
             const char* __restrict__ c = CH_COL(s * BC + l);
@@ -385,12 +476,11 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
     }
     CH_ISSUE_FENCE();
     if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
-    // one block: coefficients, sum, update, request of the block NSLOT blocks ahead into the freed slot S
-    auto block = [&](const int i, auto slot_c) {
+    static_assert(NSLOT == 2, "one block ahead: the block being updated and the block whose dots run under its sums");
+    // the coefficients of the block in slot S against w as it is now
+    auto dots = [&](const int i, auto slot_c, double (&val)[BC]) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_c)::value;
-        const int nvalid = total - i * BC;           // links of this block (>= BC except in the last one)
-        double val[BC];
-        // the block's coefficients against the not yet updated w
+        const int nvalid = total - i * BC;
 #pragma unroll
         for (int l = 0; l < BC; ++l) {
             double acc0 = 0.0, acc1 = 0.0;
@@ -404,30 +494,66 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
             }
             val[l] = (l < nvalid) ? acc0 + acc1 : 0.0;
         }
-        blk_sum_work<BC>(val, sm);
+    };
+    double val[BC];
+    dots(0, std::integral_constant<int, 0>{}, val);
+    // one block: its sums go out (val: taken BEFORE the previous block's update, see blk_alphas), the NEXT block's dots run
+    // while they are exchanged, then the update and the request of the block NSLOT blocks ahead into the freed slot S
+    auto block = [&](const int i, auto slot_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_c)::value;
+        const int nvalid = total - i * BC;           // links of this block (>= BC except in the last one)
+        {
+            constexpr int NW = CH_BS / 64;
+            const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+            for (int v = 0; v < BC; ++v) {
+                const double ws = wave_sum_dpp(val[v]);
+                if (lane == 0) sm.part[v * NW + wid] = ws;
+            }
+        }
+        ch_lds_barrier();          // A: the partial sums are in LDS, the communication wave takes over
+        // The NEXT block is requested now, into the slot the previous block's update has freed - BEHIND the communication
+        // wave's publication of the partial sums in the compute unit's memory queue, not in front of it (a request issued
+        // before the sum keeps the publication waiting for the whole stream: the sum and the stream took turns).  At the end
+        // of the chain: the block before the last once more (the new column's row of the Gram table wants both).
+        if constexpr (!dbg_nost) {
+            if constexpr ((ONEX ? BLK_REQ_SLEEP_ONEX : BLK_REQ_SLEEP) > 0)
+                __builtin_amdgcn_s_sleep(ONEX ? BLK_REQ_SLEEP_ONEX : BLK_REQ_SLEEP);
+            const int nxt = (i + 1 < nblk) ? i + 1 : i - 1;
+#pragma unroll
+            for (int l = 0; l < BC; ++l) {
+                const char* __restrict__ c = CH_COL(nxt * BC + l);
+#pragma unroll
+                for (int r = 0; r < R2; ++r) ring[1 - S][l][r] = CH_ROW(c, r);
+            }
+        }
+        CH_ISSUE_FENCE();
+        double valn[BC];
+        dots(i + 1, std::integral_constant<int, 1 - S>{}, valn);      // (behind the last block: the re-requested block, discarded)
+        // (the barriers order memory operations only: without this the compiler moves the dots behind barrier B)
+#pragma unroll
+        for (int l = 0; l < BC; ++l) asm volatile("" : "+v"(valn[l]) : : "memory");
+        ch_lds_barrier();          // B: the block's coefficients (formed by the communication wave, blk_alphas) are in LDS
         double alpha[BC];
-        blk_alphas<BC>(sm.tot, nvalid, alpha);
 #pragma unroll
         for (int l = 0; l < BC; ++l) {
-            const double al = (a.debug == 4) ? alpha[l] * 0.5 : alpha[l];      // ... a faked timeout leaves garbage behind
+            alpha[l] = sm.al[l];
+            val[l] = valn[l];
+        }
+        (void)nvalid;
+#pragma unroll
+        for (int l = 0; l < BC; ++l) {
+            const double al = alpha[l];
 #pragma unroll
             for (int r = 0; r < R2; ++r) {          // (one rounding per entry: this kernel is not the bit-for-bit one)
                 w[r].x = CH_OK(r) ? fma(-al, ring[S][l][r].x, w[r].x) : 0.0;
                 w[r].y = CH_OK(r) ? fma(-al, ring[S][l][r].y, w[r].y) : 0.0;
             }
         }
-        // the slot is free: the block NSLOT blocks ahead - or, at the end of the chain, this block again (the last
-        // block's columns are wanted once more, for the new column's row of the Gram table)
-        if constexpr (!dbg_nost) {
-            const int nxt = (i + NSLOT < nblk) ? i + NSLOT : i;
+        // w is COMPUTED here: otherwise the next requests into this slot are scheduled in front of the update and the
+        // slot's old values go to scratch memory
 #pragma unroll
-            for (int l = 0; l < BC; ++l) {
-                const char* __restrict__ c = CH_COL(nxt * BC + l);
-#pragma unroll
-                for (int r = 0; r < R2; ++r) ring[S][l][r] = CH_ROW(c, r);
-            }
-        }
-        CH_ISSUE_FENCE();
+        for (int r = 0; r < R2; ++r) asm volatile("" : "+v"(w[r].x), "+v"(w[r].y) : : "memory");
     };
     // The steady-state loop has NO conditional inside: a block that may or may not request columns leaves the compiler's
     // wait counts at "everything" on the back edge (s_waitcnt vmcnt(0) in front of every block: no column would ever be
@@ -441,7 +567,7 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
     });
 #undef CH_ROW
 #undef CH_COL
-    double nv[BC];
+    double nv[2 * BC];
     {
         double acc = 0.0;
 #pragma unroll
@@ -450,27 +576,35 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
             acc = fma(w[r].y, w[r].y, acc);
         }
         nv[0] = acc;
-        // <v_m, w> for the first BC - 1 columns of the last block (requested again), which sits in slot (nblk - 1) % NSLOT
+        // <v_m, w> for the new column's row of the table: the block before its own (BC columns) and the earlier columns of its
+        // own block.  Both are among the last two blocks of the chain, which were requested again and sit in the ring: the last
+        // block in slot (nblk - 1) % 2.  New column total = bnew * BC + pnew: pnew > 0 - own block = last block, the block before
+        // it in the other slot; pnew == 0 - no earlier column of its own block, the block before it = last block.
         const int sl = (nblk - 1) % NSLOT;
+        const int pnew = total % BC, bnew = total / BC;
+        const int sprev = (pnew > 0) ? 1 - sl : sl;
 #pragma unroll
-        for (int m = 0; m < BC - 1; ++m) {
-            double acc0 = 0.0, acc1 = 0.0;
+        for (int m = 0; m < 2 * BC - 1; ++m) {
+            const int col = (m < BC) ? m : m - BC;                // column within its block
+            const int sm_ = (m < BC) ? sprev : sl;                // the slot it sits in
+            // (both slots' sums, the wanted one selected afterwards: a select between two elements of the ring becomes an
+            // indexed access and sends the whole ring to scratch memory)
+            double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
-                double2 v = ring[0][m][r];
-#pragma unroll
-                for (int s2 = 1; s2 < NSLOT; ++s2) {
-                    v.x = (sl == s2) ? ring[s2][m][r].x : v.x;
-                    v.y = (sl == s2) ? ring[s2][m][r].y : v.y;
-                }
-                if (MASKED && !CH_OK(r)) v = make_double2(0.0, 0.0);
-                acc0 = fma(v.x, w[r].x, acc0);
-                acc1 = fma(v.y, w[r].y, acc1);
+                double2 v0 = ring[0][col][r], v1 = ring[1][col][r];
+                if (MASKED && !CH_OK(r)) v0 = v1 = make_double2(0.0, 0.0);
+                s0a = fma(v0.x, w[r].x, s0a);
+                s0b = fma(v0.y, w[r].y, s0b);
+                s1a = fma(v1.x, w[r].x, s1a);
+                s1b = fma(v1.y, w[r].y, s1b);
             }
-            nv[1 + m] = (m < nlast) ? acc0 + acc1 : 0.0;
+            const bool ok = (m < BC) ? (bnew >= 1) : (m - BC < pnew);
+            const double sum = (sm_ == 1) ? s1a + s1b : s0a + s0b;
+            nv[1 + m] = ok ? sum : 0.0;
         }
     }
-    blk_sum_work<BC>(nv, sm);
+    blk_sum_work<2 * BC>(nv, sm);
     const double h = sqrt(fabs(sm.tot[0]));
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
 #pragma unroll
@@ -482,13 +616,7 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
             st_nt2(vn2 + (int64_t)r * CH_BS, o);
         }
     }
-    if (bid == 0 && a.hpin != nullptr) {
-        __syncthreads();          // the H entries were written by the communication wave of this workgroup
-        for (int i = tid; i < a.hcount; i += CH_BS)
-            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        CH_SIGNAL_DONE(a);
-    }
+    finish();
 #undef CH_OK
 }
 

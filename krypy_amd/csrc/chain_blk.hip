@@ -10,7 +10,7 @@ namespace kh {
 static constexpr size_t BLK_GRAN_WORDS = (size_t)2 * CH_GMAX * BLK_NVS * 2;
 static constexpr size_t BLK_GRAN2_WORDS = (size_t)2 * BLK_NG2 * BLK_NVS * 2;
 static constexpr size_t BLK_RES_WORDS = (size_t)16 * 2 * BLK_NVS * 2;
-static constexpr size_t BLK_TAB_WORDS = (size_t)BLK_TABCOLS * BLK_BC;   // doubles: BLK_BC entries per column
+static constexpr size_t BLK_TAB_WORDS = (size_t)BLK_TABCOLS * BLK_TW;   // doubles: BLK_TW entries per column
 
 // granule buffers of the blocked kernel's sums; zero = "no epoch yet" (epochs start at 1)
 hipError_t chain_blk_reset(kh_ctx ctx) {
@@ -30,7 +30,7 @@ void chain_blk_free(kh_ctx ctx) {
 }
 
 template <int R2, bool MASKED, int FND, bool ONEX, int DBG = 0>
-static hipError_t launch_blk(kh_ctx ctx, int G, ChainArgs& a, const BlkBufs& bf) {
+static hipError_t launch_blk(kh_ctx ctx, int G, ChainArgs& a, BlkBufs bf) {
     static int blocks_per_cu = -1;
     auto kern = k_mgs_chain_blk<R2, BLK_BC, BLK_NSLOT, MASKED, FND, ONEX, DBG>;
     if (blocks_per_cu < 0) {
@@ -40,11 +40,17 @@ static hipError_t launch_blk(kh_ctx ctx, int G, ChainArgs& a, const BlkBufs& bf)
         blocks_per_cu = nb;
     }
     if ((int64_t)blocks_per_cu * (ONEX ? ctx->ncu / 8 : ctx->ncu) < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL(kern, dim3(ONEX ? 8 * G + 8 : G), dim3(CH_BS + 64), 0, ctx->stream, a, bf);
+    // workgroups WITHOUT rows in front of the G with rows (chain_blk.h, BlkBufs::nx): when the chip has room for them, and
+    // from as many workgroups on as the two-level exchange takes (fewer: the leaders gather everything themselves)
+    bf.nx = 0;
+    if (!ONEX && DBG == 0 && ctx->blk_nx > 0 && (int64_t)blocks_per_cu * ctx->ncu >= G + ctx->blk_nx && G + ctx->blk_nx <= CH_GMAX / 2)
+        bf.nx = ctx->blk_nx;
+    if (bf.nx > 0) ctx->n_blk_rowless += 1;
+    hipLaunchKernelGGL(kern, dim3(ONEX ? 8 * G + 8 : G + bf.nx), dim3(CH_BS + 64), 0, ctx->stream, a, bf);
     return hipGetLastError();
 }
 
-// The Gram table (device): row j = <v_m, v_j> for the columns m < j of j's block of BLK_BC columns.
+// The Gram table (device): row j = <v_m, v_j> for the BLK_BC columns of the block before j's and the columns m < j of j's block.
 double* chain_blk_table(kh_ctx ctx) {
     if (ctx->blk_gran == nullptr && chain_blk_reset(ctx) != hipSuccess) return nullptr;
     return reinterpret_cast<double*>(ctx->blk_gran + BLK_GRAN_WORDS + BLK_GRAN2_WORDS + BLK_RES_WORDS);
@@ -53,7 +59,7 @@ double* chain_blk_table(kh_ctx ctx) {
 // can the blocked kernel take this step at all (shape only; the table is the caller's business)?
 bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd) {
     return r2 == 4 && !a.presub && a.sweeps == 1 && a.col0 == 0 && (fnd == 0 || fnd == 5 || fnd == 7) && G <= CH_GMAX / 2 &&
-           a.ncol + 2 <= BLK_TABCOLS;
+           a.ncol > BLK_BC * (BLK_NSLOT - 1) && a.ncol + 2 <= BLK_TABCOLS;      // (at least BLK_NSLOT blocks: the kernel assumes it)
 }
 
 // One Arnoldi step k = ncol - 1 of basis block V (columns 0 .. k, one sweep) on the blocked kernel.  r2: rows of 16 B per

@@ -94,13 +94,16 @@ struct kh_ctx_s {
     int64_t n_chain_small = 0;
     // ... and its blocked form: one grid-wide sum per block of 4 columns (chain_blk.h; KRYPY_AMD_CHAIN_BLK)
     int chain_blk = 1;
-    int64_t blk_onex_maxn = 100000;   // vectors longer than this run the blocked kernel spread over the chip, not on one XCD: the
-                                      // one XCD's memory port is the bound from there on (16.6k vs 14.6k it/s at 62,500 rows, 13.4k either way at
-                                      // 10^5, 12.0k vs 13.1k at 129,600; KRYPY_AMD_BLK_ONEX_MAXN)
+    int blk_nx = 8;                   // workgroups without rows in front of a blocked launch that is spread over the chip (they
+                                      // gather the sums on compute units that carry no column stream; KRYPY_AMD_BLK_NX, 0: none)
+    int64_t blk_onex_maxn = 70000;    // vectors longer than this run the blocked kernel spread over the chip, not on one XCD: the
+                                      // one XCD's memory port is the bound from there on (15.6k vs 15.1k it/s at 62,500 rows, 13.8k vs
+                                      // 15.0k at 80,089, 12.9k vs 14.0k at 10^5; KRYPY_AMD_BLK_ONEX_MAXN)
     int64_t n_chain_blk = 0;
     unsigned long long* blk_gran = nullptr;   // granules + per-XCD totals of the blocked kernel's sums + its Gram table (chain_blk.hip)
     const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...
     int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
+    int64_t n_blk_rowless = 0;       // blocked launches with workgroups without rows in front (chain_blk.h, BlkBufs::nx)
     int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
     // reference-order Gram-Schmidt with one reduction per step on N ranks (krylov_hip.hip: try_lowsync_mgs; KRYPY_AMD_MGS_LOWSYNC)
     int mgs_lowsync = 1;
@@ -252,7 +255,8 @@ bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd);
 #ifndef KH_BLK_BC_CFG
 #define KH_BLK_BC_CFG 4
 #endif
-constexpr int KH_BLK_BC = KH_BLK_BC_CFG;   // (= BLK_BC of chain_blk.h) columns per block, entries per row of the Gram table
+constexpr int KH_BLK_BC = KH_BLK_BC_CFG;   // (= BLK_BC of chain_blk.h) columns per block
+constexpr int KH_BLK_TW = 2 * KH_BLK_BC;   // (= BLK_TW) entries per row of the Gram table: the block before the column's, then its own
 // an entry point writes to block v: the Gram table of an Arnoldi sequence on it (chain_blk.hip) is no longer vouched for
 static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
     if (ctx->blk_V == v) ctx->blk_next = -1;

@@ -784,7 +784,9 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 if (gt == nullptr) return fail(KH_ERR_NOMEM, "chain_blk: no memory for the Gram table");
                 for (int64_t j = 1; j <= k; ++j) {
                     const int64_t b0 = (j / KH_BLK_BC) * KH_BLK_BC;
-                    if (j > b0) KH_TRY(::dot_panel_dev(ctx, V, b0, j - b0, V->col(j), gt + j * KH_BLK_BC, 0));
+                    if (b0 >= KH_BLK_BC)      // the block before column j's (the kernel takes its dots one block ahead)
+                        KH_TRY(::dot_panel_dev(ctx, V, b0 - KH_BLK_BC, KH_BLK_BC, V->col(j), gt + j * KH_BLK_TW, 0));
+                    if (j > b0) KH_TRY(::dot_panel_dev(ctx, V, b0, j - b0, V->col(j), gt + j * KH_BLK_TW + KH_BLK_BC, 0));
                 }
                 ctx->blk_V = V;
                 ctx->blk_next = k;
@@ -1304,6 +1306,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->mgs_lowsync = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK_ONEX_MAXN");
         if (e != nullptr) ctx->blk_onex_maxn = atoll(e);
+        e = getenv("KRYPY_AMD_BLK_NX");
+        if (e != nullptr) ctx->blk_nx = atoi(e) > 0 ? 8 : 0;
         e = getenv("KRYPY_AMD_CHAIN_ONEX");
         ctx->chain_onex = (e == nullptr) ? 1 : atoi(e);
         if (ctx->chain_onex) {
@@ -1431,6 +1435,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "proj_reg")) ctx->proj_reg = value != 0;
     else if (!strcmp(key, "proj_panel")) ctx->proj_panel = value != 0;
     else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;
+    else if (!strcmp(key, "blk_nx")) ctx->blk_nx = value > 0 ? 8 : 0;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
@@ -1460,6 +1465,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_blk")) *value = ctx->chain_blk;
     else if (!strcmp(key, "n_chain_blk")) *value = ctx->n_chain_blk;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
+    else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;
+    else if (!strcmp(key, "blk_nx")) *value = ctx->blk_nx;
     else if (!strcmp(key, "tag_wait")) *value = ctx->tag_wait;
     else if (!strcmp(key, "n_tag_waits")) *value = ctx->n_tag_waits;
     else if (!strcmp(key, "n_chain_small")) *value = ctx->n_chain_small;

@@ -17,15 +17,19 @@ def _cycle(linsys, utils, ls, **kw):
         return e.solver
 
 
-@pytest.mark.parametrize("nx,ny", [(260, 250), (640, 500), (1000, 1000)])
-def test_blocked_kernel_equals_the_per_column_kernels(hip, nx, ny):
+@pytest.mark.parametrize("nx,ny,rowless", [(260, 250, 1), (640, 500, 1), (640, 500, 0), (1000, 1000, 1), (1000, 1000, 0),
+                                           (1024, 1024, 1)])
+def test_blocked_kernel_equals_the_per_column_kernels(hip, nx, ny, rowless):
     """One GMRES(100) cycle with the blocked kernel and with the per-column kernel of the same shape: residual history,
     Hessenberg matrix and iterate at 1e-10, the basis as orthogonal (||V^T V - I||_F within a factor two).  65,000 rows:
     all workgroups on one XCD (every communication wave gathers from the L2); 320,000: spread over the chip, the XCD
-    leaders gather all records; 10^6: the two-level exchange.  The Gram table is rebuilt once per sequence (the first
-    blocked step) and carried by the launches from then on."""
+    leaders gather all records; 10^6: the two-level exchange.  Spread over the chip, eight workgroups WITHOUT rows run in
+    front of the others and gather the sums (rowless = 0: switched off; 1024 x 1024: 256 workgroups with rows, no
+    room for them).  The Gram table is rebuilt once per sequence (the first blocked step) and carried by the launches
+    from then on."""
     from krypy_amd import linsys, utils
 
+    hip.set("blk_nx", 8 if rowless else 0)
     A = ref.laplace2d(nx, ny)
     b = np.random.default_rng(3).standard_normal(A.shape[0])
     ls = linsys.LinearSystem(A, b)
@@ -33,19 +37,22 @@ def test_blocked_kernel_equals_the_per_column_kernels(hip, nx, ny):
     for blk in (1, 0):
         hip.set("chain_blk", blk)
         try:
-            n0, r0 = hip.get("n_chain_blk"), hip.get("n_blk_rebuild")
+            n0, r0, x0 = hip.get("n_chain_blk"), hip.get("n_blk_rebuild"), hip.get("n_blk_rowless")
             s = _cycle(linsys, utils, ls)
             Vb = s.arnoldi._V
             G = hip.gemm_tn(Vb, 0, 101, Vb, 0, 101)
             out[blk] = dict(res=np.array(s.resnorms), H=np.array(s.H), x=np.array(s.xk),
                             orth=float(np.linalg.norm(G - np.eye(101))), launches=hip.get("n_chain_blk") - n0,
-                            rebuilds=hip.get("n_blk_rebuild") - r0)
+                            rebuilds=hip.get("n_blk_rebuild") - r0, rowless=hip.get("n_blk_rowless") - x0)
             del s, Vb
         finally:
             hip.set("chain_blk", 1)
+    hip.set("blk_nx", 8)
     a, c = out[1], out[0]
     assert a["launches"] == 93 and c["launches"] == 0, (a["launches"], c["launches"])      # steps k = 7 .. 99
     assert a["rebuilds"] == 1, a["rebuilds"]
+    # (one XCD: nobody without rows; 1024 x 1024: 256 workgroups with rows fill the chip)
+    assert a["rowless"] == (93 if rowless and 70000 < nx * ny <= 248 * 4096 else 0), a["rowless"]
     assert np.max(np.abs(a["res"] - c["res"]) / c["res"]) < 1e-10
     assert np.linalg.norm(a["H"] - c["H"]) < 1e-10 * np.linalg.norm(c["H"])
     assert np.linalg.norm(a["x"] - c["x"]) < 1e-10 * np.linalg.norm(c["x"])
