@@ -31,7 +31,7 @@ configs)
   cat gpurun_out/ev/r04_configs.jsonl | cut -c1-300
   ;;
 small)
-  python tools/blk_bench.py 100 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/blk_bench.log; cat gpurun_out/ev/blk_bench.log
+  python tools/blk_bench.py 100 200 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/blk_bench.log; cat gpurun_out/ev/blk_bench.log
   python tools/small_bench.py 64 100 200 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/small_bench.log; cat gpurun_out/ev/small_bench.log
   python tools/proj_bench.py 2>/dev/null | grep "N =" > gpurun_out/ev/proj_bench.log; cat gpurun_out/ev/proj_bench.log
   for ny in 1250 625 313; do for o in cgs mgs; do python bench.py --force-sharded --nx 4000 --ny $ny --ortho $o --no-roofline --steps 10 --other-modes none 2>/dev/null | python -c "
