@@ -197,9 +197,12 @@ struct BlkSm {
 // The order of the additions is a function of the workgroup numbers alone: every workgroup gets the same bits, run
 // after run, wherever the workgroups were placed.
 template <int NV, bool ONEX>
-__device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf, int G, int bid, int* err, BlkSm& sm,
+__device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf, int G, int bid, int rid, int* err, BlkSm& sm,
                                                const GridRole role, bool skip = false, int nv_all = NV,
                                                double extra = 0.0, bool barrier_b = true) {
+    // bid: this workgroup's number (which group it adds up); rid: the record its partial sums go to - the workgroups with rows
+    // first, in their order, the ones without rows (zeros) behind them: the additions meet the same values in the same
+    // order whether the launch has workgroups without rows or not (and as on one XCD)
     // (lanes NV .. nv_all-1 put `extra` - the block's Gram entries from the table - behind the totals)
     constexpr int NW = CH_BS / 64;
     constexpr int NGRP = 64 / NV;
@@ -215,7 +218,7 @@ __device__ __forceinline__ double blk_sum_comm(unsigned epoch, const BlkBufs& bf
         double s = sm.part[lane * NW];
 #pragma unroll
         for (int i = 1; i < NW; ++i) s += sm.part[lane * NW + i];
-        blk_put(slot + ((size_t)bid * BLK_NVS + lane) * 2, epoch, s, ONEX);
+        blk_put(slot + ((size_t)rid * BLK_NVS + lane) * 2, epoch, s, ONEX);
     }
     double t;
     if (skip) {                                        // measurement: no exchange, the workgroup's own partial sums
@@ -348,6 +351,7 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
         role = grid_role(a.xcc_leader, a.epoch0, &slead);
     }
     const bool rowless = bid < nx;
+    const int rid = rowless ? G - nx + bid : bid - nx;      // its record in the exchange (blk_sum_comm)
     unsigned epoch = a.epoch0;
     const int total = a.ncol;                               // links (one sweep, columns 0 .. ncol-1: blocks are aligned)
     const int nblk = (total + BC - 1) / BC;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
                 if (ib * BC + l < total)
                     gval = __hip_atomic_load(bf.gtab + (size_t)(ib * BC + l) * BLK_TW + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            (void)blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex, NT, gval, false);
+            (void)blk_sum_comm<BC, ONEX>(epoch++, bf, G, bid, rid, a.err, sm, role, dbg_noex, NT, gval, false);
             {
                 double alpha[BC];
                 const int nvalid = total - ib * BC;
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(CH_BS + 64) void k_mgs_chain_blk(ChainArgs a, BlkBu
         }
         // the norm, and <v_m, w> for the columns of the new column's row of the table: lanes 1 .. BC the block before the new
         // column's, lanes BC + 1 .. 2 BC - 1 the earlier columns of its own block
-        const double tf = blk_sum_comm<2 * BC, ONEX>(epoch++, bf, G, bid, a.err, sm, role, dbg_noex);
+        const double tf = blk_sum_comm<2 * BC, ONEX>(epoch++, bf, G, bid, rid, a.err, sm, role, dbg_noex);
         const double h = sqrt(fabs(sm.tot[0]));
         if (writer) a.hdev[a.hnext] = h;
         {
