@@ -412,3 +412,50 @@ def test_givens_scalars_equal_the_givens_class():
             assert abs(complex(g.r) - complex(r)) < 1e-300
         else:
             assert type(c) is type(g.c) and (g.c, g.s, g.r) == (c, s, r), (a, b)
+
+
+def test_blocked_one_ahead_recurrence_is_the_reference_loop():
+    """The recurrence of k_mgs_chain_blk (chain_blk.h, blk_alphas) restated in NumPy: the coefficients of a block of four
+    columns are taken against a w that neither the block itself NOR the block before it has updated, and corrected with
+    the Gram entries (the table's rows: the four columns of the previous block, the earlier columns of the own block).  In
+    exact arithmetic that is the reference's sequential loop (krypy/utils.py:1012-1029); here: a basis that is orthonormal
+    only to 1e-4, so the corrections are anything but negligible, every ragged length of the last block."""
+    import numpy as np
+
+    rng = np.random.default_rng(7)
+    n, bc = 400, 4
+    for k in (8, 9, 10, 11, 12, 23):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, k)))
+        V = Q + 1e-4 * rng.standard_normal((n, k))
+        w0 = rng.standard_normal(n)
+        # the reference's loop
+        w, ref_alpha = w0.copy(), np.zeros(k)
+        for j in range(k):
+            ref_alpha[j] = V[:, j] @ w
+            w = w - ref_alpha[j] * V[:, j]
+        # the kernel's: c of block i + 1 against the w that block i has not updated
+        G = V.T @ V
+        nblk = (k + bc - 1) // bc
+        w_upd = w0.copy()                     # updated by the blocks < i
+        alpha, aprev = np.zeros(k), np.zeros(bc)
+        c_next = V[:, 0:bc].T @ w_upd         # block 0 against the initial w
+        for i in range(nblk):
+            cols = list(range(i * bc, min((i + 1) * bc, k)))
+            c = c_next
+            if i + 1 < nblk:                  # (under the exchange of block i's sums)
+                c_next = V[:, (i + 1) * bc: min((i + 2) * bc, k)].T @ w_upd
+            a_blk = np.zeros(bc)
+            for l, j in enumerate(cols):
+                a = c[l]
+                if i > 0:
+                    for m in range(bc):
+                        a -= aprev[m] * G[(i - 1) * bc + m, j]
+                for m in range(l):
+                    a -= a_blk[m] * G[cols[m], j]
+                a_blk[l] = a
+                alpha[j] = a
+            for l, j in enumerate(cols):
+                w_upd = w_upd - a_blk[l] * V[:, j]
+            aprev = a_blk
+        assert np.max(np.abs(alpha - ref_alpha)) < 1e-12 * np.max(np.abs(ref_alpha)), k
+        assert np.linalg.norm(w_upd - w) < 1e-12 * np.linalg.norm(w0), k
