@@ -14,8 +14,10 @@ timed region is a fixed number of cycles and the expected ConvergenceError is ca
 Inputs (CSR matrix, b) are resident in HBM before the timed region starts.
 
 value = K*100 iterations / wall time (max over ranks, barrier + device sync on both sides).
-For N > 1 the matrix rows and all vectors are sharded in contiguous slabs (one process per
-GPU, launched with torch.distributed.run or any launcher that sets RANK / WORLD_SIZE / MASTER_*); halo
+For N > 1 the matrix rows and all vectors are sharded in contiguous slabs, one process per GPU.  ``python bench.py
+--gpus N`` with no RANK / WORLD_SIZE in the environment starts the N rank processes ITSELF (`_launch`: LOCAL_RANK = i,
+KRYPY_AMD_DEVICE = i, a free MASTER_PORT on 127.0.0.1; fewer than N visible devices is an error, never a silent N = 1);
+under torch.distributed.run or any launcher that sets RANK / WORLD_SIZE / MASTER_* it is one of those ranks; halo
 exchange + dot-product all-reduces go through RCCL inside libkrylov_hip.so; the ncclUniqueId reaches the
 ranks, and the timing barrier / max-over-ranks run, over krypy_amd.dist.TcpRendezvous (plain sockets: no
 PyTorch on the host side).  Total work is fixed -> "scaling": "strong".
@@ -237,7 +239,79 @@ class _StdoutToStderr(object):
         os.close(self._saved)
 
 
+def _free_port():
+    import socket
+    best = None
+    for _ in range(16):          # TcpRendezvous listens on one of the eight ports BEHIND MASTER_PORT
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        best = sk.getsockname()[1]
+        sk.close()
+        if best < 65000:
+            break
+    return best
+
+
+def _visible_devices():
+    """Number of GPUs this process can see (kh_device_count of the HIP library; built first if missing)."""
+    from krypy_amd import _hip
+    if not os.path.exists(_hip.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _hip.device_count()
+
+
+def _launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) here, relay rank 0's
+    ONE JSON line and the ranks' exit codes.  The children are this very command line again (sys.argv) with RANK,
+    LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT and KRYPY_AMD_DEVICE set - what torch.distributed.run would set."""
+    import subprocess
+    n = args.gpus
+    have = _visible_devices()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU%s visible: refusing to run (a smaller run would be "
+                         "reported as n_gpus=%d)\n" % (n, have, "" if have == 1 else "s", n))
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KRYPY_AMD_DEVICE=str(r))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
+        procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    line = procs[0].stdout.read()          # rank 0 prints the one JSON line; EOF when it exits
+    rcs = [None] * n
+    deadline = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs) or rcs[0] == 0:
+            # a rank failed (its peers would wait in a collective for ever), or rank 0 is done: give the others a
+            # grace period, then stop them - by PID, these are our own children
+            if deadline is None:
+                deadline = time.time() + 60.0
+            elif time.time() > deadline:
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        p.kill()
+                        rcs[r] = -9
+        time.sleep(0.05)
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        return 1
+    sys.stdout.write(line.decode() if isinstance(line, bytes) else line)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(_launch(args))
     with _StdoutToStderr():
         out, rank, dist = _run()
     if rank == 0:
@@ -251,15 +325,23 @@ def main():
         dist.close()
 
 
+def _world(args):
+    """(rank, world, local_rank) of this process; --gpus must be the number of ranks that really run."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: the line would not say what ran" % (args.gpus, world))
+    if not (0 <= rank < world):
+        raise SystemExit("bench.py: RANK=%d outside WORLD_SIZE=%d" % (rank, world))
+    return rank, world, local_rank
+
+
 def _run():
     args = parse_args()
     if args.config == 5:
         return _run_config5(args)
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank, world, local_rank = _world(args)
     os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
 
     sharded = world > 1 or args.force_sharded
@@ -474,11 +556,7 @@ def _run_config5(args):
     slab of them; the small eigenproblem is replicated host work); solve 2: DeflatedGmres(U, maxiter=m), timed - a
     *step* is one such solve of m iterations from x0 = 0 (reference flow: recycling/linsys.py:51-103,
     deflation.py:93-163).  Same JSON contract as config 2; `scaling` is "strong" (the grid is fixed)."""
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rank, world, local_rank = _world(args)
     os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
     sharded = world > 1 or args.force_sharded
     if args.force_sharded:

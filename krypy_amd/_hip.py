@@ -914,6 +914,15 @@ class Context(object):
 _default_ctx = None
 
 
+def device_count():
+    """GPUs visible to this process (``kh_device_count``); 0 when HIP reports none.  Raises :class:`BackendError` when the
+    library itself is missing - a launcher must know how many ranks it can start before it starts them."""
+    lib = load_library()
+    n = _INT(0)
+    rc = lib.kh_device_count(ctypes.byref(n))
+    return int(n.value) if rc == 0 else 0
+
+
 def get_context():
     """The process-wide device context (device = ``LOCAL_RANK`` or ``KRYPY_AMD_DEVICE`` or 0).
 

@@ -1192,6 +1192,15 @@ static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t
 #undef KH_DX2
     if (e != hipSuccess) {
         (void)hipGetLastError();
+        // On N ranks this form has a different PATTERN of all-reduces than the per-link path (one of 2 k + 1 values against
+        // k + 1 of one value): a rank that declined here on its own while its peers went ahead would mismatch the collectives
+        // (a hang, or sums of unrelated numbers).  Every decision up to this point (lowsync_eligible: switches, the longest
+        // slab of the run, k; the table rebuild: (ls_V, ls_next), which follow the call sequence every rank makes alike) is
+        // the same on every rank - a launch failure is not, so with a communicator it is an error, never a fallback.
+        if (multi)
+            return fail(KH_ERR_HIP, "one-reduction Gram-Schmidt: the dots kernel could not be launched (%s); no rank-local "
+                                    "fallback on a communicator (the peers would wait in a different all-reduce)",
+                        hipGetErrorString(e));
         return 0;
     }
     // [c_0 .. c_k | g_0 .. g_{k-1}]: one reduction launch, ONE all-reduce

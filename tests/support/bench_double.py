@@ -1,0 +1,29 @@
+"""bench.py with the NumPy test double standing in for the device - TEST INFRASTRUCTURE, CPU suite only.
+
+``python tests/support/bench_double.py --gpus 2 ...`` is ``python bench.py --gpus 2 ...`` in a container without a GPU:
+the double is installed as the process-wide context and the visible-device count is faked (``BENCH_DOUBLE_DEVICES``,
+default 8), then ``bench.main()`` runs unchanged.  Because bench.py's own launcher re-executes ``sys.argv`` for each rank,
+every rank process it starts comes through this file again and gets the double too: the launcher-free path
+(`bench._launch`) is exercised exactly as the driver would hit it, process tree and all.  The product has no hook
+for this - it is all done from the outside, here."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def main():
+    from krypy_amd import _hip
+    from tests.support.numpy_context import NumpyContext
+
+    _hip._install_context_for_testing(NumpyContext())
+    _hip.device_count = lambda: int(os.environ.get("BENCH_DOUBLE_DEVICES", "8"))
+    import bench
+
+    bench.main()
+
+
+if __name__ == "__main__":
+    main()

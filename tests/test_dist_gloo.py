@@ -260,11 +260,100 @@ def _bench_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
+def _bench_self_spawn(argv, devices=8, timeout=600):
+    """`python bench.py --gpus N ...` with NO launcher environment: bench.py starts its N ranks itself (bench._launch).
+    tests/support/bench_double.py is bench.py with the NumPy double installed from the outside; the launcher re-executes
+    that same command line for each rank."""
+    import json
+    import subprocess
+    import sys
+    env = dict((k, v) for k, v in os.environ.items()
+               if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                            "KRYPY_AMD_DEVICE"))
+    env["BENCH_DOUBLE_DEVICES"] = str(devices)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "support", "bench_double.py")] + argv, env=env,
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def _single_process_bench_residual(nx, ny, m, ortho="cgs"):
+    from krypy_amd import _hip, linsys, utils
+    from tests.support.numpy_context import NumpyContext
+    import bench
+    old = _hip._install_context_for_testing(NumpyContext())
+    try:
+        A = bench.laplace2d(nx, ny)
+        b = np.random.default_rng(0).standard_normal(A.shape[0])
+        ls = linsys.LinearSystem(A, b)
+        x0 = None
+        for ncyc in (1, 2):          # warm-up cycle, then the two timed ones from its iterate
+            try:
+                s = linsys.RestartedGmres(ls, x0=x0, maxiter=m, max_restarts=ncyc - 1, tol=1e-8, ortho=ortho)
+            except utils.ConvergenceError as e:
+                s = e.solver
+            x0 = s.xk
+        return s.resnorms[-1]
+    finally:
+        _hip._install_context_for_testing(old)
+
+
 @pytest.mark.parametrize("world", [2, 4])
-def test_bench_sharded_path_runs_on_n_ranks(world):
-    """The N > 1 leg of bench.py (row slabs of the grid, unique-id broadcast, comm_init, the panel form as default,
-    max-over-ranks timing, the JSON contract) has never run on more than one GPU: at least its host logic runs
-    here on gloo ranks, at a toy size, and must do the same iterations as one process."""
+def test_bench_gpus_n_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` with a clean environment (what the driver runs for N = 1; what VERDICT r04 asked for
+    N > 1): N rank processes are started by bench.py itself, exactly ONE JSON line comes back, it says n_gpus = N, and
+    the iterations are the single-process ones."""
+    import json
+    rc, lines, err = _bench_self_spawn(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--nx", "40", "--ny",
+                                        "36", "--restart", "12", "--no-roofline", "--no-cpu-baseline"])
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == world and o["steps"] == 2 and o["warmup"] == 1 and o["unit"] == "iterations/s"
+    assert o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24
+    assert o["config"]["parallelism"] == "row-sharded x%d (RCCL)" % world
+    assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 24) < 1e-6
+    want = _single_process_bench_residual(40, 36, 12)
+    assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
+    assert o["config"]["basis_orthogonality_fro"]["cgs"] < 1e-10
+
+
+def test_bench_gpus_n_refuses_when_fewer_devices_are_visible():
+    """Never a silent N = 1: --gpus 4 with 2 visible devices exits non-zero, prints no JSON line and says why; so does
+    a launcher environment that disagrees with --gpus (WORLD_SIZE = 1 included)."""
+    import subprocess
+    import sys
+    rc, lines, err = _bench_self_spawn(["--gpus", "4", "--steps", "1", "--warmup", "0", "--nx", "40", "--ny", "36"],
+                                       devices=2, timeout=120)
+    assert rc != 0 and lines == [] and "only 2 GPUs visible" in err, (rc, lines, err[-500:])
+    rc, lines, err = _bench_self_spawn(["--config", "5", "--gpus", "2", "--steps", "1", "--warmup", "0"], devices=1,
+                                       timeout=120)
+    assert rc != 0 and lines == [] and "only 1 GPU visible" in err, (rc, lines, err[-500:])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for cfg in ([], ["--config", "5"]):
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        p = subprocess.run([sys.executable, os.path.join(root, "tests", "support", "bench_double.py"), "--gpus", "2",
+                            "--steps", "1", "--warmup", "0"] + cfg, env=env, cwd=root, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode != 0 and p.stdout.strip() == b"" and b"WORLD_SIZE=1" in p.stderr, p.stderr[-500:]
+
+
+def test_bench_gpus_n_reports_a_failed_rank():
+    """A rank that dies must not leave the launcher waiting nor a JSON line behind: here every rank fails at argument
+    checks that only the rank processes run (restart length larger than the local slab allows is fine; an unknown
+    Gram-Schmidt variant is not)."""
+    rc, lines, err = _bench_self_spawn(["--gpus", "2", "--steps", "1", "--warmup", "0", "--nx", "40", "--ny", "36",
+                                        "--restart", "12", "--ortho", "no-such-variant", "--no-roofline",
+                                        "--no-cpu-baseline"], timeout=300)
+    assert rc != 0 and lines == [] and "ranks failed" in err, (rc, lines, err[-800:])
+
+
+def test_bench_sharded_path_under_an_external_launcher():
+    """The same leg as a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) starts it:
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Every rank reports the same (max-over-ranks) time and
+    the same residual."""
+    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -279,33 +368,11 @@ def test_bench_sharded_path_runs_on_n_ranks(world):
     for p in procs:
         p.join(timeout=60)
     o = outs[0]
-    assert o["n_gpus"] == world and o["steps"] == 2 and o["warmup"] == 1 and o["unit"] == "iterations/s"
-    assert o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24
-    assert o["config"]["parallelism"] == "row-sharded x%d (RCCL)" % world
-    assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 24) < 1e-6
-    # every rank reports the same (max-over-ranks) time and the same residual
+    assert o["n_gpus"] == world and o["config"]["iterations_timed"] == 24
     assert len({round(outs[r]["value"], 6) for r in outs}) == 1
     assert len({outs[r]["config"]["final_relres"] for r in outs}) == 1
-    # ... and that residual is the single-process one
-    from krypy_amd import _hip, linsys, utils
-    from tests.support.numpy_context import NumpyContext
-    import bench
-    old = _hip._install_context_for_testing(NumpyContext())
-    try:
-        A = bench.laplace2d(40, 36)
-        b = np.random.default_rng(0).standard_normal(A.shape[0])
-        ls = linsys.LinearSystem(A, b)
-        x0 = None
-        for ncyc in (1, 2):          # warm-up cycle, then the two timed ones from its iterate
-            try:
-                s = linsys.RestartedGmres(ls, x0=x0, maxiter=12, max_restarts=ncyc - 1, tol=1e-8, ortho="cgs")
-            except utils.ConvergenceError as e:
-                s = e.solver
-            x0 = s.xk
-        assert abs(s.resnorms[-1] - o["config"]["final_relres"]) <= 1e-9 * s.resnorms[-1]
-        assert o["config"]["basis_orthogonality_fro"]["cgs"] < 1e-10
-    finally:
-        _hip._install_context_for_testing(old)
+    want = _single_process_bench_residual(40, 36, 12)
+    assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
 
 
 def _bench5_worker(rank, world, port, q):
@@ -335,20 +402,29 @@ def test_bench_config5_leg_on_n_ranks(world):
     """The config-5 leg of bench.py (z-slabs of the 3-D grid, plain GMRES to harvest Ritz vectors that stay sharded on
     the device, DeflatedGmres timed) on gloo ranks at a toy size: same JSON contract as config 2, every rank sees the
     same numbers, and those are the CPU oracle's (gmres -> Ritz vectors of smallest magnitude -> deflated_gmres;
-    reference flow recycling/linsys.py:51-103, deflation.py:93-163)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bench5_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    outs = {}
-    for _ in range(world):
-        rank, status, payload = q.get(timeout=600)
-        assert status == "ok", payload
-        outs[rank] = payload
-    for p in procs:
-        p.join(timeout=60)
+    reference flow recycling/linsys.py:51-103, deflation.py:93-163).  world = 2: under an external launcher's
+    environment (all ranks' lines compared); world = 4: `bench.py --config 5 --gpus 4` starting its own ranks."""
+    if world == 4:
+        import json
+        rc, lines, err = _bench_self_spawn(["--config", "5", "--gpus", "4", "--steps", "2", "--warmup", "1", "--nx", "12",
+                                            "--ny", "10", "--nz", "16", "--restart", "30", "--defl", "5",
+                                            "--no-cpu-baseline"])
+        assert rc == 0 and len(lines) == 1, err[-3000:]
+        outs = {0: json.loads(lines[0])}
+    else:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_bench5_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        outs = {}
+        for _ in range(world):
+            rank, status, payload = q.get(timeout=600)
+            assert status == "ok", payload
+            outs[rank] = payload
+        for p in procs:
+            p.join(timeout=60)
     o = outs[0]
     assert o["n_gpus"] == world and o["steps"] == 2 and o["unit"] == "iterations/s" and o["scaling"] == "strong"
     assert o["config"]["iterations_timed"] == 60 and o["config"]["deflation_vectors"] == 5

@@ -1,0 +1,70 @@
+"""`bench.py --gpus N` on real devices (VERDICT r04 "missing 1").
+
+Rounds 1-4 never put two ranks through RCCL: every box had one GPU.  These tests adapt to the box:
+* one visible GPU (today's boxes): `--gpus 2` must REFUSE - non-zero exit, a reason on stderr, no JSON line - for config 2
+  and config 5 alike (never a silent n_gpus = 1 run);
+* two or more visible GPUs: `python bench.py --gpus 2` with a clean environment starts two rank processes by itself
+  (one per device, RCCL communicator, halo exchange + all-reduced dots), prints ONE line with n_gpus = 2, and the
+  iterations are the one-GPU ones (the sharded operator replaces /root/reference/krypy/utils.py:1593-1594, the
+  all-reduced inner products utils.py:182-183).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                  "KRYPY_AMD_DEVICE", "KRYPY_AMD_FORCE_MULTI")
+
+
+def _bench(argv, timeout=900):
+    env = dict((k, v) for k, v in os.environ.items() if k not in _LAUNCHER_VARS)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    return p.returncode, lines, p.stderr.decode()
+
+
+def test_bench_gpus_n_refuses_without_n_devices(hip):
+    from krypy_amd import _hip
+    have = _hip.device_count()
+    assert have >= 1
+    want = have + 1
+    for cfg in ([], ["--config", "5"]):
+        rc, lines, err = _bench(["--gpus", str(want), "--steps", "1", "--warmup", "0", "--nx", "64", "--ny", "48"] + cfg,
+                                timeout=300)
+        assert rc != 0 and lines == [], (rc, lines)
+        assert "only %d GPU" % have in err, err[-600:]
+
+
+def test_bench_two_real_ranks_match_one(hip):
+    from krypy_amd import _hip
+    if _hip.device_count() < 2:
+        pytest.skip("one GPU on this box: the two-rank RCCL run needs two (the refusal test above ran instead)")
+    common = ["--steps", "2", "--warmup", "1", "--nx", "400", "--ny", "300", "--restart", "40", "--no-cpu-baseline",
+              "--no-roofline", "--ortho", "cgs", "--other-modes", "none"]
+    rc, lines, err = _bench(["--gpus", "2"] + common)
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    two = json.loads(lines[0])
+    assert two["n_gpus"] == 2 and two["config"]["parallelism"] == "row-sharded x2 (RCCL)"
+    assert two["config"]["iterations_timed"] == 80
+    rc, lines, err = _bench(["--gpus", "1"] + common)
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    one = json.loads(lines[0])
+    assert one["n_gpus"] == 1
+    r1, r2 = one["config"]["final_relres"], two["config"]["final_relres"]
+    assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
+    # reference-order MGS on two ranks (one all-reduce of 2k + 1 values per step) against the same
+    rc, lines, err = _bench(["--gpus", "2"] + [a if a != "cgs" else "mgs" for a in common])
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    two_mgs = json.loads(lines[0])
+    rc, lines, err = _bench(["--gpus", "1"] + [a if a != "cgs" else "mgs" for a in common])
+    one_mgs = json.loads(lines[0])
+    r1, r2 = one_mgs["config"]["final_relres"], two_mgs["config"]["final_relres"]
+    assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
