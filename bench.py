@@ -371,6 +371,9 @@ def _run():
         from krypy_amd import dist as kdist
         uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
         ctx.comm_init(rank, world, uid)
+        # the sums across the ranks through IPC-mapped mailboxes (csrc/xr.hip) when every rank can map every peer's and a
+        # self-test of a few sums passes on all of them - otherwise ncclAllReduce, on every rank alike (KRYPY_AMD_XR=0: RCCL)
+        xr_on = kdist.enable_xr(ctx, dist)
         # contiguous slabs of grid rows (y index): every shard holds whole x-lines
         cuts = [(ny * p) // world for p in range(world + 1)]
         Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
@@ -385,6 +388,7 @@ def _run():
         b = np.random.default_rng(0).standard_normal(N)
 
     ls = linsys.LinearSystem(A_for_ls, b)
+    xr_on = bool(locals().get("xr_on", False))
 
     cycle_marks = []
 
@@ -530,6 +534,9 @@ def _run():
                                % (m, nx, ny, N, nnz_global),
                    "n": N, "ortho": ortho, "restart": m, "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "row-sharded x%d (RCCL)" % world,
+                   # sums across the ranks: "xr" = one kernel of system-scope stores into the peers' IPC-mapped mailboxes
+                   # per panel (csrc/xr.hip), "rccl" = ncclAllReduce; the halo exchange is RCCL point-to-point either way
+                   "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
                    # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
                    # total time (the contract); the median cycle says what a typical one took
@@ -587,6 +594,7 @@ def _run_config5(args):
         from krypy_amd import dist as kdist
         uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
         ctx.comm_init(rank, world, uid)
+        xr_on = kdist.enable_xr(ctx, dist)
         cuts = [(nz * p) // world for p in range(world + 1)]          # whole planes per rank
         z0, z1 = cuts[rank], cuts[rank + 1]
         Aloc = laplace3d(nx, ny, nz, z0, z1)
@@ -656,6 +664,7 @@ def _run_config5(args):
                    "n": N, "rows_per_gpu": nloc, "ortho": ortho, "restart": m, "deflation_vectors": d,
                    "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "z-slabs x%d (RCCL)" % world,
+                   "cross_rank_sums": None if not sharded else ("xr" if locals().get("xr_on") else "rccl"),
                    "plain_relres": plain_relres, "deflated_relres": float(s1.resnorms[-1]),
                    "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
                    "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms))},

@@ -98,6 +98,18 @@ int kh_comm_init(kh_ctx ctx, int rank, int nranks, const unsigned char id[128]);
 int kh_comm_destroy(kh_ctx ctx);
 /* in-place sum all-reduce of `count` host doubles through a device staging buffer (setup paths) */
 int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count);
+/* xr - sums across the ranks of ONE node without a library call (csrc/xr.hip; replaces the ncclAllReduce of the inner
+ * products of /root/reference/krypy/utils.py:182-183 on N ranks).  kh_xr_export allocates this rank's mailbox in
+ * fine-grained device memory and returns its 64-byte hipIpcMemHandle_t; the launcher gathers the handles of all ranks
+ * (rank order) and hands the 64 * nranks bytes to kh_xr_attach, which maps every peer's mailbox.  After EVERY rank has
+ * attached successfully the launcher sets kh_ctx_set(ctx, "xr", 1) on all of them (the choice must be the same on every
+ * rank): all-reduces of panels then run as one kernel of tagged 8-byte system-scope stores into the peers' mailboxes and
+ * a rank-ordered sum (the same bits on every rank).  Works with or without an RCCL communicator (without one: sums
+ * cross the ranks, halos do not).  A peer that does not arrive within KRYPY_AMD_XR_TIMEOUT_S (60) seconds is reported as
+ * KH_ERR_COMM by the next call that synchronises with the host. */
+int kh_xr_export(kh_ctx ctx, unsigned char handle[64]);
+int kh_xr_attach(kh_ctx ctx, int rank, int nranks, const unsigned char* handles);
+int kh_xr_detach(kh_ctx ctx);
 /* describe the halo of a block-row-sharded matrix: this rank sends `nsend_*` of its first/last
  * local rows to the previous/next rank and receives as many ghost entries from them.  After
  * this call kh_apply() on `A` exchanges halos (ncclSend/ncclRecv) before the local SpMV; the

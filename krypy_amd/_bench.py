@@ -28,7 +28,7 @@ K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 _SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h", "chain_blk.h",
-            "chain_blk.hip", "proj_reg.h", "proj_reg.hip")
+            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip")
 
 
 def source_stamp():
@@ -172,6 +172,9 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
                 solver = run_ms(ms, solver_name, comp, comp + 8.0 * n * (m + 1) / 2.0 * rr,
                                 (8.0 * nd * n if fused else op) + 16.0 * n * (m + 1) / 2.0 + 8.0 * n)
                 solver["fused_operator"] = bool(fused)
+                # (the PMC passes see the chain kernel's launches, i.e. the steps k >= 1 - step k = 0 is the one-column
+                # Lanczos kernel: what their traffic is compared with is the compulsory bytes of THOSE steps)
+                solver["compulsory_bytes_k_ge_1"] = op + 8.0 * n * (m * (m + 1) / 2.0 - 1.0) / (m - 1.0) + 8.0 * n if m > 1 else comp
                 solver["links_per_launch_avg"] = (m + 1) / 2.0
                 solver["us_per_link"] = ms * 1e3 / ((m + 1) / 2.0)
             del Vm
@@ -246,7 +249,7 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
     elif solver is not None:
         k, name, traffic_keys = solver, solver_name, ("k_mgs_chain_solver",)
     elif chain is not None:
-        k, name, traffic_keys = chain, chain_name, ("k_mgs_chain",)
+        k, name, traffic_keys = chain, chain_name, ("k_mgs_chain_micro",)
     else:
         k, name, traffic_keys = kernels["k_gs_link<A_PART,T_DOT>"], "k_gs_link<A_PART,T_DOT>", ()
     ms = k["avg_ms"]
@@ -281,7 +284,8 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
                             "v_{k+1} out - SURVEY 8(d)'s per-unit figures with the column's second use NOT charged to HBM",
             "source_stamp": stamp}
     if traffic is not None:
-        roof["traffic_over_bytes"] = traffic / comp
+        # like with like: the solver key's traffic is the average over the steps k >= 1, so are the bytes under it
+        roof["traffic_over_bytes"] = traffic / (k.get("compulsory_bytes_k_ge_1", comp) if traffic_keys == ("k_mgs_chain_solver",) else comp)
         roof["traffic_gbs"] = _gbs(traffic, ms)
         roof["frac_traffic"] = _gbs(traffic, ms) / peak_gbs
         roof["traffic_source"] = ("rocprofv3 PMC, separate passes: 2 x FETCH_SIZE + WRITE_SIZE (the guide's gfx950 "

@@ -61,6 +61,9 @@ _SIGNATURES = {
     "kh_comm_init": [_H, _INT, _INT, ctypes.c_char_p],
     "kh_comm_destroy": [_H],
     "kh_comm_allreduce_host": [_H, _c_double_p, _I64],
+    "kh_xr_export": [_H, ctypes.c_char_p],
+    "kh_xr_attach": [_H, _INT, _INT, ctypes.c_char_p],
+    "kh_xr_detach": [_H],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
     "kh_mat_set_ghost": [_H, _c_double_p, _I64],
     "kh_mat_get_ghost": [_H, _c_double_p, _I64],
@@ -514,6 +517,28 @@ class Context(object):
     def comm_init(self, rank, nranks, unique_id):
         _check(self._lib, self._lib.kh_comm_init(self._h, rank, nranks, unique_id), "kh_comm_init")
         self.rank, self.nranks = rank, nranks
+
+    # xr: cross-rank sums through IPC-mapped mailboxes (csrc/xr.hip); see krypy_amd.dist.enable_xr for the whole protocol
+    def xr_export(self):
+        """This rank's mailbox as a 64-byte ``hipIpcMemHandle_t`` (``kh_xr_export``)."""
+        buf = ctypes.create_string_buffer(64)
+        _check(self._lib, self._lib.kh_xr_export(self._h, buf), "kh_xr_export")
+        return buf.raw
+
+    def xr_attach(self, rank, nranks, handles):
+        """Map every peer's mailbox: ``handles`` = the ``nranks`` handles in rank order, 64 bytes each."""
+        handles = bytes(handles)
+        if len(handles) != 64 * nranks:
+            raise BackendError("xr_attach: %d bytes of handles for %d ranks" % (len(handles), nranks))
+        _check(self._lib, self._lib.kh_xr_attach(self._h, rank, nranks, handles), "kh_xr_attach")
+
+    def xr_enable(self, rank, nranks):
+        """All-reduces take the mailboxes from now on (every rank must do the same: ``dist.enable_xr``)."""
+        self.set("xr", 1)
+        self.rank, self.nranks = rank, nranks
+
+    def xr_detach(self):
+        self._lib.kh_xr_detach(self._h)
 
     def allreduce_host(self, vals):
         a = numpy.ascontiguousarray(vals, dtype=numpy.float64)

@@ -13,15 +13,21 @@ static constexpr size_t BLK_RES_WORDS = (size_t)16 * 2 * BLK_NVS * 2;
 static constexpr size_t BLK_TAB_WORDS = (size_t)BLK_TABCOLS * BLK_TW;   // doubles: BLK_TW entries per column
 
 // granule buffers of the blocked kernel's sums; zero = "no epoch yet" (epochs start at 1)
+// (an existing buffer: the granules only - the Gram table behind them belongs to the Arnoldi sequence that is running and
+// an epoch wrap in the middle of it must not zero rows that (ctx->blk_V, ctx->blk_next) still vouch for)
 hipError_t chain_blk_reset(kh_ctx ctx) {
+    size_t words = BLK_GRAN_WORDS + BLK_GRAN2_WORDS + BLK_RES_WORDS;
     if (ctx->blk_gran == nullptr) {
         hipError_t e = hipMalloc(&ctx->blk_gran, sizeof(unsigned long long) * (BLK_GRAN_WORDS + BLK_GRAN2_WORDS + BLK_RES_WORDS + BLK_TAB_WORDS));
         if (e != hipSuccess) {
             ctx->blk_gran = nullptr;
             return e;
         }
+        words += BLK_TAB_WORDS;
+        ctx->blk_V = nullptr;
+        ctx->blk_next = -1;
     }
-    return hipMemsetAsync(ctx->blk_gran, 0, sizeof(unsigned long long) * (BLK_GRAN_WORDS + BLK_GRAN2_WORDS + BLK_RES_WORDS + BLK_TAB_WORDS), ctx->stream);
+    return hipMemsetAsync(ctx->blk_gran, 0, sizeof(unsigned long long) * words, ctx->stream);
 }
 
 void chain_blk_free(kh_ctx ctx) {

@@ -69,7 +69,12 @@ int load_rccl() {
 namespace kh {
 
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
-    if (ctx->comm == nullptr || count == 0) return 0;   // a 1-rank communicator still goes through RCCL
+    if (count == 0) return 0;
+    if (ctx->xr_on) {                                   // mailboxes over IPC / xGMI (xr.hip): no library call
+        ctx->n_allreduce += 1;
+        return xr_allreduce_dev(ctx, dev, count);
+    }
+    if (ctx->comm == nullptr) return 0;                 // a 1-rank communicator still goes through RCCL
     ctx->n_allreduce += 1;
     KH_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm,
                              ctx->stream));
@@ -197,8 +202,14 @@ int kh_comm_init(kh_ctx ctx, int rank, int nranks, const unsigned char id[128]) 
 }
 
 int kh_comm_destroy(kh_ctx ctx) {
-    if (!ctx || !ctx->comm) return 0;
+    if (!ctx) return 0;
     (void)hipStreamSynchronize(ctx->stream);
+    kh::xr_free(ctx);
+    if (!ctx->comm) {
+        if (ctx->commbuf) (void)hipFree(ctx->commbuf);
+        ctx->commbuf = nullptr;
+        return 0;
+    }
     g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr;
     ctx->force_multi = 0;
@@ -219,13 +230,14 @@ int kh_comm_destroy(kh_ctx ctx) {
 
 int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count) {
     KH_ARG(ctx && (vals || count == 0), "kh_comm_allreduce_host: NULL");
-    if (ctx->comm == nullptr || count == 0) return 0;
+    if ((ctx->comm == nullptr && !ctx->xr_on) || count == 0) return 0;
     KH_ARG(count <= kh::SCAL_CAP, "kh_comm_allreduce_host: at most %d values", kh::SCAL_CAP);
+    if (ctx->commbuf == nullptr) KH_HIP(hipMalloc(&ctx->commbuf, sizeof(double) * kh::SCAL_CAP));      // (xr without a communicator)
     KH_HIP(hipMemcpyAsync(ctx->commbuf, vals, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
     KH_TRY(kh::comm_allreduce_dev(ctx, ctx->commbuf, count));
     KH_HIP(hipMemcpyAsync(vals, ctx->commbuf, sizeof(double) * count, hipMemcpyDeviceToHost, ctx->stream));
     KH_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return kh::xr_check(ctx);
 }
 
 int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next, int64_t nrecv_prev,
@@ -235,6 +247,9 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
     const int width = A->kind == KH_MAT_ZCSR ? 2 : 1;
     KH_ARG(nsend_prev >= 0 && nsend_next >= 0 && nrecv_prev >= 0 && nrecv_next >= 0, "negative halo");
     KH_ARG(nsend_prev <= A->n_rows && nsend_next <= A->n_rows, "halo wider than the local slab");
+    KH_ARG(!(ctx->comm == nullptr && ctx->nranks > 1 && (nsend_prev + nsend_next + nrecv_prev + nrecv_next) > 0),
+           "kh_mat_set_halo: %d ranks joined through the xr transport alone (no RCCL communicator): sums cross ranks, halos "
+           "do not - initialise the communicator (kh_comm_init) for an operator that couples the slabs", ctx->nranks);
     KH_ARG(A->n_cols == A->n_rows + nrecv_prev + nrecv_next,
            "kh_mat_set_halo: n_cols %lld != n_rows %lld + ghosts %lld", (long long)A->n_cols,
            (long long)A->n_rows, (long long)(nrecv_prev + nrecv_next));

@@ -104,6 +104,7 @@ struct kh_ctx_s {
     const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...
     int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
     int64_t n_blk_rowless = 0;       // blocked launches with workgroups without rows in front (chain_blk.h, BlkBufs::nx)
+    int64_t blk_refused_n = -1;      // vector length whose blocked launch was refused (occupancy ...): not tried - nor its table rebuilt - again
     int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
     // reference-order Gram-Schmidt with one reduction per step on N ranks (krylov_hip.hip: try_lowsync_mgs; KRYPY_AMD_MGS_LOWSYNC)
     int mgs_lowsync = 1;
@@ -119,6 +120,10 @@ struct kh_ctx_s {
     unsigned long long* proj_gran = nullptr;   // granules, per-XCD totals and leader stamps of its 16-value sums
     unsigned proj_epoch = 1;
     int64_t n_proj_reg = 0;
+    int* proj_err = nullptr;         // its OWN device error word (a timed-out sum), mirrored to pinned memory behind every launch:
+    int* proj_err_pin = nullptr;     // kh_arnoldi_step_end / kh_proj_apply_complement re-run without this kernel
+    int proj_fault = 0;              // tests: the next launch behaves like a timed-out one (kh_ctx_set "proj_fault")
+    int64_t n_proj_recovered = 0;
     int proj_panel = 1;              // ... or, on N ranks, its passes through the register-resident panel kernels (KRYPY_AMD_PROJ_PANEL)
     int64_t n_proj_panel = 0;        // sweeps that took them
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle
@@ -155,6 +160,7 @@ struct kh_ctx_s {
     int tag_wait = 1;       // KRYPY_AMD_TAG_WAIT=0: events for every step
     int64_t n_tag_waits = 0;
     unsigned chain_epoch = 1;
+    int64_t n_epoch_wraps = 0;       // times the epoch counter was brought back to 1 (granules zeroed, Gram-table key withdrawn)
     int chain_debug = 0;
     int roctx = 0;          // KRYPY_AMD_ROCTX=1: roctx ranges around the entry points of the hot loop
     int chain_fault = 0;    // tests: the next chain launch reports a timeout and leaves garbage behind
@@ -176,6 +182,22 @@ struct kh_ctx_s {
     int64_t n_halo_exchange = 0;    // grouped ncclSend / ncclRecv exchanges issued
     int64_t n_allreduce = 0;        // ncclAllReduce calls issued (kh_ctx_get "n_allreduce")
     double* commbuf = nullptr;  // device staging for host all-reduces
+    // ---- xr: sums across the ranks of ONE node without a library call (xr.hip) ----
+    // Every rank owns a mailbox in fine-grained device memory, exported with hipIpcGetMemHandle and mapped by its peers
+    // (kh_xr_export / kh_xr_attach; the handles travel over the launcher's rendezvous).  A sum is then ONE small kernel:
+    // system-scope stores of tagged 8-byte granules into every peer's mailbox (over xGMI), a poll of the own mailbox,
+    // the contributions added in rank order - the same bits on every rank - instead of an ncclAllReduce kernel per panel.
+    unsigned long long* xr_box = nullptr;              // my mailbox
+    unsigned long long* xr_peer[16] = {nullptr};       // every rank's mailbox as mapped here (xr_peer[rank] == xr_box)
+    int xr_rank = 0, xr_nranks = 0;                    // as attached (0: not attached)
+    int xr_on = 0;                                     // kh_ctx_set "xr": all-reduces take this path (the host layer switches it
+                                                       // on after EVERY rank has attached: the choice must be the same everywhere)
+    int xr_own_comm = 0;                               // no RCCL communicator: rank / nranks come from the attach
+    unsigned xr_epoch = 1;                             // one per exchange kernel; tags the granules
+    int* xr_err_pin = nullptr;                         // mapped pinned word a timed-out exchange writes (checked where the host syncs)
+    int64_t xr_timeout_ms = 0;                         // how long a gather waits for a peer (0: KRYPY_AMD_XR_TIMEOUT_S or 60 s)
+    int64_t n_xr = 0;                                  // exchanges issued
+    int64_t n_xr_fused = 0;                            // ... of which in the same launch as the reduction of the partial sums
 };
 
 struct kh_vec_s {
@@ -245,6 +267,16 @@ namespace kh {
 int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
 int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream, int width = 1);
 int comm_halo_exchange_panel(kh_ctx ctx, kh_mat A, const double* X, int64_t ldx, int64_t ncols, hipStream_t stream);
+// xr.hip
+constexpr int XR_MAXV = 512;        // values per exchange kernel (larger panels go in chunks)
+constexpr int XR_MAXRANKS = 16;
+int xr_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
+// out[c] = sum over the ranks of the fixed-order sum of part[c * pstride + 0 .. nb): k_reduce_partials (mode 0) and the
+// all-reduce in ONE launch when the xr transport is on and count <= XR_MAXV; otherwise the reduction launch followed by
+// comm_allreduce_dev.  `multi` false: the reduction alone.
+int reduce_partials_allreduce(kh_ctx ctx, const double* part, int nb, int pstride, double* out, int count, bool multi);
+void xr_free(kh_ctx ctx);
+int xr_check(kh_ctx ctx);           // KH_ERR_COMM when an exchange has timed out since the last look
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);
 // chain_blk.hip

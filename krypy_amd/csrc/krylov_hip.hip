@@ -135,7 +135,7 @@ static int fetch_scalars(kh_ctx ctx, const double* dev, int64_t count, double* o
                           ctx->stream));
     KH_HIP(hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->hpin, count * sizeof(double));
-    return 0;
+    return xr_check(ctx);          // (a cross-rank sum that timed out upstream of these scalars: an error, xr.hip)
 }
 
 static int push_scalars(kh_ctx ctx, const double* host, int64_t count, double* dev) {
@@ -617,10 +617,15 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
         KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
         KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
         if (ctx->blk_gran != nullptr) {
+            // (the blocked kernel's granules only: chain_blk_reset leaves the Gram table of the running Arnoldi sequence
+            // alone when the buffer exists - ADVICE r04: a zeroed table behind a still matching (blk_V, blk_next) key
+            // silently dropped the corrections.  The key is withdrawn as well: the next blocked step rebuilds its rows.)
             KH_HIP(chain_blk_reset(ctx));
             KH_HIP(hipStreamSynchronize(ctx->stream));
+            ctx->blk_next = -1;
         }
         ctx->chain_epoch = 1;
+        ctx->n_epoch_wraps += 1;
     }
     ChainArgs a;
     a.n2 = n2;
@@ -774,7 +779,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             a.onex_clear = ctx->onex_ticket + ((slot_ + 128u) & 255u);
         }
         // a long chain: the blocked form - one grid-wide sum per FOUR columns (chain_blk.h)
-        if (blk_takes_step(ctx, a, r2) && padded && chain_blk_shape_ok(r2, G, a, fused ? a.offs.nd : 0)) {
+        if (blk_takes_step(ctx, a, r2) && padded && chain_blk_shape_ok(r2, G, a, fused ? a.offs.nd : 0) && ctx->blk_refused_n != n) {
             int nsums = 0;
             // the Gram table: valid when this is the next step of the sequence that owns it; otherwise (a sequence's
             // first blocked step, a block grown / recycled / written by another entry point since) its rows are
@@ -808,6 +813,10 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
             }
             (void)hipGetLastError();
+            // refused (occupancy: other kernels resident, fewer compute units ...): remembered for vectors of this length, so
+            // that the steps to come do not rebuild the table - up to 2 k panel products - just to be refused again
+            // (kh_ctx_set("chain_blk", 1) forgets it)
+            ctx->blk_refused_n = n;
         }
 #define KH_SM(R, X)                                                                                          \
     (fused ? (a.offs.nd == 5 ? launch_chain_small<R, false, 5, X>(ctx, G, a) : launch_chain_small<R, false, 7, X>(ctx, G, a)) \
@@ -1021,10 +1030,8 @@ static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, c
         // one sweep: the coefficients ARE the H entries - reduce (and all-reduce) straight into the H
         // column, which the caller then need not clear, and skip the accumulate launch
         if (sweeps == 1) coef = hdev + cw * start;
-        hipLaunchKernelGGL(k_reduce_partials, dim3((int)(cw * ncol)), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
-                           CGS_PSTRIDE, coef, 0);
-        KH_HIP(hipGetLastError());
-        if (multi) KH_TRY(comm_allreduce_dev(ctx, coef, cw * ncol));
+        // (N ranks with the xr transport: the reduction of the wave partials and the sum across the ranks in ONE launch)
+        KH_TRY(reduce_partials_allreduce(ctx, ctx->cgs_part, nwave, CGS_PSTRIDE, coef, (int)(cw * ncol), multi));
         if (sweeps > 1)
             hipLaunchKernelGGL(k_waxpby, dim3(1), dim3(BS), 0, ctx->stream, cw * ncol, hdev + cw * start, 1.0,
                                hdev + cw * start, 1.0, coef);
@@ -1205,10 +1212,7 @@ static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t
     }
     // [c_0 .. c_k | g_0 .. g_{k-1}]: one reduction launch, ONE all-reduce
     double* cg = ctx->scal + SC_LS;
-    hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)(2 * ncol - 1)), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave,
-                       CGS_PSTRIDE, cg, 0);
-    KH_HIP(hipGetLastError());
-    if (multi) KH_TRY(comm_allreduce_dev(ctx, cg, 2 * ncol - 1));
+    KH_TRY(reduce_partials_allreduce(ctx, ctx->cgs_part, nwave, CGS_PSTRIDE, cg, 2 * ncol - 1, multi));
     hipLaunchKernelGGL(k_lowsync_solve, dim3(1), dim3(LS_MAXCOL), sizeof(double) * ((size_t)k * (k + 1) + 2), ctx->stream, (int)k, cg,
                        ctx->ls_tab, coef, hdev);
     KH_HIP(hipGetLastError());
@@ -1374,7 +1378,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
 int kh_ctx_sync(kh_ctx ctx) {
     KH_ARG(ctx != nullptr, "kh_ctx_sync: NULL ctx");
     KH_HIP(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return xr_check(ctx);
 }
 
 int kh_ctx_info(kh_ctx ctx, int64_t info[4]) {
@@ -1430,7 +1434,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "lanczos_fused")) ctx->lanczos_fused = value != 0;
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
-    else if (!strcmp(key, "chain_blk")) ctx->chain_blk = value != 0;
+    else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
     else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
     else if (!strcmp(key, "lowsync_rows")) {        // (local slab length << 32) | longest slab of the run
         const int64_t loc = value >> 32, mx = value & 0xffffffffll;
@@ -1441,11 +1445,34 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
         ctx->ls_rows_local[slot] = loc;
         ctx->ls_rows_max[slot] = mx;
     }
+    else if (!strcmp(key, "xr")) {
+        // the cross-rank sums through IPC mailboxes (xr.hip).  EVERY rank must make the same setting: the host layer
+        // (krypy_amd/dist.py: enable_xr) switches it on after all ranks have attached
+        if (value != 0) {
+            KH_ARG(ctx->xr_nranks > 0, "kh_ctx_set(\"xr\", 1): kh_xr_attach first");
+            if (ctx->comm == nullptr) {          // no RCCL communicator: the attach defines the ranks
+                ctx->rank = ctx->xr_rank;
+                ctx->nranks = ctx->xr_nranks;
+                ctx->xr_own_comm = 1;
+            }
+            ctx->xr_on = 1;
+        } else {
+            ctx->xr_on = 0;
+            if (ctx->xr_own_comm) {
+                ctx->rank = 0;
+                ctx->nranks = 1;
+                ctx->xr_own_comm = 0;
+            }
+        }
+    }
+    else if (!strcmp(key, "xr_timeout_ms")) ctx->xr_timeout_ms = value;
     else if (!strcmp(key, "proj_reg")) ctx->proj_reg = value != 0;
+    else if (!strcmp(key, "proj_fault")) ctx->proj_fault = value != 0;
     else if (!strcmp(key, "proj_panel")) ctx->proj_panel = value != 0;
     else if (!strcmp(key, "blk_onex_maxn")) ctx->blk_onex_maxn = value;
     else if (!strcmp(key, "blk_nx")) ctx->blk_nx = value > 0 ? 8 : 0;
     else if (!strcmp(key, "tag_wait")) ctx->tag_wait = value != 0;
+    else if (!strcmp(key, "chain_epoch")) ctx->chain_epoch = (unsigned)value;      // tests: bring the epoch counter of the grid-wide sums near its wrap
     else if (!strcmp(key, "chain_debug")) ctx->chain_debug = (int)value;    // measurement: phases switched off (garbage results)
     else return fail(KH_ERR_ARG, "kh_ctx_set: unknown key '%s'", key);
     return 0;
@@ -1484,7 +1511,11 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_cg_cycle_steps")) *value = ctx->n_cg_cycle_steps;
     else if (!strcmp(key, "mgs_lowsync")) *value = ctx->mgs_lowsync;
     else if (!strcmp(key, "proj_reg")) *value = ctx->proj_reg;
+    else if (!strcmp(key, "xr")) *value = ctx->xr_on;
+    else if (!strcmp(key, "n_xr")) *value = ctx->n_xr;
+    else if (!strcmp(key, "n_xr_fused")) *value = ctx->n_xr_fused;
     else if (!strcmp(key, "n_proj_reg")) *value = ctx->n_proj_reg;
+    else if (!strcmp(key, "n_proj_recovered")) *value = ctx->n_proj_recovered;
     else if (!strcmp(key, "proj_panel")) *value = ctx->proj_panel;
     else if (!strcmp(key, "n_proj_panel")) *value = ctx->n_proj_panel;
     else if (!strcmp(key, "n_lowsync")) *value = ctx->n_lowsync;
@@ -1492,6 +1523,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
     else if (!strcmp(key, "n_allreduce")) *value = ctx->n_allreduce;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
+    else if (!strcmp(key, "chain_epoch")) *value = ctx->chain_epoch;
+    else if (!strcmp(key, "n_epoch_wraps")) *value = ctx->n_epoch_wraps;
     else return fail(KH_ERR_ARG, "kh_ctx_get: unknown key '%s'", key);
     return 0;
 }
@@ -2104,12 +2137,11 @@ static int proj_apply_dev(kh_ctx ctx, kh_proj p, double* z, double* ya_dev, int6
         const int rc_d = panel ? cgs_panel_pass(ctx, p->W, d, z, zld, nullptr, false, &nwave) : 0;
         if (rc_d < 0) return rc_d;
         if (rc_d == 1) {
-            hipLaunchKernelGGL(k_reduce_partials, dim3(d), dim3(BS), 0, ctx->stream, ctx->cgs_part, nwave, CGS_PSTRIDE, p->c0, 0);
-            KH_HIP(hipGetLastError());
+            KH_TRY(reduce_partials_allreduce(ctx, ctx->cgs_part, nwave, CGS_PSTRIDE, p->c0, d, kh_multi(ctx)));
         } else {
             KH_TRY(dot_panel_dev(ctx, p->W, 0, d, z, p->c0, 0));
+            if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, d));
         }
-        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, p->c0, d));
         if (it == 0 && ya_dev != nullptr)
             hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->WRH, p->c0, ya_dev);
         hipLaunchKernelGGL(k_small_matvec, dim3(1), dim3(BS), 0, ctx->stream, d, p->T, p->c0, p->c1);
@@ -2534,9 +2566,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         double* vn = V->col(k + 1);
         double* pn = P ? P->col(k + 1) : nullptr;
         if (multi) {
-            hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, nrm_part, nrm_count, 0,
-                               tmp + 1, 0);
-            KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
+            KH_TRY(reduce_partials_allreduce(ctx, nrm_part, nrm_count, 0, tmp + 1, 1, true));
             hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, mw, vn,
                                pn, nullptr, 0, tmp + 1, hs, hdev, (int)(k + 2 + pd), ctx->hslot_pin[slot]);
         } else {
@@ -2584,6 +2614,20 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
     } else {
         KH_HIP(hipEventSynchronize(ctx->hev[slot]));
     }
+    KH_TRY(xr_check(ctx));
+    // the one-launch projector of a deflated step (proj_reg.h) reports a timed-out sum in a word of its own: the step - its w
+    // was garbage whatever Gram-Schmidt kernels followed - is re-run below with the four-launch projector, the kernel stays
+    // off for this context
+    bool proj_timeout = false;
+    if (ctx->proj_err_pin != nullptr && *ctx->proj_err_pin != 0 && ctx->step[slot].kind != 0 && ctx->step[slot].proj != nullptr) {
+        proj_timeout = true;
+        *ctx->proj_err_pin = 0;
+        ctx->proj_reg = 0;
+        ctx->n_proj_recovered += 1;
+        fprintf(stderr, "krylov_hip: the grid-wide sum of the one-launch deflation projector timed out (a GPU shared with other "
+                        "work?); it stays off for this context, the four-launch projector takes over\n");
+        *ctx->chain_err_pin[slot] = 1;
+    }
     if (*ctx->chain_err_pin[slot] != 0) {
         // The grid-wide reduction of the chain kernel timed out (its workgroups were not co-resident: a shared
         // or partially masked GPU).  Column k+1 of the basis and this H column are garbage, columns 0..k are
@@ -2591,10 +2635,14 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         // Steps begun after it (look-ahead) consumed the garbage; each of them reports the error in its own
         // slot and is recovered in turn when the host asks for it, in order.
         *ctx->chain_err_pin[slot] = 0;
-        if (ctx->chain_enabled) chain_switch_off(ctx);      // (look-ahead steps that saw the same timeout do not count again)
-        ctx->n_chain_recovered += 1;
+        if (ctx->chain_enabled && !proj_timeout) chain_switch_off(ctx);      // (look-ahead steps that saw the same timeout do not count again)
+        ctx->n_chain_recovered += proj_timeout ? 0 : 1;
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
+        if (proj_timeout) {
+            KH_HIP(hipMemset(ctx->proj_err, 0, sizeof(int)));
+            *ctx->proj_err_pin = 0;          // (look-ahead steps in flight copied the set word again)
+        }
         for (int s2 = 0; s2 < KH_NSLOT; ++s2)      // later steps in flight saw the same error word
             if (s2 != slot && *ctx->chain_err_pin[s2] == 0 && ctx->step[s2].kind != 0 &&
                 ctx->step[s2].V == ctx->step[slot].V && ctx->step[s2].k > ctx->step[slot].k)
@@ -2614,7 +2662,10 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         else
             return fail(KH_ERR_HIP, "grid-wide reduction of the MGS chain kernel timed out and the step cannot be "
                                     "re-run (no record of it)");
-        KH_HIP(hipEventSynchronize(ctx->hev[slot]));
+        // (after a projector timeout the chain kernels are still on: the re-run step may have ended in a chain launch that
+        // signals through its completion tag and records NO event - wait for the stream itself)
+        KH_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->wait_tag[slot] = false;
     }
     memcpy(hcol_out, ctx->hslot_pin[slot], sizeof(double) * count);
     return 0;
@@ -3092,7 +3143,25 @@ int kh_proj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_v
     if (!(A == Z && acol == zcol))
         KH_HIP(hipMemcpyAsync(Z->col(zcol), A->col(acol), sizeof(double) * A->n, hipMemcpyDeviceToDevice,
                               ctx->stream));
+    const int64_t pr0 = ctx->n_proj_reg;
     KH_TRY(proj_apply_dev(ctx, p, Z->col(zcol), ya_out ? p->ya : nullptr, Z->ld));
+    if (ctx->n_proj_reg != pr0) {
+        // the one-launch form ran: its error word (a timed-out grid-wide sum) is looked at HERE - nobody else would
+        KH_HIP(hipStreamSynchronize(ctx->stream));
+        if (*ctx->proj_err_pin != 0) {
+            *ctx->proj_err_pin = 0;
+            KH_HIP(hipMemset(ctx->proj_err, 0, sizeof(int)));
+            ctx->proj_reg = 0;
+            ctx->n_proj_recovered += 1;
+            fprintf(stderr, "krylov_hip: the grid-wide sum of the one-launch deflation projector timed out; it stays off for this "
+                            "context, the four-launch projector takes over\n");
+            if (A == Z && acol == zcol)
+                return fail(KH_ERR_HIP, "kh_proj_apply_complement: the one-launch projector timed out on an in-place call (the "
+                                        "input has been overwritten); call again with the input restored");
+            KH_HIP(hipMemcpyAsync(Z->col(zcol), A->col(acol), sizeof(double) * A->n, hipMemcpyDeviceToDevice, ctx->stream));
+            KH_TRY(proj_apply_dev(ctx, p, Z->col(zcol), ya_out ? p->ya : nullptr, Z->ld));
+        }
+    }
     if (ya_out) return fetch_scalars(ctx, p->ya, p->d, ya_out);
     return 0;
 }

@@ -26,6 +26,10 @@ static hipError_t proj_reg_reset(kh_ctx ctx) {
 void proj_reg_free(kh_ctx ctx) {
     if (ctx->proj_gran != nullptr) (void)hipFree(ctx->proj_gran);
     ctx->proj_gran = nullptr;
+    if (ctx->proj_err != nullptr) (void)hipFree(ctx->proj_err);
+    if (ctx->proj_err_pin != nullptr) (void)hipHostFree(ctx->proj_err_pin);
+    ctx->proj_err = nullptr;
+    ctx->proj_err_pin = nullptr;
 }
 
 template <int R2>
@@ -62,6 +66,12 @@ int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G,
         if (ctx->proj_gran != nullptr) KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(proj_reg_reset(ctx));
     }
+    if (ctx->proj_err == nullptr) {
+        KH_HIP(hipMalloc(&ctx->proj_err, sizeof(int)));
+        KH_HIP(hipMemsetAsync(ctx->proj_err, 0, sizeof(int), ctx->stream));
+        KH_HIP(hipHostMalloc(&ctx->proj_err_pin, sizeof(int), hipHostMallocDefault));
+        *ctx->proj_err_pin = 0;
+    }
     ProjRegArgs a;
     a.n2 = (n + 1) >> 1;
     a.chunk2 = chunk2;
@@ -78,7 +88,7 @@ int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G,
     a.res = ctx->proj_gran + PR_GRAN_WORDS;
     a.xcc_leader = reinterpret_cast<unsigned*>(ctx->proj_gran + PR_GRAN_WORDS + PR_RES_WORDS);
     a.epoch0 = ctx->proj_epoch;
-    a.err = ctx->chain_err;
+    a.err = ctx->proj_err;      // (its own word: a timeout here must not make the chain kernels that follow break out of THEIR waits)
     hipError_t e;
     switch (r2) {
         case 16: e = launch_proj<16>(ctx, G, a); break;
@@ -95,6 +105,14 @@ int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G,
     }
     ctx->proj_epoch += (unsigned)p->iterations;
     ctx->n_proj_reg += 1;
+    if (ctx->proj_fault) {          // tests: what a timed-out sum leaves behind - the error word set, garbage in z
+        ctx->proj_fault = 0;
+        KH_HIP(hipMemsetAsync(ctx->proj_err, 1, 1, ctx->stream));
+        KH_HIP(hipMemsetAsync(z, 0, sizeof(double) * (size_t)(n < 4096 ? n : 4096), ctx->stream));
+    }
+    // the word travels to pinned memory behind the launch: whoever synchronises next (kh_arnoldi_step_end for a deflated
+    // step whatever its Gram-Schmidt variant, kh_proj_apply_complement) sees it and runs the four-launch projector instead
+    KH_HIP(hipMemcpyAsync(ctx->proj_err_pin, ctx->proj_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     return 1;
 }
 

@@ -30,7 +30,7 @@ import scipy.sparse
 
 from . import _hip, utils
 
-__all__ = ["slab_cuts", "localize_columns", "ShardedCSROperator", "TcpRendezvous"]
+__all__ = ["slab_cuts", "localize_columns", "ShardedCSROperator", "TcpRendezvous", "enable_xr"]
 
 
 class TcpRendezvous(object):
@@ -151,6 +151,28 @@ class TcpRendezvous(object):
         """max over the ranks of one double (every rank gets it)."""
         return self._reduce(float(x), max)
 
+    def allreduce_min(self, x):
+        """min over the ranks of one double (every rank gets it): "did EVERY rank succeed?"."""
+        return self._reduce(float(x), min)
+
+    def allgather_bytes(self, data):
+        """Every rank's ``data`` (equal lengths), in rank order, on every rank."""
+        data = bytes(data)
+        if self.world <= 1:
+            return [data]
+        if self.rank == 0:
+            parts = [data] + [self._recv(s) for s in self._peers]
+            blob = b"".join(parts)
+            for s in self._peers:
+                self._send(s, blob)
+        else:
+            self._send(self._peers[0], data)
+            blob = self._recv(self._peers[0])
+        n = len(data)
+        if len(blob) != n * self.world:
+            raise RuntimeError("TcpRendezvous.allgather_bytes: contributions of unequal length")
+        return [blob[i * n:(i + 1) * n] for i in range(self.world)]
+
     def barrier(self):
         self._reduce(0.0, max)
 
@@ -163,6 +185,65 @@ class TcpRendezvous(object):
         self._peers = []
 
     destroy_process_group = close        # (the name the launcher-side code knew the torch.distributed module by)
+
+
+def enable_xr(ctx, rdv, rank=None, world=None):
+    """Switch the cross-rank sums of ``ctx`` to the IPC mailboxes of ``csrc/xr.hip`` - on EVERY rank or on none.
+
+    Every rank exports its mailbox (``kh_xr_export``), the handles are gathered over the launcher's rendezvous ``rdv``
+    (``allgather_bytes`` / ``allreduce_min``: :class:`TcpRendezvous` or anything with those two methods), every rank
+    maps its peers' mailboxes (``kh_xr_attach``), and only when ALL ranks report success is the transport switched on
+    (``kh_ctx_set "xr"``): whether a sum runs as a mailbox kernel or as ``ncclAllReduce`` must come out the same on
+    every rank.  Works without an RCCL communicator too (then ``rank`` / ``world`` define the ranks: sums cross them, halos
+    do not).  ``KRYPY_AMD_XR=0`` keeps RCCL.  Returns True when the transport is on."""
+    rank = rdv.rank if rank is None else rank
+    world = rdv.world if world is None else world
+    want = (os.environ.get("KRYPY_AMD_XR", "1") != "0" and hasattr(ctx, "xr_export") and world <= 16)
+    ok, handle = 0.0, b"\0" * 64
+    if want:
+        try:
+            handle = ctx.xr_export()
+            ok = 1.0
+        except _hip.BackendError:
+            ok = 0.0
+    handles = rdv.allgather_bytes(handle)
+    if rdv.allreduce_min(ok) < 1.0:
+        return False
+    try:
+        ctx.xr_attach(rank, world, b"".join(handles))
+        ok = 1.0
+    except _hip.BackendError:
+        ok = 0.0
+    if rdv.allreduce_min(ok) < 1.0:
+        if ok:
+            ctx.xr_detach()
+        return False
+    before = (ctx.rank, ctx.nranks)
+    ctx.xr_enable(rank, world)
+    # a short self-test before anything depends on it: a few sums whose results every rank can work out by itself, with
+    # a short timeout.  Stale or invisible stores (a platform where fine-grained IPC memory does not behave as assumed)
+    # show up here as a timeout or a wrong sum - then EVERY rank goes back to RCCL, together.
+    good = 1.0
+    try:
+        ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_SELFTEST_S", "8")) * 1e3))
+        for t, count in enumerate((1, 37, 512, 700, 5, 1, 1, 64)):
+            def contrib(r):
+                return numpy.random.default_rng(1000 * t + r).standard_normal(count)
+            want = contrib(0)
+            for r in range(1, world):
+                want = want + contrib(r)                      # rank order, like the kernel
+            got = ctx.allreduce_host(contrib(rank))
+            if not numpy.array_equal(got, want):
+                good = 0.0
+    except _hip.BackendError:
+        good = 0.0
+    if rdv.allreduce_min(good) < 1.0:
+        ctx.set("xr", 0)
+        ctx.xr_detach()
+        ctx.rank, ctx.nranks = before
+        return False
+    ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_TIMEOUT_S", "60")) * 1e3))
+    return True
 
 
 def slab_cuts(n, nranks, align=1):

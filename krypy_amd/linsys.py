@@ -498,6 +498,11 @@ class Cg(_KrylovSolver):
                     trace.append((i, float(ct[6 * i]), float(ct[6 * i + 1]), float(ct[6 * i + 2]), float(ct[6 * i + 3]),
                                   int(ct[6 * i + 4])))
                 if why == _hip.CYCLE_CHECK:
+                    # the iterations k .. k_done-1 the call DID record belong to the solver's state first (what the
+                    # per-step path leaves behind when step k_done fails: rhos, resnorms and iter agree with each other)
+                    for i in range(k, k_done):
+                        rhos.append(float(cr[i + 1]))
+                        self.resnorms.append(numpy.float64(ct[6 * i + 5]) / bnorm)
                     self.iter = k_done
                     self.xk = self._get_xk(yk)
                     raise _hip.BackendError(

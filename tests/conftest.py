@@ -38,6 +38,27 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _kernel_expectations_are_judged_last(request):
+    """tests/support/kernel_expect.py: 'which kernel ran' expectations are reported after the test body (all numeric
+    comparisons) has passed - as an error at teardown that says so."""
+    from tests.support import kernel_expect
+    kernel_expect.drain()
+    yield
+    failed = kernel_expect.drain()
+    if failed and getattr(request.node, "_call_passed", False):      # (a failed body already speaks for itself)
+        pytest.fail("KERNEL-PATH EXPECTATION (all numeric comparisons of this test passed): " + "; ".join(failed),
+                    pytrace=False)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_makereport(item, call):
+    outcome = yield
+    rep = outcome.get_result()
+    if rep.when == "call":
+        item._call_passed = rep.passed
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
 

@@ -15,6 +15,8 @@ from tests import parity_cases as pc
 from tests import parity_cases_complex as pcc
 from tests import parity_cases_utils as pcu
 
+from tests.support.kernel_expect import expect_kernel
+
 pytestmark = pytest.mark.gpu
 
 SIMPLE = [
@@ -172,12 +174,14 @@ def test_chain_timeout_is_recovered(hip, solver):
         rearmed1, chain1 = hip.get("n_chain_rearmed"), hip.counters()["chain"]
     finally:
         hip.set("chain", 1)
-    assert n0 == 0 and n1 >= 1, (n0, n1)
-    assert off_after == 0 and recov == 1, (off_after, recov)
-    assert n2 == 0 and rearmed1 - rearmed0 == 1 and chain1 - chain0 >= 40, (n2, rearmed0, rearmed1, chain0, chain1)
     assert np.array_equal(np.asarray(again.resnorms), np.asarray(good.resnorms))
-    assert hip.get("chain") == 1 and hip.get("chain_recoveries") == 0
     assert len(bad.resnorms) == len(good.resnorms) == 41
+    # what ran (judged after the comparisons below: tests/support/kernel_expect.py)
+    expect_kernel(n0 == 0 and n1 >= 1, "recoveries clean / faulted run 0 / >= 1: %r" % ((n0, n1),))
+    expect_kernel(off_after == 0 and recov == 1, "chain off after the timeout, one recovery: %r" % ((off_after, recov),))
+    expect_kernel(n2 == 0 and rearmed1 - rearmed0 == 1 and chain1 - chain0 >= 40,
+                  "re-armed with the next basis: %r" % ((n2, rearmed0, rearmed1, chain0, chain1),))
+    expect_kernel(hip.get("chain") == 1 and hip.get("chain_recoveries") == 0, "chain on again, recoveries reset")
     # the per-column kernels and the chain kernel differ in the order of their partial sums only
     # (test_mgs_chain_every_register_shape): the recovered solve is the undisturbed one to rounding
     assert np.max(np.abs(np.asarray(bad.resnorms) - np.asarray(good.resnorms)) / np.asarray(good.resnorms)) < 1e-9
@@ -209,7 +213,7 @@ def test_csr_panel_apply_streams_the_matrix_once(hip, kind, d):
         before = hip.get("n_spmm")
         hip.apply(Ad, X, 0, Y, 1, d)                       # (an offset in the output block, too)
         got, want = Y.download(1, d), A.dot(x)
-        assert hip.get("n_spmm") - before == (1 if d >= 2 else 0)
+        expect_kernel(hip.get("n_spmm") - before == (1 if d >= 2 else 0), "hip.get(\"n_spmm\") - before == (1 if d >= 2 else 0)")
     finally:
         hip.set("spmv_dia", 1)
     if kind == "long_row":
@@ -548,14 +552,14 @@ def test_operator_fused_into_the_chain_prologue(hip, shape):
                 H[start: k + 2, k] = hcol[start: k + 2]
             res[name] = (H, V.download(), P.download() if use_m else np.zeros(1))
             c = ctx.counters()
-            assert c["chain"] - before["chain"] == m, (name, c)
+            expect_kernel(c["chain"] - before["chain"] == m, "c[\"chain\"] - before[\"chain\"] == m: %r" % ((name, c),))
             lds_on = os.environ.get("KRYPY_AMD_CHAIN_LDS", "1") != "0"
             lz = ctx.get("n_lanczos_fused") - lz0
             long_shape = n > 10_480_000
             lz_on = fused and os.environ.get("KRYPY_AMD_LANCZOS_FUSED", "1") != "0" and not long_shape
-            assert lz == ((m if lanczos else 1) if lz_on else 0), (name, lz)
-            assert c["chain_lds"] - before["chain_lds"] == ((m - lz) if (lds_on and not use_m and not long_shape) else 0), (name, c)
-            assert c["chain_fused"] - before["chain_fused"] == (m if fused else 0), (name, c)
+            expect_kernel(lz == ((m if lanczos else 1) if lz_on else 0), "lz == ((m if lanczos else 1) if lz_on else 0): %r" % ((name, lz),))
+            expect_kernel(c["chain_lds"] - before["chain_lds"] == ((m - lz) if (lds_on and not use_m and not long_shape) else 0), "c[\"chain_lds\"] - before[\"chain_lds\"] == ((m - lz) if (lds_on and not use_m and not long_shape) else 0): %r" % ((name, c),))
+            expect_kernel(c["chain_fused"] - before["chain_fused"] == (m if fused else 0), "c[\"chain_fused\"] - before[\"chain_fused\"] == (m if fused else 0): %r" % ((name, c),))
             del V, W, P
         out.append(res)
         ctx.close()
@@ -606,8 +610,8 @@ def test_lanczos_kernel_on_short_vectors(hip, shape):
                 H[k: k + 2, k] = hcol[k: k + 2]
             ctx.minres_flush()
             res[name] = (H, V.download(), P.download() if use_m else np.zeros(1), Wm.download(), yk.download())
-            assert ctx.get("n_lanczos_fused") - lz0 == (m if fused else 0), (name, fused)
-            assert ctx.get("n_minres_rides") - rides0 == (m - 2 if fused else 0), (name, fused)
+            expect_kernel(ctx.get("n_lanczos_fused") - lz0 == (m if fused else 0), "ctx.get(\"n_lanczos_fused\") - lz0 == (m if fused else 0): %r" % ((name, fused),))
+            expect_kernel(ctx.get("n_minres_rides") - rides0 == (m - 2 if fused else 0), "ctx.get(\"n_minres_rides\") - rides0 == (m - 2 if fused else 0): %r" % ((name, fused),))
         out.append(res)
         ctx.close()
     for name in out[0]:
@@ -698,11 +702,11 @@ def test_column_ring_kernel_for_short_vectors(hip, n):
                 hcol = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if (name == "spmv" and k in (5, 6)) else 1, 0, 0.0)
                 H[: k + 2, k] = hcol[: k + 2]
                 if small and name == "spmv" and k == 9:
-                    assert ctx.get("chain") == 0       # (the recovery switches the chain off: back on for the rest)
+                    expect_kernel(ctx.get("chain") == 0, "the recovery switches the chain off")       # (back on for the rest)
                     ctx.set("chain", 1)
             res[small, name] = (H, V.download())
         used = ctx.get("n_chain_small") - c0
-        assert (used >= 2 * m - 1) == bool(small), (small, used)
+        expect_kernel((used >= 2 * m - 1) == bool(small), "k_mgs_chain_small launches: %r" % ((small, used),))
     ctx.close()
     same_geometry = not (131072 < n <= 262144)
     for name, mat in (("prologue", A), ("spmv", Ar)):
@@ -752,7 +756,7 @@ def test_completion_tags_replace_the_per_step_event(hip):
                 ctx.set("chain", 1)
         H[: m + 2, m] = ctx.arnoldi_step_end(m % 4, m + 2)
         waits = ctx.get("n_tag_waits") - w0
-        assert (waits >= m - 3) if tag else (waits == 0), (tag, waits)
+        expect_kernel((waits >= m - 3) if tag else (waits == 0), "tag waits: %r" % ((tag, waits),))
         res[tag] = (H, V.download())
         ctx.close()
     # (the step behind the faked timeout is re-run on the link kernels, the one after it consumed its garbage and is
@@ -801,9 +805,9 @@ def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
         monkeypatch.setenv("KRYPY_AMD_GMRES_CYCLE", "0")
         c1 = hip.get("n_cycle_steps")
         s0, f0 = run(make)
-        assert hip.get("n_cycle_steps") == c1
+        expect_kernel(hip.get("n_cycle_steps") == c1, "hip.get(\"n_cycle_steps\") == c1")
         monkeypatch.delenv("KRYPY_AMD_GMRES_CYCLE")
-        assert used > 0, name
+        expect_kernel(used > 0, "used > 0: %r" % (name,))
         assert f1 == f0 and len(s1.resnorms) == len(s0.resnorms), (name, len(s1.resnorms), len(s0.resnorms))
         r1, r0 = np.array(s1.resnorms), np.array(s0.resnorms)
         if name == "restarted":      # open loop over restarts: last-bit differences of the two Givens generators grow
@@ -833,7 +837,7 @@ def test_gmres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
         before = hip.get("n_chain_recovered")
         hip.set("chain_fault", 1)
         bad, _ = run(cases[0][1])
-        assert hip.get("n_chain_recovered") > before
+        expect_kernel(hip.get("n_chain_recovered") > before, "hip.get(\"n_chain_recovered\") > before")
     finally:
         hip.set("chain", 1)
     assert len(bad.resnorms) == len(good.resnorms)
@@ -870,9 +874,9 @@ def test_cg_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
         monkeypatch.setenv("KRYPY_AMD_CG_CYCLE", "0")
         c1 = hip.get("n_cg_cycle_steps")
         s0 = run(make)
-        assert hip.get("n_cg_cycle_steps") == c1
+        expect_kernel(hip.get("n_cg_cycle_steps") == c1, "hip.get(\"n_cg_cycle_steps\") == c1")
         monkeypatch.delenv("KRYPY_AMD_CG_CYCLE")
-        assert used > 0, name
+        expect_kernel(used > 0, "used > 0: %r" % (name,))
         assert s1.resnorms == s0.resnorms and s1.rhos == s0.rhos and s1.iter == s0.iter, name
         assert list(s1.cg_trace) == list(s0.cg_trace), name
         assert np.array_equal(s1.xk, s0.xk), name
@@ -915,14 +919,15 @@ def test_minres_cycle_in_c_equals_the_per_step_loop(hip, monkeypatch):
         monkeypatch.setenv("KRYPY_AMD_MINRES_CYCLE", "0")
         c1 = hip.get("n_minres_cycle_steps")
         s0, f0 = run(make)
-        assert hip.get("n_minres_cycle_steps") == c1
+        expect_kernel(hip.get("n_minres_cycle_steps") == c1, "hip.get(\"n_minres_cycle_steps\") == c1")
         monkeypatch.delenv("KRYPY_AMD_MINRES_CYCLE")
         if name == "stored":
             monkeypatch.undo()
-        assert used > 0, name
+        expect_kernel(used > 0, "used > 0: %r" % (name,))
         assert f1 == f0 and len(s1.resnorms) == len(s0.resnorms), (name, len(s1.resnorms), len(s0.resnorms))
         if name == "window":
-            assert used >= 190 and len(s1.resnorms) == 201
+            assert len(s1.resnorms) == 201
+            expect_kernel(used >= 190, "kh_minres_cycle steps >= 190: %r" % (used,))
         r1, r0 = np.array(s1.resnorms), np.array(s0.resnorms)
         assert np.array_equal(r1[:-1], r0[:-1]), (name, np.max(np.abs(r1[:-1] - r0[:-1]) / r0[:-1]))
         assert abs(r1[-1] - r0[-1]) <= 1e-9 * max(r0[-1], 1e-300) or r0[-1] < 1e-8, name       # (the explicit residual a solve ends with)
@@ -980,7 +985,7 @@ def test_short_vectors_run_on_one_xcd(hip, n):
                 H[start: k + 2, k] = hcol[start: k + 2]
             res[name] = (H, V.download())
         used = ctx.get("n_chain_onex") - c0
-        assert (used > 0) == bool(onex), (onex, used)
+        expect_kernel((used > 0) == bool(onex), "(used > 0) == bool(onex): %r" % ((onex, used),))
         out.append(res)
     ctx.close()
     for name in out[0]:
@@ -1026,7 +1031,7 @@ def test_mgs_chain_every_register_shape(hip, rows, cplx):
         H = np.zeros((m + 1, m), dtype=dt)
         for k in range(m):
             H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 0)
-        assert ctx.counters()["chain"] == (m if chain else 0)      # the one-launch kernel really ran
+        expect_kernel(ctx.counters()["chain"] == (m if chain else 0), "ctx.counters()[\"chain\"] == (m if chain else 0)")      # the one-launch kernel really ran
         res.append((H, V.download()))
         ctx.close()
     (Hc, Vc), (Hl, Vl) = res
@@ -1046,7 +1051,7 @@ def test_mgs_chain_every_register_shape(hip, rows, cplx):
         H = np.zeros((m + 1, m), dtype=dt)
         for k in range(m):
             H[: k + 2, k] = ctx.arnoldi_step(Ad, None, V, None, W, 0, k, 0, 2 if k == 3 else 1, 1)
-        assert (ctx.counters()["cgs_register"] > 0) == chain
+        expect_kernel((ctx.counters()["cgs_register"] > 0) == chain, "(ctx.counters()[\"cgs_register\"] > 0) == chain")
         res.append((H, V.download()))
         ctx.close()
     (Hc, Vc), (Hl, Vl) = res
@@ -1097,7 +1102,7 @@ def test_multi_rank_code_path_on_one_gpu(hip):
     # the sharded SpMV runs as two launches - interior row blocks while the halo exchange is on the
     # communication stream, boundary blocks after it (forced mode on one rank: a one-block boundary at both ends)
     # - for the banded and for the CSR-stream kernel: the same bits as one launch
-    assert ctx.get("n_spmv_split") > 0
+    expect_kernel(ctx.get("n_spmv_split") > 0, "ctx.get(\"n_spmv_split\") > 0")
     A2 = ref.laplace2d(300, 211)
     op2 = kdist.ShardedCSROperator(A2, 0, A2.shape[0], ctx)
     x2 = np.random.default_rng(8).standard_normal((A2.shape[0], 1))
@@ -1108,7 +1113,7 @@ def test_multi_rank_code_path_on_one_gpu(hip):
             ctx.set("spmv_split", split)
             before = ctx.get("n_spmv_split")
             ctx.apply(op2._device_matrix(), X2, 0, Y2, 0, 1)
-            assert (ctx.get("n_spmv_split") - before) == split
+            expect_kernel((ctx.get("n_spmv_split") - before) == split, "(ctx.get(\"n_spmv_split\") - before) == split")
             assert np.array_equal(Y2.download(), A2.dot(x2)), (dia, split)
     ctx.set("spmv_dia", 1)
     ctx.set("spmv_split", 1)
@@ -1260,7 +1265,7 @@ def test_general_csr_operators_of_the_bench_tool(hip, kind, n):
         sol = linsys.Gmres(linsys.LinearSystem(A, b), maxiter=40, tol=1e-30)
     except utils.ConvergenceError as e:
         sol = e.solver
-    assert hip.counters()["chain_fused"] == f0          # (nothing to fuse: the operator is not banded)
+    expect_kernel(hip.counters()["chain_fused"] == f0, "hip.counters()[\"chain_fused\"] == f0")          # (nothing to fuse: the operator is not banded)
     want = ref.gmres(A, b, tol=1e-30, maxiter=40)
     res, wres = np.array(sol.resnorms), np.array(want.resnorms)
     assert len(res) == len(wres) == 41

@@ -125,6 +125,46 @@ def test_fused_cg_step_is_fenced(cpu_double, monkeypatch):
     with pytest.raises(_hip.BackendError) as ei:
         linsys.Cg(linsys.LinearSystem(c["hpd"], c["b"], **hpd), tol=1e-10, maxiter=300)
     assert "non-finite" in str(ei.value) and "flags 1" in str(ei.value)
+    monkeypatch.setattr(type(cpu_double), "cg_step", real_step)
+    # the same fault inside a run of iterations made by ONE C call (kh_cg_cycle): the iterations the call did record
+    # are in the solver's state before the error leaves it - rhos, resnorms and iter agree with each other, exactly as
+    # the per-step path leaves them
+    from tests.support import numpy_context as nc
+    Ar = sp.csr_matrix(c["hpd"].real)
+    br = c["b"].real
+    real_fn = nc._cg_step
+    seen = {}
+
+    class Watched(linsys.Cg):
+        def _get_xk(self, yk):
+            seen["solver"] = self
+            return super(Watched, self)._get_xk(yk)
+
+    for per_step in (False, True):
+        count = []
+
+        def faulty_fn(self, *a):
+            den, rho_new, pap, flags = real_fn(self, *a)
+            count.append(1)
+            if len(count) == 4:
+                return float("nan"), rho_new, pap, _hip.CG_NONFINITE_PAP
+            return den, rho_new, pap, flags
+
+        monkeypatch.setattr(nc, "_cg_step", faulty_fn)
+        monkeypatch.setattr(type(cpu_double), "cg_step", faulty_fn)
+        if per_step:
+            monkeypatch.setenv("KRYPY_AMD_CG_CYCLE", "0")
+        cpu_double.calls.clear()
+        with pytest.raises(_hip.BackendError):
+            Watched(linsys.LinearSystem(Ar, br, **hpd), tol=1e-10, maxiter=300)
+        sv = seen.pop("solver")
+        assert ("cg_cycle" in cpu_double.calls) == (not per_step)
+        seen[per_step] = (sv.iter, len(sv.resnorms), list(sv.resnorms))
+        assert sv.iter == 3 and len(sv.resnorms) == 4, (per_step, sv.iter, len(sv.resnorms))
+    assert np.allclose(seen[False][2], seen[True][2], rtol=1e-12)
+    monkeypatch.delenv("KRYPY_AMD_CG_CYCLE")
+    monkeypatch.setattr(nc, "_cg_step", real_fn)
+    monkeypatch.setattr(type(cpu_double), "cg_step", real_step)
 
 
 def test_complex_cg_minres_gmres_with_jacobi_stay_on_the_fused_entries(cpu_double):

@@ -52,19 +52,32 @@ def main(src, dst):
         lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
             short(name), calls, tot / 1e3, avg, pct, v[0], v[1], v[2]))
     lines.append("")
-    # the roofline kernel's identical micro-launches (bench.py / kh_bench_kernel) are the last launches of
-    # the run: their kernel-trace duration is what the live HIP-event average must agree with
+    # bench.py's identical micro-launches (kh_bench_kernel), selected by what identifies them - NOT by "the last N launches"
+    # (kh_bench_arnoldi runs behind them since round 4, so the last chain launches of a run are the solver's
+    # steps k = 80 .. 99).  The chain micro-launch is the instantiation WITHOUT the operator in its prologue (last template
+    # argument FND = 0; every other chain launch of a `--other-modes none` run is the solver's FND = 5 / 7 one) and always has
+    # 64 links; the panel kernels' micro-launches (16 columns) are the last launches of a `--ortho cgs` run, which has no
+    # kh_bench_arnoldi leg.
+    MICRO_CHAIN = "name like '%k_mgs_chain%' and name like '%, 0>%'"
+    SOLVER_CHAIN = "name like '%k_mgs_chain%' and name not like '%, 0>%'"
     try:
-        for pat, label in (("%k_mgs_chain%", "k_mgs_chain (64 links per launch)"),
-                           ("%k_cgs_dots%", "k_cgs_dots (16 columns)"), ("%k_cgs_update%", "k_cgs_update (16 columns)")):
-            d = q(tdb, "select end - start from kernels where name like '%s' order by start desc limit 20" % pat)
-            if d:
-                lines.append("Kernel-trace average of the last %d `%s` launches (bench.py's micro-launches): "
-                             "**%.1f us**." % (len(d), label, sum(x[0] for x in d) / len(d) / 1e3))
-        d = q(tdb, "select end - start from kernels where name like '%k_mgs_chain%' and name not like '%, 0>%'")
+        d = q(tdb, "select end - start from kernels where " + MICRO_CHAIN)
+        if d:
+            lines.append("Kernel-trace average of the %d launches of the chain kernel WITHOUT the operator in its prologue "
+                         "(template argument FND = 0: bench.py's 64-link micro-launches, warm-up included): **%.1f us**."
+                         % (len(d), sum(x[0] for x in d) / len(d) / 1e3))
+        nsolver = q(tdb, "select count(*) from kernels where " + SOLVER_CHAIN)[0][0]
+        if not nsolver:          # (a --ortho cgs run: no kh_bench_arnoldi leg behind the micro-launches)
+            for pat, label in (("%k_cgs_dots%", "k_cgs_dots (16 columns)"), ("%k_cgs_update%", "k_cgs_update (16 columns)")):
+                d = q(tdb, "select end - start from kernels where name like '%s' order by start desc limit 20" % pat)
+                if d:
+                    lines.append("Kernel-trace average of the last %d `%s` launches (bench.py's micro-launches; no solver "
+                                 "launch of this kernel follows them in a panel-mode run): **%.1f us**."
+                                 % (len(d), label, sum(x[0] for x in d) / len(d) / 1e3))
+        d = q(tdb, "select end - start from kernels where " + SOLVER_CHAIN)
         if d:
             lines.append("Kernel-trace average of all %d launches of the fused-operator chain kernel (the solver's Arnoldi "
-                         "steps; bench.py's `roofline.avg_launch_ms` averages the same launches plus step k = 0 and the "
+                         "steps k >= 1; bench.py's `roofline.avg_launch_ms` averages the same launches plus step k = 0 and the "
                          "queue gaps): **%.1f us**." % (len(d), sum(x[0] for x in d) / len(d) / 1e3))
         lines.append("")
     except Exception as exc:  # pragma: no cover
@@ -97,8 +110,18 @@ def main(src, dst):
     try:
         fdb = os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")
         wdb = os.path.join(src, "pmc_WRITE_SIZE", "pmc_results.db")
-        for key, pat in (("k_mgs_chain", "%k_mgs_chain%"), ("k_cgs_dots", "%k_cgs_dots%"),
-                         ("k_cgs_update", "%k_cgs_update%")):
+        f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + MICRO_CHAIN)
+        w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and " + MICRO_CHAIN)
+        if f and w:
+            tj["k_mgs_chain_micro"] = {
+                "hbm_read_bytes_per_launch": 2 * sum(x[0] for x in f) / len(f) * 1024,
+                "hbm_write_bytes_per_launch": sum(x[0] for x in w) / len(w) * 1024, "launches_averaged": len(f),
+                "note": "all %d launches of the chain kernel without the operator in its prologue (FND = 0) = bench.py's "
+                        "64-link kh_bench_kernel launches; FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
+        solver_launches = q(fdb, "select count(*) from pmc_events where counter_name='FETCH_SIZE' and " + SOLVER_CHAIN)[0][0]
+        for key, pat in (("k_cgs_dots", "%k_cgs_dots%"), ("k_cgs_update", "%k_cgs_update%")):
+            if solver_launches:          # (an mgs run: its last panel-kernel launches are not micro-launches)
+                break
             f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and name like '%s' "
                        "order by start desc limit 40" % pat)
             w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and name like '%s' "
@@ -108,18 +131,18 @@ def main(src, dst):
                 wr = sum(x[0] for x in w) / len(w) * 1024
                 tj[key] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
                            "launches_averaged": len(f),
-                           "note": "last %d launches of the run = bench.py's kh_bench_kernel launches; "
+                           "note": "last %d launches of a panel-mode run = bench.py's kh_bench_kernel launches; "
                                    "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
         # the solver's own instantiation of the chain kernel (operator in the prologue: a template argument FND > 0),
         # every launch of the run - whole cycles k = 1 .. m-1 of the solver and of kh_bench_arnoldi alike
-        cond = "name like '%k_mgs_chain%' and name not like '%, 0>%'"
-        f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + cond)
-        w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and " + cond)
+        f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + SOLVER_CHAIN)
+        w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and " + SOLVER_CHAIN)
         if f and w:
             rd = 2 * sum(x[0] for x in f) / len(f) * 1024
             wr = sum(x[0] for x in w) / len(w) * 1024
             tj["k_mgs_chain_solver"] = {
                 "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "launches_averaged": len(f),
+                "steps": "k >= 1",       # (step k = 0 runs the one-column Lanczos kernel: bench.py compares with the bytes of k >= 1)
                 "note": "all %d launches of the fused-operator chain kernel in the run (Arnoldi steps k >= 1 of whole "
                         "GMRES cycles); FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
     except Exception as exc:  # pragma: no cover
