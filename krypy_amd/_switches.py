@@ -39,6 +39,10 @@ SWITCHES = [
     ("KRYPY_AMD_CHAIN_BLK", "1", "kernel-path", "0",
      "0: short vectors (4 rows per lane, 8 or more Gram-Schmidt links in the step) take the per-column ring kernel instead of the "
      "blocked kernel (`csrc/chain_blk.h`: one grid-wide sum per four columns)"),
+    ("KRYPY_AMD_CHAIN_BLK2", "1", "kernel-path", "0",
+     "0: vectors of 5 / 6 rows per lane (1.05 M ... 1.57 M rows) keep the per-column ring kernel on one GPU, and on N ranks with the xr "
+     "transport on `ortho='mgs'` keeps the one-reduction form (two cross-rank sums per step, the local basis read twice) instead of the "
+     "eight-wave blocked kernel with the cross-rank sums INSIDE the launch (`csrc/chain_blk2.h`: the basis read once, no all-reduce call)"),
     ("KRYPY_AMD_BLK_ONEX_MAXN", "70000", "tuning", None,
      "vectors longer than this run the blocked kernel spread over the chip instead of on one XCD"),
     ("KRYPY_AMD_BLK_NX", "8", "kernel-path", "0",

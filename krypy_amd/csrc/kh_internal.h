@@ -103,6 +103,12 @@ struct kh_ctx_s {
     unsigned long long* blk_gran = nullptr;   // granules + per-XCD totals of the blocked kernel's sums + its Gram table (chain_blk.hip)
     const void* blk_V = nullptr;     // the basis block whose Arnoldi sequence owns the Gram table ...
     int64_t blk_next = -1;           // ... and the step that finds it valid (-1: nobody)
+    int blk_kind = 1;                // whose table it is: 1 = k_mgs_chain_blk (entries of the block before + the own block), 2 =
+                                     // k_mgs_chain_blk2 (own block only)
+    int chain_blk2 = 1;              // KRYPY_AMD_CHAIN_BLK2: the eight-wave blocked kernel (4 ... 6 rows per lane; on N ranks with the
+                                     // cross-rank sums inside the launch)
+    int64_t n_chain_blk2 = 0;
+    int64_t blk2_refused_n = -1;
     int64_t n_blk_rowless = 0;       // blocked launches with workgroups without rows in front (chain_blk.h, BlkBufs::nx)
     int64_t blk_refused_n = -1;      // vector length whose blocked launch was refused (occupancy ...): not tried - nor its table rebuilt - again
     int64_t n_blk_rebuild = 0;       // times the Gram table was rebuilt from the basis (a sequence's first blocked step)
@@ -295,6 +301,13 @@ static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
     if (ctx->ls_V == v) ctx->ls_next = -1;       // (the one-reduction form's table, krylov_hip.hip: same rule)
 }
 hipError_t chain_blk_reset(kh_ctx ctx);
+// chain_blk2.hip: the eight-wave blocked kernel with the cross-rank stage
+bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out);
+int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount,
+                    bool multi);
+// krylov_hip.hip: the epoch counter of the grid-wide sums brought back to 1 when it nears its wrap; <V[:, j0 .. j0+ncols), w> on the device
+int chain_epoch_check(kh_ctx ctx);
+int dot_panel_raw(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* w, double* out_dev);
 void chain_blk_free(kh_ctx ctx);
 // proj_reg.hip
 int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G, double* ya_dev);

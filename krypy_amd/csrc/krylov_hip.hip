@@ -559,6 +559,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     // (from 4096 rows on: below that a vector is a fraction of one workgroup's chunk)
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
+    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);      // (chain_blk2.h: 4 ... 6 rows)
     return ld == 0 ? 32 : ld;
 }
 
@@ -571,6 +572,29 @@ static inline bool blk_takes_step(kh_ctx ctx, const ChainArgs& a, int r2) {
 
 // returns 1 if the chain was launched, 0 if this step is not eligible (caller uses the link
 // kernels), negative on error
+// the epoch counter of the grid-wide sums nears its wrap: everything that carries tags is zeroed, the count starts over
+int chain_epoch_check(kh_ctx ctx) {
+    if (ctx->chain_epoch <= 0xfff00000u) return 0;
+    KH_HIP(hipStreamSynchronize(ctx->stream));
+    KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
+    KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
+    if (ctx->blk_gran != nullptr) {
+        // (the blocked kernels' granules only: chain_blk_reset leaves the Gram table of the running Arnoldi sequence
+        // alone when the buffer exists - ADVICE r04: a zeroed table behind a still matching (blk_V, blk_next) key
+        // silently dropped the corrections.  The key is withdrawn as well: the next blocked step rebuilds its rows.)
+        KH_HIP(chain_blk_reset(ctx));
+        KH_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->blk_next = -1;
+    }
+    ctx->chain_epoch = 1;
+    ctx->n_epoch_wraps += 1;
+    return 0;
+}
+
+int dot_panel_raw(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* w, double* out_dev) {
+    return ::dot_panel_dev(ctx, V, j0, ncols, w, out_dev, 0);
+}
+
 static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
                      kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
                      const double* h_km1_dev, double* hdev, int slot, bool cplx = false, double* hpin = nullptr,
@@ -607,26 +631,28 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
     }
     if (cplx && 4 * G > 2 * CH_GMAX) return 0;      // grid_sum2: four granules per workgroup
     if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n || (P && P->ld <= n))) return 0;
+    // 1.05 M ... 1.57 M rows (8 rows per lane in the general geometry, 5 / 6 here), no preconditioner, a long chain: the
+    // eight-wave blocked kernel (chain_blk2.h) - one grid-wide sum per four columns, columns read once.  It loads w: with the
+    // operator to be fused (Afuse) nothing is launched here, the caller runs the SpMV and comes back without it.
+    {
+        int r2b = 0, Gb = 0;
+        if (ctx->chain_blk2 && ctx->chain_blk && ctx->chain_small && r2 == 8 && !want_onex && B == V && dg == nullptr && !cplx && !presub &&
+            sweeps == 1 && start == 0 && k + 1 >= KH_BLK_MIN_LINKS && (ctx->chain_debug == 0) && n != ctx->blk2_refused_n &&
+            chain_blk2_shape(ctx, n, &r2b, &Gb) && r2b > 4) {
+            if (Afuse != nullptr) return 0;
+            const int rc = chain_blk2_step(ctx, V, w, wld, k, hdev, slot, hpin, hcount, false);
+            if (rc != 0) {
+                if (rc == 1) ctx->n_chain_lds += 1;      // (the column is used twice from the chip: counted with that family)
+                return rc;
+            }
+        }
+    }
     const int64_t chunk2 = (int64_t)r2 * CH_BS;
     // predicate-free kernel iff every block involved is padded to G whole chunks
     const int64_t need_ld = (int64_t)G * chunk2 * 2;
     const bool padded = V->ld >= need_ld && B->ld >= need_ld && (P == nullptr || P->ld >= need_ld) &&
                         wld >= need_ld;
-    if (ctx->chain_epoch > 0xfff00000u) {
-        KH_HIP(hipStreamSynchronize(ctx->stream));
-        KH_HIP(hipMemset(ctx->chain_gran, 0, sizeof(unsigned long long) * 4 * CH_GMAX));
-        KH_HIP(hipMemset(ctx->chain_xcc, 0, sizeof(unsigned long long) * 128 + sizeof(unsigned) * 16));
-        if (ctx->blk_gran != nullptr) {
-            // (the blocked kernel's granules only: chain_blk_reset leaves the Gram table of the running Arnoldi sequence
-            // alone when the buffer exists - ADVICE r04: a zeroed table behind a still matching (blk_V, blk_next) key
-            // silently dropped the corrections.  The key is withdrawn as well: the next blocked step rebuilds its rows.)
-            KH_HIP(chain_blk_reset(ctx));
-            KH_HIP(hipStreamSynchronize(ctx->stream));
-            ctx->blk_next = -1;
-        }
-        ctx->chain_epoch = 1;
-        ctx->n_epoch_wraps += 1;
-    }
+    KH_TRY(chain_epoch_check(ctx));
     ChainArgs a;
     a.n2 = n2;
     a.chunk2 = chunk2;
@@ -784,7 +810,7 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
             // the Gram table: valid when this is the next step of the sequence that owns it; otherwise (a sequence's
             // first blocked step, a block grown / recycled / written by another entry point since) its rows are
             // rebuilt from the basis - one panel product per column, once
-            if (!(ctx->blk_V == V && ctx->blk_next == k)) {
+            if (!(ctx->blk_V == V && ctx->blk_next == k && ctx->blk_kind == 1)) {
                 double* gt = chain_blk_table(ctx);
                 if (gt == nullptr) return fail(KH_ERR_NOMEM, "chain_blk: no memory for the Gram table");
                 for (int64_t j = 1; j <= k; ++j) {
@@ -795,10 +821,12 @@ static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wl
                 }
                 ctx->blk_V = V;
                 ctx->blk_next = k;
+                ctx->blk_kind = 1;
                 ctx->n_blk_rebuild += 1;
             }
             e = chain_blk_launch(ctx, r2, G, want_onex, padded, fused ? a.offs.nd : 0, a, V, &nsums);
             if (e == hipSuccess) {
+                ctx->blk_kind = 1;
                 if (a.debug == 4) ctx->chain_fault = 0;
                 ctx->n_chain += 1;
                 ctx->n_chain_small += 1;
@@ -1311,6 +1339,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_small = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK");
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_BLK2");
+        ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");
         ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_PANEL");
@@ -1435,6 +1465,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_onex")) ctx->chain_onex = value != 0;
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
+    else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
     else if (!strcmp(key, "lowsync_rows")) {        // (local slab length << 32) | longest slab of the run
         const int64_t loc = value >> 32, mx = value & 0xffffffffll;
@@ -1500,6 +1531,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_small")) *value = ctx->chain_small;
     else if (!strcmp(key, "chain_blk")) *value = ctx->chain_blk;
     else if (!strcmp(key, "n_chain_blk")) *value = ctx->n_chain_blk;
+    else if (!strcmp(key, "chain_blk2")) *value = ctx->chain_blk2;
+    else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;
     else if (!strcmp(key, "blk_nx")) *value = ctx->blk_nx;
@@ -2383,13 +2416,26 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     // N ranks, reference order: all coefficients of the step from one pass and ONE all-reduce (try_lowsync_mgs below)
     const bool want_lowsync = (kh_multi(ctx) && gs_mode == KH_GS_MGS && sweeps == 1 && start == 0 && !presub && Md == nullptr &&
                                lowsync_eligible(ctx, V, W->ld, k));
+    // ... or, with the xr transport on and slabs of up to 6 rows per lane: the blocked kernel with the cross-rank sums INSIDE the
+    // launch (chain_blk2.h) - the local basis is read once, no all-reduce call in the step.  Eligibility is decided for the
+    // longest slab of the run (like the one-reduction form's), so every rank decides alike; from there on a refusal is an error.
+    bool want_blk2 = false;
+    if (kh_multi(ctx) && ctx->xr_on && ctx->chain_blk2 && ctx->chain_configured && gs_mode == KH_GS_MGS && sweeps == 1 && start == 0 &&
+        !presub && Md == nullptr) {
+        int64_t nmax = ctx->nranks > 1 ? 0 : n;
+        for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
+            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        int r2m = 0, gm = 0;
+        want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm) && k + 3 <= 4096;
+    }
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
-                            A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync);
+                            A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync && !want_blk2);
     // the H column accumulates over sweeps, so it starts from zero - except under the chain kernel, whose
     // first sweep assigns (one memset launch and its queue bubble less per step)
     // (nor under the single-sweep register-resident panel kernels, which write the entries directly)
     const bool want_cgs1 = (gs_mode == KH_GS_CGS && sweeps == 1 && ctx->chain_enabled);
-    if (!want_chain && !want_cgs1) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
+    // (... nor under the blocked kernel with the cross-rank sums inside, which assigns every entry as well)
+    if (!want_chain && !want_cgs1 && !(want_blk2 && pd == 0)) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
     // 1. operator
     bool fused_chain = false;
     if (A != nullptr) {
@@ -2446,6 +2492,11 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         if (!chained) {   // not eligible after all: clear the column now, nothing has been accumulated yet
             KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2), ctx->stream));
         }
+    }
+    if (!chained && want_blk2) {
+        const int rc = chain_blk2_step(ctx, V, w, W->ld, k, hdev, slot, ctx->hslot_pin[slot], (int)(k + 2 + pd), true);
+        if (rc < 0) return rc;
+        chained = (rc == 1);
     }
     bool lowsync = false;
     if (!chained && want_lowsync) {
@@ -2627,6 +2678,16 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         fprintf(stderr, "krylov_hip: the grid-wide sum of the one-launch deflation projector timed out (a GPU shared with other "
                         "work?); it stays off for this context, the four-launch projector takes over\n");
         *ctx->chain_err_pin[slot] = 1;
+    }
+    if (*ctx->chain_err_pin[slot] != 0 && kh_multi(ctx) && !proj_timeout) {
+        // (chain kernels run on a communicator only as the blocked kernel with the cross-rank sums inside: whatever timed
+        // out - a workgroup of this launch, a peer rank - re-running the step HERE alone on other kernels would change the
+        // pattern of collectives the peers see)
+        const int code = *ctx->chain_err_pin[slot];
+        *ctx->chain_err_pin[slot] = 0;
+        return fail(KH_ERR_COMM, "a sum inside the blocked Gram-Schmidt kernel timed out on rank %d of %d (%s); no rank-local recovery on "
+                                 "a communicator", ctx->rank, ctx->nranks, code == 2 ? "a peer rank's contribution did not arrive" :
+                                 "a workgroup of the launch did not arrive");
     }
     if (*ctx->chain_err_pin[slot] != 0) {
         // The grid-wide reduction of the chain kernel timed out (its workgroups were not co-resident: a shared

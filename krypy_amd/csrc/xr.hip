@@ -34,6 +34,7 @@
 
 #include "kh_internal.h"
 #include "kernels.h"
+#include "xr_dev.h"
 
 namespace kh {
 
@@ -47,52 +48,18 @@ struct XrArgs {
 
 static constexpr size_t XR_BOX_WORDS = (size_t)2 * XR_MAXRANKS * XR_MAXV * 2;      // [parity][sender][value][lo, hi]
 
-__device__ __forceinline__ size_t xr_slot(unsigned epoch, int sender, int v) {
-    return (((size_t)(epoch & 1u) * XR_MAXRANKS + (size_t)sender) * XR_MAXV + (size_t)v) * 2;
-}
-
 // my value v to every rank's mailbox (mine included: the gather below reads every contribution from the mailbox, so one
 // code path - and a 1-rank loopback runs all of it)
 __device__ __forceinline__ void xr_publish(const XrArgs& a, int v, double x) {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
-    const unsigned long long tag = (unsigned long long)a.epoch << 32;
-    const unsigned long long lo = tag | (bits & 0xffffffffull), hi = tag | (bits >> 32);
-    const size_t s = xr_slot(a.epoch, a.rank, v);
-    for (int r = 0; r < a.nranks; ++r) {
-        // start with the next rank: the writes of N ranks do not all land on rank 0's link first
-        const int q = (a.rank + 1 + r) % a.nranks;
-        __hip_atomic_store(a.peer[q] + s, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(a.peer[q] + s + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    xr_put_all(a.peer, a.rank, a.nranks, a.epoch, v, x);
 }
 
 // the sum over the ranks of value v, contributions added in rank order
 __device__ __forceinline__ double xr_gather(const XrArgs& a, int v) {
-    const unsigned long long* box = a.peer[a.rank];
-    double total = 0.0;
-    long long t0 = 0;
-    for (int r = 0; r < a.nranks; ++r) {
-        const unsigned long long* e = box + xr_slot(a.epoch, r, v);
-        unsigned long long x0, x1;
-        unsigned spins = 0;
-        while (true) {
-            x0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            x1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if ((unsigned)(x0 >> 32) == a.epoch && (unsigned)(x1 >> 32) == a.epoch) break;
-            if ((++spins & 255u) == 0) {
-                const long long now = (long long)wall_clock64();
-                if (t0 == 0) t0 = now;
-                if (now - t0 > a.timeout_ticks) {
-                    __hip_atomic_store(a.err, 1 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return __longlong_as_double(0x7ff8000000000000ll);      // NaN: whatever consumes it shows
-                }
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        const double d = __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
-        total = (r == 0) ? d : total + d;
-    }
-    return total;
+    int bad = 0;
+    const double t = xr_take_all(a.peer[a.rank], a.nranks, a.epoch, v, a.timeout_ticks, &bad);
+    if (bad) __hip_atomic_store(a.err, bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return t;
 }
 
 // vals[i] <- sum over the ranks of vals[i], i < count <= XR_MAXV; one lane per value

@@ -55,6 +55,10 @@ def main():
             checked += 1
     # 2. solves
     A, b = block(rank)
+    # (what dist.ShardedCSROperator announces for a sharded operator: the longest slab of the run - the reference-order step
+    # then takes the blocked kernel with the cross-rank sums inside the launch, csrc/chain_blk2.h)
+    nmax = int(rdv.allreduce_max(float(A.shape[0])))
+    ctx.set("lowsync_rows", (int(A.shape[0]) << 32) | nmax)
     res = {}
     for ortho in ("mgs", "cgs"):
         ls = linsys.LinearSystem(A, b)
@@ -64,6 +68,7 @@ def main():
     c = linsys.Cg(linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True), tol=1e-9, maxiter=500)
     res["cg_resnorms"], res["cg_x"] = np.array(c.resnorms), c.xk[:, 0].copy()
     res["n_xr"], res["n_xr_fused"], res["panels_checked"] = ctx.get("n_xr"), ctx.get("n_xr_fused"), checked
+    res["n_chain_blk2"] = ctx.get("n_chain_blk2")
     np.savez(os.path.join(out, "rank%d.npz" % rank), **res)
     rdv.barrier()
     # 3. a peer that does not arrive

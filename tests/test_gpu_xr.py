@@ -49,6 +49,8 @@ def test_one_rank_loopback_equals_the_rccl_path(forced_ctx):
     from krypy_amd import dist as kdist, linsys, utils
 
     ctx = forced_ctx
+    ctx.set("chain_blk2", 0)      # (with the transport on 'mgs' would take the blocked kernel with the sums inside the launch -
+    #                                not a bit-for-bit kernel, tests/test_gpu_blk2.py; here the exchange KERNELS are compared with RCCL)
     A = ref.laplace2d(300, 260)
     b = np.random.default_rng(3).standard_normal(A.shape[0])
 
@@ -144,7 +146,9 @@ def test_two_processes_sum_through_ipc_mailboxes(hip, placement):
     x = np.concatenate([r[0]["cg_x"], r[1]["cg_x"]])
     assert np.linalg.norm(x - c.xk[:, 0]) < 1e-7 * np.linalg.norm(c.xk)
     assert int(r[0]["panels_checked"]) == int(r[1]["panels_checked"]) == 420
-    expect_kernel(int(r[0]["n_xr"]) == int(r[1]["n_xr"]) and int(r[0]["n_xr"]) > 3000, "both ranks issued the same exchanges: %r" % ((int(r[0]["n_xr"]), int(r[1]["n_xr"])),))
+    expect_kernel(int(r[0]["n_xr"]) == int(r[1]["n_xr"]) and int(r[0]["n_xr"]) > 1000, "both ranks issued the same exchanges: %r" % ((int(r[0]["n_xr"]), int(r[1]["n_xr"])),))
     expect_kernel(int(r[0]["n_xr_fused"]) > 100, "the panel form took the fused reduce-and-exchange kernel")
+    expect_kernel(int(r[0]["n_chain_blk2"]) == int(r[1]["n_chain_blk2"]) and int(r[0]["n_chain_blk2"]) > 30,
+                  "the reference order took the blocked kernel with the cross-rank sums inside the launch: %r" % ((int(r[0]["n_chain_blk2"]), int(r[1]["n_chain_blk2"])),))
     # the peer that did not arrive: rank 0's sum ended in an error that says so
     assert open(os.path.join(out, "rank0.done")).read().strip() == "1"
