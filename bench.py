@@ -365,6 +365,7 @@ def _run():
     nx, ny, m = args.nx, args.ny, args.restart
     N = nx * ny
     ortho = args.ortho
+    auto_sharded = sharded and ortho == "auto"
     if ortho == "auto":
         ortho = "cgs" if sharded else "mgs"
     if sharded:
@@ -400,11 +401,11 @@ def _run():
             super(StampedGmres, self)._finalize()
             cycle_marks.append(time.perf_counter())
 
-    def run_cycles(ncyc, x0, ortho=ortho):
+    def run_cycles(ncyc, x0, ortho=None):
         try:
             # RestartedGmres == _RestartedSolver(Gmres, ...) (linsys.py:1075-1081)
             sol = linsys._RestartedSolver(StampedGmres, ls, x0=x0, maxiter=m,
-                                          max_restarts=ncyc - 1, tol=1e-8, ortho=ortho)
+                                          max_restarts=ncyc - 1, tol=1e-8, ortho=ortho or ortho_timed[0])
         except utils.ConvergenceError as e:
             sol = e.solver
         return sol
@@ -413,6 +414,49 @@ def _run():
         ctx.sync()
         if dist is not None:
             dist.barrier()
+
+    # ---- N > 1 ranks, --ortho auto: which Gram-Schmidt form is faster on THIS node is a property of its links - the panel
+    # form needs two sums across the ranks per step and reads the local basis twice; the reference order runs (xr transport
+    # on, slabs of up to 6 rows per lane) as the blocked kernel with one exchange per four columns INSIDE the launch and
+    # reads the basis once, else as the one-reduction form.  One untimed cycle of each, the max over the ranks decides - on
+    # every rank alike.  Both forms pass the 1e-10 parity tests.  A failure of the candidate (its in-launch sums have never
+    # run between two GPUs) must not cost the run its line: every rank then goes back to RCCL and the panel form, together.
+    ortho_timed = [ortho]
+    auto_report = None
+    if auto_sharded and hasattr(ctx, "get"):
+        auto_report = {}
+        probe_ok = 1.0
+        for cand in ("cgs", "mgs"):
+            try:
+                if cand == "mgs" and xr_on:
+                    ctx.set("xr_timeout_ms", 10000)
+                barrier()
+                b2 = ctx.get("n_chain_blk2")
+                t1 = time.perf_counter()
+                run_cycles(1, None, ortho=cand)
+                ctx.sync()
+                d1 = time.perf_counter() - t1
+                auto_report[cand] = {"ms_per_cycle": dist.allreduce_max(d1) * 1e3,
+                                     "sums_inside_the_launch": bool(ctx.get("n_chain_blk2") > b2)}
+            except _hip.BackendError as exc:
+                probe_ok = 0.0
+                auto_report[cand] = {"error": str(exc)[:300]}
+            if cand == "mgs":
+                if dist.allreduce_min(probe_ok) < 1.0:
+                    # some rank's candidate failed: the mailboxes' epochs may no longer agree - off with them, everywhere
+                    ctx.set("chain_blk2", 0)
+                    if xr_on:
+                        ctx.set("xr", 0)
+                        ctx.xr_detach()
+                        xr_on = False
+                    auto_report.setdefault("mgs", {})["disabled"] = "a rank failed: every rank back to ncclAllReduce and the panel form"
+                    auto_report["mgs"].pop("ms_per_cycle", None)
+                elif xr_on:
+                    ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_TIMEOUT_S", "60")) * 1e3))
+        if "ms_per_cycle" in auto_report.get("mgs", {}) and auto_report["mgs"]["ms_per_cycle"] < auto_report["cgs"]["ms_per_cycle"]:
+            ortho_timed[0] = "mgs"
+        ortho = ortho_timed[0]
+        auto_report["chosen"] = ortho
 
     x0 = None
     sol = None
@@ -537,6 +581,7 @@ def _run():
                    # sums across the ranks: "xr" = one kernel of system-scope stores into the peers' IPC-mapped mailboxes
                    # per panel (csrc/xr.hip), "rccl" = ncclAllReduce; the halo exchange is RCCL point-to-point either way
                    "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),
+                   "ortho_auto": auto_report,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
                    # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
                    # total time (the contract); the median cycle says what a typical one took

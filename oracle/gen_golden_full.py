@@ -26,6 +26,7 @@ import scipy.sparse as sp
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import refshim  # noqa: E402
+from oracle.inputs import dense_spd_system_blocked  # noqa: E402
 from oracle.krylov_ref import laplace2d  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -108,19 +109,8 @@ def gen_config3(krypy, steps=60):
 def gen_config4(krypy, n=32768):
     """The whole CG solve on the dense SPD matrix of order 32768, and the reference's own movement when every row sum
     of the matrix-vector product is taken in 2 / 3 / 5 pieces (what another summation order looks like from outside)."""
-    # dense_spd_system(n) = (G G^T / n + I, b) with G, b from rng(0).  Its one-shot G.dot(G.T) at n = 32768 brings this
-    # container's OpenBLAS down (segfault in a dgemm copy kernel, twice), so the product is taken in row blocks here: the
-    # same matrix to the rounding of the dgemm blocking - which differs from host to host anyway (the GPU box builds its A
-    # with the one-shot call; the test checks the first diagonal entries at 1e-13 and b bit for bit).
-    rng = np.random.default_rng(0)
-    G = rng.standard_normal((n, n))
-    A = np.empty((n, n))
-    for i0 in range(0, n, 4096):
-        A[i0:i0 + 4096] = G[i0:i0 + 4096].dot(G.T)
-    del G
-    A /= n
-    A[np.diag_indices(n)] += 1.0
-    b = rng.standard_normal(n)
+    # (G G^T / n + I, b) with G, b from rng(0), the product taken in row blocks: oracle/inputs.py says why
+    A, b = dense_spd_system_blocked(n)
 
     def solve(op):
         ls = krypy.linsys.LinearSystem(op, b, self_adjoint=True, positive_definite=True)

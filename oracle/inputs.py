@@ -49,6 +49,21 @@ def dense_spd_system(n):
     return A, rng.standard_normal(n)
 
 
+def dense_spd_system_blocked(n, rows=4096):
+    """dense_spd_system(n) with G G^T taken in row blocks: the same matrix to the rounding of the dgemm blocking.  (The one-shot
+    product at n = 32768 brought the build container's OpenBLAS down twice - a segfault in a dgemm copy kernel; the full-size
+    fixture of config 4 and everything compared with it build their matrix this way.)"""
+    rng = np.random.default_rng(0)
+    G = rng.standard_normal((n, n))
+    A = np.empty((n, n))
+    for i0 in range(0, n, rows):
+        A[i0:i0 + rows] = G[i0:i0 + rows].dot(G.T)
+    del G
+    A /= n
+    A[np.diag_indices(n)] += 1.0
+    return A, rng.standard_normal(n)
+
+
 def kernel_panel(N, k, seed):
     rng = np.random.default_rng(seed)
     return rng.standard_normal((N, k)), rng.standard_normal((N, 1))

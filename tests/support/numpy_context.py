@@ -120,6 +120,13 @@ class NumpyContext(object):
     def counters(self):
         return dict(chain=0, chain_lds=0, chain_fused=0, cgs_register=0)
 
+    # kh_ctx_get / kh_ctx_set: the double has no kernels to select - it remembers what it is told and counts nothing
+    def get(self, key):
+        return self.__dict__.setdefault("_kv", {}).get(key, 0)
+
+    def set(self, key, value):
+        self.__dict__.setdefault("_kv", {})[key] = int(value)
+
     def info(self):
         return dict(compute_units=0, mem_total=0, mem_free=0, reduce_blocks=0)
 

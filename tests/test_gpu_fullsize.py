@@ -178,11 +178,11 @@ def test_config4_against_the_reference_at_full_size(hip, golden):
     pieces (measured by the generator with the reference: sens_* in the fixture; the residual recurrence at 1e-8 ||b||
     keeps eight digits less than the iterate)."""
     from krypy_amd import linsys
-    from oracle.inputs import dense_spd_system
+    from oracle.inputs import dense_spd_system_blocked
 
     g = golden("config4_full")
     n = int(g["n"])
-    A, b = dense_spd_system(n)
+    A, b = dense_spd_system_blocked(n)
     # same inputs: b bit for bit (a seeded stream), A = G G^T / n + I to the rounding of this host's dgemm blocking
     assert np.array_equal(b[:64], g["b_head"]) and np.allclose(np.diag(A)[:64], g["A_diag_head"], rtol=1e-13, atol=0)
     t0 = time.perf_counter()

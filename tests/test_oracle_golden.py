@@ -354,7 +354,8 @@ def test_oracle_against_the_fullsize_fixtures(golden, config):
             assert dev["resnorms_max_rel"] < max(RTOL, 10 * float(g["sens_resnorms"])) and dev["H_rel_fro"] < RTOL and dev["xk_norm_rel"] < RTOL
         else:
             g = golden("config4_full")
-            A, b = dense_spd_system(int(g["n"]))
+            from oracle.inputs import dense_spd_system_blocked
+            A, b = dense_spd_system_blocked(int(g["n"]))
             o = ref.cg(A, b, tol=1e-8, maxiter=200)
             assert len(o.resnorms) == len(g["resnorms"])
             dev = dict(resnorms_max_rel=relmax(np.array(o.resnorms), g["resnorms"]), xk_rel=rel(o.xk, g["xk"]))

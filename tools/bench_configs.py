@@ -2,6 +2,13 @@
 """Secondary measurements (not the bench.py contract): BASELINE.json configs 3, 4 and the
 single-GPU shape of config 5 at full size, iterations/s with inputs resident in HBM.
   python tools/bench_configs.py [3] [4] [5]      -> one JSON line per config
+
+Every line carries the same three keys:
+  bytes_per_iteration   the ALGORITHMIC bytes of one iteration, every datum once (the convention of bench.py's roofline.bytes_per_launch)
+  frac                  bytes_per_iteration x iterations/s / 8 TB/s
+  traffic_over_bytes    fabric traffic of the solver's kernels (PMC passes of tools/profile_config.sh, which fills it in) over those
+                        bytes; null in a plain run
+and `iterations_in_process`, the iterations all solves of the process made (what the PMC totals are divided by).
 """
 import json
 import os
@@ -43,8 +50,10 @@ def config3(ctx, steps=400):
     fused = ctx.get("n_lanczos_fused") > 0
     moved = (92.2 if fused else 104.0) * N + 48.0 * N
     nb = 12.0 * A.nnz + 4.0 * (N + 1) + 16.0 * N + 12 * 8.0 * N
+    comp = (88.0 if fused else 104.0) * N + 48.0 * N          # the same without the 4.2 N of rows that come back from memory
     out.update(config="3: MINRES + Jacobi, 2-D Laplacian N=1e7, ortho=lanczos, %d steps" % steps,
                iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
+               bytes_per_iteration=comp, frac=comp * n_it / dt / 8e12, traffic_over_bytes=None, iterations_in_process=2 * n_it,
                moved_gb_per_iteration=moved / 1e9, moved_gbs=moved * n_it / dt / 1e9,
                frac_moved_of_8TBs=moved * n_it / dt / 8e12,
                survey_8d_gbs=nb * n_it / dt / 1e9,
@@ -66,7 +75,8 @@ def config4(ctx, n=32768):
     nb = 8.0 * n * n + 10 * 8.0 * n
     return dict(config="4: dense SPD n=%d CG tol 1e-8" % n, iterations=n_it,
                 iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
-                algorithmic_gbs=nb * n_it / dt / 1e9, frac_of_8TBs=nb * n_it / dt / 8e12,
+                bytes_per_iteration=nb, frac=nb * n_it / dt / 8e12, traffic_over_bytes=None, iterations_in_process=2 * n_it,
+                algorithmic_gbs=nb * n_it / dt / 1e9,
                 final_relres=float(s.resnorms[-1]))
 
 
@@ -94,7 +104,14 @@ def config5(ctx, nx=200, m=100, d=16, nz=None, ortho="mgs"):
         dts.append(time.perf_counter() - t0)
     dt = min(dts[1:])
     n_it = len(s1.resnorms) - 1
-    return dict(config="5 (one-GPU shape): 3-D 7-pt %dx%dx%d (N=%d), DeflatedGmres(%d) with %d Ritz vectors, ortho=%s"
+    # every datum once: the operator (diagonal-major copy, nd diagonals) and v_k, w out and in again around the projector
+    # (operator launch -> one-launch projector -> chain: 32 N), the projector's two bases in each of its two sweeps (32 d N), the
+    # Gram-Schmidt columns (8 N each, (m + 1) / 2 on average), v_{k+1} out
+    Amat = ls.A._device_matrix()
+    nd = Amat.diagonals or 7
+    comp = 8.0 * nd * N + 8.0 * N + 32.0 * N + 32.0 * d * N + 8.0 * N * (m + 1) / 2.0 + 8.0 * N
+    return dict(bytes_per_iteration=comp, frac=comp * n_it / dt / 8e12, traffic_over_bytes=None,
+                iterations_in_process=m + 6 * n_it,config="5 (one-GPU shape): 3-D 7-pt %dx%dx%d (N=%d), DeflatedGmres(%d) with %d Ritz vectors, ortho=%s"
                        % (nx, nx, nx if nz is None else nz, N, m, d, ortho), iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
                 solve_ms=[round(x * 1e3, 1) for x in dts],
                 plain_relres=float(s0.resnorms[-1]), deflated_relres=float(s1.resnorms[-1]))
@@ -155,6 +172,8 @@ def config_csr(ctx, kind, n):
     lens = np.diff(A.indptr)
     return dict(config="general CSR '%s': N=%d, nnz=%d (%d ... %d per row, mean %.1f), GMRES(100) mgs" % (
                     kind, N, A.nnz, lens.min(), lens.max(), lens.mean()),
+                bytes_per_iteration=nbytes + 16.0 * N + 8.0 * N * 101 / 2.0 + 8.0 * N, frac=(nbytes + 16.0 * N + 8.0 * N * 101 / 2.0 + 8.0 * N) * n_it / dt / 8e12,
+                traffic_over_bytes=None, iterations_in_process=500,
                 spmv_us=ms * 1e3, spmv_algorithmic_bytes=nbytes, spmv_gbs=nbytes / ms / 1e6, spmv_frac_of_8TBs=nbytes / ms / 1e6 / 8000.0,
                 spmv_bit_identical_to_scipy=same, iterations_per_s=n_it / dt, ms_per_iteration=dt / n_it * 1e3,
                 chain_launches=ctx.counters()["chain"], chain_fused=ctx.counters()["chain_fused"])

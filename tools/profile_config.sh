@@ -53,6 +53,25 @@ if pm:
         tbs = (rd + wr) / us if us else None          # MB / us = TB/s
         out.append("| \`%s\` | %d | %.1f | %.1f | %.1f | %s | %s |" % (name[:70], f[0], rd, wr, rd + wr,
                                                                    "%.2f" % tbs if tbs else "", "%.2f" % (tbs / 8.0) if tbs else ""))
+# the config's line with `traffic_over_bytes` filled in: fabric traffic of everything but the set-up kernels (copies, fills, the
+# diagonal-major copy of the operator) over the algorithmic bytes of the iterations the process made
+try:
+    skip = ("copyBuffer", "fillBuffer", "k_dia_fill", "k_zdia_fill")
+    total = 0.0
+    for name, dd in pm.items():
+        if any(t in name for t in skip):
+            continue
+        f = dd.get("FETCH_SIZE", (0, 0.0))
+        w = dd.get("WRITE_SIZE", (0, 0.0))
+        total += 2 * f[0] * f[1] * 1024 + w[0] * w[1] * 1024
+    if pm and d.get("bytes_per_iteration") and d.get("iterations_in_process"):
+        d["traffic_over_bytes"] = total / (d["bytes_per_iteration"] * d["iterations_in_process"])
+        out += ["", "Fabric traffic of the solver's kernels over the algorithmic bytes of the %d iterations of the process: **%.3f** "
+                    "(`traffic_over_bytes`; bytes_per_iteration = %.3f GB, frac = %.3f)." % (d["iterations_in_process"], d["traffic_over_bytes"],
+                                                                                          d["bytes_per_iteration"] / 1e9, d.get("frac", 0.0))]
+except Exception as exc:
+    out += ["", "(traffic_over_bytes unavailable: %r)" % exc]
+open("$OUT/line.json", "w").write(json.dumps(d) + "\n")
 open("$OUT/summary.md", "w").write("\n".join(out) + "\n")
 print("\n".join(out[:14]))
 PY

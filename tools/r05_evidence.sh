@@ -26,9 +26,14 @@ bench)
   tail -c 400 gpurun_out/ev/r05_bench.json
   ;;
 configs)
-  for c in 3 4 5 5s; do bash tools/profile_config.sh $c > gpurun_out/ev/profile_cfg$c.log 2>&1; cp gpurun_out/prof_cfg$c/summary.md gpurun_out/ev/r05_config$c.md; done
-  for c in 3 4 5 5s band ragged; do python tools/bench_configs.py $c 2>/dev/null | tail -1; done > gpurun_out/ev/r05_configs.jsonl
-  cat gpurun_out/ev/r05_configs.jsonl | cut -c1-300
+  # kernel trace + PMC passes of each secondary configuration; every line of r05_configs.jsonl carries bytes_per_iteration, frac and
+  # traffic_over_bytes (the last from the PMC passes: tools/profile_config.sh)
+  : > gpurun_out/ev/r05_configs.jsonl
+  for c in 3 4 5 5s; do bash tools/profile_config.sh $c > gpurun_out/ev/profile_cfg$c.log 2>&1; cp gpurun_out/prof_cfg$c/summary.md gpurun_out/ev/r05_config$c.md; cat gpurun_out/prof_cfg$c/line.json >> gpurun_out/ev/r05_configs.jsonl; done
+  for c in band ragged; do python tools/bench_configs.py $c 2>/dev/null | tail -1 >> gpurun_out/ev/r05_configs.jsonl; done
+  # (the rates of an unprofiled run beside them)
+  for c in 3 4 5 5s; do python tools/bench_configs.py $c 2>/dev/null | tail -1; done > gpurun_out/ev/r05_configs_unprofiled.jsonl
+  cat gpurun_out/ev/r05_configs.jsonl | cut -c1-400
   ;;
 small)
   python tools/blk_bench.py 100 200 316 500 1000 2>/dev/null | grep "N =" > gpurun_out/ev/blk_bench.log; cat gpurun_out/ev/blk_bench.log
