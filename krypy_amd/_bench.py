@@ -28,7 +28,8 @@ K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 _SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h", "chain_blk.h",
-            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip")
+            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip", "xr_dev.h", "chain_blk2.h", "chain_blk2.hip", "cycles.hip",
+            "bench_abi.hip", "krylov_steps.h")
 
 
 def source_stamp():

@@ -130,6 +130,8 @@ struct kh_ctx_s {
     int* proj_err_pin = nullptr;     // kh_arnoldi_step_end / kh_proj_apply_complement re-run without this kernel
     int proj_fault = 0;              // tests: the next launch behaves like a timed-out one (kh_ctx_set "proj_fault")
     int64_t n_proj_recovered = 0;
+    int proj_reg_why = -1;           // why proj_reg_apply declined last time (1: switches / shape of the projector, 2: short vector, 3: blocks
+                                     // not padded alike, 4: the launch failed; 0: it ran)
     int proj_panel = 1;              // ... or, on N ranks, its passes through the register-resident panel kernels (KRYPY_AMD_PROJ_PANEL)
     int64_t n_proj_panel = 0;        // sweeps that took them
     int64_t n_cycle_steps = 0;   // GMRES iterations recorded by kh_gmres_cycle

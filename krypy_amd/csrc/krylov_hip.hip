@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "chain.h"
 #include "lanczos.h"
+#include "krylov_steps.h"
 #include <stdlib.h>
 
 extern "C" {
@@ -39,7 +40,7 @@ struct Roctx {
     bool tried = false;
 };
 static Roctx g_roctx;
-static inline void roctx_push(kh_ctx ctx, const char* fmt, long long a, long long b) {
+void roctx_push(kh_ctx ctx, const char* fmt, long long a, long long b) {
     if (!ctx->roctx) return;
     if (!g_roctx.tried) {
         g_roctx.tried = true;
@@ -56,16 +57,11 @@ static inline void roctx_push(kh_ctx ctx, const char* fmt, long long a, long lon
         g_roctx.push(buf);
     }
 }
-static inline void roctx_pop(kh_ctx ctx) {
+void roctx_pop(kh_ctx ctx) {
     if (ctx->roctx && g_roctx.pop) g_roctx.pop();
 }
-struct RoctxScope {        // one range per C entry point of the hot loop
-    kh_ctx ctx;
-    RoctxScope(kh_ctx c, const char* fmt, long long a = 0, long long b = 0) : ctx(c) { roctx_push(c, fmt, a, b); }
-    ~RoctxScope() { roctx_pop(ctx); }
-};
 
-static inline int grid_for(kh_ctx ctx, int64_t n) {
+int grid_for(kh_ctx ctx, int64_t n) {
     // enough workgroups to cover n/2 double2 elements, capped at the fixed reduction grid
     int64_t need = ((n >> 1) + BS - 1) / BS;
     if (need < 1) need = 1;
@@ -73,18 +69,12 @@ static inline int grid_for(kh_ctx ctx, int64_t n) {
 }
 
 // partial-sum slots inside ctx->part
-static inline double* part_slot(kh_ctx ctx, int slot) { return ctx->part + (int64_t)slot * NB_MAX; }
-constexpr int SLOT_PING = MAXC, SLOT_PONG = MAXC + 1, SLOT_NRM = MAXC + 2;
-
-// device scalar layout inside ctx->scal
-constexpr int SC_TMP = 6144;     // scratch scalars (dot0 of the fused SpMV, norms, ...)
-constexpr int SC_COEF = 6400;    // panel coefficients for axpy_panel / gemm_nn (<= 1024)
-constexpr int SC_LS = 7424;      // [c | g] of the one-reduction Gram-Schmidt (2 * LS_MAXCOL)
+double* part_slot(kh_ctx ctx, int slot) { return ctx->part + (int64_t)slot * NB_MAX; }
 
 // H-column slots: up to NSLOT Arnoldi steps can be in flight on the stream (the host processes
 // step k's column while steps k+1.. already run), each with its own device column, pinned copy
 // and completion event.
-static int ensure_hcap(kh_ctx ctx, int64_t need) {
+int ensure_hcap(kh_ctx ctx, int64_t need) {
     if (need <= ctx->hcap) return 0;
     // a larger basis begins a step: the slots grow, and a column that is complete but not fetched yet
     // (another basis' look-ahead step) moves into the new buffers - nothing in flight is dropped
@@ -121,7 +111,7 @@ static int ensure_hcap(kh_ctx ctx, int64_t need) {
     return 0;
 }
 
-static int check_vec(kh_vec v, int64_t col, int64_t ncols, const char* what) {
+int check_vec(kh_vec v, int64_t col, int64_t ncols, const char* what) {
     KH_ARG(v != nullptr, "%s: NULL vector handle", what);
     KH_ARG(col >= 0 && ncols >= 0 && col + ncols <= v->ncols,
            "%s: columns [%lld, %lld) out of range (ncols=%lld)", what, (long long)col,
@@ -129,7 +119,7 @@ static int check_vec(kh_vec v, int64_t col, int64_t ncols, const char* what) {
     return 0;
 }
 
-static int fetch_scalars(kh_ctx ctx, const double* dev, int64_t count, double* out) {
+int fetch_scalars(kh_ctx ctx, const double* dev, int64_t count, double* out) {
     KH_ARG(count <= SCAL_CAP, "fetch_scalars: %lld > capacity", (long long)count);
     KH_HIP(hipMemcpyAsync(ctx->hpin, dev, count * sizeof(double), hipMemcpyDeviceToHost,
                           ctx->stream));
@@ -138,7 +128,7 @@ static int fetch_scalars(kh_ctx ctx, const double* dev, int64_t count, double* o
     return xr_check(ctx);          // (a cross-rank sum that timed out upstream of these scalars: an error, xr.hip)
 }
 
-static int push_scalars(kh_ctx ctx, const double* host, int64_t count, double* dev) {
+int push_scalars(kh_ctx ctx, const double* host, int64_t count, double* dev) {
     // pinned staging is reused: wait for earlier consumers of hpin first
     KH_ARG(count <= SCAL_CAP, "push_scalars: %lld > capacity", (long long)count);
     KH_HIP(hipStreamSynchronize(ctx->stream));
@@ -307,7 +297,7 @@ static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const 
 
 // y = A x for one column; epi/aux select the fused epilogue of the CSR kernel (its partial sums
 // land in A->part and are reduced into scal_out with `rmode` of k_reduce_partials).
-static int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
+int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
                      double* scal_out, int rmode) {
     if (A->kind == KH_MAT_CSR) {
         const bool halo = kh_multi(ctx) && (A->nrecv_prev + A->nrecv_next + A->nsend_prev + A->nsend_next) > 0;
@@ -521,7 +511,7 @@ static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJo
 }
 
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
-static bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, bool onex = false) {
+bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, bool onex) {
     if (n < 2) return false;
     // an odd n is handled as n+1: the extra element is the (always zero) padding behind the column
     const int64_t n2 = (n + 1) >> 1;
@@ -595,10 +585,10 @@ int dot_panel_raw(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double*
     return ::dot_panel_dev(ctx, V, j0, ncols, w, out_dev, 0);
 }
 
-static int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
-                     kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
-                     const double* h_km1_dev, double* hdev, int slot, bool cplx = false, double* hpin = nullptr,
-                     int hcount = 0, kh_mat Afuse = nullptr, const double* xk = nullptr, const MinresJob* mr = nullptr) {
+int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, const double* dg,
+              kh_vec P, int64_t k, int64_t start, int sweeps, bool presub, double h_km1,
+              const double* h_km1_dev, double* hdev, int slot, bool cplx, double* hpin,
+              int hcount, kh_mat Afuse, const double* xk, const MinresJob* mr) {
     // Afuse: compute w = Afuse * xk in the kernel's prologue instead of reading w (banded operators;
     // returns 0 without launching anything when that variant does not apply - the caller then runs the
     // SpMV and calls again without Afuse)
@@ -1003,9 +993,9 @@ static hipError_t launch_cgs(kh_ctx ctx, int G, CgsArgs& a, bool update) {
 // partials are in SLOT_NRM.., *nrm_count of them), 0 when not eligible, negative on error.
 // cplx: V, B, w are complex blocks (real views of even length), hdev / coef hold (re, im) pairs and `start` counts
 // complex entries of the H column; no Jacobi tail then (dg must be NULL).
-static int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, const double* dg, double* mw,
-                       int64_t start, int64_t ncol, int sweeps, bool multi, double* hdev, double* coef,
-                       int* nrm_count, bool cplx = false) {
+int try_cgs_reg(kh_ctx ctx, kh_vec V, kh_vec B, double* w, int64_t wld, const double* dg, double* mw,
+                int64_t start, int64_t ncol, int sweeps, bool multi, double* hdev, double* coef,
+                int* nrm_count, bool cplx) {
     if (!ctx->chain_enabled || ncol > CGS_MAXCOL) return 0;
     if (cplx && (dg != nullptr || (V->n & 1))) return 0;
     const int cw = cplx ? 2 : 1;           // doubles per coefficient
@@ -1256,7 +1246,7 @@ static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t
     return 1;
 }
 
-static inline int grid_lin(kh_ctx ctx, int64_t n) {
+int grid_lin(kh_ctx ctx, int64_t n) {
     int64_t need = (n + BS - 1) / BS;
     if (need < 1) need = 1;
     return (int)std::min<int64_t>(need, (int64_t)ctx->nb * 2);
@@ -1549,6 +1539,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_xr_fused")) *value = ctx->n_xr_fused;
     else if (!strcmp(key, "n_proj_reg")) *value = ctx->n_proj_reg;
     else if (!strcmp(key, "n_proj_recovered")) *value = ctx->n_proj_recovered;
+    else if (!strcmp(key, "proj_reg_why")) *value = ctx->proj_reg_why;
     else if (!strcmp(key, "proj_panel")) *value = ctx->proj_panel;
     else if (!strcmp(key, "n_proj_panel")) *value = ctx->n_proj_panel;
     else if (!strcmp(key, "n_lowsync")) *value = ctx->n_lowsync;
@@ -1617,7 +1608,6 @@ static void forget_steps(kh_ctx ctx, const void* handle) {
     }
 }
 
-static int minres_flush(kh_ctx ctx);
 
 int kh_vec_free(kh_vec v) {
     if (!v) return 0;
@@ -1626,7 +1616,7 @@ int kh_vec_free(kh_vec v) {
     // job would leave W and yk one recurrence step short.
     {
         const auto& j = v->ctx->mr_pending;
-        if (j.on && (j.V == v || j.W == v || j.YK == v)) (void)minres_flush(v->ctx);
+        if (j.on && (j.V == v || j.W == v || j.YK == v)) (void)kh_minres_flush(v->ctx);
     }
     (void)hipStreamSynchronize(v->ctx->stream);
     forget_steps(v->ctx, v);
@@ -2740,416 +2730,6 @@ int kh_arnoldi_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec 
     return kh_arnoldi_step_end(ctx, 0, k + 2, hcol_out);
 }
 
-// BLAS drotg (reference implementation): c, s with [c s; -s c] [a; b] = [r; 0]
-static inline void host_drotg(double a, double b, double* c, double* s) {
-    const double roe = std::fabs(a) > std::fabs(b) ? a : b;
-    const double scale = std::fabs(a) + std::fabs(b);
-    if (scale == 0.0) {
-        *c = 1.0;
-        *s = 0.0;
-        return;
-    }
-    double r = scale * std::sqrt((a / scale) * (a / scale) + (b / scale) * (b / scale));
-    if (roe < 0.0) r = -r;
-    *c = a / r;
-    *s = b / r;
-}
-
-// the rotation of a C host loop: the caller's own BLAS drotg when it has handed one over (kh_ctx_set_rotg: the same bits
-// as the per-step loop of the host layer), the reference formula otherwise
-static inline void ctx_rotg(kh_ctx ctx, double a, double b, double* c, double* s) {
-    if (ctx->rotg != nullptr) {
-        double a_ = a, b_ = b;
-        ctx->rotg(&a_, &b_, c, s);
-    } else {
-        host_drotg(a, b, c, s);
-    }
-}
-
-int kh_ctx_set_rotg(kh_ctx ctx, void (*drotg)(double*, double*, double*, double*)) {
-    KH_ARG(ctx != nullptr, "kh_ctx_set_rotg: NULL context");
-    ctx->rotg = drotg;
-    return 0;
-}
-
-int kh_gmres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
-                   int64_t k_last, int sweeps, int gs_mode, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
-                   double* R, int64_t ldr, double* cs, double* y, double* h2_io, double* resn, int64_t* k_done,
-                   int* reason) {
-    KH_ARG(ctx && A && V && W && enq_io && H && R && cs && y && h2_io && resn && k_done && reason, "kh_gmres_cycle: NULL");
-    KH_ARG(k0 >= 0 && k0 <= k_stop && k_stop <= k_last + 1 && k_last + 2 <= V->ncols, "kh_gmres_cycle: steps [%lld, %lld), last %lld, %lld basis columns",
-           (long long)k0, (long long)k_stop, (long long)k_last, (long long)V->ncols);
-    KH_ARG(*enq_io >= k0 && *enq_io <= k0 + KH_NSLOT - 1, "kh_gmres_cycle: %lld steps in flight", (long long)(*enq_io - k0));
-    KH_ARG(ldh >= k_stop && ldr >= k_stop, "kh_gmres_cycle: leading dimensions");
-    RoctxScope range_(ctx, "kh_gmres_cycle");
-    int64_t enq = *enq_io;
-    double h2 = *h2_io;
-    *reason = KH_CYCLE_LIMIT;
-    int64_t k = k0;
-    std::vector<double> col((size_t)k_stop + 2);
-    for (; k < k_stop; ++k) {
-        // look-ahead: step k + 1 depends on device data only - it is enqueued before the host waits for step k
-        const int64_t last = std::min<int64_t>(k + 1, k_last);
-        while (enq <= last) {
-            KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, 0, enq, 0, sweeps, gs_mode, 0.0, (int)(enq % KH_NSLOT)));
-            ++enq;
-        }
-        KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), k + 2, col.data()));
-        const double hn = col[(size_t)k + 1];
-        // invariance pre-test of the host layer (utils.py:1035-1039 through the Frobenius norm): when it does not
-        // clear the step, the caller decides - the column stays in its slot, nothing of it is recorded here
-        double c2 = 0.0;
-        for (int64_t i = 0; i <= k + 1; ++i) c2 += col[(size_t)i] * col[(size_t)i];
-        const double fro = std::sqrt(h2 + c2);
-        if (!(fro > 0.0) || !(hn / fro > 1e-14) || !std::isfinite(fro)) {
-            *reason = KH_CYCLE_CHECK;
-            break;
-        }
-        h2 += c2;
-        for (int64_t i = 0; i <= k + 1; ++i) H[i * ldh + k] = col[(size_t)i];
-        // the new column through the previous rotations, then its own (linsys.py:980-991)
-        for (int64_t i = 0; i < k; ++i) {
-            const double c = cs[2 * i], s = cs[2 * i + 1];
-            const double t0 = col[(size_t)i], t1 = col[(size_t)i + 1];
-            col[(size_t)i] = c * t0 + s * t1;
-            col[(size_t)i + 1] = -s * t0 + c * t1;
-        }
-        double c, s;
-        ctx_rotg(ctx, col[(size_t)k], col[(size_t)k + 1], &c, &s);
-        cs[2 * k] = c;
-        cs[2 * k + 1] = s;
-        {
-            const double t0 = col[(size_t)k], t1 = col[(size_t)k + 1];
-            col[(size_t)k] = c * t0 + s * t1;
-            col[(size_t)k + 1] = -s * t0 + c * t1;
-        }
-        for (int64_t i = 0; i <= k + 1; ++i) R[i * ldr + k] = col[(size_t)i];
-        {
-            const double t0 = y[k], t1 = y[k + 1];
-            y[k] = c * t0 + s * t1;
-            y[k + 1] = -s * t0 + c * t1;
-        }
-        resn[k] = std::fabs(y[k + 1]);
-        if (!(resn[k] / bnorm > tol)) {      // the caller's own test, linsys.py:476 (also a nan: its loop sees it)
-            ++k;
-            *reason = KH_CYCLE_TOL;
-            break;
-        }
-    }
-    *k_done = k;
-    *enq_io = enq;
-    *h2_io = h2;
-    ctx->n_cycle_steps += k - k0;
-    return 0;
-}
-
-int kh_residual(kh_ctx ctx, kh_mat A, kh_vec Bv, int64_t bcol, kh_vec X, int64_t xcol, kh_vec R,
-                int64_t rcol, double* nrm) {
-    KH_ARG(ctx && A && nrm, "kh_residual: NULL");
-    RoctxScope range_(ctx, "kh_residual");
-    KH_TRY(check_vec(Bv, bcol, 1, "kh_residual(B)"));
-    KH_TRY(check_vec(X, xcol, 1, "kh_residual(X)"));
-    KH_TRY(check_vec(R, rcol, 1, "kh_residual(R)"));
-    KH_ARG(Bv->n == A->n_rows && R->n == A->n_rows, "kh_residual: dimension mismatch");
-    KH_ARG(!(R == X && rcol == xcol), "kh_residual: r must not alias x");
-    double* tmp = ctx->scal + SC_TMP;
-    if (A->kind == KH_MAT_CSR && A->nblk > 0) {
-        KH_TRY(apply_one(ctx, A, X->col(xcol), R->col(rcol), EPI_RES, Bv->col(bcol), tmp,
-                         kh_multi(ctx) ? 0 : 2));
-        if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
-        KH_TRY(fetch_scalars(ctx, tmp, 1, nrm));
-        if (kh_multi(ctx)) *nrm = sqrt(fabs(*nrm));
-        return 0;
-    }
-    KH_ARG(!(R == Bv && rcol == bcol), "kh_residual: r must not alias b for non-CSR operators");
-    KH_TRY(apply_one(ctx, A, X->col(xcol), R->col(rcol), EPI_NONE, nullptr, nullptr, 0));
-    KH_TRY(kh_waxpby(ctx, R, rcol, 1.0, Bv, bcol, -1.0, R, rcol));
-    return kh_nrm2(ctx, R, rcol, nrm);
-}
-
-// run a deferred MINRES recurrence update now, as a launch of its own
-static int minres_flush(kh_ctx ctx) {
-    if (!ctx->mr_pending.on) return 0;
-    auto& j = ctx->mr_pending;
-    j.on = 0;
-    const int64_t n = j.V->n;
-    hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, j.V->col(j.vcol),
-                       j.W->col(j.slot), j.W->col(1 - j.slot), j.r0, j.r1, j.r2, j.y0, j.YK->col(j.ycol));
-    KH_HIP(hipGetLastError());
-    return 0;
-}
-
-int kh_minres_flush(kh_ctx ctx) {
-    KH_ARG(ctx, "kh_minres_flush: NULL ctx");
-    return minres_flush(ctx);
-}
-
-int kh_minres_update_deferred(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
-                              double r2, double y0, kh_vec YK, int64_t ycol) {
-    KH_ARG(ctx, "kh_minres_update_deferred: NULL ctx");
-    KH_TRY(check_vec(V, k, 1, "kh_minres_update_deferred(V)"));
-    KH_TRY(check_vec(Wk, 0, 2, "kh_minres_update_deferred(W)"));
-    KH_TRY(check_vec(YK, ycol, 1, "kh_minres_update_deferred(yk)"));
-    KH_ARG(slot == 0 || slot == 1, "kh_minres_update_deferred: slot");
-    KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_minres_update_deferred: length mismatch");
-    KH_TRY(minres_flush(ctx));          // updates run in the order they were given
-    auto& j = ctx->mr_pending;
-    j.V = V; j.vcol = k; j.W = Wk; j.slot = slot; j.YK = YK; j.ycol = ycol;
-    j.r0 = r0; j.r1 = r1; j.r2 = r2; j.y0 = y0;
-    j.on = 1;
-    return 0;
-}
-
-int kh_minres_update(kh_ctx ctx, kh_vec V, int64_t k, kh_vec Wk, int slot, double r0, double r1,
-                     double r2, double y0, kh_vec YK, int64_t ycol) {
-    KH_ARG(ctx, "kh_minres_update: NULL ctx");
-    KH_TRY(check_vec(V, k, 1, "kh_minres_update(V)"));
-    KH_TRY(check_vec(Wk, 0, 2, "kh_minres_update(W)"));
-    KH_TRY(check_vec(YK, ycol, 1, "kh_minres_update(yk)"));
-    KH_ARG(slot == 0 || slot == 1, "kh_minres_update: slot");
-    KH_ARG(V->n == Wk->n && V->n == YK->n, "kh_minres_update: length mismatch");
-    KH_TRY(minres_flush(ctx));
-    const int64_t n = V->n;
-    hipLaunchKernelGGL(k_minres_update, dim3(grid_lin(ctx, n)), dim3(BS), 0, ctx->stream, n, V->col(k),
-                       Wk->col(slot), Wk->col(1 - slot), r0, r1, r2, y0, YK->col(ycol));
-    KH_HIP(hipGetLastError());
-    return 0;
-}
-
-// A run of MINRES iterations in one call (krypy/linsys.py:791-853; the header has the contract)
-int kh_minres_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec V, kh_vec P, kh_vec W, int64_t k0, int64_t k_stop,
-                    int64_t k_last, int64_t base, int64_t* enq_io, double tol, double bnorm, double* H, int64_t ldh,
-                    kh_vec Wm, int* wslot_io, kh_vec YK, int64_t ycol, double* st, double* h2_io, double* resn,
-                    int64_t* k_done, int* reason) {
-    KH_ARG(ctx && A && V && W && enq_io && H && Wm && wslot_io && YK && st && h2_io && resn && k_done && reason,
-           "kh_minres_cycle: NULL");
-    KH_ARG(base >= 0 && k0 >= base && k0 <= k_stop && k_stop <= k_last + 1 && k_last + 2 - base <= V->ncols,
-           "kh_minres_cycle: steps [%lld, %lld), last %lld, window base %lld, %lld basis columns", (long long)k0,
-           (long long)k_stop, (long long)k_last, (long long)base, (long long)V->ncols);
-    KH_ARG(k0 == 0 || k0 - 1 >= base, "kh_minres_cycle: column k0 - 1 is not in the window");
-    KH_ARG(*enq_io >= k0 && *enq_io <= k0 + KH_NSLOT - 1, "kh_minres_cycle: %lld steps in flight", (long long)(*enq_io - k0));
-    KH_ARG(ldh >= k_stop, "kh_minres_cycle: leading dimension of H");
-    KH_ARG(*wslot_io == 0 || *wslot_io == 1, "kh_minres_cycle: W slot");
-    KH_ARG(Wm->ncols >= 2 && Wm->n == V->n && YK->n == V->n, "kh_minres_cycle: W / yk shape");
-    RoctxScope range_(ctx, "kh_minres_cycle");
-    int64_t enq = *enq_io;
-    double h2 = *h2_io;
-    int wslot = *wslot_io;
-    // st: the two remembered rotations (older first), how many of them exist, the rotated right-hand side
-    double g1c = st[0], g1s = st[1], g2c = st[2], g2s = st[3];
-    int nrot = (int)st[4];
-    double y0 = st[5], y1 = st[6];
-    *reason = KH_CYCLE_LIMIT;
-    int64_t k = k0;
-    for (; k < k_stop; ++k) {
-        // look-ahead (utils.Arnoldi._begin): a Lanczos step takes H[e, e-1] from the host when its predecessor has been
-        // fetched, from the predecessor's device-side H column (NaN) when it is still in flight
-        const int64_t last = std::min<int64_t>(k + 1, k_last);
-        while (enq <= last) {
-            const int64_t e = enq;
-            double h_km1 = 0.0;
-            if (e > 0) h_km1 = (e <= k) ? H[e * ldh + (e - 1)] : std::nan("");
-            KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, Md, V, P, W, 0, e - base, e > 0 ? e - base : 0, 1, KH_GS_MGS, h_km1,
-                                         (int)(e % KH_NSLOT)));
-            ++enq;
-        }
-        // the step's column arrives in window coordinates: only its last two entries are this step's
-        const int64_t kp = k - base;
-        std::vector<double>& colv = ctx->cyc_col;
-        if ((int64_t)colv.size() < kp + 2) colv.resize((size_t)(kp + 2) + 64);
-        KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), kp + 2, colv.data()));
-        const double alpha = colv[(size_t)kp], hn = colv[(size_t)kp + 1];
-        const double hkm = (k > 0) ? H[k * ldh + (k - 1)] : 0.0;       // H[k-1, k] = H[k, k-1]  (utils.py:1000-1003)
-        // invariance pre-test (utils.py:1035-1039 through the Frobenius norm); a step that does not clear it is not
-        // recorded: it stays in its slot and the caller's Arnoldi.advance decides it with the exact 2-norm
-        const double c2 = (k > 0 ? hkm * hkm : 0.0) + alpha * alpha + hn * hn;
-        const double fro = std::sqrt(h2 + c2);
-        if (!(fro > 0.0) || !(hn / fro > 1e-14) || !std::isfinite(fro)) {
-            *reason = KH_CYCLE_CHECK;
-            break;
-        }
-        h2 += c2;
-        if (k > 0) H[(k - 1) * ldh + k] = hkm;
-        H[k * ldh + k] += alpha;
-        H[(k + 1) * ldh + k] = hn;
-        // QR update of the Lanczos matrix with the two remembered rotations (linsys.py:826-841), the expressions of
-        // the host layer's loop term for term
-        double R0 = 0.0, R1 = (k > 0) ? hkm : 0.0;
-        if (nrot >= 2) {
-            const double u = R0, v = R1;
-            R0 = g1c * u + g1s * v;
-            R1 = -g1s * u + g1c * v;
-        }
-        double R2 = H[k * ldh + k];
-        const double R3 = hn;
-        if (nrot >= 1) {
-            const double u = R1, v = R2;
-            R1 = g2c * u + g2s * v;
-            R2 = -g2s * u + g2c * v;
-        }
-        g1c = g2c; g1s = g2s;
-        double c, s;
-        ctx_rotg(ctx, R2, R3, &c, &s);
-        g2c = c; g2s = s;
-        nrot = nrot < 2 ? nrot + 1 : 2;
-        R2 = c * R2 + s * R3;
-        {
-            const double u = y0, v = y1;
-            y0 = c * u + s * v;
-            y1 = -s * u + c * v;
-        }
-        // z = (v_k - R0 W0 - R1 W1) / R2;  W <- [W1, z];  yk += y0 z   (linsys.py:844-846), carried by the next launch
-        KH_TRY(kh_minres_update_deferred(ctx, V, kp, Wm, wslot, R0, R1, R2, y0, YK, ycol));
-        wslot = 1 - wslot;
-        y0 = y1;
-        y1 = 0.0;
-        resn[k] = std::fabs(y0);
-        if (!(resn[k] / bnorm > tol)) {      // the caller's own test, linsys.py:476
-            ++k;
-            *reason = KH_CYCLE_TOL;
-            break;
-        }
-    }
-    st[0] = g1c; st[1] = g1s; st[2] = g2c; st[3] = g2s; st[4] = (double)nrot; st[5] = y0; st[6] = y1;
-    *wslot_io = wslot;
-    *k_done = k;
-    *enq_io = enq;
-    *h2_io = h2;
-    ctx->n_minres_cycle_steps += k - k0;
-    return 0;
-}
-
-int kh_cg_update(kh_ctx ctx, double alpha, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
-                 int64_t ycol, kh_vec R, int64_t rcol, kh_mat Md, kh_vec Z, int64_t zcol,
-                 double* rho_new) {
-    KH_ARG(ctx && rho_new, "kh_cg_update: NULL");
-    KH_TRY(check_vec(Pd, pcol, 1, "kh_cg_update(p)"));
-    KH_TRY(check_vec(AP, apcol, 1, "kh_cg_update(Ap)"));
-    KH_TRY(check_vec(YK, ycol, 1, "kh_cg_update(yk)"));
-    KH_TRY(check_vec(R, rcol, 1, "kh_cg_update(r)"));
-    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_update: Md must be diagonal");
-    if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_update(z)"));
-    const int64_t n = R->n;
-    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && (!Md || (Md->n_rows == n && Z->n == n)),
-           "kh_cg_update: length mismatch");
-    double* part = part_slot(ctx, SLOT_NRM);
-    const int grid = grid_lin(ctx, n);
-    if (Md)
-        hipLaunchKernelGGL((k_cg_update<true>), dim3(grid), dim3(BS), 0, ctx->stream, n, alpha,
-                           Pd->col(pcol), AP->col(apcol), YK->col(ycol), R->col(rcol), Md->diag,
-                           Z->col(zcol), part);
-    else
-        hipLaunchKernelGGL((k_cg_update<false>), dim3(grid), dim3(BS), 0, ctx->stream, n, alpha,
-                           Pd->col(pcol), AP->col(apcol), YK->col(ycol), R->col(rcol), nullptr, nullptr,
-                           part);
-    KH_HIP(hipGetLastError());
-    double* tmp = ctx->scal + SC_TMP;
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp, 0);
-    KH_HIP(hipGetLastError());
-    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
-    return fetch_scalars(ctx, tmp, 1, rho_new);
-}
-
-// sanity word of a fused CG step (KH_CG_* bits of the header): the step length never visits the host, so a divisor
-// that is not a positive finite number (an operator that is not positive definite - or a fault) is reported with
-// the scalars; k_cg_update leaves yk and r untouched when the step length is not finite
-static inline int cg_sanity(double d, double rho_new, double rho) {
-    int f = 0;
-    if (!std::isfinite(d)) f |= KH_CG_NONFINITE_PAP;
-    else if (!(d > 0.0)) f |= KH_CG_NONPOSITIVE_PAP;
-    // the device clamps a step length that is not finite to "no step" (k_cg_update): a zero (or tiny) divisor under
-    // a finite rho is neither what the reference does nor an ordinary indefinite operator - the host is told
-    if (std::isfinite(d) && std::isfinite(rho) && !std::isfinite(rho / d)) f |= KH_CG_STEP_CLAMPED;
-    if (!std::isfinite(rho_new)) f |= KH_CG_NONFINITE_RHO;
-    else if (rho_new < 0.0) f |= KH_CG_NEGATIVE_RHO;
-    return f;
-}
-
-int kh_cg_step(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK,
-               int64_t ycol, kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int first, double omega,
-               double rho, double* out) {
-    KH_ARG(ctx && A && out, "kh_cg_step: NULL");
-    RoctxScope range_(ctx, "kh_cg_step");
-    KH_TRY(check_vec(Pd, pcol, 1, "kh_cg_step(p)"));
-    KH_TRY(check_vec(AP, apcol, 1, "kh_cg_step(Ap)"));
-    KH_TRY(check_vec(YK, ycol, 1, "kh_cg_step(yk)"));
-    KH_TRY(check_vec(R, rcol, 1, "kh_cg_step(r)"));
-    KH_ARG(A->kind <= KH_MAT_DIAG, "kh_cg_step: real operator expected");
-    KH_ARG(Md == nullptr || Md->kind == KH_MAT_DIAG, "kh_cg_step: Md must be diagonal");
-    if (Md) KH_TRY(check_vec(Z, zcol, 1, "kh_cg_step(z)"));
-    const int64_t n = R->n;
-    KH_ARG(Pd->n == n && AP->n == n && YK->n == n && A->n_rows == n && (!Md || (Md->n_rows == n && Z->n == n)),
-           "kh_cg_step: length mismatch");
-    KH_ARG(!(Pd == AP && pcol == apcol), "kh_cg_step: p and Ap must be different columns");
-    double* p = Pd->col(pcol);
-    double* ap = AP->col(apcol);
-    double* r = R->col(rcol);
-    double* z = Md ? Z->col(zcol) : r;
-    const int grid = grid_lin(ctx, n);
-    double* tmp = ctx->scal + SC_TMP;       // tmp[0] = <p, Ap>, tmp[1] = rho_new
-    if (!first)                             // p = z + omega p   (linsys.py:627)
-        hipLaunchKernelGGL(k_waxpby, dim3(grid), dim3(BS), 0, ctx->stream, n, p, 1.0, z, omega, p);
-    if (A->kind == KH_MAT_CSR) {            // Ap = A p with <p, Ap> fused into the SpMV
-        KH_TRY(apply_one(ctx, A, p, ap, EPI_DOT, p, tmp, 0));
-    } else {
-        KH_TRY(apply_one(ctx, A, p, ap, EPI_NONE, nullptr, nullptr, 0));
-        KH_TRY(dot_panel_dev(ctx, Pd, pcol, 1, ap, tmp, 0));
-    }
-    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp, 1));
-    double* part = part_slot(ctx, SLOT_NRM);
-    if (Md)
-        hipLaunchKernelGGL((k_cg_update<true>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
-                           YK->col(ycol), r, Md->diag, z, part, tmp);
-    else
-        hipLaunchKernelGGL((k_cg_update<false>), dim3(grid), dim3(BS), 0, ctx->stream, n, rho, p, ap,
-                           YK->col(ycol), r, nullptr, nullptr, part, tmp);
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, part, grid, 0, tmp + 1, 0);
-    KH_HIP(hipGetLastError());
-    if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, tmp + 1, 1));
-    KH_TRY(fetch_scalars(ctx, tmp, 2, out));
-    out[2] = (double)cg_sanity(out[0], out[1], rho);
-    return 0;
-}
-
-// A run of CG iterations in one call (krypy/linsys.py:622-690; the header has the contract)
-int kh_cg_cycle(kh_ctx ctx, kh_mat A, kh_mat Md, kh_vec Pd, int64_t pcol, kh_vec AP, int64_t apcol, kh_vec YK, int64_t ycol,
-                kh_vec R, int64_t rcol, kh_vec Z, int64_t zcol, int64_t k0, int64_t k_stop, double tol, double bnorm,
-                double* rhos, double* trace, int64_t* k_done, int* reason) {
-    KH_ARG(ctx && A && rhos && trace && k_done && reason, "kh_cg_cycle: NULL");
-    KH_ARG(k0 >= 0 && k0 <= k_stop, "kh_cg_cycle: iterations [%lld, %lld)", (long long)k0, (long long)k_stop);
-    RoctxScope range_(ctx, "kh_cg_cycle");
-    *reason = KH_CYCLE_LIMIT;
-    int64_t k = k0;
-    for (; k < k_stop; ++k) {
-        const double rho = rhos[k];
-        const double omega = (k > 0) ? rho / rhos[k - 1] : 0.0;          // p = z + rhos[-1] / rhos[-2] p  (linsys.py:627)
-        double out[3];
-        KH_TRY(kh_cg_step(ctx, A, Md, Pd, pcol, AP, apcol, YK, ycol, R, rcol, Z, zcol, k == 0, omega, rho, out));
-        double* t = trace + 6 * k;
-        t[0] = rho; t[1] = out[0]; t[2] = out[0]; t[3] = out[1]; t[4] = out[2]; t[5] = 0.0;
-        const int flags = (int)out[2];
-        if ((flags & (KH_CG_NONFINITE_PAP | KH_CG_NONFINITE_RHO | KH_CG_STEP_CLAMPED)) && std::isfinite(rho)) {
-            *reason = KH_CYCLE_CHECK;            // finite data in, inf / nan out: the caller raises with the trace
-            break;
-        }
-        // ||M Ml r_k|| in the M^-1 norm, then rho AS THE CALLER FORMS IT: `MMlrk_norm ** 2` on a NumPy scalar is libm's
-        // pow(x, 2.0), which is not always the correctly rounded x * x - the call goes through a volatile pointer so that
-        // the compiler does not replace it by the multiplication
-        static double (*volatile libm_pow)(double, double) = &pow;
-        const double nrm = std::sqrt(std::fabs(out[1]));
-        t[5] = nrm;
-        rhos[k + 1] = libm_pow(nrm, 2.0);
-        if (!(nrm / bnorm > tol)) {              // the caller's own test, linsys.py:476: that iteration is the caller's to finalise
-            ++k;
-            *reason = KH_CYCLE_TOL;
-            break;
-        }
-    }
-    *k_done = k;
-    ctx->n_cg_cycle_steps += k - k0;
-    return 0;
-}
-
 int kh_proj_create(kh_ctx ctx, kh_vec W, kh_vec V, int64_t d, const double* T, const double* WRH,
                    int iterations, kh_proj* out) {
     KH_ARG(ctx && W && V && out, "kh_proj_create: NULL");
@@ -3226,208 +2806,6 @@ int kh_proj_apply_complement(kh_ctx ctx, kh_proj p, kh_vec A, int64_t acol, kh_v
     if (ya_out) return fetch_scalars(ctx, p->ya, p->d, ya_out);
     return 0;
 }
-
-// Timing harness for bench.py: `reps` back-to-back launches of one hot kernel between two HIP
-// events on the context's stream.  The launches rotate through the columns of V exactly like the
-// solver does (p = V[:, j], vnext = V[:, j+1]) so cache behaviour matches the real chain.
-int kh_bench_kernel(kh_ctx ctx, int which, kh_vec V, kh_vec W, int reps, double* avg_ms) {
-    KH_ARG(ctx && V && W && avg_ms, "kh_bench_kernel: NULL");
-    KH_ARG(V->ncols >= 17 && W->ncols >= 2 && V->n == W->n, "kh_bench_kernel: need >= 17 basis columns");
-    KH_ARG(reps >= 1, "kh_bench_kernel: reps");
-    const int64_t n = V->n;
-    const int grid = grid_for(ctx, n);
-    double* w = W->col(0);
-    double* mw = W->col(1);
-    double* pa = part_slot(ctx, SLOT_PING);
-    double* pb = part_slot(ctx, SLOT_PONG);
-    KH_TRY(ensure_hcap(ctx, 1024));
-    KH_HIP(hipMemsetAsync(pa, 0, sizeof(double) * NB_MAX * 2, ctx->stream));  // alpha = 0: w unchanged
-    KH_HIP(hipMemsetAsync(ctx->scal + SC_COEF, 0, sizeof(double) * MAXC, ctx->stream));
-    const double four = 4.0;  // k_scale_store divides by sqrt(4)
-    KH_TRY(push_scalars(ctx, &four, 1, ctx->scal + SC_TMP + 8));
-    ColPtrs cp;
-    for (int i = 0; i < MAXC; ++i) cp.c[i] = V->col(i);
-    KH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    for (int r = 0; r < reps; ++r) {
-        const int j = r % 16;
-        switch (which) {
-            case 0:
-                hipLaunchKernelGGL((k_gs_link<A_PART, T_DOT>), dim3(grid), dim3(BS), 0, ctx->stream, n,
-                                   V->col(j), V->col(j + 1), w, nullptr, nullptr, (r & 1) ? pb : pa, grid,
-                                   nullptr, 0.0, (r & 1) ? pa : pb, nullptr);
-                break;
-            case 1:
-                hipLaunchKernelGGL((k_multidot<16>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp, w, ctx->part,
-                                   NB_MAX);
-                break;
-            case 2:
-                hipLaunchKernelGGL((k_multiaxpy<16, T_NONE, 1>), dim3(grid), dim3(BS), 0, ctx->stream, n, cp,
-                                   ctx->scal + SC_COEF, 1.0, 1.0, w, nullptr, nullptr, nullptr);
-                break;
-            case 3:
-                hipLaunchKernelGGL((k_gs_link<A_PART, T_NRM>), dim3(grid), dim3(BS), 0, ctx->stream, n,
-                                   V->col(j), nullptr, w, nullptr, nullptr, pa, grid, nullptr, 0.0,
-                                   part_slot(ctx, SLOT_NRM), nullptr);
-                break;
-            case 4:
-                hipLaunchKernelGGL((k_scale_store<A_SCAL>), dim3(grid), dim3(BS), 0, ctx->stream, n, w, nullptr,
-                                   mw, nullptr, nullptr, 0, ctx->scal + SC_TMP + 8, nullptr);
-                break;
-            case 5:
-            case 6:
-            case 7: {
-                // the register-resident chain over 16 columns x 4 sweeps = 64 links per launch
-                ctx->chain_debug = which - 5;
-                KH_HIP(hipMemsetAsync(ctx->hslot_dev[0], 0, sizeof(double) * 64, ctx->stream));
-                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 15, 0, 4, false, 0.0,
-                                         nullptr, ctx->hslot_dev[0], 0);
-                ctx->chain_debug = 0;
-                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
-                break;
-            }
-            case 20:
-            case 21:
-            case 22:
-            case 23: {
-                // the blocked chain (chain_blk.h) over 64 columns, one sweep, Gram entries from the table (steady state
-                // of a sequence; the table's content does not matter for the time); 21 / 22 / 23: without the exchange
-                // between workgroups / without the column stream / without both
-                KH_ARG(V->ncols >= 66, "kh_bench_kernel: the blocked chain needs 66 basis columns");
-                ctx->chain_debug = which - 20;
-                ctx->blk_V = V;
-                ctx->blk_next = 63;
-                const int64_t nb0 = ctx->n_chain_blk;
-                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 63, 0, 1, false, 0.0, nullptr,
-                                         ctx->hslot_dev[0], 0);
-                ctx->chain_debug = 0;
-                ctx->blk_next = -1;
-                if (rc != 1 || ctx->n_chain_blk == nb0) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: blocked chain kernel not eligible");
-                break;
-            }
-            case 24: {     // ... and the per-column kernel on the same 64 columns
-                const int keep = ctx->chain_blk;
-                ctx->chain_blk = 0;
-                const int rc = try_chain(ctx, V, V, w, W->ld, nullptr, nullptr, 63, 0, 1, false, 0.0, nullptr,
-                                         ctx->hslot_dev[0], 0);
-                ctx->chain_blk = keep;
-                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: chain kernel not eligible");
-                break;
-            }
-            case 8: {
-                // register-resident panel GS over 16 columns: k_cgs_dots + reduce + k_cgs_update
-                int cnt = 0;
-                KH_HIP(hipMemsetAsync(ctx->hslot_dev[0], 0, sizeof(double) * 64, ctx->stream));
-                const int rc = try_cgs_reg(ctx, V, V, w, W->ld, nullptr, nullptr, 0, 16, 1, false,
-                                           ctx->hslot_dev[0], ctx->scal + SC_COEF, &cnt);
-                if (rc != 1) return fail(KH_ERR_UNSUPPORTED, "kh_bench_kernel: cgs kernels not eligible");
-                break;
-            }
-            case 9:     // attainable ceiling: copy of 8 columns (8 N doubles read + 8 N written per launch)
-                hipLaunchKernelGGL(k_stream_copy, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 8) >> 1,
-                                   reinterpret_cast<const double2*>(V->col(0)), reinterpret_cast<double2*>(V->col(8)));
-                break;
-            case 10:    // attainable ceiling: triad a = b + s c on 4-column chunks (2 reads + 1 write)
-                hipLaunchKernelGGL(k_stream_triad, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 4) >> 1,
-                                   reinterpret_cast<const double2*>(V->col(0)),
-                                   reinterpret_cast<const double2*>(V->col(4)), 0.5,
-                                   reinterpret_cast<double2*>(V->col(8)));
-                break;
-            case 11:    // attainable ceiling: read-only sum of 16 columns (what a dot phase does)
-                hipLaunchKernelGGL(k_stream_read, dim3(ctx->ncu * 8), dim3(BS), 0, ctx->stream, (V->ld * 16) >> 1,
-                                   reinterpret_cast<const double2*>(V->col(0)), part_slot(ctx, SLOT_PING));
-                break;
-#define KH_PROBE_COPY(U, NTS)                                                                                  \
-    hipLaunchKernelGGL((k_probe_copy<U, NTS>), dim3((unsigned)((((V->ld * 8) >> 1) + U * BS - 1) / (U * BS))),  \
-                       dim3(BS), 0, ctx->stream, (V->ld * 8) >> 1, reinterpret_cast<const double2*>(V->col(0)), \
-                       reinterpret_cast<double2*>(V->col(8)))
-            case 12: KH_PROBE_COPY(1, false); break;
-            case 13: KH_PROBE_COPY(4, false); break;
-            case 14: KH_PROBE_COPY(8, false); break;
-            case 15: KH_PROBE_COPY(4, true); break;
-#undef KH_PROBE_COPY
-#define KH_PROBE_READ(U)                                                                                       \
-    hipLaunchKernelGGL((k_probe_read<U>), dim3((unsigned)((((V->ld * 16) >> 1) + U * BS - 1) / (U * BS))),       \
-                       dim3(BS), 0, ctx->stream, (V->ld * 16) >> 1, reinterpret_cast<const double2*>(V->col(0)), \
-                       part_slot(ctx, SLOT_PING))
-            case 16: KH_PROBE_READ(4); break;
-            case 17: KH_PROBE_READ(8); break;
-            case 18: KH_PROBE_READ(16); break;
-#undef KH_PROBE_READ
-            default:
-                return fail(KH_ERR_ARG, "kh_bench_kernel: unknown kernel id %d", which);
-        }
-    }
-    KH_HIP(hipGetLastError());
-    KH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    KH_HIP(hipEventSynchronize(ctx->ev1));
-    float ms = 0.f;
-    KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    *avg_ms = (double)ms / reps;
-    return 0;
-}
-
-// The solver's own launch sequence, timed: `reps` times the Arnoldi steps k = 0 .. m-1 on basis V (column 0 = the
-// caller's unit vector), begun with one step of look-ahead and fetched in order exactly like kh_gmres_cycle does -
-// without the Givens bookkeeping.  avg_step_ms = HIP-event time / (reps * m): with a banded operator and w in
-// registers that is the average duration of ONE launch of the fused chain kernel over k+1 = 1 .. m links.
-int kh_bench_arnoldi(kh_ctx ctx, kh_mat A, kh_vec V, kh_vec W, int64_t m, int gs_mode, int reps, double* avg_step_ms) {
-    KH_ARG(ctx && A && V && W && avg_step_ms, "kh_bench_arnoldi: NULL");
-    KH_ARG(m >= 1 && V->ncols >= m + 1 && reps >= 1, "kh_bench_arnoldi: need m + 1 = %lld basis columns, have %lld",
-           (long long)(m + 1), (long long)V->ncols);
-    std::vector<double> col((size_t)m + 2);
-    KH_HIP(hipEventRecord(ctx->ev0, ctx->stream));
-    for (int r = 0; r < reps; ++r) {
-        int64_t enq = 0;
-        for (int64_t k = 0; k < m; ++k) {
-            const int64_t last = std::min<int64_t>(k + 1, m - 1);
-            while (enq <= last) {
-                KH_TRY(kh_arnoldi_step_begin(ctx, A, nullptr, nullptr, V, nullptr, W, 0, enq, 0, 1, gs_mode, 0.0,
-                                             (int)(enq % KH_NSLOT)));
-                ++enq;
-            }
-            KH_TRY(kh_arnoldi_step_end(ctx, (int)(k % KH_NSLOT), k + 2, col.data()));
-        }
-    }
-    KH_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    KH_HIP(hipEventSynchronize(ctx->ev1));
-    float ms = 0.f;
-    KH_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    *avg_step_ms = (double)ms / ((double)reps * (double)m);
-    return 0;
-}
-
-#ifdef KH_CHAIN_TRACE
-// Diagnostic build only (make -C krypy_amd/csrc trace; tools/chain_trace.py): one traced 64-link launch of
-// the chain kernel (16 columns x 4 sweeps, like kh_bench_kernel); out gets [G][64][2 waves][8] stamps of
-// the constant 100 MHz clock.  Not part of the C ABI of the product.
-int kh_chain_trace(kh_ctx ctx, kh_vec V, kh_vec W, unsigned long long* out, int64_t cap, int* g_out) {
-    KH_ARG(ctx && V && W && out && g_out, "kh_chain_trace: NULL");
-    KH_ARG(V->ncols >= 17 && W->ncols >= 1 && V->n == W->n, "kh_chain_trace: need >= 17 basis columns");
-    int r2 = 0, G = 0;
-    KH_ARG(chain_geometry(ctx, V->n, &r2, &G), "kh_chain_trace: chain not eligible");
-    const size_t words = (size_t)G * 64 * 2 * 8;
-    KH_ARG((int64_t)words <= cap, "kh_chain_trace: buffer too small (%zu words)", words);
-    KH_TRY(ensure_hcap(ctx, 1024));
-    unsigned long long* dev = nullptr;
-    KH_HIP(hipMalloc(&dev, words * sizeof(unsigned long long)));
-    KH_HIP(hipMemset(dev, 0, words * sizeof(unsigned long long)));
-    for (int rep = 0; rep < 4; ++rep) {
-        ctx->chain_trace = (rep == 3) ? dev : nullptr;
-        const int rc = try_chain(ctx, V, V, W->col(0), W->ld, nullptr, nullptr, 15, 0, 4, false, 0.0, nullptr,
-                                 ctx->hslot_dev[0], 0);
-        ctx->chain_trace = nullptr;
-        if (rc != 1) {
-            (void)hipFree(dev);
-            return fail(KH_ERR_UNSUPPORTED, "kh_chain_trace: chain kernel not eligible");
-        }
-    }
-    KH_HIP(hipStreamSynchronize(ctx->stream));
-    KH_HIP(hipMemcpy(out, dev, words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    (void)hipFree(dev);
-    *g_out = G;
-    return 0;
-}
-#endif
 
 }  // extern "C"
 

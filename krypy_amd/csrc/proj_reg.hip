@@ -56,12 +56,17 @@ static hipError_t launch_proj(kh_ctx ctx, int G, ProjRegArgs& a) {
 // r2 / G: the chain-kernel geometry of vectors of this length (krylov_hip.hip: chain_geometry).  Returns 1 when the
 // launch was made, 0 when this shape / state is not served (the caller runs the four-launch form), negative on error.
 int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G, double* ya_dev) {
+    // (ctx->proj_reg_why: why the last call declined - kh_ctx_get "proj_reg_why"; 0 = it ran)
+    ctx->proj_reg_why = 1;
     if (!ctx->proj_reg || !ctx->chain_enabled || kh_multi(ctx) || p->cplx || p->d < 1 || p->d > PR_NV || p->iterations < 1) return 0;
+    ctx->proj_reg_why = 2;
     if (r2 < 16 || G > CH_GMAX / 2 || G > 256) return 0;       // (short vectors: the four launches are latency-bound either way)
     const int64_t n = p->W->n;
     const int64_t chunk2 = (int64_t)r2 * CH_BS;
     const int64_t need_ld = (int64_t)G * chunk2 * 2;
+    ctx->proj_reg_why = 3;
     if (p->W->ld != p->V->ld || p->W->ld < need_ld || zld < need_ld) return 0;      // padded blocks only
+    ctx->proj_reg_why = 4;
     if (ctx->proj_gran == nullptr || ctx->proj_epoch > 0xfff00000u) {
         if (ctx->proj_gran != nullptr) KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(proj_reg_reset(ctx));
@@ -103,6 +108,7 @@ int proj_reg_apply(kh_ctx ctx, kh_proj p, double* z, int64_t zld, int r2, int G,
         (void)hipGetLastError();
         return 0;
     }
+    ctx->proj_reg_why = 0;
     ctx->proj_epoch += (unsigned)p->iterations;
     ctx->n_proj_reg += 1;
     if (ctx->proj_fault) {          // tests: what a timed-out sum leaves behind - the error word set, garbage in z

@@ -447,13 +447,13 @@ def test_projector_timeout_is_recovered(hip):
             Z = hip.alloc(N, 1)
             r0, u0 = hip.get("n_proj_recovered"), hip.get("n_proj_reg")
             ya = hip.proj_apply_complement(pj, Ad, 0, Z, 0, want_ya=True)
-            outs.append((Z.download()[:, 0], np.array(ya), hip.get("n_proj_recovered") - r0, hip.get("proj_reg"), hip.get("n_proj_reg") - u0))
+            outs.append((Z.download()[:, 0], np.array(ya), hip.get("n_proj_recovered") - r0, hip.get("proj_reg"), hip.get("n_proj_reg") - u0, hip.get("proj_reg_why")))
         z = a - Wh.dot(Wh.T.dot(a))
         z = z - Wh.dot(Wh.T.dot(z))
-        for zz, ya, _, _, _ in outs:
+        for zz, ya, _, _, _, _ in outs:
             assert np.linalg.norm(zz - z) < 1e-12 * np.linalg.norm(z)
             assert np.linalg.norm(ya - Wh.T.dot(a)) < 1e-12 * np.linalg.norm(a)
-        expect_kernel(outs[0][2] == 0 and outs[1][2] == 1 and outs[0][3] == 1 and outs[1][3] == 0,
+        expect_kernel(outs[0][2:5] == (0, 1, 1) and outs[1][2:5] == (1, 0, 1),
                       "stand-alone: (recoveries, kernel on, one-launch calls) (0, 1, 1) / (1, 0, 1): %r" % ([o[2:] for o in outs],))
     finally:
         hip.set("proj_fault", 0)
