@@ -581,6 +581,9 @@ def _run():
                    # sums across the ranks: "xr" = one kernel of system-scope stores into the peers' IPC-mapped mailboxes
                    # per panel (csrc/xr.hip), "rccl" = ncclAllReduce; the halo exchange is RCCL point-to-point either way
                    "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),
+                   # the halo of the sharded SpMV: "in-launch" = boundary rows stored into the neighbours' IPC-mapped ghost granules
+                   # by the banded kernel itself (kh_mat_xh_*), "rccl" = grouped ncclSend / ncclRecv on the communication stream
+                   "halo": None if not sharded else ("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl"),
                    "ortho_auto": auto_report,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
                    # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
@@ -710,6 +713,7 @@ def _run_config5(args):
                    "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "z-slabs x%d (RCCL)" % world,
                    "cross_rank_sums": None if not sharded else ("xr" if locals().get("xr_on") else "rccl"),
+                   "halo": None if not sharded else ("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl"),
                    "plain_relres": plain_relres, "deflated_relres": float(s1.resnorms[-1]),
                    "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
                    "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms))},

@@ -110,6 +110,17 @@ int kh_comm_allreduce_host(kh_ctx ctx, double* vals, int64_t count);
 int kh_xr_export(kh_ctx ctx, unsigned char handle[64]);
 int kh_xr_attach(kh_ctx ctx, int rank, int nranks, const unsigned char* handles);
 int kh_xr_detach(kh_ctx ctx);
+/* xh - the halo of a block-row shard through the same kind of mailboxes: after kh_mat_set_halo, kh_mat_xh_export allocates this
+ * shard's ghost GRANULES in fine-grained device memory and returns their 64-byte IPC handle; the launcher hands every rank its two
+ * neighbours' handles (kh_mat_xh_attach: `prev_ng` / `next_ng` = the ghost entries nrecv_prev + nrecv_next of THEIR boxes, `prev_off`
+ * = the previous rank's nrecv_prev; NULL = no such neighbour; self_loop = 1: the slab of an operator that is periodic across the slab
+ * boundary, the rank is its own neighbour) and, after EVERY rank has attached, switches it on everywhere (kh_mat_xh_enable).  The
+ * banded SpMV of the shard (the operator of /root/reference/krypy/utils.py:1593-1594 on this rank's rows) then stores its boundary
+ * rows into the neighbours' granules and polls its own INSIDE its one launch: no ncclSend / ncclRecv kernel, no second stream. */
+int kh_mat_xh_export(kh_ctx ctx, kh_mat A, unsigned char handle[64]);
+int kh_mat_xh_attach(kh_ctx ctx, kh_mat A, const unsigned char* prev, int64_t prev_ng, int64_t prev_off, const unsigned char* next,
+                     int64_t next_ng, int self_loop);
+int kh_mat_xh_enable(kh_ctx ctx, kh_mat A, int on);
 /* describe the halo of a block-row-sharded matrix: this rank sends `nsend_*` of its first/last
  * local rows to the previous/next rank and receives as many ghost entries from them.  After
  * this call kh_apply() on `A` exchanges halos (ncclSend/ncclRecv) before the local SpMV; the

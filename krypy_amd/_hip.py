@@ -64,6 +64,9 @@ _SIGNATURES = {
     "kh_xr_export": [_H, ctypes.c_char_p],
     "kh_xr_attach": [_H, _INT, _INT, ctypes.c_char_p],
     "kh_xr_detach": [_H],
+    "kh_mat_xh_export": [_H, _H, ctypes.c_char_p],
+    "kh_mat_xh_attach": [_H, _H, ctypes.c_char_p, _I64, _I64, ctypes.c_char_p, _I64, _INT],
+    "kh_mat_xh_enable": [_H, _H, _INT],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
     "kh_mat_set_ghost": [_H, _c_double_p, _I64],
     "kh_mat_get_ghost": [_H, _c_double_p, _I64],
@@ -539,6 +542,19 @@ class Context(object):
 
     def xr_detach(self):
         self._lib.kh_xr_detach(self._h)
+
+    # xh: the halo of a shard through IPC-mapped granules inside the banded SpMV's launch (krypy_amd.dist.ShardedCSROperator)
+    def xh_export(self, A):
+        buf = ctypes.create_string_buffer(64)
+        _check(self._lib, self._lib.kh_mat_xh_export(self._h, A.handle, buf), "kh_mat_xh_export")
+        return buf.raw
+
+    def xh_attach(self, A, prev, prev_ng, prev_off, next_, next_ng, self_loop=False):
+        _check(self._lib, self._lib.kh_mat_xh_attach(self._h, A.handle, prev, int(prev_ng), int(prev_off), next_, int(next_ng),
+                                                      1 if self_loop else 0), "kh_mat_xh_attach")
+
+    def xh_enable(self, A, on=True):
+        _check(self._lib, self._lib.kh_mat_xh_enable(self._h, A.handle, 1 if on else 0), "kh_mat_xh_enable")
 
     def allreduce_host(self, vals):
         a = numpy.ascontiguousarray(vals, dtype=numpy.float64)

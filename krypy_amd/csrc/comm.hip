@@ -83,7 +83,14 @@ int comm_allreduce_dev(kh_ctx ctx, double* dev, int64_t count) {
 
 int comm_halo_exchange(kh_ctx ctx, kh_mat A, const double* x, hipStream_t stream, int width) {
     // width: doubles per vector entry (1 real, 2 complex); counts and offsets below are in entries
-    if (ctx->comm == nullptr) return 0;
+    if (ctx->comm == nullptr) {
+        // ranks joined through the xr transport alone: sums cross them, and a halo only inside the banded kernel's launch
+        // (kh_mat_xh_*) - which this call is not
+        if (ctx->nranks > 1)
+            return fail(KH_ERR_COMM, "sharded SpMV: %d ranks without an RCCL communicator and this operator's halo is not exchanged "
+                                     "inside its launch (kh_mat_xh_enable)", ctx->nranks);
+        return 0;
+    }
     const int64_t nloc = A->n_rows;
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     if (ctx->halo_loopback && ctx->nranks == 1) {
@@ -247,9 +254,6 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
     const int width = A->kind == KH_MAT_ZCSR ? 2 : 1;
     KH_ARG(nsend_prev >= 0 && nsend_next >= 0 && nrecv_prev >= 0 && nrecv_next >= 0, "negative halo");
     KH_ARG(nsend_prev <= A->n_rows && nsend_next <= A->n_rows, "halo wider than the local slab");
-    KH_ARG(!(ctx->comm == nullptr && ctx->nranks > 1 && (nsend_prev + nsend_next + nrecv_prev + nrecv_next) > 0),
-           "kh_mat_set_halo: %d ranks joined through the xr transport alone (no RCCL communicator): sums cross ranks, halos "
-           "do not - initialise the communicator (kh_comm_init) for an operator that couples the slabs", ctx->nranks);
     KH_ARG(A->n_cols == A->n_rows + nrecv_prev + nrecv_next,
            "kh_mat_set_halo: n_cols %lld != n_rows %lld + ghosts %lld", (long long)A->n_cols,
            (long long)A->n_rows, (long long)(nrecv_prev + nrecv_next));
@@ -259,6 +263,7 @@ int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next
     A->nrecv_next = nrecv_next;
     (void)hipFree(A->ghost);
     A->ghost = nullptr;
+    kh::xh_free(A);                 // (granules sized for another halo)
     const int64_t ng = nrecv_prev + nrecv_next;
     if (ng > 0) {
         KH_HIP(hipMalloc(&A->ghost, sizeof(double) * width * ng));

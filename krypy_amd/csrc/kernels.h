@@ -11,6 +11,7 @@
 //    `Av -= alpha * V[:, [j]]`; fused multiply-adds are used only where written as fma().
 #pragma once
 #include "kh_internal.h"
+#include "xr_dev.h"
 
 namespace kh {
 
@@ -653,7 +654,10 @@ static __global__ __launch_bounds__(BS) void k_dia_fill(const int32_t* __restric
     }
 }
 
-template <int EPI, int ND, int RPT, bool HALO>
+// XH (with HALO): the halo travels through IPC-mapped granules (xr_dev.h) inside THIS launch - every lane first stores the rows
+// of x it owns among the slab's first nsend_prev / last nsend_next into the neighbours' ghost granules (system scope: xGMI
+// writes), and a ghost entry is read by polling the own granules for this exchange's epoch.  Same arithmetic, same order.
+template <int EPI, int ND, int RPT, bool HALO, bool XH = false>
 __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __restrict__ dia,
                                                  int64_t ld, int64_t n, int nblk,
                                                  const double* __restrict__ x,
@@ -661,12 +665,27 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                                                  int nnext, double* __restrict__ y,
                                                  const double* __restrict__ aux,
                                                  double* __restrict__ part_out,
-                                                 int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0) {
+                                                 int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0,
+                                                 XhArgs xh = XhArgs()) {
     __shared__ double sm[8];
     int lb = xcd_remap(blockIdx.x, gridDim.x);       // (subset launches: see k_spmv_stream)
     lb = lb < blk_lo ? lb : lb + blk_skip;
     const int64_t base = (int64_t)lb * (2 * BS * RPT);
     const int64_t last = n - 1;
+    if constexpr (XH) {
+#pragma unroll
+        for (int u = 0; u < RPT; ++u) {
+            const int64_t r = base + 2 * (threadIdx.x + u * BS);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t i = r + h;
+                if (i < n) {
+                    if (i < xh.nsend_prev) xh_put(xh.prev, xh.prev_ng, xh.prev_off + i, xh.epoch, x[i]);
+                    if (i >= n - xh.nsend_next) xh_put(xh.next, xh.next_ng, i - (n - xh.nsend_next), xh.epoch, x[i]);
+                }
+            }
+        }
+    }
     const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     double s0[RPT], s1[RPT];
 #pragma unroll
@@ -690,8 +709,13 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                 const int64_t lo = -(int64_t)nprev, hi = last + nnext;
                 c0 = c0 < lo ? lo : (c0 > hi ? hi : c0);
                 c1 = c1 < lo ? lo : (c1 > hi ? hi : c1);
-                x0[u] = c0 < 0 ? ghost[c0 + nprev] : (c0 > last ? ghost[nprev + (c0 - n)] : x[c0]);
-                x1[u] = c1 < 0 ? ghost[c1 + nprev] : (c1 > last ? ghost[nprev + (c1 - n)] : x[c1]);
+                if constexpr (XH) {
+                    x0[u] = c0 < 0 ? xh_take(xh, c0 + nprev) : (c0 > last ? xh_take(xh, nprev + (c0 - n)) : x[c0]);
+                    x1[u] = c1 < 0 ? xh_take(xh, c1 + nprev) : (c1 > last ? xh_take(xh, nprev + (c1 - n)) : x[c1]);
+                } else {
+                    x0[u] = c0 < 0 ? ghost[c0 + nprev] : (c0 > last ? ghost[nprev + (c0 - n)] : x[c0]);
+                    x1[u] = c1 < 0 ? ghost[c1 + nprev] : (c1 > last ? ghost[nprev + (c1 - n)] : x[c1]);
+                }
             } else {
                 c0 = c0 < 0 ? 0 : (c0 > last ? last : c0);
                 c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);

@@ -188,6 +188,7 @@ struct kh_ctx_s {
     int64_t n_spmv_split = 0;
     int halo_loopback = 0;          // tests: a 1-rank communicator exchanges its halo with itself (periodic slab)
     int64_t n_halo_exchange = 0;    // grouped ncclSend / ncclRecv exchanges issued
+    int64_t n_halo_xh = 0;          // sharded SpMVs whose halo travelled inside their own launch (kh_mat_xh_*)
     int64_t n_allreduce = 0;        // ncclAllReduce calls issued (kh_ctx_get "n_allreduce")
     double* commbuf = nullptr;  // device staging for host all-reduces
     // ---- xr: sums across the ranks of ONE node without a library call (xr.hip) ----
@@ -251,6 +252,16 @@ struct kh_mat_s {
     int64_t ghost_panel_cols = 0;
     // row blocks [b0, b1) of the banded / the CSR-stream kernel touch no ghost column (interior of the slab)
     int dia_b0 = 0, dia_b1 = 0, csr_b0 = 0, csr_b1 = 0;
+    // xh: the halo through IPC-mapped mailboxes (xr.hip, kh_mat_xh_*): the banded SpMV itself stores this slab's boundary rows
+    // into the neighbours' ghost granules and polls its own - ONE launch per sharded SpMV, no RCCL kernel, no second stream
+    unsigned long long* xh_box = nullptr;      // my ghost granules: [2 parities][nrecv_prev + nrecv_next][lo, hi]
+    unsigned long long* xh_prev = nullptr;     // the previous / next rank's box as mapped here (loopback: my own)
+    unsigned long long* xh_next = nullptr;
+    int64_t xh_prev_ng = 0, xh_next_ng = 0;    // ghost entries of the neighbours' boxes (the stride of a parity)
+    int64_t xh_prev_off = 0;                   // where my first rows go in the previous rank's box: behind ITS ghosts from its prev
+    unsigned xh_epoch = 1;                     // one per sharded SpMV of this operator; tags the granules
+    int xh_on = 0;                             // the host layer switches it on after EVERY rank has attached (kh_mat_xh_enable)
+    int xh_self = 0;                           // loopback: the neighbours' boxes are my own (nothing to close)
 };
 
 // true when reductions must be all-reduced / halos exchanged (several ranks, or a 1-rank
@@ -284,6 +295,7 @@ int xr_allreduce_dev(kh_ctx ctx, double* dev, int64_t count);
 // comm_allreduce_dev.  `multi` false: the reduction alone.
 int reduce_partials_allreduce(kh_ctx ctx, const double* part, int nb, int pstride, double* out, int count, bool multi);
 void xr_free(kh_ctx ctx);
+void xh_free(kh_mat A);
 int xr_check(kh_ctx ctx);           // KH_ERR_COMM when an exchange has timed out since the last look
 // krylov_hip.hip
 int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A);

@@ -250,9 +250,33 @@ static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* 
                           const SpmvRange& rg) {
     const int grid = rg.grid < 0 ? A->dia_nblk : rg.grid;
     if (grid == 0) return;
+    if constexpr (HALO) {
+        if (A->xh_on) {
+            // the halo inside this launch (xr_dev.h): every block of the slab, one epoch per SpMV of this operator
+            XhArgs xh;
+            xh.mine = A->xh_box;
+            xh.prev = A->xh_prev != nullptr ? A->xh_prev : A->xh_box;
+            xh.next = A->xh_next != nullptr ? A->xh_next : A->xh_box;
+            xh.my_ng = A->nrecv_prev + A->nrecv_next;
+            xh.prev_ng = A->xh_prev_ng;
+            xh.next_ng = A->xh_next_ng;
+            xh.prev_off = A->xh_prev_off;
+            xh.nsend_prev = A->xh_prev != nullptr ? (int)A->nsend_prev : 0;
+            xh.nsend_next = A->xh_next != nullptr ? (int)A->nsend_next : 0;
+            xh.epoch = A->xh_epoch++;
+            xh.timeout_ticks = (long long)(ctx->xr_timeout_ms > 0 ? ctx->xr_timeout_ms : 60000) * 100000ll;
+            void* dp = nullptr;
+            (void)hipHostGetDevicePointer(&dp, ctx->xr_err_pin, 0);
+            xh.err = static_cast<int*>(dp);
+            hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT, true, true>), dim3(grid), dim3(BS), 0, ctx->stream, o, A->dia,
+                               A->dia_ld, A->n_rows, A->dia_nblk, x, A->ghost, (int)A->nrecv_prev, (int)A->nrecv_next, y,
+                               aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, xh);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_spmv_dia<EPI, ND, RPT, HALO>), dim3(grid), dim3(BS), 0, ctx->stream, o, A->dia,
                        A->dia_ld, A->n_rows, A->dia_nblk, x, A->ghost, (int)A->nrecv_prev, (int)A->nrecv_next, y,
-                       aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off);
+                       aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, XhArgs());
 }
 
 template <int EPI>
@@ -306,6 +330,26 @@ int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const d
             return 0;
         }
         const bool dia = use_dia(ctx, A, y);
+        if (A->xh_on && halo) {
+            // the halo travels inside the banded kernel's own launch (kh_mat_xh_*): ONE launch, no RCCL kernel, no second
+            // stream.  Every rank switched this on together - a shape the banded kernel does not serve is an error here, not a
+            // fallback to the RCCL exchange its neighbours are not taking part in.
+            if (!dia)
+                return fail(KH_ERR_COMM, "sharded SpMV: the halo is exchanged inside the banded kernel (xh) but this call cannot take "
+                                         "it (KRYPY_AMD_SPMV_DIA=0, or an output column that is not 16-byte aligned)");
+            if (A->xh_epoch > 0xfff00000u)
+                return fail(KH_ERR_COMM, "xh: the epoch counter of this operator's halo exchange is exhausted; upload it again");
+            if (epi == EPI_NONE) launch_spmv<EPI_NONE>(ctx, A, x, y, nullptr, SpmvRange());
+            if (epi == EPI_DOT) launch_spmv<EPI_DOT>(ctx, A, x, y, aux, SpmvRange());
+            if (epi == EPI_RES) launch_spmv<EPI_RES>(ctx, A, x, y, aux, SpmvRange());
+            KH_HIP(hipGetLastError());
+            ctx->n_halo_xh += 1;
+            if (epi != EPI_NONE) {
+                hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(BS), 0, ctx->stream, A->part, A->dia_nblk, 0, scal_out, rmode);
+                KH_HIP(hipGetLastError());
+            }
+            return 0;
+        }
         // a shard's rows that touch no ghost column (the bulk of a slab) do not wait for the halo: the exchange
         // runs on the communication stream while they are multiplied, the boundary rows follow it
         const int lo = dia ? A->dia_b0 : A->csr_b0, hi = dia ? A->dia_b1 : A->csr_b1;
@@ -1545,6 +1589,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_lowsync")) *value = ctx->n_lowsync;
     else if (!strcmp(key, "n_ls_rebuild")) *value = ctx->n_ls_rebuild;
     else if (!strcmp(key, "n_halo_exchange")) *value = ctx->n_halo_exchange;
+    else if (!strcmp(key, "n_halo_xh")) *value = ctx->n_halo_xh;
     else if (!strcmp(key, "n_allreduce")) *value = ctx->n_allreduce;
     else if (!strcmp(key, "n_chain_recovered")) *value = ctx->n_chain_recovered;
     else if (!strcmp(key, "chain_epoch")) *value = ctx->chain_epoch;
@@ -2027,6 +2072,7 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->diag);
     (void)hipFree(A->ghost);
     (void)hipFree(A->ghost_panel);
+    xh_free(A);
     delete A;
     return 0;
 }
@@ -2333,7 +2379,7 @@ static bool step_poisoned(kh_ctx ctx, int slot) {
     for (int s2 = 0; s2 < KH_NSLOT; ++s2) {
         const kh_step_s& o = ctx->step[s2];
         if (s2 != slot && o.kind != 0 && o.V == st.V && o.k == st.k - 1 && *ctx->chain_err_pin[s2] != 0) {
-            *ctx->chain_err_pin[slot] = 1;
+            *ctx->chain_err_pin[slot] = *ctx->chain_err_pin[s2];      // (3: "to be re-run" behind a projector timeout - not the chain's fault)
             return true;
         }
     }
@@ -2685,19 +2731,22 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         // intact: switch the chain off for this context and run the SAME step again on the per-column kernels.
         // Steps begun after it (look-ahead) consumed the garbage; each of them reports the error in its own
         // slot and is recovered in turn when the host asks for it, in order.
+        // (code 3: a step that consumed the garbage a PROJECTOR timeout left behind - re-run like any other, but the chain
+        // kernels are not to blame and stay on)
+        if (*ctx->chain_err_pin[slot] == 3) proj_timeout = true;
         *ctx->chain_err_pin[slot] = 0;
         if (ctx->chain_enabled && !proj_timeout) chain_switch_off(ctx);      // (look-ahead steps that saw the same timeout do not count again)
         ctx->n_chain_recovered += proj_timeout ? 0 : 1;
         KH_HIP(hipStreamSynchronize(ctx->stream));
         KH_HIP(hipMemset(ctx->chain_err, 0, sizeof(int)));
-        if (proj_timeout) {
+        if (proj_timeout && ctx->proj_err != nullptr) {
             KH_HIP(hipMemset(ctx->proj_err, 0, sizeof(int)));
             *ctx->proj_err_pin = 0;          // (look-ahead steps in flight copied the set word again)
         }
         for (int s2 = 0; s2 < KH_NSLOT; ++s2)      // later steps in flight saw the same error word
             if (s2 != slot && *ctx->chain_err_pin[s2] == 0 && ctx->step[s2].kind != 0 &&
                 ctx->step[s2].V == ctx->step[slot].V && ctx->step[s2].k > ctx->step[slot].k)
-                *ctx->chain_err_pin[s2] = 1;
+                *ctx->chain_err_pin[s2] = proj_timeout ? 3 : 1;
         const kh_step_s st = ctx->step[slot];
         struct InRecovery {
             kh_ctx c;

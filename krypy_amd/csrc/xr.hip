@@ -32,6 +32,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include "kh_internal.h"
 #include "kernels.h"
 #include "xr_dev.h"
@@ -140,6 +142,9 @@ int xr_check(kh_ctx ctx) {
     if (ctx->xr_err_pin == nullptr || *ctx->xr_err_pin == 0) return 0;
     const int who = *ctx->xr_err_pin - 1;
     *ctx->xr_err_pin = 0;
+    if (who == 99)
+        return fail(KH_ERR_COMM, "xh: a neighbour's boundary rows did not arrive within the timeout in a sharded SpMV on rank %d of %d "
+                                 "(KRYPY_AMD_XR_TIMEOUT_S): a peer has died or applies a different sequence of operators", ctx->rank, ctx->nranks);
     return fail(KH_ERR_COMM, "xr: rank %d's contribution to a cross-rank sum did not arrive within the timeout (rank %d of %d "
                              "waited; KRYPY_AMD_XR_TIMEOUT_S): a peer has died or runs a different sequence of collectives",
                 who, ctx->xr_rank, ctx->xr_nranks);
@@ -163,11 +168,114 @@ void xr_free(kh_ctx ctx) {
     ctx->xr_nranks = 0;
 }
 
+void xh_free(kh_mat A) {
+    if (A == nullptr) return;
+    A->xh_on = 0;
+    if (!A->xh_self) {
+        if (A->xh_prev != nullptr) (void)hipIpcCloseMemHandle(A->xh_prev);
+        if (A->xh_next != nullptr) (void)hipIpcCloseMemHandle(A->xh_next);
+    }
+    A->xh_prev = A->xh_next = nullptr;
+    if (A->xh_box != nullptr) (void)hipFree(A->xh_box);
+    A->xh_box = nullptr;
+}
+
 }  // namespace kh
 
 using namespace kh;
 
 extern "C" {
+
+// ---- xh: the halo of a block-row shard through IPC-mapped granules (kernels.h: k_spmv_dia<..., XH>) ----
+int kh_mat_xh_export(kh_ctx ctx, kh_mat A, unsigned char handle[64]) {
+    KH_ARG(ctx && A && handle, "kh_mat_xh_export: NULL");
+    KH_ARG(A->kind == KH_MAT_CSR, "kh_mat_xh_export: a real CSR shard expected");
+    KH_HIP(hipSetDevice(ctx->device));
+    if (A->xh_box == nullptr) {
+        const int64_t ng = A->nrecv_prev + A->nrecv_next;
+        const size_t bytes = sizeof(unsigned long long) * (size_t)std::max<int64_t>(2 * ng * 2, 2);
+        void* p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            e = hipMalloc(&p, bytes);
+        }
+        KH_HIP(e);
+        A->xh_box = static_cast<unsigned long long*>(p);
+        KH_HIP(hipMemset(A->xh_box, 0, bytes));
+        KH_HIP(hipDeviceSynchronize());
+    }
+    hipIpcMemHandle_t h;
+    KH_HIP(hipIpcGetMemHandle(&h, A->xh_box));
+    memcpy(handle, &h, 64);
+    return 0;
+}
+
+// prev / next: the neighbours' 64-byte handles (NULL: no such neighbour, or - self_loop - this rank's own box: the slab of an
+// operator that is periodic across the slab boundary, kh_ctx_set "halo_loopback"); prev_ng / next_ng: the ghost entries
+// (nrecv_prev + nrecv_next) of THEIR boxes, prev_off: the previous rank's nrecv_prev (my first rows are its ghosts from its
+// next rank, which sit behind its ghosts from its previous one)
+int kh_mat_xh_attach(kh_ctx ctx, kh_mat A, const unsigned char* prev, int64_t prev_ng, int64_t prev_off, const unsigned char* next,
+                     int64_t next_ng, int self_loop) {
+    KH_ARG(ctx && A, "kh_mat_xh_attach: NULL");
+    KH_ARG(A->xh_box != nullptr, "kh_mat_xh_attach: kh_mat_xh_export first");
+    KH_ARG(A->xh_prev == nullptr && A->xh_next == nullptr, "kh_mat_xh_attach: already attached");
+    KH_HIP(hipSetDevice(ctx->device));
+    if (self_loop) {
+        A->xh_self = 1;
+        A->xh_prev = A->xh_next = A->xh_box;
+        A->xh_prev_ng = A->xh_next_ng = A->nrecv_prev + A->nrecv_next;
+        A->xh_prev_off = A->nrecv_prev;
+        return 0;
+    }
+    auto open = [&](const unsigned char* hb, unsigned long long** out) -> int {
+        hipIpcMemHandle_t h;
+        memcpy(&h, hb, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(KH_ERR_COMM, "kh_mat_xh_attach: cannot map a neighbour's ghost granules (%s)", hipGetErrorString(e));
+        }
+        *out = static_cast<unsigned long long*>(p);
+        return 0;
+    };
+    if (prev != nullptr && A->nsend_prev > 0) KH_TRY(open(prev, &A->xh_prev));
+    if (next != nullptr && A->nsend_next > 0) {
+        const int rc = open(next, &A->xh_next);
+        if (rc != 0) {
+            if (A->xh_prev != nullptr) (void)hipIpcCloseMemHandle(A->xh_prev);
+            A->xh_prev = nullptr;
+            return rc;
+        }
+    }
+    A->xh_prev_ng = prev_ng;
+    A->xh_next_ng = next_ng;
+    A->xh_prev_off = prev_off;
+    return 0;
+}
+
+// on: the sharded SpMV of this operator exchanges its halo inside its own launch from now on (EVERY rank must make the same
+// setting: krypy_amd/dist.py switches it on after all ranks have attached)
+int kh_mat_xh_enable(kh_ctx ctx, kh_mat A, int on) {
+    KH_ARG(ctx && A, "kh_mat_xh_enable: NULL");
+    if (on) {
+        KH_ARG(A->xh_box != nullptr, "kh_mat_xh_enable: kh_mat_xh_export / _attach first");
+        KH_ARG(A->dia != nullptr, "kh_mat_xh_enable: the banded kernel carries the exchange; this shard has no diagonal-major copy");
+        KH_ARG((A->nsend_prev == 0 || A->xh_prev != nullptr) && (A->nsend_next == 0 || A->xh_next != nullptr),
+               "kh_mat_xh_enable: a neighbour this slab sends to is not attached");
+        if (ctx->xr_err_pin == nullptr) {
+            KH_HIP(hipHostMalloc(&ctx->xr_err_pin, sizeof(int), hipHostMallocMapped));
+            *ctx->xr_err_pin = 0;
+        }
+    }
+    A->xh_on = on ? 1 : 0;
+    return 0;
+}
 
 int kh_xr_export(kh_ctx ctx, unsigned char handle[64]) {
     KH_ARG(ctx && handle, "kh_xr_export: NULL");

@@ -62,4 +62,48 @@ __device__ __forceinline__ double xr_take_all(const unsigned long long* box, int
     return total;
 }
 
+// ---- xh: the halo of a block-row shard through the same kind of granules (kernels.h: k_spmv_dia<..., XH>) ----
+struct XhArgs {
+    unsigned long long* mine;      // my ghost granules [2 parities][my_ng][lo, hi]
+    unsigned long long* prev;      // the previous rank's (my first nsend_prev rows go to [prev_off + i])
+    unsigned long long* next;      // the next rank's (my last nsend_next rows go to [i])
+    long long my_ng, prev_ng, next_ng, prev_off;
+    int nsend_prev, nsend_next;
+    unsigned epoch;
+    long long timeout_ticks;
+    int* err;                      // mapped pinned host word (the xr transport's)
+};
+
+__device__ __forceinline__ void xh_put(unsigned long long* box, long long ng, long long idx, unsigned epoch, double x) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const unsigned long long tag = (unsigned long long)epoch << 32;
+    unsigned long long* e = box + ((size_t)(epoch & 1u) * (size_t)ng + (size_t)idx) * 2;
+    __hip_atomic_store(e, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(e + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ghost entry idx of this exchange: polled until both granules carry the epoch (a neighbour that never pushes: NaN and the
+// error word after the timeout)
+__device__ __forceinline__ double xh_take(const XhArgs& a, long long idx) {
+    const unsigned long long* e = a.mine + ((size_t)(a.epoch & 1u) * (size_t)a.my_ng + (size_t)idx) * 2;
+    unsigned long long x0, x1;
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (true) {
+        x0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        x1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(x0 >> 32) == a.epoch && (unsigned)(x1 >> 32) == a.epoch) break;
+        if ((++spins & 255u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now;
+            if (now - t0 > a.timeout_ticks) {
+                __hip_atomic_store(a.err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return __longlong_as_double(0x7ff8000000000000ll);
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
+}
+
 }  // namespace kh

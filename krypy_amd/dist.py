@@ -313,6 +313,7 @@ class ShardedCSROperator(utils.LinearOperator):
         self._dmats = {}
         dt = numpy.dtype(complex if numpy.dtype(A_local.dtype).kind == "c" else float)
         self._dmat = self._image(dt)
+        self.halo_in_launch = False if dt.kind == "c" else self._xh_setup(self._dmat, table)
         super(ShardedCSROperator, self).__init__((nloc, nloc), dt, self._dot_host)
 
     def _image(self, dt):
@@ -323,6 +324,47 @@ class ShardedCSROperator(utils.LinearOperator):
             self._ctx.set_halo(dm, *self.halo)
             self._dmats[kind] = dm
         return dm
+
+    def _xh_setup(self, dm, table):
+        """The halo of this operator inside its SpMV's own launch (``kh_mat_xh_*``: IPC-mapped ghost granules, no RCCL kernel) -
+        on EVERY rank or on none: each rank exports its granules, the 64-byte handles are gathered through the context's own
+        cross-rank sums (one byte per double: exact), every rank maps its two neighbours', and only when all report success is
+        it switched on.  Needs the xr transport (the sums) and a banded shard on every rank (the banded kernel carries it);
+        ``KRYPY_AMD_XH=0`` keeps the RCCL exchange.  Returns True when on."""
+        ctx = self._ctx
+        nr, r = ctx.nranks, ctx.rank
+        if not (hasattr(ctx, "xh_export") and hasattr(ctx, "get") and nr > 1 and ctx.get("xr") == 1
+                and os.environ.get("KRYPY_AMD_XH", "1") != "0"):
+            return False
+        ok, handle = 1.0, b"\0" * 64
+        try:
+            if dm.diagonals > 0:
+                handle = ctx.xh_export(dm)
+            else:
+                ok = 0.0
+        except _hip.BackendError:
+            ok = 0.0
+        tab = numpy.zeros(65 * nr)
+        tab[65 * r: 65 * r + 64] = numpy.frombuffer(handle, dtype=numpy.uint8)
+        tab[65 * r + 64] = ok
+        tab = ctx.allreduce_host(tab)
+        if tab[64::65].min() < 1.0:
+            return False
+
+        def hbytes(q):
+            return bytes(bytearray(int(v) for v in tab[65 * q: 65 * q + 64]))
+
+        ng = [int(table[3 * q] + table[3 * q + 1]) for q in range(nr)]
+        ok = 1.0
+        try:
+            ctx.xh_attach(dm, hbytes(r - 1) if r > 0 else None, ng[r - 1] if r > 0 else 0, int(table[3 * (r - 1)]) if r > 0 else 0,
+                          hbytes(r + 1) if r + 1 < nr else None, ng[r + 1] if r + 1 < nr else 0)
+        except _hip.BackendError:
+            ok = 0.0
+        if ctx.allreduce_host(numpy.array([1.0 - ok]))[0] > 0.0:
+            return False
+        ctx.xh_enable(dm, True)
+        return True
 
     def _device_matrix(self, ctx=None, dtype=None):
         if dtype is not None and numpy.dtype(dtype).kind == "c":

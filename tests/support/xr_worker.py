@@ -67,6 +67,21 @@ def main():
         res["gmres_%s_x" % ortho] = s.xk[:, 0].copy()
     c = linsys.Cg(linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True), tol=1e-9, maxiter=500)
     res["cg_resnorms"], res["cg_x"] = np.array(c.resnorms), c.xk[:, 0].copy()
+    # 2b. a COUPLED system: one 2-D Laplacian in two slabs - every operator application exchanges a halo, and with no RCCL
+    # communicator that halo can only travel inside the banded SpMV's own launch (kh_mat_xh_*: the neighbour's ghost granules)
+    from oracle import krylov_ref as ref
+    nxc = 120
+    Ac = ref.laplace2d(nxc, 96)
+    bc = np.random.default_rng(77).standard_normal(Ac.shape[0])
+    cuts = kdist.slab_cuts(Ac.shape[0], world, align=nxc)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    op = kdist.ShardedCSROperator(Ac[r0:r1], r0, Ac.shape[0], ctx)
+    assert op.halo_in_launch, "the halo did not go into the launch"
+    for ortho in ("mgs", "cgs"):
+        sc = linsys.RestartedGmres(linsys.LinearSystem(op, bc[r0:r1]), maxiter=40, max_restarts=40, tol=1e-9, ortho=ortho)
+        res["coupled_%s_resnorms" % ortho] = np.array(sc.resnorms)
+        res["coupled_%s_x" % ortho] = sc.xk[:, 0].copy()
+    res["n_halo_xh"], res["n_halo_exchange"] = ctx.get("n_halo_xh"), ctx.get("n_halo_exchange")
     res["n_xr"], res["n_xr_fused"], res["panels_checked"] = ctx.get("n_xr"), ctx.get("n_xr_fused"), checked
     res["n_chain_blk2"] = ctx.get("n_chain_blk2")
     np.savez(os.path.join(out, "rank%d.npz" % rank), **res)

@@ -103,6 +103,48 @@ def test_periodic_slab_exchanges_its_halo_with_itself(loop_ctx, kind):
     ctx.set("spmv_split", 1)
 
 
+@pytest.mark.parametrize("kind", ["lap2d", "lap3d", "nonsym"])
+def test_halo_inside_the_spmv_launch(loop_ctx, kind):
+    """xh (csrc/xr_dev.h, kernels.h: k_spmv_dia<..., XH>): the banded SpMV of a shard stores its boundary rows into the
+    neighbours' IPC-mapped ghost granules and polls its own INSIDE its one launch - no ncclSend / ncclRecv kernel, no second
+    stream, no split.  Here the rank is its own neighbour (the periodic slab of the tests above): product, fused residual
+    and fused dot bit for bit the RCCL exchange's / SciPy's on the tripled operator, a hundred applications back to back
+    (epochs, both parities), and the counters say which path ran."""
+    from krypy_amd import dist
+
+    ctx = loop_ctx
+    rng = np.random.default_rng(3)
+    Abig, n = _stencil(kind, rng)
+    A_local, nrp, nrn = dist.localize_columns(Abig[n:2 * n], n, 3 * n)
+    Ad = ctx.csr(A_local, n_cols=A_local.shape[1])
+    ctx.set_halo(Ad, nrn, nrp, nrp, nrn)
+    if Ad.diagonals == 0:
+        pytest.skip("no diagonal-major copy of the shard (KRYPY_AMD_SPMV_DIA=0): the banded kernel carries the in-launch halo")
+    handle = ctx.xh_export(Ad)
+    assert len(handle) == 64
+    ctx.xh_attach(Ad, None, 0, 0, None, 0, self_loop=True)
+    ctx.xh_enable(Ad, True)
+    b = rng.standard_normal(n)
+    R, B, Y = ctx.alloc(n, 1), ctx.upload(b), ctx.alloc(n, 1)
+    e0, x0 = ctx.get("n_halo_exchange"), ctx.get("n_halo_xh")
+    for rep in range(100):
+        x = rng.standard_normal(n)
+        want = Abig[n:2 * n].dot(np.tile(x, 3))
+        X = ctx.upload(x)
+        ctx.apply(Ad, X, 0, Y, 0, 1)
+        assert np.array_equal(Y.download()[:, 0], want), (kind, rep)
+        if rep % 10 == 0:
+            nrm = ctx.residual(Ad, B, 0, X, 0, R, 0)
+            assert np.array_equal(R.download()[:, 0], b - want), (kind, rep)
+            assert abs(nrm - np.linalg.norm(b - want)) <= 1e-13 * nrm
+    expect_kernel(ctx.get("n_halo_exchange") == e0 and ctx.get("n_halo_xh") - x0 == 110,
+                  "no RCCL exchange, 110 in-launch ones: %r" % ((ctx.get("n_halo_exchange") - e0, ctx.get("n_halo_xh") - x0),))
+    ctx.xh_enable(Ad, False)                    # ... and the RCCL exchange again
+    ctx.apply(Ad, X, 0, Y, 0, 1)
+    assert np.array_equal(Y.download()[:, 0], want)
+    expect_kernel(ctx.get("n_halo_exchange") == e0 + 1, "back on the RCCL exchange")
+
+
 @pytest.mark.parametrize("kind", ["lap2d", "random"])
 def test_sharded_panel_apply_exchanges_once_and_streams_the_matrix_once(loop_ctx, kind):
     """kh_apply of a shard to a block of d vectors (A U of the deflation set-up, deflation.py:47; Ritz residuals,

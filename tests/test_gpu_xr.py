@@ -20,7 +20,10 @@ import scipy.sparse as sp
 from oracle import krylov_ref as ref
 from tests.support.kernel_expect import expect_kernel
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("KRYPY_AMD_XR", "1") == "0",
+                                 reason="KRYPY_AMD_XR=0: the transport these tests are about is switched off (the RCCL path is what every "
+                                        "other multi-rank test of the suite runs)")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -145,6 +148,22 @@ def test_two_processes_sum_through_ipc_mailboxes(hip, placement):
     assert np.max(np.abs(r[0]["cg_resnorms"][:40] - want[:40]) / want[:40]) < 1e-9
     x = np.concatenate([r[0]["cg_x"], r[1]["cg_x"]])
     assert np.linalg.norm(x - c.xk[:, 0]) < 1e-7 * np.linalg.norm(c.xk)
+    # the coupled Laplacian in two slabs: halos inside the SpMV launches, sums through the mailboxes, no RCCL anywhere
+    Ac = ref.laplace2d(120, 96)
+    bc = np.random.default_rng(77).standard_normal(Ac.shape[0])
+    for ortho in ("mgs", "cgs"):
+        s = linsys.RestartedGmres(linsys.LinearSystem(Ac, bc), maxiter=40, max_restarts=40, tol=1e-9, ortho=ortho)
+        want = np.array(s.resnorms)
+        for k in range(2):
+            got = r[k]["coupled_%s_resnorms" % ortho]
+            assert len(got) == len(want), (ortho, k, len(got), len(want))
+            assert np.max(np.abs(got[:41] - want[:41]) / want[:41]) < 1e-10, (ortho, k)
+        assert np.array_equal(r[0]["coupled_%s_resnorms" % ortho], r[1]["coupled_%s_resnorms" % ortho])
+        x = np.concatenate([r[0]["coupled_%s_x" % ortho], r[1]["coupled_%s_x" % ortho]])
+        assert np.linalg.norm(Ac.dot(x) - bc) <= 1.0001e-9 * np.linalg.norm(bc)
+        assert np.linalg.norm(x - s.xk[:, 0]) < 1e-7 * np.linalg.norm(s.xk)
+    expect_kernel(int(r[0]["n_halo_xh"]) > 100 and int(r[0]["n_halo_exchange"]) == 0 and int(r[1]["n_halo_exchange"]) == 0,
+                  "every halo travelled inside an SpMV launch: %r" % ((int(r[0]["n_halo_xh"]), int(r[0]["n_halo_exchange"])),))
     assert int(r[0]["panels_checked"]) == int(r[1]["panels_checked"]) == 420
     expect_kernel(int(r[0]["n_xr"]) == int(r[1]["n_xr"]) and int(r[0]["n_xr"]) > 1000, "both ranks issued the same exchanges: %r" % ((int(r[0]["n_xr"]), int(r[1]["n_xr"])),))
     expect_kernel(int(r[0]["n_xr_fused"]) > 100, "the panel form took the fused reduce-and-exchange kernel")
