@@ -445,6 +445,8 @@ def _run():
                 if dist.allreduce_min(probe_ok) < 1.0:
                     # some rank's candidate failed: the mailboxes' epochs may no longer agree - off with them, everywhere
                     ctx.set("chain_blk2", 0)
+                    if hasattr(A_for_ls, "halo_through_rccl"):
+                        A_for_ls.halo_through_rccl()
                     if xr_on:
                         ctx.set("xr", 0)
                         ctx.xr_detach()

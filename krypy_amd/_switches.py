@@ -76,6 +76,10 @@ SWITCHES = [
     ("KRYPY_AMD_XR", "1", "kernel-path", "0",
      "0: the sums across the ranks of a node stay `ncclAllReduce` calls instead of the IPC-mailbox kernels of `csrc/xr.hip` "
      "(`krypy_amd.dist.enable_xr`: switched on only when EVERY rank could map every peer's mailbox and a self-test passed)"),
+    ("KRYPY_AMD_XH", "1", "kernel-path", "0",
+     "0: the halo of a banded shard stays a grouped `ncclSend` / `ncclRecv` on the communication stream around split SpMV launches "
+     "instead of travelling INSIDE the banded kernel's one launch through IPC-mapped ghost granules (`kh_mat_xh_*`; needs the xr "
+     "transport; `ShardedCSROperator` switches it on only when every rank could map its neighbours' granules)"),
     ("KRYPY_AMD_XR_TIMEOUT_S", "60", "tuning", None,
      "seconds a cross-rank sum waits for a peer's contribution before the next host synchronisation reports `KH_ERR_COMM`"),
     ("KRYPY_AMD_XR_SELFTEST_S", "8", "tuning", None, "the same timeout during `enable_xr`'s self-test of a few sums"),

@@ -1412,6 +1412,8 @@ int kh_ctx_destroy(kh_ctx ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     kh_comm_destroy(ctx);
+    if (ctx->xr_err_pin != nullptr) (void)hipHostFree(ctx->xr_err_pin);
+    ctx->xr_err_pin = nullptr;
     for (int s = 0; s < KH_NSLOT; ++s) {
         if (ctx->hslot_dev[s]) (void)hipFree(ctx->hslot_dev[s]);
         if (ctx->hslot_pin[s]) (void)hipHostFree(ctx->hslot_pin[s]);

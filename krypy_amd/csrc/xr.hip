@@ -158,8 +158,7 @@ void xr_free(kh_ctx ctx) {
     }
     if (ctx->xr_box != nullptr) (void)hipFree(ctx->xr_box);
     ctx->xr_box = nullptr;
-    if (ctx->xr_err_pin != nullptr) (void)hipHostFree(ctx->xr_err_pin);
-    ctx->xr_err_pin = nullptr;
+    // (the error word stays: an operator whose halo travels inside its launch - xh - reports through it too; kh_ctx_destroy frees it)
     if (ctx->xr_own_comm) {
         ctx->rank = 0;
         ctx->nranks = 1;

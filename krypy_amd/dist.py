@@ -366,6 +366,13 @@ class ShardedCSROperator(utils.LinearOperator):
         ctx.xh_enable(dm, True)
         return True
 
+    def halo_through_rccl(self):
+        """Back to the grouped ``ncclSend`` / ``ncclRecv`` exchange (every rank must do the same: a launcher whose self-test
+        of the mailboxes failed calls this on all of them)."""
+        if self.halo_in_launch:
+            self._ctx.xh_enable(self._dmat, False)
+            self.halo_in_launch = False
+
     def _device_matrix(self, ctx=None, dtype=None):
         if dtype is not None and numpy.dtype(dtype).kind == "c":
             return self._image(numpy.dtype(complex))
