@@ -364,6 +364,28 @@ class ShardedCSROperator(utils.LinearOperator):
         if ctx.allreduce_host(numpy.array([1.0 - ok]))[0] > 0.0:
             return False
         ctx.xh_enable(dm, True)
+        # one application with a known answer before anything depends on it, under a short timeout: x = 1 on every rank, so
+        # every ghost entry is 1 and the product is this slab's row sums (the banded kernel adds a row in SciPy's order: the same
+        # bits).  A neighbour's stores that do not become visible here show up as a timeout or a wrong boundary row - then EVERY
+        # rank goes back to the RCCL exchange, together.
+        good = 1.0
+        try:
+            ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_SELFTEST_S", "8")) * 1e3))
+            nloc = self._A_local.shape[0]
+            Xd = ctx.upload(numpy.ones((nloc, 1)))
+            Yd = ctx.alloc(nloc, 1)
+            ctx.apply(dm, Xd, 0, Yd, 0, 1)
+            got = Yd.download()[:, 0]
+            want = self._A_local.dot(numpy.ones(self._A_local.shape[1]))
+            if not numpy.allclose(got, want, rtol=1e-12, atol=1e-12 * max(1.0, float(numpy.abs(want).max()))):
+                good = 0.0
+        except _hip.BackendError:
+            good = 0.0
+        finally:
+            ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_TIMEOUT_S", "60")) * 1e3))
+        if ctx.allreduce_host(numpy.array([1.0 - good]))[0] > 0.0:
+            ctx.xh_enable(dm, False)
+            return False
         return True
 
     def halo_through_rccl(self):
