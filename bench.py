@@ -137,6 +137,15 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing: take the multi-GPU code path (gloo init, RCCL communicator, "
                          "ShardedCSROperator, all-reduced reductions) even with one rank")
+    ap.add_argument("--transport", default="rccl", choices=("rccl", "xr"),
+                    help="N > 1 ranks.  rccl (default): an RCCL communicator, with the sums across the ranks (and a banded shard's "
+                         "halo) moved to the IPC mailboxes of csrc/xr.hip when every rank can use them.  xr: NO RCCL communicator "
+                         "at all - sums, halos and the in-launch exchange of the blocked kernel through the mailboxes alone (a run "
+                         "that cannot do that fails)")
+    ap.add_argument("--share-devices", action="store_true",
+                    help="testing: --gpus N ranks on FEWER than N devices (rank r on device r mod the visible ones); only with "
+                         "--transport xr (RCCL refuses two ranks on one device).  The line then reports n_gpus = the devices "
+                         "really used and config.ranks = N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the kernel micro-benchmarks (profiling runs that want the solver's kernels only)")
@@ -268,7 +277,8 @@ def _launch(args):
     import subprocess
     n = args.gpus
     have = _visible_devices()
-    if have < n:
+    share = args.share_devices and args.transport == "xr" and have >= 1
+    if have < n and not share:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU%s visible: refusing to run (a smaller run would be "
                          "reported as n_gpus=%d)\n" % (n, have, "" if have == 1 else "s", n))
         return 2
@@ -277,7 +287,8 @@ def _launch(args):
     for r in range(n):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KRYPY_AMD_DEVICE=str(r))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), KRYPY_AMD_DEVICE=str(r % have if share else r),
+                   KRYPY_AMD_BENCH_DEVICES=str(min(n, have)))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
@@ -370,11 +381,14 @@ def _run():
         ortho = "cgs" if sharded else "mgs"
     if sharded:
         from krypy_amd import dist as kdist
-        uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
-        ctx.comm_init(rank, world, uid)
+        if args.transport == "rccl":
+            uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
+            ctx.comm_init(rank, world, uid)
         # the sums across the ranks through IPC-mapped mailboxes (csrc/xr.hip) when every rank can map every peer's and a
         # self-test of a few sums passes on all of them - otherwise ncclAllReduce, on every rank alike (KRYPY_AMD_XR=0: RCCL)
         xr_on = kdist.enable_xr(ctx, dist)
+        if args.transport == "xr" and not xr_on:
+            raise SystemExit("bench.py --transport xr: the mailboxes did not come up on every rank, and there is no RCCL communicator")
         # contiguous slabs of grid rows (y index): every shard holds whole x-lines
         cuts = [(ny * p) // world for p in range(world + 1)]
         Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
@@ -442,7 +456,11 @@ def _run():
                 probe_ok = 0.0
                 auto_report[cand] = {"error": str(exc)[:300]}
             if cand == "mgs":
-                if dist.allreduce_min(probe_ok) < 1.0:
+                all_ok = dist.allreduce_min(probe_ok) >= 1.0
+                if not all_ok and args.transport == "xr":
+                    raise SystemExit("bench.py --transport xr: the reference-order candidate failed on some rank and there is no RCCL "
+                                     "communicator to go back to: %r" % (auto_report,))
+                if not all_ok:
                     # some rank's candidate failed: the mailboxes' epochs may no longer agree - off with them, everywhere
                     ctx.set("chain_blk2", 0)
                     if hasattr(A_for_ls, "halo_through_rccl"):
@@ -572,14 +590,15 @@ def _run():
 
     out = {
         "metric": "GMRES iterations/sec + SpMV HBM GB/s, n=10^7 5-pt Laplacian fp64",
-        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+        "value": its, "unit": "iterations/s", "n_gpus": int(os.environ.get("KRYPY_AMD_BENCH_DEVICES", world)), "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "GMRES(%d) restart cycles, 2-D 5-pt Laplacian %dx%d CSR (N=%d, nnz=%d), "
                                "b=rng(0) normal, x0=0, tol=1e-8 (BASELINE.json configs[1])"
                                % (m, nx, ny, N, nnz_global),
                    "n": N, "ortho": ortho, "restart": m, "iterations_timed": n_iters,
-                   "parallelism": "1 GPU" if not sharded else "row-sharded x%d (RCCL)" % world,
+                   "parallelism": "1 GPU" if not sharded else "row-sharded x%d (%s)" % (world, "RCCL" if args.transport == "rccl" else "mailboxes only"),
+                   "ranks": world,
                    # sums across the ranks: "xr" = one kernel of system-scope stores into the peers' IPC-mapped mailboxes
                    # per panel (csrc/xr.hip), "rccl" = ncclAllReduce; the halo exchange is RCCL point-to-point either way
                    "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),

@@ -94,6 +94,9 @@ SWITCHES = [
     ("KRYPY_AMD_BENCH_SHARDED_EXTRAS", "0", "bench", None,
      "1: a `bench.py` run on N > 1 ranks also times the other Gram-Schmidt order (`mgs` beside the `cgs` default) and reports its "
      "cross-rank sums per iteration and orthogonality, outside the timed region (on one rank in `--force-sharded` mode it always does)"),
+    ("KRYPY_AMD_BENCH_DEVICES", "unset", "bench", None,
+     "set by `bench.py`'s own launcher for the rank processes it starts: the number of distinct devices the run uses (`n_gpus` of the line; "
+     "differs from the number of ranks only in the `--share-devices` test mode)"),
     ("KRYPY_AMD_BENCH_ORTHO", "auto", "bench", None, "`bench.py --ortho` default (`auto` = `mgs` on 1 GPU, `cgs` sharded)"),
     ("KRYPY_AMD_TEST_RLIMIT_GB", "96", "test", None,
      "cap (GB) on the host memory of the GPU test session (`RLIMIT_DATA`, set once the HIP context exists): a test asking for absurd "

@@ -68,3 +68,33 @@ def test_bench_two_real_ranks_match_one(hip):
     one_mgs = json.loads(lines[0])
     r1, r2 = one_mgs["config"]["final_relres"], two_mgs["config"]["final_relres"]
     assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
+
+
+def test_bench_two_ranks_share_the_one_gpu_through_the_mailboxes(hip):
+    """The whole N > 1 path of bench.py on a box with ONE GPU: `python bench.py --gpus 2 --share-devices --transport xr` starts
+    two rank processes by itself, both on device 0, with NO RCCL communicator (RCCL refuses two ranks on one device): the sums
+    across the ranks through the IPC mailboxes (csrc/xr.hip), the halo of the two slabs inside the banded SpMV's own launch
+    (xh), the reference-order candidate of `--ortho auto` through the blocked kernel with the exchange inside its launch
+    (chain_blk2.h).  ONE line comes back; it says two ranks on one device, which transports ran, and the residual after the
+    same iterations is the one-rank run's (the sharded operator: /root/reference/krypy/utils.py:1593-1594, the summed inner
+    products: utils.py:182-183)."""
+    common = ["--steps", "2", "--warmup", "1", "--nx", "400", "--ny", "300", "--restart", "40", "--no-cpu-baseline",
+              "--no-roofline", "--other-modes", "none"]
+    res = {}
+    for ortho in ("cgs", "mgs", "auto"):
+        rc, lines, err = _bench(["--gpus", "2", "--share-devices", "--transport", "xr", "--ortho", ortho] + common)
+        assert rc == 0, err[-3000:]
+        assert len(lines) == 1, lines
+        two = json.loads(lines[0])
+        c = two["config"]
+        assert two["n_gpus"] == 1 and c["ranks"] == 2 and c["parallelism"] == "row-sharded x2 (mailboxes only)"
+        assert c["cross_rank_sums"] == "xr" and c["halo"] == "in-launch" and c["iterations_timed"] == 80
+        res[ortho] = two
+    assert res["auto"]["config"]["ortho"] in ("cgs", "mgs") and set(res["auto"]["config"]["ortho_auto"]) >= {"cgs", "mgs", "chosen"}
+    assert res["auto"]["config"]["ortho_auto"]["mgs"]["sums_inside_the_launch"] is True
+    for ortho in ("cgs", "mgs"):
+        rc, lines, err = _bench(["--gpus", "1", "--ortho", ortho] + common)
+        assert rc == 0 and len(lines) == 1, err[-3000:]
+        one = json.loads(lines[0])
+        r1, r2 = one["config"]["final_relres"], res[ortho]["config"]["final_relres"]
+        assert abs(r1 - r2) <= 1e-9 * r1, (ortho, r1, r2)
