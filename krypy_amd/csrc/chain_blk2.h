@@ -30,6 +30,10 @@
 
 namespace kh {
 
+#ifndef BLK2_REQ_SLEEP
+#define BLK2_REQ_SLEEP 8          // s_sleep units (64 clocks) between barrier A and the other waves' requests of the next block
+#endif
+
 // the cross-rank stage of a sum of NV values: lanes 0 .. NV-1 of the calling wave hold the rank's totals
 template <int NV>
 __device__ __forceinline__ double blk2_cross_rank(const XrDev& xr, unsigned xepoch, double t, int* err) {
@@ -123,6 +127,16 @@ __device__ __forceinline__ double blk2_collect(unsigned epoch, unsigned xepoch, 
     return t;
 }
 
+// The same as a CALL: at 5 rows per lane on one GPU the working waves' code keeps more of the ring in registers when wave 0's
+// gathering is not inlined into it (A / B on one box, GMRES(100) at 1.25 M rows: 6,339-6,469 -> 6,617-6,631 it/s; with the
+// cross-rank stage or 6 rows per lane the call's save area costs more than it gives: 5,371-5,404 -> 4,943-5,004 and
+// 4,987-5,008 -> 4,617-4,756 - those stay inlined)
+template <int NV, bool XR>
+__device__ __noinline__ double blk2_collect_call(unsigned epoch, unsigned xepoch, const BlkBufs& bf, const XrDev& xr, int G, int bid, int* err,
+                                                 BlkSm& sm, unsigned xcc, bool leader, int nv_all, double extra) {
+    return blk2_collect<NV, XR>(epoch, xepoch, bf, xr, G, bid, err, sm, xcc, leader, nv_all, extra);
+}
+
 // alpha_l = c_l - sum_{m<l} alpha_m G_{m,l} in the order of the reference's loop; tot = [c_0 .. c_{BC-1} | G_01, G_02, G_12, G_03 ...]
 template <int BC>
 __device__ __forceinline__ void blk2_alphas(const double* tot, int nvalid, double (&alpha)[BC]) {
@@ -180,12 +194,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
             blk2_publish<BC>(epoch, bf, rid, sm);
         } else {
             ch_lds_barrier();                               // A
-            if constexpr (BLK_REQ_SLEEP > 0) __builtin_amdgcn_s_sleep(BLK_REQ_SLEEP);      // the publication goes out first
+            if constexpr (BLK2_REQ_SLEEP > 0) __builtin_amdgcn_s_sleep(BLK2_REQ_SLEEP);      // the publication goes out first
         }
     };
     auto sum_end = [&](const int ib, const double gval) __attribute__((always_inline)) {
         if (wave0) {
-            (void)blk2_collect<BC, XR>(epoch, xepoch, bf, xr, G, bid, a.err, sm, role.xcc, role.leader, BC + NG, gval);
+            if constexpr (R2 == 5 && !XR)
+                (void)blk2_collect_call<BC, XR>(epoch, xepoch, bf, xr, G, bid, a.err, sm, role.xcc, role.leader, BC + NG, gval);
+            else
+                (void)blk2_collect<BC, XR>(epoch, xepoch, bf, xr, G, bid, a.err, sm, role.xcc, role.leader, BC + NG, gval);
             double alpha[BC];
             blk2_alphas<BC>(sm.tot, total - ib * BC, alpha);
 #pragma unroll
