@@ -499,3 +499,101 @@ def test_blocked_one_ahead_recurrence_is_the_reference_loop():
             aprev = a_blk
         assert np.max(np.abs(alpha - ref_alpha)) < 1e-12 * np.max(np.abs(ref_alpha)), k
         assert np.linalg.norm(w_upd - w) < 1e-12 * np.linalg.norm(w0), k
+
+
+def test_enable_xr_is_all_or_nothing():
+    """`dist.enable_xr`: whether the sums across the ranks run as mailbox kernels or as ncclAllReduce changes what a peer has to
+    take part in, so it must come out the same on EVERY rank - whatever fails on whichever rank (the export, the attach, the
+    self-test of a few sums).  Three ranks as threads, a rendezvous in memory, contexts that fail where they are told to."""
+    import threading
+
+    import numpy as np
+    from krypy_amd import _hip, dist
+
+    world = 3
+
+    class Rdv(object):
+        lock, cond = threading.Lock(), None
+        slots, gen = {}, [0]
+
+        def __init__(self, rank):
+            self.rank, self.world = rank, world
+
+        def _exchange(self, value):
+            cls = Rdv
+            with cls.cond:
+                g = cls.gen[0]
+                cls.slots.setdefault(g, {})[self.rank] = value
+                if len(cls.slots[g]) == world:
+                    cls.gen[0] += 1
+                    cls.cond.notify_all()
+                else:
+                    while cls.gen[0] == g:
+                        cls.cond.wait(timeout=30)
+                return [cls.slots[g][r] for r in range(world)]
+
+        def allgather_bytes(self, data):
+            return self._exchange(bytes(data))
+
+        def allreduce_min(self, x):
+            return min(self._exchange(float(x)))
+
+    Rdv.cond = threading.Condition(Rdv.lock)
+
+    class Ctx(object):
+        def __init__(self, rank, fail):
+            self.rank, self.nranks, self.fail, self.on, self.detached = 0, 1, fail, False, False
+            self.kv = {}
+
+        def xr_export(self):
+            if self.fail == "export":
+                raise _hip.BackendError("no fine-grained memory")
+            return bytes([self._r]) * 64
+
+        def xr_attach(self, rank, nranks, handles):
+            assert len(handles) == 64 * nranks and all(handles[64 * q] in (q, 0) for q in range(nranks))
+            if self.fail == "attach":
+                raise _hip.BackendError("cannot map")
+
+        def xr_enable(self, rank, nranks):
+            self.on, self.rank, self.nranks = True, rank, nranks
+
+        def xr_detach(self):
+            self.detached = True
+
+        def set(self, key, value):
+            self.kv[key] = value
+            if key == "xr" and value == 0:
+                self.on = False
+
+        def allreduce_host(self, vals):
+            # the self-test's sums: every rank can work the answer out itself (rng streams by rank) - unless told to fail
+            if self.fail == "selftest":
+                raise _hip.BackendError("rank %d's contribution did not arrive" % self.rank)
+            count = len(vals)
+            t = self._t
+            self._t += 1
+            out = np.random.default_rng(1000 * t + 0).standard_normal(count)
+            for r in range(1, world):
+                out = out + np.random.default_rng(1000 * t + r).standard_normal(count)
+            return out
+
+    for failing_rank, fail in ((None, None), (1, "export"), (2, "attach"), (0, "selftest")):
+        ctxs, res = [], [None] * world
+
+        def work(r):
+            c = Ctx(r, fail if r == failing_rank else None)
+            c._r, c._t = r, 0
+            ctxs.append((r, c))
+            res[r] = dist.enable_xr(c, Rdv(r))
+
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in ths]
+        [t.join(timeout=60) for t in ths]
+        assert all(x is not None for x in res), (fail, res)
+        assert len(set(res)) == 1, (fail, res)                     # every rank the same answer
+        assert res[0] is (fail is None), (fail, res)
+        for r, c in ctxs:
+            assert c.on == (fail is None), (fail, r)
+            if fail is not None and c.on is False and fail != "export":
+                assert c.detached or r == failing_rank or fail == "attach", (fail, r)
