@@ -52,28 +52,29 @@ def main(src, dst):
         lines.append("| `%s` | %d | %.2f | %.2f | %.2f | %s | %s | %s |" % (
             short(name), calls, tot / 1e3, avg, pct, v[0], v[1], v[2]))
     lines.append("")
-    # bench.py's identical micro-launches (kh_bench_kernel), selected by what identifies them - NOT by "the last N launches"
-    # (kh_bench_arnoldi runs behind them since round 4, so the last chain launches of a run are the solver's
-    # steps k = 80 .. 99).  The chain micro-launch is the instantiation WITHOUT the operator in its prologue (last template
-    # argument FND = 0; every other chain launch of a `--other-modes none` run is the solver's FND = 5 / 7 one) and always has
-    # 64 links; the panel kernels' micro-launches (16 columns) are the last launches of a `--ortho cgs` run, which has no
-    # kh_bench_arnoldi leg.
-    MICRO_CHAIN = "name like '%k_mgs_chain%' and name like '%, 0>%'"
+    # bench.py's identical micro-launches (kh_bench_kernel) lie between two launches of `k_bench_marker` (an empty kernel the
+    # harness issues in front of and behind its loop): selected by THAT - not by "the last N launches" (VERDICT r04:
+    # kh_bench_arnoldi runs behind them since round 4) and not by a template argument (the orthogonality runs of bench.py
+    # launch the same FND = 0 instantiation with other link counts)
     SOLVER_CHAIN = "name like '%k_mgs_chain%' and name not like '%, 0>%'"
+
+    def between_markers(db, table, value, pat):
+        marks = [r[0] for r in q(db, "select start from %s where name like '%%k_bench_marker%%' order by start" % table)]
+        out = []
+        for lo, hi in zip(marks[0::2], marks[1::2]):
+            out += [r[0] for r in q(db, "select %s from %s where name like '%s' and start > %d and start < %d" % (value, table, pat, lo, hi))]
+        return out
+
     try:
-        d = q(tdb, "select end - start from kernels where " + MICRO_CHAIN)
+        d = between_markers(tdb, "kernels", "end - start", "%k_mgs_chain%")
         if d:
-            lines.append("Kernel-trace average of the %d launches of the chain kernel WITHOUT the operator in its prologue "
-                         "(template argument FND = 0: bench.py's 64-link micro-launches, warm-up included): **%.1f us**."
-                         % (len(d), sum(x[0] for x in d) / len(d) / 1e3))
-        nsolver = q(tdb, "select count(*) from kernels where " + SOLVER_CHAIN)[0][0]
-        if not nsolver:          # (a --ortho cgs run: no kh_bench_arnoldi leg behind the micro-launches)
-            for pat, label in (("%k_cgs_dots%", "k_cgs_dots (16 columns)"), ("%k_cgs_update%", "k_cgs_update (16 columns)")):
-                d = q(tdb, "select end - start from kernels where name like '%s' order by start desc limit 20" % pat)
-                if d:
-                    lines.append("Kernel-trace average of the last %d `%s` launches (bench.py's micro-launches; no solver "
-                                 "launch of this kernel follows them in a panel-mode run): **%.1f us**."
-                                 % (len(d), label, sum(x[0] for x in d) / len(d) / 1e3))
+            lines.append("Kernel-trace average of the %d chain launches between the harness' markers (bench.py's 64-link "
+                         "micro-launches, warm-up included): **%.1f us**." % (len(d), sum(d) / len(d) / 1e3))
+        for pat, label in (("%k_cgs_dots%", "k_cgs_dots (16 columns)"), ("%k_cgs_update%", "k_cgs_update (16 columns)")):
+            d = between_markers(tdb, "kernels", "end - start", pat)
+            if d:
+                lines.append("Kernel-trace average of the %d `%s` launches between the harness' markers (bench.py's "
+                             "micro-launches): **%.1f us**." % (len(d), label, sum(d) / len(d) / 1e3))
         d = q(tdb, "select end - start from kernels where " + SOLVER_CHAIN)
         if d:
             lines.append("Kernel-trace average of all %d launches of the fused-operator chain kernel (the solver's Arnoldi "
@@ -82,6 +83,14 @@ def main(src, dst):
         lines.append("")
     except Exception as exc:  # pragma: no cover
         lines += ["(micro-launch durations unavailable: %r)" % exc, ""]
+    def _pmc_between(db, cname, pat):
+        marks = [r[0] for r in q(db, "select start from pmc_events where counter_name='%s' and name like '%%k_bench_marker%%' order by start" % cname)]
+        out = []
+        for lo, hi in zip(marks[0::2], marks[1::2]):
+            out += [r[0] for r in q(db, "select counter_value from pmc_events where counter_name='%s' and name like '%s' and start > %d "
+                                        "and start < %d" % (cname, pat, lo, hi))]
+        return out
+
     pm = {}
     for cname in ("FETCH_SIZE", "WRITE_SIZE"):
         db = os.path.join(src, "pmc_" + cname, "pmc_results.db")
@@ -110,29 +119,15 @@ def main(src, dst):
     try:
         fdb = os.path.join(src, "pmc_FETCH_SIZE", "pmc_results.db")
         wdb = os.path.join(src, "pmc_WRITE_SIZE", "pmc_results.db")
-        f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + MICRO_CHAIN)
-        w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and " + MICRO_CHAIN)
-        if f and w:
-            tj["k_mgs_chain_micro"] = {
-                "hbm_read_bytes_per_launch": 2 * sum(x[0] for x in f) / len(f) * 1024,
-                "hbm_write_bytes_per_launch": sum(x[0] for x in w) / len(w) * 1024, "launches_averaged": len(f),
-                "note": "all %d launches of the chain kernel without the operator in its prologue (FND = 0) = bench.py's "
-                        "64-link kh_bench_kernel launches; FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
-        solver_launches = q(fdb, "select count(*) from pmc_events where counter_name='FETCH_SIZE' and " + SOLVER_CHAIN)[0][0]
-        for key, pat in (("k_cgs_dots", "%k_cgs_dots%"), ("k_cgs_update", "%k_cgs_update%")):
-            if solver_launches:          # (an mgs run: its last panel-kernel launches are not micro-launches)
-                break
-            f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and name like '%s' "
-                       "order by start desc limit 40" % pat)
-            w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and name like '%s' "
-                       "order by start desc limit 40" % pat)
+        for key, pat, what in (("k_mgs_chain_micro", "%k_mgs_chain%", "chain launches"), ("k_cgs_dots", "%k_cgs_dots%", "k_cgs_dots launches"),
+                               ("k_cgs_update", "%k_cgs_update%", "k_cgs_update launches")):
+            f = [r for r in _pmc_between(fdb, "FETCH_SIZE", pat)]
+            w = [r for r in _pmc_between(wdb, "WRITE_SIZE", pat)]
             if f and w:
-                rd = 2 * sum(x[0] for x in f) / len(f) * 1024
-                wr = sum(x[0] for x in w) / len(w) * 1024
-                tj[key] = {"hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                tj[key] = {"hbm_read_bytes_per_launch": 2 * sum(f) / len(f) * 1024, "hbm_write_bytes_per_launch": sum(w) / len(w) * 1024,
                            "launches_averaged": len(f),
-                           "note": "last %d launches of a panel-mode run = bench.py's kh_bench_kernel launches; "
-                                   "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
+                           "note": "the %d %s between the harness' k_bench_marker launches = bench.py's kh_bench_kernel launches; "
+                                   "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % (len(f), what)}
         # the solver's own instantiation of the chain kernel (operator in the prologue: a template argument FND > 0),
         # every launch of the run - whole cycles k = 1 .. m-1 of the solver and of kh_bench_arnoldi alike
         f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + SOLVER_CHAIN)
