@@ -43,6 +43,10 @@ SWITCHES = [
      "0: vectors of 5 / 6 rows per lane (1.05 M ... 1.57 M rows) keep the per-column ring kernel on one GPU, and on N ranks with the xr "
      "transport on `ortho='mgs'` keeps the one-reduction form (two cross-rank sums per step, the local basis read twice) instead of the "
      "eight-wave blocked kernel with the cross-rank sums INSIDE the launch (`csrc/chain_blk2.h`: the basis read once, no all-reduce call)"),
+    ("KRYPY_AMD_BLK2_CW", "1", "kernel-path", "0",
+     "0: every wave of the eight-wave blocked kernel carries rows (512 lanes, up to 1.57 M rows) instead of wave 0 being a communication "
+     "wave without rows wherever that shape fits (448 lanes with rows, up to 1.33 M rows: no register spills, the total of a sum seen "
+     "without waiting for the wave's own rows)"),
     ("KRYPY_AMD_BLK_ONEX_MAXN", "70000", "tuning", None,
      "vectors longer than this run the blocked kernel spread over the chip instead of on one XCD"),
     ("KRYPY_AMD_BLK_NX", "8", "kernel-path", "0",

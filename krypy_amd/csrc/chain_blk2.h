@@ -7,9 +7,14 @@
 // order.  ONE grid-wide sum per block - and, on N ranks, one exchange between the ranks per block.
 //
 // What is different from k_mgs_chain_blk (chain_blk.h), and why it is a kernel of its own:
-//   * No ninth (communication) wave: nine waves leave 168 registers per lane, i.e. two blocks of 4 rows per lane and no
-//     more - 1,048,576 rows.  One of eight ranks holds 1.25 M rows of the benchmark problem (5 rows per lane x 245
-//     workgroups).  Eight waves have 256 registers: two blocks of up to 6 rows (216) + w (24).
+//   * No NINTH wave: nine waves leave 168 registers per lane, i.e. two blocks of 4 rows per lane and no more - 1,048,576
+//     rows - and one of eight ranks holds 1.25 M rows of the benchmark problem.  Eight waves have 256 registers: two blocks of
+//     up to 6 rows (216) + w (24).  Where the shape fits (CW: up to 1.33 M rows) wave 0 of the eight is the communication
+//     wave and owns NO rows (448 lanes with rows): the working waves' code then holds nothing of the gathering (239 registers,
+//     no scratch at 6 rows - 256 + 320 B of scratch when wave 0 works as well) and wave 0's polls return as soon as the total
+//     is there instead of behind its own rows of the next block.  A / B on one box (profiles/r05_blk2_cw.log): 1.25 M rows
+//     6,600 -> 6,990 it/s on one GPU, 5,380 -> 6,070 through the forced multi-rank path, 1.32 M rows 5,280 -> 6,740.
+//     Beyond that (up to 1.57 M rows) every wave carries rows.
 //   * No dots "one block ahead" against the un-updated w (no X entries of the table): the next block is REQUESTED
 //     behind the publication of the partial sums - its stream runs under the exchange - but its dots are taken after the
 //     update, as the reference takes them.  Wave 0 of every workgroup is the one that publishes, gathers and forms the
@@ -154,11 +159,15 @@ __device__ __forceinline__ void blk2_alphas(const double* tot, int nvalid, doubl
     }
 }
 
-template <int R2, bool MASKED, bool XR>
+// CW: wave 0 of every workgroup owns NO rows - it publishes, gathers and forms the coefficients, and a poll of a wave that has
+// requested nothing returns as soon as the total is there (vector-memory results return to a wave in order: with rows of its
+// own wave 0 sees the total only behind its rows of the next block).  The other seven waves carry the rows: 448 lanes.
+template <int R2, bool MASKED, bool XR, bool CW = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs bf, XrDev xr) {
     constexpr int BC = BLK_BC;
     constexpr int NG = BlkShape<BC>::NG;
     constexpr int NW = CH_BS / 64;
+    constexpr int NWORK = CW ? CH_BS - 64 : CH_BS;          // lanes with rows
     static_assert(R2 >= 4 && R2 <= 6, "two blocks of BC columns and w: 36 R2 registers of the 256 a lane has");
     __shared__ BlkSm sm;
     __shared__ int slead;
@@ -244,9 +253,13 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
             CH_SIGNAL_DONE(a);
         }
     };
-    if (rowless) {
-        // no rows: partial sums of zero, and the barriers of the nblk + 1 sums
-        for (int i = tid; i < BLK_NVMAX * NW; i += CH_BS) sm.part[i] = 0.0;
+    if (rowless || (CW && wave0)) {
+        // no rows: partial sums of zero, and the barriers of the nblk + 1 sums (a communication wave zeroes its own entries only)
+        if (rowless) {
+            for (int i = tid; i < BLK_NVMAX * NW; i += CH_BS) sm.part[i] = 0.0;
+        } else if (lane < BLK_NVMAX) {
+            sm.part[lane * NW] = 0.0;
+        }
         for (int ib = 0; ib < nblk; ++ib) {
             double gval;
             sum_begin(ib, gval);
@@ -256,12 +269,12 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
         finish();
         return;
     }
-    const int64_t first = (int64_t)(bid - nx) * a.chunk2 + tid;
+    const int64_t first = (int64_t)(bid - nx) * a.chunk2 + (CW ? tid - 64 : tid);
     const int64_t left = a.n2 - first;
     const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
-#define CH_OK(r) (!MASKED || (r) * CH_BS < rem)
+#define CH_OK(r) (!MASKED || (r) * NWORK < rem)
 #define CH_COL(j) (reinterpret_cast<const char*>(a.V + (a.col0 + ((j) < total ? (j) : total - 1)) * a.ld))
-#define CH_ROW(c, r) (*reinterpret_cast<const double2*>((c) + (size_t)(r) * (CH_BS * sizeof(double2)) + boff))
+#define CH_ROW(c, r) (*reinterpret_cast<const double2*>((c) + (size_t)(r) * (NWORK * sizeof(double2)) + boff))
     const unsigned boff = (unsigned)first * (unsigned)sizeof(double2);
     double2 ring[2][BC][R2];
     double2 w[R2];
@@ -269,7 +282,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
 #pragma unroll
         for (int r = 0; r < R2; ++r) {
-            const double2 v = ld_nt2(win2 + (int64_t)r * CH_BS);
+            const double2 v = ld_nt2(win2 + (int64_t)r * NWORK);
             w[r].x = CH_OK(r) ? v.x : 0.0;
             w[r].y = CH_OK(r) ? v.y : 0.0;
         }
@@ -394,11 +407,11 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
 #pragma unroll
     for (int r = 0; r < R2; ++r) {
-        if (r * CH_BS < rem) {
+        if (r * NWORK < rem) {
             double2 o;
             o.x = w[r].x / h;
             o.y = w[r].y / h;
-            st_nt2(vn2 + (int64_t)r * CH_BS, o);
+            st_nt2(vn2 + (int64_t)r * NWORK, o);
         }
     }
     finish();

@@ -12,30 +12,35 @@ namespace kh {
 static constexpr size_t BLK_GRAN_WORDS = (size_t)2 * CH_GMAX * BLK_NVS * 2;
 static constexpr size_t BLK_GRAN2_WORDS = (size_t)2 * BLK_NG2 * BLK_NVS * 2;
 
-// rows of 16 B per lane (4, 5 or 6) and workgroups WITH rows for a vector of n doubles: the fewest rows whose grid fits the
-// chip - beside the workgroups without rows when there is room for them
-bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out) {
+// rows of 16 B per lane (4, 5 or 6), workgroups WITH rows and whether wave 0 is a communication wave (448 lanes with rows instead of
+// 512) for a vector of n doubles: the fewest rows whose grid fits the chip - beside the workgroups without rows when there is room
+// for them; with a communication wave where that fits (KRYPY_AMD_BLK2_CW: 1 = where it fits, 0 = never), else without
+bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out) {
     if (n < 2 || ctx->ncu > CH_GMAX / 2) return false;
     const int64_t n2 = (n + 1) >> 1;
     const int room = ctx->ncu - (ctx->blk_nx > 0 ? ctx->blk_nx : 0);
-    for (int pass = 0; pass < 2; ++pass) {              // first with room left for the workgroups without rows, then without
-        const int cap = pass == 0 ? room : ctx->ncu;
-        for (int r2 = 4; r2 <= 6; ++r2) {
-            const int64_t g = (n2 + (int64_t)r2 * CH_BS - 1) / ((int64_t)r2 * CH_BS);
-            if (g >= 1 && g <= cap) {
-                *r2_out = r2;
-                *g_out = (int)g;
-                return true;
+    for (int cw = ctx->blk2_cw ? 1 : 0; cw >= 0; --cw) {
+        const int nwork = cw ? CH_BS - 64 : CH_BS;
+        for (int pass = 0; pass < 2; ++pass) {              // first with room left for the workgroups without rows, then without
+            const int cap = pass == 0 ? room : ctx->ncu;
+            for (int r2 = 4; r2 <= 6; ++r2) {
+                const int64_t g = (n2 + (int64_t)r2 * nwork - 1) / ((int64_t)r2 * nwork);
+                if (g >= 1 && g <= cap) {
+                    *r2_out = r2;
+                    *g_out = (int)g;
+                    if (cw_out) *cw_out = cw;
+                    return true;
+                }
             }
         }
     }
     return false;
 }
 
-template <int R2, bool MASKED, bool XR>
+template <int R2, bool MASKED, bool XR, bool CW>
 static hipError_t launch_blk2(kh_ctx ctx, int G, ChainArgs& a, BlkBufs bf, const XrDev& xr) {
     static int blocks_per_cu = -1;
-    auto kern = k_mgs_chain_blk2<R2, MASKED, XR>;
+    auto kern = k_mgs_chain_blk2<R2, MASKED, XR, CW>;
     if (blocks_per_cu < 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, 0);
@@ -59,8 +64,8 @@ static hipError_t launch_blk2(kh_ctx ctx, int G, ChainArgs& a, BlkBufs bf, const
 int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount,
                     bool multi) {
     const int64_t n = V->n;
-    int r2 = 0, G = 0;
-    if (!ctx->chain_blk2 || !ctx->chain_configured || !chain_blk2_shape(ctx, n, &r2, &G) || k + 3 > BLK_TABCOLS ||
+    int r2 = 0, G = 0, cwi = 0;
+    if (!ctx->chain_blk2 || !ctx->chain_configured || !chain_blk2_shape(ctx, n, &r2, &G, &cwi) || k + 3 > BLK_TABCOLS ||
         ((n & 1) && (V->ld <= n || wld <= n)) || (!multi && ctx->blk2_refused_n == n)) {
         if (multi) return fail(KH_ERR_COMM, "blocked Gram-Schmidt with in-kernel cross-rank sums: a slab of %lld rows is not served "
                                             "here although the run's longest slab was found eligible", (long long)n);
@@ -68,7 +73,8 @@ int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t 
     }
     if (multi && !ctx->xr_on) return fail(KH_ERR_COMM, "chain_blk2_step: the xr transport is off");
     KH_TRY(chain_epoch_check(ctx));
-    const int64_t chunk2 = (int64_t)r2 * CH_BS;
+    const bool cw = cwi != 0;
+    const int64_t chunk2 = (int64_t)r2 * (cw ? CH_BS - 64 : CH_BS);
     const int64_t need_ld = (int64_t)G * chunk2 * 2;
     const bool padded = V->ld >= need_ld && wld >= need_ld;
     BlkBufs bf;
@@ -138,9 +144,11 @@ int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t 
         xr.timeout_ticks = (long long)(ctx->xr_timeout_ms > 0 ? ctx->xr_timeout_ms : 60000) * 100000ll;
     }
     hipError_t e;
-#define KH_B2(R) (multi ? (padded ? launch_blk2<R, false, true>(ctx, G, a, bf, xr) : launch_blk2<R, true, true>(ctx, G, a, bf, xr)) \
-                        : (padded ? launch_blk2<R, false, false>(ctx, G, a, bf, xr) : launch_blk2<R, true, false>(ctx, G, a, bf, xr)))
+#define KH_B2C(R, C) (multi ? (padded ? launch_blk2<R, false, true, C>(ctx, G, a, bf, xr) : launch_blk2<R, true, true, C>(ctx, G, a, bf, xr)) \
+                            : (padded ? launch_blk2<R, false, false, C>(ctx, G, a, bf, xr) : launch_blk2<R, true, false, C>(ctx, G, a, bf, xr)))
+#define KH_B2(R) (cw ? KH_B2C(R, true) : KH_B2C(R, false))
     e = r2 == 4 ? KH_B2(4) : (r2 == 5 ? KH_B2(5) : KH_B2(6));
+#undef KH_B2C
 #undef KH_B2
     if (e != hipSuccess) {
         (void)hipGetLastError();

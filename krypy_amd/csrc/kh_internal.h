@@ -107,6 +107,7 @@ struct kh_ctx_s {
                                      // k_mgs_chain_blk2 (own block only)
     int chain_blk2 = 1;              // KRYPY_AMD_CHAIN_BLK2: the eight-wave blocked kernel (4 ... 6 rows per lane; on N ranks with the
                                      // cross-rank sums inside the launch)
+    int blk2_cw = 1;                 // KRYPY_AMD_BLK2_CW: wave 0 of the eight-wave blocked kernel owns no rows where that shape fits (448 lanes with rows)
     int64_t n_chain_blk2 = 0;
     int64_t blk2_refused_n = -1;
     int64_t n_blk_rowless = 0;       // blocked launches with workgroups without rows in front (chain_blk.h, BlkBufs::nx)
@@ -316,7 +317,7 @@ static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
 }
 hipError_t chain_blk_reset(kh_ctx ctx);
 // chain_blk2.hip: the eight-wave blocked kernel with the cross-rank stage
-bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out);
+bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out = nullptr);
 int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount,
                     bool multi);
 // krylov_hip.hip: the epoch counter of the grid-wide sums brought back to 1 when it nears its wrap; <V[:, j0 .. j0+ncols), w> on the device

@@ -593,7 +593,9 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     // (from 4096 rows on: below that a vector is a fraction of one workgroup's chunk)
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
-    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);      // (chain_blk2.h: 4 ... 6 rows)
+    int cw = 0;
+    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g, &cw))      // (chain_blk2.h: 4 ... 6 rows, 448 or 512 lanes with rows)
+        ld = std::max(ld, (int64_t)g * r2 * (cw ? CH_BS - 64 : CH_BS) * 2);
     return ld == 0 ? 32 : ld;
 }
 
@@ -1375,6 +1377,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK2");
         ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_BLK2_CW");
+        ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");
         ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_PANEL");
