@@ -44,9 +44,10 @@ SWITCHES = [
      "transport on `ortho='mgs'` keeps the one-reduction form (two cross-rank sums per step, the local basis read twice) instead of the "
      "eight-wave blocked kernel with the cross-rank sums INSIDE the launch (`csrc/chain_blk2.h`: the basis read once, no all-reduce call)"),
     ("KRYPY_AMD_BLK2_CW", "1", "kernel-path", "0",
-     "0: every wave of the eight-wave blocked kernel carries rows (512 lanes, up to 1.57 M rows) instead of wave 0 being a communication "
-     "wave without rows wherever that shape fits (448 lanes with rows, up to 1.33 M rows: no register spills, the total of a sum seen "
-     "without waiting for the wave's own rows)"),
+     "0: every wave of the eight-wave blocked kernel carries rows (512 lanes, 4 ... 6 rows per lane, up to 1.57 M rows) instead of wave 0 "
+     "being a communication wave without rows (448 lanes with rows, 4 ... 7 rows per lane, up to 1.6 M rows: no register spills up to 6 "
+     "rows, the total of a sum seen without waiting for the wave's own rows); 2: the communication wave up to 6 rows per lane, 512 lanes "
+     "beyond (the A / B of the 7-row shape)"),
     ("KRYPY_AMD_BLK_ONEX_MAXN", "70000", "tuning", None,
      "vectors longer than this run the blocked kernel spread over the chip instead of on one XCD"),
     ("KRYPY_AMD_BLK_NX", "8", "kernel-path", "0",

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
     constexpr int NG = BlkShape<BC>::NG;
     constexpr int NW = CH_BS / 64;
     constexpr int NWORK = CW ? CH_BS - 64 : CH_BS;          // lanes with rows
-    static_assert(R2 >= 4 && R2 <= 6, "two blocks of BC columns and w: 36 R2 registers of the 256 a lane has");
+    static_assert(R2 >= 4 && R2 <= (CW ? 7 : 6), "two blocks of BC columns and w: 36 R2 registers of the 256 a lane has");
     __shared__ BlkSm sm;
     __shared__ int slead;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;

@@ -594,7 +594,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
     int cw = 0;
-    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g, &cw))      // (chain_blk2.h: 4 ... 6 rows, 448 or 512 lanes with rows)
+    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g, &cw))      // (chain_blk2.h: 4 ... 7 rows, 448 or 512 lanes with rows)
         ld = std::max(ld, (int64_t)g * r2 * (cw ? CH_BS - 64 : CH_BS) * 2);
     return ld == 0 ? 32 : ld;
 }
@@ -1379,6 +1379,7 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK2_CW");
         ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
+        ctx->blk2_cw_maxrows = ctx->blk2_cw == 2 ? 6 : 7;
         e = getenv("KRYPY_AMD_PROJ_REG");
         ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_PANEL");
@@ -1506,6 +1507,11 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
+    else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
+        ctx->blk2_cw = (int)value;
+        ctx->blk2_cw_maxrows = value == 2 ? 6 : 7;
+        ctx->blk2_refused_n = -1;
+    }
     else if (!strcmp(key, "mgs_lowsync")) ctx->mgs_lowsync = value != 0;
     else if (!strcmp(key, "lowsync_rows")) {        // (local slab length << 32) | longest slab of the run
         const int64_t loc = value >> 32, mx = value & 0xffffffffll;
@@ -1572,6 +1578,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_blk")) *value = ctx->chain_blk;
     else if (!strcmp(key, "n_chain_blk")) *value = ctx->n_chain_blk;
     else if (!strcmp(key, "chain_blk2")) *value = ctx->chain_blk2;
+    else if (!strcmp(key, "chain_blk2_cw")) *value = ctx->blk2_cw;
     else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;

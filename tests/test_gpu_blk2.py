@@ -21,13 +21,23 @@ def _cycle(linsys, utils, ls, m=100, **kw):
         return e.solver
 
 
-@pytest.mark.parametrize("nx,ny", [(4000, 313), (1500, 1000), (1201, 907)])
-def test_one_gpu_long_short_vectors_against_the_per_column_kernels(hip, nx, ny):
-    """One GPU, 1.09 ... 1.5 M rows (5 and 6 rows per lane; the first shape is the slab one of eight ranks holds of the
+@pytest.mark.parametrize("nx,ny,cw", [(4000, 313, 1), (1500, 1000, 1), (1201, 907, 1), (1250, 1270, 1), (1500, 1000, 2), (1201, 907, 0)])
+def test_one_gpu_long_short_vectors_against_the_per_column_kernels(hip, nx, ny, cw):
+    """One GPU, 1.09 ... 1.59 M rows (5, 6 and 7 rows per lane; the first shape is the slab one of eight ranks holds of the
     benchmark problem): a whole GMRES(100) cycle through the blocked kernel - steps of eight links and more - against the
     same cycle on the per-column kernels: residual history, Hessenberg matrix and iterate at 1e-10, the basis as orthogonal
-    (within a factor two)."""
+    (within a factor two).  cw = 1 is what runs by default (wave 0 without rows; 7 rows per lane from 1.38 M rows on), cw = 2
+    stops that form at 6 rows (1.5 M rows then take the 512-lane form with 6 rows), cw = 0 is the 512-lane form throughout."""
     from krypy_amd import linsys, utils
+
+    hip.set("chain_blk2_cw", cw)
+    try:
+        _one_gpu_case(hip, linsys, utils, nx, ny)
+    finally:
+        hip.set("chain_blk2_cw", 1)
+
+
+def _one_gpu_case(hip, linsys, utils, nx, ny):
 
     A = ref.laplace2d(nx, ny)
     b = np.random.default_rng(3).standard_normal(A.shape[0])
