@@ -137,6 +137,10 @@ def parse_args():
     ap.add_argument("--force-sharded", action="store_true",
                     help="testing: take the multi-GPU code path (gloo init, RCCL communicator, "
                          "ShardedCSROperator, all-reduced reductions) even with one rank")
+    ap.add_argument("--loop-halo", action="store_true",
+                    help="with --force-sharded: the one rank's slab is a MIDDLE slab of the problem split over N ranks, with itself as "
+                         "previous and next neighbour (periodic across its cuts): boundary rows out and ghost rows in exactly as a "
+                         "middle rank has them - through the in-launch exchange of the banded SpMV when the mailboxes are on")
     ap.add_argument("--transport", default="rccl", choices=("rccl", "xr"),
                     help="N > 1 ranks.  rccl (default): an RCCL communicator, with the sums across the ranks (and a banded shard's "
                          "halo) moved to the IPC mailboxes of csrc/xr.hip when every rank can use them.  xr: NO RCCL communicator "
@@ -391,8 +395,14 @@ def _run():
             raise SystemExit("bench.py --transport xr: the mailboxes did not come up on every rank, and there is no RCCL communicator")
         # contiguous slabs of grid rows (y index): every shard holds whole x-lines
         cuts = [(ny * p) // world for p in range(world + 1)]
-        Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
-        op = kdist.ShardedCSROperator(Aloc, cuts[rank] * nx, N, ctx)
+        if args.loop_halo:
+            if not (args.force_sharded and world == 1):
+                raise SystemExit("bench.py --loop-halo: with --force-sharded on one rank")
+            Aloc = laplace2d(nx, 3 * ny, ny, 2 * ny)
+            op = kdist.ShardedCSROperator(Aloc, ny * nx, 3 * N, ctx, self_loop=True)
+        else:
+            Aloc = laplace2d(nx, ny, cuts[rank], cuts[rank + 1])
+            op = kdist.ShardedCSROperator(Aloc, cuts[rank] * nx, N, ctx)
         b_full = np.random.default_rng(0).standard_normal(N)
         b = b_full[cuts[rank] * nx: cuts[rank + 1] * nx].copy()
         A_for_ls = op
@@ -604,7 +614,8 @@ def _run():
                    "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),
                    # the halo of the sharded SpMV: "in-launch" = boundary rows stored into the neighbours' IPC-mapped ghost granules
                    # by the banded kernel itself (kh_mat_xh_*), "rccl" = grouped ncclSend / ncclRecv on the communication stream
-                   "halo": None if not sharded else ("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl"),
+                   "halo": None if not sharded else (("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl") +
+                                                    (" (the slab is its own neighbour)" if args.loop_halo else "")),
                    "ortho_auto": auto_report,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
                    # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
@@ -661,9 +672,12 @@ def _run_config5(args):
     b_rng = np.random.default_rng(0)
     if sharded:
         from krypy_amd import dist as kdist
-        uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
-        ctx.comm_init(rank, world, uid)
+        if args.transport == "rccl":
+            uid = dist.broadcast_bytes(ctx.comm_unique_id() if rank == 0 else None)
+            ctx.comm_init(rank, world, uid)
         xr_on = kdist.enable_xr(ctx, dist)
+        if args.transport == "xr" and not xr_on:
+            raise SystemExit("bench.py --transport xr: the mailboxes did not come up on every rank, and there is no RCCL communicator")
         cuts = [(nz * p) // world for p in range(world + 1)]          # whole planes per rank
         z0, z1 = cuts[rank], cuts[rank + 1]
         Aloc = laplace3d(nx, ny, nz, z0, z1)
@@ -724,7 +738,8 @@ def _run_config5(args):
         (32.0 * d + 48.0) * N
     out = {
         "metric": "DeflatedGmres iterations/sec, 3-D 7-pt Laplacian n=10^8 row-sharded, 16 recycled Ritz vectors, fp64",
-        "value": its, "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": its, "unit": "iterations/s", "n_gpus": int(os.environ.get("KRYPY_AMD_BENCH_DEVICES", world)), "steps": args.steps,
+        "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "DeflatedGmres(%d) solves with %d recycled Ritz vectors, 3-D 7-pt Laplacian %dx%dx%d CSR "
@@ -732,9 +747,11 @@ def _run_config5(args):
                                "from one plain GMRES(%d) solve, untimed" % (m, d, nx, ny, nz, N, nnz_global, m),
                    "n": N, "rows_per_gpu": nloc, "ortho": ortho, "restart": m, "deflation_vectors": d,
                    "iterations_timed": n_iters,
-                   "parallelism": "1 GPU" if not sharded else "z-slabs x%d (RCCL)" % world,
+                   "parallelism": "1 GPU" if not sharded else "z-slabs x%d (%s)" % (world, "RCCL" if args.transport == "rccl" else "mailboxes only"),
+                   "ranks": world,
                    "cross_rank_sums": None if not sharded else ("xr" if locals().get("xr_on") else "rccl"),
-                   "halo": None if not sharded else ("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl"),
+                   "halo": None if not sharded else (("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl") +
+                                                    (" (the slab is its own neighbour)" if args.loop_halo else "")),
                    "plain_relres": plain_relres, "deflated_relres": float(s1.resnorms[-1]),
                    "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
                    "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms))},

@@ -285,11 +285,19 @@ class ShardedCSROperator(utils.LinearOperator):
     local slab; halo exchange and all-reduces happen below the C ABI.
     """
 
-    def __init__(self, A_rows, row0, n_global, ctx=None):
+    def __init__(self, A_rows, row0, n_global, ctx=None, self_loop=False):
         ctx = _hip.get_context() if ctx is None else ctx
         self._ctx = ctx
         A_local, nrp, nrn = localize_columns(A_rows, row0, n_global)
         nloc = A_local.shape[0]
+        self._self_loop = bool(self_loop)
+        if self._self_loop:
+            # measurement / test aid on ONE rank in forced multi-rank mode: the slab is a ring's only member - its own previous
+            # and next neighbour (what a middle rank of N does, kernel for kernel: boundary rows out, ghost rows in; the operator
+            # becomes the slab periodic across its cut)
+            if ctx.nranks != 1 or not (nrp > 0 and nrn > 0):
+                raise utils.ArgumentError("self_loop: one rank, and a slab with rows above and below it")
+            ctx.set("halo_loopback", 1)
         # every rank learns its neighbours' halo widths: what rank p receives from p-1 is what
         # p-1 has to send "next", and vice versa
         table = numpy.zeros(3 * ctx.nranks)
@@ -299,6 +307,8 @@ class ShardedCSROperator(utils.LinearOperator):
         table = ctx.allreduce_host(table)
         nsend_prev = int(table[3 * (ctx.rank - 1) + 1]) if ctx.rank > 0 else 0
         nsend_next = int(table[3 * (ctx.rank + 1)]) if ctx.rank + 1 < ctx.nranks else 0
+        if self._self_loop:
+            nsend_prev, nsend_next = nrn, nrp         # what goes to the previous slab is ITS "next" ghost region
         # the LONGEST slab of the run: kernel choices that change the pattern of all-reduces (the one-reduction form of
         # reference-order Gram-Schmidt) must come out the same on every rank, so they are made for that length
         if hasattr(ctx, "set") and ctx.nranks > 1:
@@ -333,7 +343,7 @@ class ShardedCSROperator(utils.LinearOperator):
         ``KRYPY_AMD_XH=0`` keeps the RCCL exchange.  Returns True when on."""
         ctx = self._ctx
         nr, r = ctx.nranks, ctx.rank
-        if not (hasattr(ctx, "xh_export") and hasattr(ctx, "get") and nr > 1 and ctx.get("xr") == 1
+        if not (hasattr(ctx, "xh_export") and hasattr(ctx, "get") and (nr > 1 or self._self_loop) and ctx.get("xr") == 1
                 and os.environ.get("KRYPY_AMD_XH", "1") != "0"):
             return False
         ok, handle = 1.0, b"\0" * 64
@@ -357,8 +367,11 @@ class ShardedCSROperator(utils.LinearOperator):
         ng = [int(table[3 * q] + table[3 * q + 1]) for q in range(nr)]
         ok = 1.0
         try:
-            ctx.xh_attach(dm, hbytes(r - 1) if r > 0 else None, ng[r - 1] if r > 0 else 0, int(table[3 * (r - 1)]) if r > 0 else 0,
-                          hbytes(r + 1) if r + 1 < nr else None, ng[r + 1] if r + 1 < nr else 0)
+            if self._self_loop:
+                ctx.xh_attach(dm, None, 0, 0, None, 0, self_loop=True)
+            else:
+                ctx.xh_attach(dm, hbytes(r - 1) if r > 0 else None, ng[r - 1] if r > 0 else 0, int(table[3 * (r - 1)]) if r > 0 else 0,
+                              hbytes(r + 1) if r + 1 < nr else None, ng[r + 1] if r + 1 < nr else 0)
         except _hip.BackendError:
             ok = 0.0
         if ctx.allreduce_host(numpy.array([1.0 - ok]))[0] > 0.0:

@@ -13,6 +13,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -98,3 +99,52 @@ def test_bench_two_ranks_share_the_one_gpu_through_the_mailboxes(hip):
         one = json.loads(lines[0])
         r1, r2 = one["config"]["final_relres"], res[ortho]["config"]["final_relres"]
         assert abs(r1 - r2) <= 1e-9 * r1, (ortho, r1, r2)
+
+
+def test_bench_one_rank_as_a_middle_slab_with_itself_as_neighbour(hip):
+    """`bench.py --force-sharded --loop-halo`: what ONE middle rank of N runs, kernel for kernel, on a box with one GPU - the
+    sums through its own mailbox inside the blocked kernel's launch, its boundary rows out and its ghost rows in inside the
+    banded SpMV's launch (the slab periodic across its cuts).  The line says so, and the residual after the same iterations
+    is the one the RCCL exchange (two launches and a send / recv kernel per product, KRYPY_AMD_XH=0) arrives at."""
+    common = ["--force-sharded", "--loop-halo", "--steps", "2", "--warmup", "1", "--nx", "400", "--ny", "300", "--restart", "40",
+              "--no-cpu-baseline", "--no-roofline", "--ortho", "mgs", "--other-modes", "none"]
+    rc, lines, err = _bench(common)
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    a = json.loads(lines[0])
+    assert a["config"]["halo"] == "in-launch (the slab is its own neighbour)" and a["config"]["cross_rank_sums"] == "xr"
+    os.environ["KRYPY_AMD_XH"] = "0"
+    try:
+        rc, lines, err = _bench(common)
+    finally:
+        del os.environ["KRYPY_AMD_XH"]
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    b = json.loads(lines[0])
+    assert b["config"]["halo"] == "rccl (the slab is its own neighbour)"
+    r1, r2 = a["config"]["final_relres"], b["config"]["final_relres"]
+    assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
+
+
+def test_bench_config5_two_ranks_share_the_one_gpu(hip):
+    """BASELINE.json configs[4]'s flow (harvest of the Ritz vectors on the device, DeflatedGmres with them:
+    /root/reference/krypy/recycling/linsys.py:51-103, deflation.py:93-163) on TWO rank processes, z-slabs of the 3-D
+    Laplacian, on a box with one GPU: no RCCL communicator - every inner product, the projector's panel products and the
+    host-side sums through the mailboxes, the slabs' halo planes inside the banded SpMV's launch.  The deflated residual
+    after the same iterations is the one-rank run's (Ritz values too): the first time this flow runs on more than one rank."""
+    common = ["--config", "5", "--steps", "1", "--warmup", "0", "--nx", "40", "--ny", "36", "--nz", "30", "--restart", "30",
+              "--defl", "6", "--no-cpu-baseline", "--no-roofline"]
+    res = {}
+    for ortho in ("cgs", "mgs"):
+        rc, lines, err = _bench(["--gpus", "2", "--share-devices", "--transport", "xr", "--ortho", ortho] + common)
+        assert rc == 0, err[-3000:]
+        assert len(lines) == 1, lines
+        two = json.loads(lines[0])
+        c = two["config"]
+        assert two["n_gpus"] == 1 and c["ranks"] == 2 and c["parallelism"] == "z-slabs x2 (mailboxes only)"
+        assert c["cross_rank_sums"] == "xr" and c["halo"] == "in-launch" and c["iterations_timed"] == 30
+        res[ortho] = two
+        rc, lines, err = _bench(["--gpus", "1", "--ortho", ortho] + common)
+        assert rc == 0 and len(lines) == 1, err[-3000:]
+        one = json.loads(lines[0])["config"]
+        assert abs(one["plain_relres"] - c["plain_relres"]) <= 1e-8 * one["plain_relres"], (ortho, one["plain_relres"], c["plain_relres"])
+        assert abs(one["deflated_relres"] - c["deflated_relres"]) <= 1e-6 * one["deflated_relres"], (ortho, one["deflated_relres"], c["deflated_relres"])
+        assert np.allclose(one["smallest_ritz_values"], c["smallest_ritz_values"], rtol=1e-8)
