@@ -446,6 +446,15 @@ __device__ __forceinline__ int xcd_remap(int b, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// the block number that xcd_remap sends to logical block lb
+__device__ __forceinline__ int xcd_unmap(int lb, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int head = r * (q + 1);
+    const int xcd = lb < head ? lb / (q + 1) : r + (lb - head) / (q > 0 ? q : 1);
+    const int idx = lb < head ? lb % (q + 1) : (lb - head) % (q > 0 ? q : 1);
+    return idx * 8 + xcd;
+}
+
 template <int EPI, int ITEMS>
 __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
@@ -668,24 +677,38 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                                                  int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0,
                                                  XhArgs xh = XhArgs()) {
     __shared__ double sm[8];
-    int lb = xcd_remap(blockIdx.x, gridDim.x);       // (subset launches: see k_spmv_stream)
-    lb = lb < blk_lo ? lb : lb + blk_skip;
-    const int64_t base = (int64_t)lb * (2 * BS * RPT);
-    const int64_t last = n - 1;
+    int lb, pslot = blockIdx.x;
     if constexpr (XH) {
-#pragma unroll
-        for (int u = 0; u < RPT; ++u) {
-            const int64_t r = base + 2 * (threadIdx.x + u * BS);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t i = r + h;
-                if (i < n) {
-                    if (i < xh.nsend_prev) xh_put(xh.prev, xh.prev_ng, xh.prev_off + i, xh.epoch, x[i]);
-                    if (i >= n - xh.nsend_next) xh_put(xh.next, xh.next_ng, i - (n - xh.nsend_next), xh.epoch, x[i]);
-                }
+        // Who stores and who polls, in dispatch order.  x is complete when this launch starts, so ANY workgroup can send the
+        // slab's first / last rows: the first workgroups dispatched do (one entry per lane).  The workgroups whose rows read
+        // ghost entries are mapped to the LAST block numbers: by the time they start, the neighbours' first workgroups - which
+        // started with ours, the ranks run in step through the sums of the orthogonalisation - have long stored, and a poll is
+        // one read.  (The owners of the boundary rows stored them and polled at once before: 33 us per product of the N/8 shard
+        // against 18 without a halo - a polling workgroup then waits for a neighbour's LAST workgroups to be dispatched.)
+        const int64_t nsend = (int64_t)xh.nsend_prev + xh.nsend_next;
+        for (int64_t j = (int64_t)blockIdx.x * BS + threadIdx.x; j < nsend; j += (int64_t)gridDim.x * BS) {
+            if (j < xh.nsend_prev) {
+                xh_put(xh.prev, xh.prev_ng, xh.prev_off + j, xh.epoch, x[j]);
+            } else {
+                const int64_t jj = j - xh.nsend_prev;
+                xh_put(xh.next, xh.next_ng, jj, xh.epoch, x[n - xh.nsend_next + jj]);
             }
         }
+        const int gi = xh.ihi - xh.ilo;                      // interior blocks [ilo, ihi): no ghost entry in their rows
+        const int b = blockIdx.x;
+        if (b < gi) {
+            lb = xh.ilo + xcd_remap(b, gi);
+        } else {
+            const int j = b - gi;
+            lb = j < xh.ilo ? j : j + gi;
+        }
+        pslot = xcd_unmap(lb, gridDim.x);                    // the partial sums in the plain launch's order: the same bits
+    } else {
+        lb = xcd_remap(blockIdx.x, gridDim.x);       // (subset launches: see k_spmv_stream)
+        lb = lb < blk_lo ? lb : lb + blk_skip;
     }
+    const int64_t base = (int64_t)lb * (2 * BS * RPT);
+    const int64_t last = n - 1;
     const bool xal = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     double s0[RPT], s1[RPT];
 #pragma unroll
@@ -696,6 +719,8 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
         const double* __restrict__ dd = dia + (int64_t)d * ld;
         double2 a[RPT];
         double x0[RPT], x1[RPT];
+        long long gix[XH ? 2 * RPT : 1];       // XH: the ghost entries this lane needs from this diagonal (-1: none)
+        bool gany = false;
 #pragma unroll
         for (int u = 0; u < RPT; ++u) {
             const int64_t r = base + 2 * (threadIdx.x + u * BS);   // ld covers the whole grid
@@ -705,13 +730,21 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                 const double2 xv = *reinterpret_cast<const double2*>(x + c0);
                 x0[u] = xv.x;
                 x1[u] = xv.y;
+                if constexpr (XH) gix[2 * u] = gix[2 * u + 1] = -1;
             } else if (HALO) {                              // rows of the neighbouring slabs: ghost[]
                 const int64_t lo = -(int64_t)nprev, hi = last + nnext;
                 c0 = c0 < lo ? lo : (c0 > hi ? hi : c0);
                 c1 = c1 < lo ? lo : (c1 > hi ? hi : c1);
                 if constexpr (XH) {
-                    x0[u] = c0 < 0 ? xh_take(xh, c0 + nprev) : (c0 > last ? xh_take(xh, nprev + (c0 - n)) : x[c0]);
-                    x1[u] = c1 < 0 ? xh_take(xh, c1 + nprev) : (c1 > last ? xh_take(xh, nprev + (c1 - n)) : x[c1]);
+                    // own rows now, ghost entries after the loop: all of a lane's polls in flight together (one after the
+                    // other - eight round trips to the uncached granules per diagonal - they were 12 us of this kernel)
+                    const long long g0 = c0 < 0 ? c0 + nprev : (c0 > last ? nprev + (c0 - n) : -1);
+                    const long long g1 = c1 < 0 ? c1 + nprev : (c1 > last ? nprev + (c1 - n) : -1);
+                    gix[2 * u] = g0;
+                    gix[2 * u + 1] = g1;
+                    gany = gany || g0 >= 0 || g1 >= 0;
+                    x0[u] = x[g0 >= 0 ? 0 : c0];
+                    x1[u] = x[g1 >= 0 ? 0 : c1];
                 } else {
                     x0[u] = c0 < 0 ? ghost[c0 + nprev] : (c0 > last ? ghost[nprev + (c0 - n)] : x[c0]);
                     x1[u] = c1 < 0 ? ghost[c1 + nprev] : (c1 > last ? ghost[nprev + (c1 - n)] : x[c1]);
@@ -721,6 +754,17 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
                 c1 = c1 < 0 ? 0 : (c1 > last ? last : c1);
                 x0[u] = x[c0];
                 x1[u] = x[c1];
+            }
+        }
+        if constexpr (XH) {
+            if (gany) {
+                double gv[2 * RPT];
+                xh_take_n<2 * RPT>(xh, gix, gv);
+#pragma unroll
+                for (int u = 0; u < RPT; ++u) {
+                    x0[u] = gix[2 * u] >= 0 ? gv[2 * u] : x0[u];
+                    x1[u] = gix[2 * u + 1] >= 0 ? gv[2 * u + 1] : x1[u];
+                }
             }
         }
 #pragma unroll
@@ -764,7 +808,7 @@ __global__ __launch_bounds__(BS) void k_spmv_dia(DiaOffs o, const double* __rest
     }
     if (EPI != EPI_NONE) {
         const double r = block_sum(acc, sm);
-        if (threadIdx.x == 0) part_out[part_off + blockIdx.x] = r;
+        if (threadIdx.x == 0) part_out[part_off + pslot] = r;
     }
 }
 

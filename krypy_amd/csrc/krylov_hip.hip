@@ -263,6 +263,8 @@ static void launch_dia_nd(kh_ctx ctx, kh_mat A, const DiaOffs& o, const double* 
             xh.prev_off = A->xh_prev_off;
             xh.nsend_prev = A->xh_prev != nullptr ? (int)A->nsend_prev : 0;
             xh.nsend_next = A->xh_next != nullptr ? (int)A->nsend_next : 0;
+            xh.ilo = A->dia_b0 < A->dia_b1 ? A->dia_b0 : 0;
+            xh.ihi = A->dia_b0 < A->dia_b1 ? A->dia_b1 : 0;
             xh.epoch = A->xh_epoch++;
             xh.timeout_ticks = (long long)(ctx->xr_timeout_ms > 0 ? ctx->xr_timeout_ms : 60000) * 100000ll;
             void* dp = nullptr;

@@ -69,6 +69,7 @@ struct XhArgs {
     unsigned long long* next;      // the next rank's (my last nsend_next rows go to [i])
     long long my_ng, prev_ng, next_ng, prev_off;
     int nsend_prev, nsend_next;
+    int ilo, ihi;                  // the blocks [ilo, ihi) of the slab whose rows touch no ghost column
     unsigned epoch;
     long long timeout_ticks;
     int* err;                      // mapped pinned host word (the xr transport's)
@@ -104,6 +105,48 @@ __device__ __forceinline__ double xh_take(const XhArgs& a, long long idx) {
         __builtin_amdgcn_s_sleep(2);
     }
     return __longlong_as_double((long long)(((x1 & 0xffffffffull) << 32) | (x0 & 0xffffffffull)));
+}
+
+// K ghost entries of this exchange at once (idx[k] < 0: not wanted): every poll of the lane in flight together, repeated
+// for the entries whose granules do not carry the epoch yet
+template <int K>
+__device__ __forceinline__ void xh_take_n(const XhArgs& a, const long long (&idx)[K], double (&out)[K]) {
+    const unsigned long long* box = a.mine + (size_t)(a.epoch & 1u) * (size_t)a.my_ng * 2;
+    unsigned pend = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) pend |= (idx[k] >= 0) ? (1u << k) : 0u;
+    unsigned spins = 0;
+    long long t0 = 0;
+    while (pend != 0) {
+        unsigned long long lo[K], hi[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const unsigned long long* e = box + (size_t)(idx[k] >= 0 ? idx[k] : 0) * 2;     // (an entry not wanted: any valid address)
+            lo[k] = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            hi[k] = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            if (((pend >> k) & 1u) && (unsigned)(lo[k] >> 32) == a.epoch && (unsigned)(hi[k] >> 32) == a.epoch) {
+                out[k] = __longlong_as_double((long long)(((hi[k] & 0xffffffffull) << 32) | (lo[k] & 0xffffffffull)));
+                pend &= ~(1u << k);
+            }
+        }
+        if (pend != 0) {
+            if ((++spins & 255u) == 0) {
+                const long long now = (long long)wall_clock64();
+                if (t0 == 0) t0 = now;
+                if (now - t0 > a.timeout_ticks) {
+                    __hip_atomic_store(a.err, 100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                        if ((pend >> k) & 1u) out[k] = __longlong_as_double(0x7ff8000000000000ll);
+                    return;
+                }
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
 }
 
 }  // namespace kh
