@@ -2,17 +2,20 @@
 # Kernel trace + fabric-traffic counters of ONE RANK'S SHARE of the benchmark problem on N = 8 ranks (a 4000 x 313 slab, 1.252 M rows)
 # through the forced multi-rank path on one MI355X: bench.py --force-sharded --ortho mgs = sharded SpMV (interior / boundary launches)
 # + k_mgs_chain_blk2 with the cross-rank sums inside the launch (every sum through the rank's own mailbox).
-#   tools/profile_shard.sh  ->  gpurun_out/prof_shard/summary.md
+#   tools/profile_shard.sh [--loop-halo]  ->  gpurun_out/prof_shard/summary.md
+# --loop-halo: the slab as a MIDDLE rank has it - itself as previous and next neighbour, boundary rows out and ghost rows in inside the
+# banded SpMV's one launch (xh), instead of the two launches without a halo
 # (rocprofv3 --kernel-trace --stats, then FETCH_SIZE / WRITE_SIZE in separate --pmc passes with --kernel-trace only;
 # FETCH_SIZE doubled - the guide's gfx950 correction for wide streams)
 set -u
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_shard
 mkdir -p $OUT
-CMD="python bench.py --force-sharded --nx 4000 --ny 313 --ortho mgs --no-roofline --steps 6 --warmup 1 --other-modes none"
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err
+EXTRA=${1:-}
+CMD="python bench.py --force-sharded $EXTRA --nx 4000 --ny 313 --ortho mgs --no-roofline --steps 6 --warmup 1 --other-modes none"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $CMD > $OUT/bench_trace.json 2> $OUT/trace.err < /dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- $CMD > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-trace -d $OUT/pmc_$C -o pmc -- $CMD > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err < /dev/null
 done
 python - <<PY
 import glob, json, sqlite3
@@ -24,7 +27,7 @@ out = ["# rocprofv3: one rank's slab of the benchmark problem on 8 ranks (4000 x
        "Command: \`rocprofv3 --kernel-trace --stats -- $CMD\`, then \`--pmc FETCH_SIZE\` / \`--pmc WRITE_SIZE\` passes of the same command "
        "with \`--kernel-trace\` only (tools/profile_shard.sh).", "",
        "Under the profiler: **%.0f iterations/s**, ortho = %s, sums across the ranks: %s (every sum of the blocked kernel goes through the rank's own "
-       "mailbox inside the launch), %d iterations timed." % (d["value"], d["config"]["ortho"], d["config"]["cross_rank_sums"], d["config"]["iterations_timed"]), "",
+       "mailbox inside the launch), halo: %s, %d iterations timed." % (d["value"], d["config"]["ortho"], d["config"]["cross_rank_sums"], d["config"]["halo"], d["config"]["iterations_timed"]), "",
        "| kernel | calls | total ms | avg us | % of kernel time |", "|---|---:|---:|---:|---:|"]
 for name, calls, total, avg in rows:
     out.append("| \`%s\` | %d | %.2f | %.2f | %.1f |" % (name[:90], calls, total / 1e3, avg, 100.0 * total / tot))
@@ -37,7 +40,7 @@ if len(k) >= 200:
     gaps = [(cyc[i + 1][0] - cyc[i][1]) / 1e3 for i in range(99)]
     slope = ((cyc[99][1] - cyc[99][0]) - (cyc[3][1] - cyc[3][0])) / 1e3 / 24.0
     out += ["", "Per block of four columns: **%.2f us** ((k = 99) - (k = 3)) / 24 blocks; the block's 4 x 10.0 MB at 6.5 TB/s would be 6.2 us.  "
-            "Between the end of one blocked launch and the start of the next: %.1f us on average (the sharded SpMV's two launches and the "
+            "Between the end of one blocked launch and the start of the next: %.1f us on average (the sharded SpMV - two launches without a halo, or one with the halo inside it - and the "
             "dependent-launch gaps)." % (slope, sum(gaps) / len(gaps))]
 pm = {}
 for cname in ("FETCH_SIZE", "WRITE_SIZE"):
