@@ -860,47 +860,74 @@ __global__ __launch_bounds__(BS) void k_spmm_dia(DiaOffs o, const double* __rest
 // One wave64 per row: lanes stride the row with double2 loads, x stays in L2 (256 KB).
 // HBM-bound (0.25 flop/B); MFMA cannot help a single right-hand side.
 // ------------------------------------------------------------------------------------------
+// ROWS rows per wave: the rows share every load of x (x is read from L2 once per ROWS rows instead of once per row - at one row
+// per wave the L2 delivers as many bytes of x as HBM delivers of A) and ROWS x 4 row loads are in flight per lane.  Every row
+// keeps its own four accumulators and their order: the same bits as with one row per wave.
+template <int ROWS>
 static __global__ __launch_bounds__(BS) void k_gemv_dense(int64_t n_rows, int64_t n_cols,
                                                    const double* __restrict__ a, int64_t lda,
                                                    const double* __restrict__ x,
                                                    double* __restrict__ y) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
-    const double* __restrict__ ar = a + row * lda;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    const int64_t row0 = ((int64_t)blockIdx.x * (BS / 64) + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= n_rows) return;
+    const double* ar[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) ar[r] = a + (row0 + r < n_rows ? row0 + r : n_rows - 1) * lda;     // (a row past the end: the last one again, not stored)
+    double acc[ROWS][4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[r][0] = acc[r][1] = acc[r][2] = acc[r][3] = 0.0;
     if (((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0)) {
-        const double2* __restrict__ a2 = reinterpret_cast<const double2*>(ar);
         const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x);
         const int64_t n2 = n_cols >> 1;
         int64_t i = lane;
-        // four independent 16-byte row loads in flight per lane (1 KB per wave instruction)
+        // four independent 16-byte loads per row in flight per lane (1 KB per wave instruction)
         for (; i + 192 < n2; i += 256) {
             // the matrix is streamed once: non-temporal, x stays in L2
-            const double2 a0 = ld_nt2(a2 + i), a1 = ld_nt2(a2 + i + 64), a2v = ld_nt2(a2 + i + 128),
-                          a3 = ld_nt2(a2 + i + 192);
-            const double2 x0 = x2[i], x1 = x2[i + 64], x2v = x2[i + 128], x3 = x2[i + 192];
-            acc0 = fma(a0.x, x0.x, acc0);
-            acc0 = fma(a0.y, x0.y, acc0);
-            acc1 = fma(a1.x, x1.x, acc1);
-            acc1 = fma(a1.y, x1.y, acc1);
-            acc2 = fma(a2v.x, x2v.x, acc2);
-            acc2 = fma(a2v.y, x2v.y, acc2);
-            acc3 = fma(a3.x, x3.x, acc3);
-            acc3 = fma(a3.y, x3.y, acc3);
+            double2 av[ROWS][4];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const double2* __restrict__ a2 = reinterpret_cast<const double2*>(ar[r]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) av[r][q] = ld_nt2(a2 + i + 64 * q);
+            }
+            double2 xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xv[q] = x2[i + 64 * q];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[r][q] = fma(av[r][q].x, xv[q].x, acc[r][q]);
+                    acc[r][q] = fma(av[r][q].y, xv[q].y, acc[r][q]);
+                }
+            }
         }
         for (; i < n2; i += 64) {
-            const double2 av = a2[i];
             const double2 xv = x2[i];
-            acc0 = fma(av.x, xv.x, acc0);
-            acc0 = fma(av.y, xv.y, acc0);
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                const double2 av = reinterpret_cast<const double2*>(ar[r])[i];
+                acc[r][0] = fma(av.x, xv.x, acc[r][0]);
+                acc[r][0] = fma(av.y, xv.y, acc[r][0]);
+            }
         }
-        if ((n_cols & 1) && lane == 0) acc0 = fma(ar[n_cols - 1], x[n_cols - 1], acc0);
+        if ((n_cols & 1) && lane == 0) {
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r][0] = fma(ar[r][n_cols - 1], x[n_cols - 1], acc[r][0]);
+        }
     } else {
-        for (int64_t i = lane; i < n_cols; i += 64) acc0 = fma(ar[i], x[i], acc0);
+        for (int64_t i = lane; i < n_cols; i += 64) {
+            const double xv = x[i];
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) acc[r][0] = fma(ar[r][i], xv, acc[r][0]);
+        }
     }
-    const double s = wave_sum((acc0 + acc1) + (acc2 + acc3));
-    if (lane == 0) y[row] = s;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const double s = wave_sum((acc[r][0] + acc[r][1]) + (acc[r][2] + acc[r][3]));
+        if (lane == 0 && row0 + r < n_rows) y[row0 + r] = s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -321,6 +321,21 @@ static void launch_spmv(kh_ctx ctx, kh_mat A, const double* x, double* y, const 
     }
 }
 
+// y = A x with a dense A.  Rows per wave (kernels.h): four from 16 K rows on - 6.91 against 6.73 TB/s at n = 32768, 1255
+// against 1308 us per CG iteration (profiles/r05_gemv_ab.log) - one below (the grid of a small matrix does not fill the chip
+// with fewer waves: measured slower at n = 8192 and 3001).
+static void gemv_dense(kh_ctx ctx, kh_mat A, const double* x, double* y) {
+    const int rows = ctx->gemv_rows > 0 ? ctx->gemv_rows : (A->n_rows >= 16 * 1024 ? 4 : 1);
+    const int rows_per_wg = (BS / 64) * rows;
+    const int grid = (int)((A->n_rows + rows_per_wg - 1) / rows_per_wg);
+    if (rows == 4)
+        hipLaunchKernelGGL(k_gemv_dense<4>, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols, A->a, A->lda, x, y);
+    else if (rows == 2)
+        hipLaunchKernelGGL(k_gemv_dense<2>, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols, A->a, A->lda, x, y);
+    else
+        hipLaunchKernelGGL(k_gemv_dense<1>, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols, A->a, A->lda, x, y);
+}
+
 // y = A x for one column; epi/aux select the fused epilogue of the CSR kernel (its partial sums
 // land in A->part and are reduced into scal_out with `rmode` of k_reduce_partials).
 int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const double* aux,
@@ -391,10 +406,7 @@ int apply_one(kh_ctx ctx, kh_mat A, const double* x, double* y, int epi, const d
     }
     KH_ARG(epi == EPI_NONE, "fused epilogues exist for CSR operators only");
     if (A->kind == KH_MAT_DENSE) {
-        const int rows_per_wg = BS / 64;
-        const int grid = (int)((A->n_rows + rows_per_wg - 1) / rows_per_wg);
-        hipLaunchKernelGGL(k_gemv_dense, dim3(grid), dim3(BS), 0, ctx->stream, A->n_rows, A->n_cols,
-                           A->a, A->lda, x, y);
+        gemv_dense(ctx, A, x, y);
     } else {
         const int grid = (int)std::min<int64_t>((A->n_rows + BS - 1) / BS, ctx->nb * 2);
         hipLaunchKernelGGL(k_diag_apply, dim3(std::max(grid, 1)), dim3(BS), 0, ctx->stream,
@@ -1509,6 +1521,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
+    else if (!strcmp(key, "gemv_rows")) ctx->gemv_rows = (int)value;       // rows per wave of the dense GEMV (0: by size; 1 / 2 / 4)
     else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
         ctx->blk2_cw = (int)value;
         ctx->blk2_cw_maxrows = value == 2 ? 6 : 7;
@@ -1581,6 +1594,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_blk")) *value = ctx->n_chain_blk;
     else if (!strcmp(key, "chain_blk2")) *value = ctx->chain_blk2;
     else if (!strcmp(key, "chain_blk2_cw")) *value = ctx->blk2_cw;
+    else if (!strcmp(key, "gemv_rows")) *value = ctx->gemv_rows;
     else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;

@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE, build container only (needs ``/root/reference``; about half an hour of host time and 45 GB of
 memory, which is why it is not part of ``python -m oracle.gen_golden``)::
 
-    python -m oracle.gen_golden_full [2] [3] [4]     # writes tests/golden/config{2,3,4}_full.npz
+    python -m oracle.gen_golden_full [2] [3] [4] [5]     # writes tests/golden/config{2,3,4}_full.npz, config5_flow.npz
 
 What rounds 1-4 compared the GPU with at these sizes was the build's own CPU restatement (``oracle/krylov_ref.py``), run
 on the GPU box for two minutes per config.  These fixtures pin the same runs to the unmodified reference itself
@@ -141,13 +141,50 @@ def gen_config4(krypy, n=32768):
          A_diag_head=np.diag(A)[:64].copy(), b_head=b[:64].copy(), reference_seconds=dt)
 
 
+def gen_config5_flow(krypy, n1=130, m=60, d=16):
+    """BASELINE.json configs[4]'s flow at a size the reference finishes in minutes (a 130^3 grid, N = 2.2 M - long enough for
+    the device's fused deflated step, one-launch projector and SpMM set-up to run as they do at 12.5 M rows per rank): plain
+    GMRES(m) as `DeflatedGmres(U=None)` (recycling/linsys.py:51-103), the d Ritz vectors of smallest magnitude
+    (deflation.py:738-847, factories.py:167-194), `DeflatedGmres(U)` (deflation.py:93-163) - and the reference's own movement
+    when U is perturbed by one rounding error per entry (the deflated solve depends on span(U) only)."""
+    from oracle.krylov_ref import laplace3d
+    A = laplace3d(n1, n1, n1)
+    N = A.shape[0]
+    b = np.random.default_rng(0).standard_normal(N)
+
+    def run(U):
+        ls = krypy.linsys.LinearSystem(A, b, self_adjoint=True)
+        try:
+            return krypy.deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, store_arnoldi=U is None)
+        except krypy.utils.ConvergenceError as e:
+            return e.solver
+
+    t0 = time.perf_counter()
+    s0 = run(None)
+    ritz = krypy.deflation.Ritz(s0)
+    idx = np.argsort(np.abs(ritz.values))[:d]
+    U = ritz.get_vectors(idx)
+    assert U.shape == (N, d)
+    s1 = run(U)
+    dt = time.perf_counter() - t0
+    print("reference flow (GMRES(%d), %d Ritz vectors, DeflatedGmres(%d)) at N = %d: %.1f s" % (m, d, m, N, dt), flush=True)
+    s1p = run(U * (1.0 + 1e-15 * np.random.default_rng(1).standard_normal(U.shape)))
+    w1, w1p = np.array(s1.resnorms), np.array(s1p.resnorms)
+    sens = float(np.max(np.abs(w1p[:-1] - w1[:-1]) / w1[:-1]))
+    print("reference's own movement under one rounding error per entry of U: %.2e" % sens, flush=True)
+    rows = np.arange(0, N, 1009)            # prime stride: 2178 sampled rows of the Ritz vectors (the span test)
+    save("config5_flow", n1=n1, m=m, d=d, plain_resnorms=np.array(s0.resnorms), ritz_values_abs=np.sort(np.abs(ritz.values[idx])),
+         deflated_resnorms=w1, sens_deflated=sens, U_rows=rows, U_sample=np.ascontiguousarray(np.asarray(U)[rows, :]),
+         U_colnorms=np.linalg.norm(np.asarray(U), axis=0), reference_seconds=dt)
+
+
 def main(argv):
     warnings.simplefilter("ignore")
     os.makedirs(OUT, exist_ok=True)
     krypy = refshim.load()
-    which = [int(a) for a in argv] or [2, 3, 4]
+    which = [int(a) for a in argv] or [2, 3, 4, 5]
     for c in which:
-        {2: gen_config2, 3: gen_config3, 4: gen_config4}[c](krypy)
+        {2: gen_config2, 3: gen_config3, 4: gen_config4, 5: gen_config5_flow}[c](krypy)
 
 
 if __name__ == "__main__":

@@ -1276,3 +1276,27 @@ def test_general_csr_operators_of_the_bench_tool(hip, kind, n):
     assert live.sum() >= 5
     assert np.max(np.abs(res[live] - wres[live]) / wres[live]) < 1e-10
     assert np.linalg.norm(sol.xk[:, 0] - want.xk) < 1e-10 * np.linalg.norm(want.xk)
+
+
+@pytest.mark.parametrize("n_rows,n_cols", [(1, 7), (5, 64), (257, 511), (1030, 1030), (4099, 2048), (16390, 1536)])
+def test_dense_gemv_rows_per_wave_same_bits(hip, n_rows, n_cols):
+    """k_gemv_dense<ROWS> (kernels.h): two or four rows of the operator per wave share every load of x; each row keeps its
+    own accumulators and their order, so the product is bit for bit the one-row-per-wave kernel's - ragged row counts
+    (a wave with fewer rows than ROWS, a workgroup with idle waves), odd column counts (the unaligned path), and the
+    default choice (four rows from 16 K rows on)."""
+    rng = np.random.default_rng(n_rows)
+    A = rng.standard_normal((n_rows, n_cols))
+    x = rng.standard_normal(n_cols)
+    Ad, X, Y = hip.dense(A), hip.upload(x), hip.alloc(n_rows, 1)
+    got = {}
+    try:
+        for rows in (1, 2, 4, 0):
+            hip.set("gemv_rows", rows)
+            Y.upload(0, np.full((n_rows, 1), np.nan))
+            hip.apply(Ad, X, 0, Y, 0, 1)
+            got[rows] = Y.download()[:, 0]
+    finally:
+        hip.set("gemv_rows", 0)
+    assert np.allclose(got[1], A.dot(x), rtol=1e-12, atol=1e-11 * np.abs(A).max() * np.abs(x).max() * n_cols)
+    for rows in (2, 4, 0):
+        assert np.array_equal(got[rows], got[1]), rows

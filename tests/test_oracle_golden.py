@@ -365,3 +365,27 @@ def test_oracle_against_the_fullsize_fixtures(golden, config):
     finally:
         if lim is not None:
             lim.restore_original_limits()
+
+
+@pytest.mark.skipif(not _FULL, reason="five minutes of host work: run with KRYPY_AMD_FULLSIZE_ORACLE=1 "
+                                      "(its output is committed as profiles/r05_fullsize_parity.log)")
+def test_oracle_against_the_config5_flow_fixture(golden):
+    """The CPU oracle's gmres -> ritz_vectors_smallest -> deflated_gmres against the reference's own run of config 5's flow at
+    N = 2.2 M (tests/golden/config5_flow.npz, oracle/gen_golden_full.py): histories, Ritz values, the span of the vectors."""
+    g = golden("config5_flow")
+    n1, m, d = int(g["n1"]), int(g["m"]), int(g["d"])
+    A = ref.laplace3d(n1, n1, n1)
+    b = np.random.default_rng(0).standard_normal(A.shape[0])
+    o0 = ref.gmres(A, b, tol=1e-12, maxiter=m)
+    vals, Uo = ref.ritz_vectors_smallest(o0, d, self_adjoint=True)
+    o1 = ref.deflated_gmres(A, b, Uo, tol=1e-12, maxiter=m)
+    S = Uo[g["U_rows"], :]
+    C = np.linalg.lstsq(S, g["U_sample"], rcond=None)[0]
+    dev = dict(plain_resnorms_max_rel=relmax(np.array(o0.resnorms)[:-1], g["plain_resnorms"][:-1]),
+               ritz_values_max_rel=relmax(np.sort(np.abs(vals)), g["ritz_values_abs"]),
+               deflated_resnorms_max_rel=relmax(np.array(o1.resnorms)[:-1], g["deflated_resnorms"][:-1]),
+               span_on_sampled_rows=float(np.linalg.norm(S.dot(C) - g["U_sample"]) / np.linalg.norm(g["U_sample"])))
+    _fullsize_report("ORACLE vs REFERENCE config 5 flow (GMRES(60) -> 16 Ritz vectors -> DeflatedGmres(60), N = 2.2e6): " +
+                     ", ".join("%s = %.3e" % kv for kv in dev.items()) + ", reference's own movement of the deflated history: %.1e" % g["sens_deflated"])
+    assert dev["plain_resnorms_max_rel"] < RTOL and dev["ritz_values_max_rel"] < 1e-8
+    assert dev["deflated_resnorms_max_rel"] < max(RTOL, 30.0 * float(g["sens_deflated"])) and dev["span_on_sampled_rows"] < 1e-7

@@ -8,7 +8,7 @@ mkdir -p gpurun_out/ev
 case $WHAT in
 tests)
   rm -f gpurun_out/ev/fullsize_parity.log
-  KRYPY_AMD_PARITY_LOG=$PWD/gpurun_out/ev/fullsize_parity.log python -m pytest tests -m gpu -q > gpurun_out/ev/gputest.log 2>&1
+  KRYPY_AMD_PARITY_LOG=$PWD/gpurun_out/ev/fullsize_parity.log python -m pytest tests -m gpu -q --durations=40 > gpurun_out/ev/gputest.log 2>&1 < /dev/null
   tail -4 gpurun_out/ev/gputest.log
   python __graft_entry__.py smoke > gpurun_out/ev/smoke.log 2>&1; tail -1 gpurun_out/ev/smoke.log
   cat gpurun_out/ev/fullsize_parity.log
@@ -56,6 +56,9 @@ fallback)
   F="tests/test_gpu_parity.py tests/test_gpu_complex.py tests/test_gpu_blocked.py tests/test_gpu_halo_loopback.py tests/test_gpu_xr.py tests/test_gpu_blk2.py"
   : > gpurun_out/ev/fallback.log
   run() { echo "## $1" >> gpurun_out/ev/fallback.log; env $1 python -m pytest $F -q -rfE -p no:cacheprovider 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|error" | cut -c1-420 >> gpurun_out/ev/fallback.log; echo >> gpurun_out/ev/fallback.log; }
+  if [ -n "${2:-}" ]; then          # tools/r05_evidence.sh fallback "<switch set>": that one set only
+    run "$2"; cat gpurun_out/ev/fallback.log; exit 0
+  fi
   run "KRYPY_AMD_TEST_FORCE_MULTI=1"
   run "KRYPY_AMD_MGS_CHAIN=0"
   run "KRYPY_AMD_CHAIN_BLK=0 KRYPY_AMD_MGS_LOWSYNC=0 KRYPY_AMD_PROJ_REG=0 KRYPY_AMD_MINRES_CYCLE=0 KRYPY_AMD_CG_CYCLE=0 KRYPY_AMD_GMRES_CYCLE=0"
@@ -63,6 +66,7 @@ fallback)
   run "KRYPY_AMD_CHAIN_PF=0 KRYPY_AMD_CHAIN_ONEX=0 KRYPY_AMD_CHAIN_SMALL=0 KRYPY_AMD_TAG_WAIT=0 KRYPY_AMD_LANCZOS_FUSED=0"
   run "KRYPY_AMD_CG_STEP=0 KRYPY_AMD_SPMV_SPLIT=0 KRYPY_AMD_PROJ_PANEL=0 KRYPY_AMD_CGS_REVERSE=0 KRYPY_AMD_BLK_NX=0 KRYPY_AMD_XR=0 KRYPY_AMD_CHAIN_BLK2=0 KRYPY_AMD_XH=0"
   run "KRYPY_AMD_BLK2_CW=0"
+  run "KRYPY_AMD_BLK2_CW=2"
   grep -c "^FAILED" gpurun_out/ev/fallback.log | sed 's/^/numeric FAILED lines in all switch sets: /' >> gpurun_out/ev/fallback.log
   cat gpurun_out/ev/fallback.log
   ;;
