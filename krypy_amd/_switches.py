@@ -75,6 +75,9 @@ SWITCHES = [
     ("KRYPY_AMD_CG_STEP", "1", "kernel-path", "0",
      "0: CG runs operator, inner product and updates as separate calls with the step length formed on the host instead of one fused "
      "`kh_cg_step` / `kh_zcg_step` per iteration"),
+    ("KRYPY_AMD_SPMV_WIN", "1", "kernel-path", "0",
+     "0: the CSR-stream SpMV gathers every entry of x from global memory instead of from an LDS window loaded once per row block "
+     "(operators whose row blocks touch at most 4096 neighbouring columns)"),
     ("KRYPY_AMD_SPMV_SPLIT", "1", "kernel-path", "0",
      "0: a sharded SpMV waits for its halo exchange and multiplies all rows in one launch instead of overlapping the exchange with the "
      "interior rows"),

@@ -455,7 +455,12 @@ __device__ __forceinline__ int xcd_unmap(int lb, int nblk) {
     return idx * 8 + xcd;
 }
 
-template <int EPI, int ITEMS>
+// WIN: the x entries a row block touches lie within `span` columns from `cmin` (blkwin, found at upload); where the span fits
+// the LDS window the workgroup loads x[cmin .. cmin + span) ONCE, coalesced, and gathers from LDS.  A gather from global memory
+// fills a 128-byte line for 8 bytes of x - on a matrix with entries at random places of a band that is ten times the bytes of
+// the matrix itself between L2 and the compute units (273 us as is, 95 us without the gather).  Same products in
+// the same order: the same bits.
+template <int EPI, int ITEMS, bool WIN = false>
 __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
                                                     const double* __restrict__ data,
@@ -466,8 +471,9 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                                                     double* __restrict__ y,
                                                     const double* __restrict__ aux,
                                                     double* __restrict__ part_out,
-                                                    int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0) {
-    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products
+                                                    int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0,
+                                                    const int32_t* __restrict__ blkwin = nullptr, int wcap = 0) {
+    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products (WIN: + wcap entries of x)
     __shared__ double sm[8];
     // a launch over a subset of the row blocks (interior / boundary rows of a shard, krylov_hip.hip): the
     // launch's blocks 0 .. blk_lo-1 are themselves, the others lie blk_skip further on
@@ -492,10 +498,24 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                 c[i] = __builtin_nontemporal_load(indices + nz0 + tc);
                 a[i] = __builtin_nontemporal_load(data + nz0 + tc);
             }
+            bool direct = true;
+            if constexpr (WIN) {
+                const int cmin = blkwin[2 * bid], span = blkwin[2 * bid + 1];
+                if (span <= wcap) {                                  // (the same for the whole workgroup)
+                    double* __restrict__ xw = prod + tile;
+                    for (int j = threadIdx.x; j < span; j += BS) xw[j] = x[cmin + j];
+                    __syncthreads();
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
-                a[i] = a[i] * xv;
+                    for (int i = 0; i < ITEMS; ++i) a[i] = a[i] * xw[c[i] - cmin];
+                    direct = false;
+                }
+            }
+            if (direct) {
+#pragma unroll
+                for (int i = 0; i < ITEMS; ++i) {
+                    const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
+                    a[i] = a[i] * xv;
+                }
             }
 #pragma unroll
             for (int i = 0; i < ITEMS; ++i) {

@@ -156,6 +156,8 @@ struct kh_ctx_s {
     } mr_pending;
     int64_t n_minres_rides = 0;   // deferred MINRES updates that went along with a Lanczos launch
     int chain_lds = 1;      // park the head of every column in LDS (k_mgs_chain_lds; KRYPY_AMD_CHAIN_LDS)
+    int spmv_win = 1;       // CSR-stream kernel: gather x from an LDS window where a row block's columns fit one (KRYPY_AMD_SPMV_WIN)
+    int64_t n_spmv_win = 0;
     int spmv_dia = 1;       // use the banded copy of a CSR operator when it has one (kh_ctx_set "spmv_dia")
     unsigned long long* chain_gran = nullptr;
     unsigned long long* chain_xcc = nullptr;   // per-XCD result granules + leader stamps of the grid-wide sums
@@ -231,6 +233,8 @@ struct kh_mat_s {
     int32_t* indices = nullptr;
     double* data = nullptr;
     int32_t* rowblk = nullptr;  // row-block boundaries of the CSR-stream kernel
+    int32_t* blkwin = nullptr;  // [nblk][cmin, span]: the columns a row block touches (k_spmv_stream<.., WIN>)
+    int win_cap = 0;            // LDS window (entries of x) of that kernel for this operator; 0: not worth it
     int nblk = 0;
     int tile = 0;
     double* part = nullptr;     // max(nblk, dia_nblk) partial sums for the fused dot / norm epilogues

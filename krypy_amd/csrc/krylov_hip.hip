@@ -239,6 +239,14 @@ static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, 
     const size_t lds = (size_t)A->tile * sizeof(double);
     const int grid = rg.grid < 0 ? A->nblk : rg.grid;
     if (grid == 0) return;
+    if (ctx->spmv_win && A->win_cap > 0 && A->blkwin != nullptr && A->nrecv_prev + A->nrecv_next == 0) {
+        // (no ghost columns: a window is a run of x itself)
+        hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS, true>), dim3(grid), dim3(BS), lds + (size_t)A->win_cap * sizeof(double),
+                           ctx->stream, A->indptr, A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
+                           aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, A->blkwin, A->win_cap);
+        ctx->n_spmv_win += 1;
+        return;
+    }
     hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(grid), dim3(BS), lds, ctx->stream, A->indptr,
                        A->indices, A->data, A->rowblk, A->nblk, A->tile,
                        A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part, rg.blk_lo, rg.blk_skip,
@@ -1394,6 +1402,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         e = getenv("KRYPY_AMD_BLK2_CW");
         ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
         ctx->blk2_cw_maxrows = ctx->blk2_cw == 2 ? 6 : 7;
+        e = getenv("KRYPY_AMD_SPMV_WIN");
+        ctx->spmv_win = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");
         ctx->proj_reg = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_PANEL");
@@ -1504,6 +1514,7 @@ int kh_ctx_tune(kh_ctx ctx, int reduce_blocks, int spmv_tile) {
 int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     KH_ARG(ctx != nullptr && key != nullptr, "kh_ctx_set: NULL");
     if (!strcmp(key, "spmv_dia")) ctx->spmv_dia = value != 0;
+    else if (!strcmp(key, "spmv_win")) ctx->spmv_win = value != 0;
     else if (!strcmp(key, "chain")) {
         ctx->chain_enabled = ctx->chain_configured = (value != 0 && ctx->ncu <= CH_GMAX);
         ctx->chain_recoveries = 0;          // (an explicit setting starts the count again)
@@ -1573,6 +1584,8 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
 int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     KH_ARG(ctx != nullptr && key != nullptr && value != nullptr, "kh_ctx_get: NULL");
     if (!strcmp(key, "spmv_dia")) *value = ctx->spmv_dia;
+    else if (!strcmp(key, "spmv_win")) *value = ctx->spmv_win;
+    else if (!strcmp(key, "n_spmv_win")) *value = ctx->n_spmv_win;
     else if (!strcmp(key, "chain")) *value = ctx->chain_enabled;
     else if (!strcmp(key, "chain_recoveries")) *value = ctx->chain_recoveries;
     else if (!strcmp(key, "n_chain_rearmed")) *value = ctx->n_chain_rearmed;
@@ -2029,6 +2042,36 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
         }
         KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
         if (banded) KH_TRY(build_dia(ctx, A, offs));
+        // the columns every row block touches (k_spmv_stream<.., WIN>): where nine blocks in ten fit an LDS window of at most
+        // SPMV_WIN_CAP entries of x, the operator's launches carry a window as wide as the widest of those
+        if (A->nblk > 0 && nnz > 0) {
+            constexpr int SPMV_WIN_CAP = 4096;              // 32 KB beside the tile of products (16 ... 32 KB)
+            std::vector<int32_t> win(2 * (size_t)A->nblk);
+            int64_t fit = 0;
+            int widest = 0;
+            for (int b = 0; b < A->nblk; ++b) {
+                const int32_t z0 = indptr[blk[b]], z1 = indptr[blk[b + 1]];
+                int32_t lo = 0, hi = -1;
+                if (z1 > z0) {
+                    lo = hi = indices[z0];
+                    for (int32_t z = z0 + 1; z < z1; ++z) {
+                        lo = std::min(lo, indices[z]);
+                        hi = std::max(hi, indices[z]);
+                    }
+                }
+                win[2 * (size_t)b] = lo;
+                win[2 * (size_t)b + 1] = hi - lo + 1;
+                if (z1 - z0 <= A->tile && hi - lo + 1 <= SPMV_WIN_CAP) {
+                    fit += 1;
+                    widest = std::max(widest, hi - lo + 1);
+                }
+            }
+            if (fit * 10 >= (int64_t)A->nblk * 9 && widest > 0) {
+                KH_HIP(hipMalloc(&A->blkwin, sizeof(int32_t) * win.size()));
+                KH_HIP(hipMemcpy(A->blkwin, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
+                A->win_cap = widest;
+            }
+        }
         return 0;
     };
     const int rc = body();
@@ -2094,6 +2137,7 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->indices);
     (void)hipFree(A->data);
     (void)hipFree(A->rowblk);
+    (void)hipFree(A->blkwin);
     (void)hipFree(A->part);
     (void)hipFree(A->dia);
     (void)hipFree(A->zdia);

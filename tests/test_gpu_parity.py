@@ -1259,8 +1259,23 @@ def test_general_csr_operators_of_the_bench_tool(hip, kind, n):
     Ad = hip.csr(A)
     assert Ad.diagonals == 0
     X, Y = hip.upload(b), hip.alloc(n, 1)
+    # the row blocks of "band" touch ~2,100 neighbouring columns each: x comes from an LDS window loaded once per block
+    # (k_spmv_stream<.., WIN>); "ragged" spans +-20,000 columns: gathers from global memory.  Both ways, the fused residual
+    # and dot epilogues included: scipy's bits.
+    w0 = hip.get("n_spmv_win")
     hip.apply(Ad, X, 0, Y, 0, 1)
     assert np.array_equal(Y.download()[:, 0], A.dot(b))
+    used = hip.get("n_spmv_win") - w0
+    R, B = hip.alloc(n, 1), hip.upload(np.arange(n) % 7 - 3.0)
+    nrm = hip.residual(Ad, B, 0, X, 0, R, 0)
+    assert np.array_equal(R.download()[:, 0], (np.arange(n) % 7 - 3.0) - A.dot(b)) and abs(nrm - np.linalg.norm(R.download())) <= 1e-13 * nrm
+    hip.set("spmv_win", 0)
+    try:
+        hip.apply(Ad, X, 0, Y, 0, 1)
+        assert np.array_equal(Y.download()[:, 0], A.dot(b))
+    finally:
+        hip.set("spmv_win", 1)
+    expect_kernel(used == (1 if kind == "band" else 0), "products through the LDS window: %r" % (used,))
     f0 = hip.counters()["chain_fused"]
     try:
         sol = linsys.Gmres(linsys.LinearSystem(A, b), maxiter=40, tol=1e-30)
