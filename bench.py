@@ -156,7 +156,10 @@ def parse_args():
     ap.add_argument("--cpu-budget-s", type=float, default=130.0,
                     help="seconds of CPU work the oracle's timed GMRES(100) cycle may take before it is cut "
                          "and extrapolated (a full cycle at N = 10^7 takes about two minutes)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.loop_halo and not (args.force_sharded and args.gpus == 1):
+        ap.error("--loop-halo: with --force-sharded on one rank (--gpus 1)")
+    return args
 
 
 def _blas_threads():

@@ -339,6 +339,18 @@ def test_bench_gpus_n_refuses_when_fewer_devices_are_visible():
         assert p.returncode != 0 and p.stdout.strip() == b"" and b"WORLD_SIZE=1" in p.stderr, p.stderr[-500:]
 
 
+def test_bench_loop_halo_needs_the_forced_one_rank_path():
+    """`--loop-halo` (one rank as a middle slab, its own neighbour) means something on ONE rank in forced multi-rank mode only:
+    anywhere else the command line is refused - it is not silently a different measurement."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for argv in (["--loop-halo"], ["--loop-halo", "--force-sharded", "--gpus", "2"]):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv + ["--steps", "1", "--warmup", "0"], cwd=root,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert p.returncode != 0 and p.stdout.strip() == b"" and b"--loop-halo" in p.stderr, p.stderr[-500:]
+
+
 def test_bench_gpus_n_reports_a_failed_rank():
     """A rank that dies must not leave the launcher waiting nor a JSON line behind: here every rank fails at argument
     checks that only the rank processes run (restart length larger than the local slab allows is fine; an unknown
