@@ -148,3 +148,23 @@ def test_bench_config5_two_ranks_share_the_one_gpu(hip):
         assert abs(one["plain_relres"] - c["plain_relres"]) <= 1e-8 * one["plain_relres"], (ortho, one["plain_relres"], c["plain_relres"])
         assert abs(one["deflated_relres"] - c["deflated_relres"]) <= 1e-6 * one["deflated_relres"], (ortho, one["deflated_relres"], c["deflated_relres"])
         assert np.allclose(one["smallest_ritz_values"], c["smallest_ritz_values"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("ranks", [3, 4])
+def test_bench_middle_ranks_share_the_one_gpu(hip, ranks):
+    """Three and four rank processes on the one device (`--share-devices --transport xr`): ranks with TWO neighbours - both
+    ghost regions of a slab filled from two other processes inside the SpMV's launch, a sum across more than two mailboxes, an
+    uneven split of the rows (300 = 75 x 4, 100 x 3; the Gram-Schmidt kernels are chosen for the longest slab) - against one
+    rank: the same residual after the same iterations, panel form and reference order."""
+    common = ["--steps", "2", "--warmup", "1", "--nx", "400", "--ny", "300", "--restart", "40", "--no-cpu-baseline",
+              "--no-roofline", "--other-modes", "none"]
+    for ortho in ("cgs", "mgs"):
+        rc, lines, err = _bench(["--gpus", str(ranks), "--share-devices", "--transport", "xr", "--ortho", ortho] + common)
+        assert rc == 0 and len(lines) == 1, err[-3000:]
+        many = json.loads(lines[0])
+        c = many["config"]
+        assert many["n_gpus"] == 1 and c["ranks"] == ranks and c["cross_rank_sums"] == "xr" and c["halo"] == "in-launch"
+        rc, lines, err = _bench(["--gpus", "1", "--ortho", ortho] + common)
+        assert rc == 0 and len(lines) == 1, err[-3000:]
+        one = json.loads(lines[0])["config"]
+        assert abs(one["final_relres"] - c["final_relres"]) <= 1e-9 * one["final_relres"], (ortho, one["final_relres"], c["final_relres"])
