@@ -149,7 +149,9 @@ def parse_args():
     ap.add_argument("--share-devices", action="store_true",
                     help="testing: --gpus N ranks on FEWER than N devices (rank r on device r mod the visible ones); only with "
                          "--transport xr (RCCL refuses two ranks on one device).  The line then reports n_gpus = the devices "
-                         "really used and config.ranks = N")
+                         "really used and config.ranks = N.  For small problems: the ranks' kernels wait for each other inside "
+                         "their launches, so all of them must fit on the shared device together (at the benchmark's size one "
+                         "rank's blocked kernel fills it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the kernel micro-benchmarks (profiling runs that want the solver's kernels only)")
