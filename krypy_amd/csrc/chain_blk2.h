@@ -162,13 +162,18 @@ __device__ __forceinline__ void blk2_alphas(const double* tot, int nvalid, doubl
 // CW: wave 0 of every workgroup owns NO rows - it publishes, gathers and forms the coefficients, and a poll of a wave that has
 // requested nothing returns as soon as the total is there (vector-memory results return to a wave in order: with rows of its
 // own wave 0 sees the total only behind its rows of the next block).  The other seven waves carry the rows: 448 lanes.
-template <int R2, bool MASKED, bool XR, bool CW = false>
+// ONE: a single block of BC columns in registers beside w (20 R2 registers instead of 36 R2): slabs of 8 ... 11 rows per lane, up to
+// 2.5 M rows - a rank's share of the benchmark problem on FOUR devices.  Nothing of the next block is in flight under a sum
+// (its registers hold the block the update still needs): the stream and the exchange take turns, and the basis is still read
+// ONCE per step where the panel forms read it twice.
+template <int R2, bool MASKED, bool XR, bool CW = false, bool ONE = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs bf, XrDev xr) {
     constexpr int BC = BLK_BC;
     constexpr int NG = BlkShape<BC>::NG;
     constexpr int NW = CH_BS / 64;
     constexpr int NWORK = CW ? CH_BS - 64 : CH_BS;          // lanes with rows
-    static_assert(R2 >= 4 && R2 <= (CW ? 7 : 6), "two blocks of BC columns and w: 36 R2 registers of the 256 a lane has");
+    static_assert(R2 >= 4 && R2 <= (ONE ? 11 : (CW ? 7 : 6)), "two blocks of BC columns and w: 36 R2 registers of the 256 a lane has (one block: 20 R2)");
+    constexpr int NSLOT = ONE ? 1 : 2;
     __shared__ BlkSm sm;
     __shared__ int slead;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
 #define CH_COL(j) (reinterpret_cast<const char*>(a.V + (a.col0 + ((j) < total ? (j) : total - 1)) * a.ld))
 #define CH_ROW(c, r) (*reinterpret_cast<const double2*>((c) + (size_t)(r) * (NWORK * sizeof(double2)) + boff))
     const unsigned boff = (unsigned)first * (unsigned)sizeof(double2);
-    double2 ring[2][BC][R2];
+    double2 ring[NSLOT][BC][R2];
     double2 w[R2];
     {
         const double2* __restrict__ win2 = reinterpret_cast<const double2*>(a.w_in) + first;
@@ -354,12 +359,15 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
         sum_begin(i, gval);
         // (behind the last block the request is clamped to the last block - no conditional around the requests, or the
         // compiler's wait counts at the loop's back edge become "everything")
-        request(i + 1, std::integral_constant<int, 1 - S>{});
+        if constexpr (!ONE) request(i + 1, std::integral_constant<int, 1 - S>{});
         sum_end(i, gval);
         update(slot_c);
-        dots(i + 1, std::integral_constant<int, 1 - S>{});      // (behind the last block: discarded)
+        if constexpr (ONE) request(i + 1, slot_c);              // (the one slot is free now)
+        dots(i + 1, std::integral_constant<int, ONE ? 0 : 1 - S>{});      // (behind the last block: discarded)
     };
-    {
+    if constexpr (ONE) {
+        for (int ib = 0; ib < nblk; ++ib) block(ib, std::integral_constant<int, 0>{});
+    } else {
         int ib = 0;
         for (; ib + 2 <= nblk; ib += 2) {
             block(ib, std::integral_constant<int, 0>{});
@@ -383,14 +391,14 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_blk2(ChainArgs a, BlkBufs b
             const double ws = wave_sum_dpp(acc);
             if (lane == 0) sm.part[0 * NW + wid] = ws;
         }
-        const int sl = (nblk - 1) & 1;
+        const int sl = ONE ? 0 : ((nblk - 1) & 1);
         const int pnew = total % BC;
 #pragma unroll
         for (int m = 0; m < BC - 1; ++m) {
             double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
-                double2 v0 = ring[0][m][r], v1 = ring[1][m][r];
+                double2 v0 = ring[0][m][r], v1 = ring[NSLOT - 1][m][r];
                 if (MASKED && !CH_OK(r)) v0 = v1 = make_double2(0.0, 0.0);
                 s0a = fma(v0.x, w[r].x, s0a);
                 s0b = fma(v0.y, w[r].y, s0b);

@@ -15,15 +15,17 @@ static constexpr size_t BLK_GRAN2_WORDS = (size_t)2 * BLK_NG2 * BLK_NVS * 2;
 // rows of 16 B per lane (4, 5 or 6), workgroups WITH rows and whether wave 0 is a communication wave (448 lanes with rows instead of
 // 512) for a vector of n doubles: the fewest rows whose grid fits the chip - beside the workgroups without rows when there is room
 // for them; with a communication wave where that fits (KRYPY_AMD_BLK2_CW: 1 = where it fits, 0 = never), else without
-bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out) {
+bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out, bool one_slot) {
     if (n < 2 || ctx->ncu > CH_GMAX / 2) return false;
     const int64_t n2 = (n + 1) >> 1;
     const int room = ctx->ncu - (ctx->blk_nx > 0 ? ctx->blk_nx : 0);
     // In order of measured speed: a communication wave and up to 6 rows per lane (no spills), the same with 7 rows (92 B of
     // scratch per lane), then all 512 lanes with rows (6 rows: 320 B of scratch).  Within each: first with room left for the
     // workgroups without rows, then without (6 rows without them beat 7 rows with them: 6,030 against 5,710 it/s at 1.36 M rows).
-    const int tiers[3][3] = {{1, 4, 6}, {1, 7, ctx->blk2_cw_maxrows}, {0, 4, 6}};       // {communication wave, rows from, rows to}
-    for (int t = ctx->blk2_cw ? 0 : 2; t < 3; ++t) {
+    // Last, when the caller takes them: 8 ... 11 rows per lane with ONE block in registers (communication wave, no spills).
+    const int tiers[4][3] = {{1, 4, 6}, {1, 7, ctx->blk2_cw_maxrows}, {0, 4, 6}, {1, 8, 11}};       // {communication wave, rows from, rows to}
+    const int ntier = (one_slot && ctx->blk2_cw) ? 4 : 3;
+    for (int t = ctx->blk2_cw ? 0 : 2; t < ntier; ++t) {
         const int cw = tiers[t][0];
         const int nwork = cw ? CH_BS - 64 : CH_BS;
         for (int pass = 0; pass < 2; ++pass) {
@@ -42,10 +44,10 @@ bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_ou
     return false;
 }
 
-template <int R2, bool MASKED, bool XR, bool CW>
+template <int R2, bool MASKED, bool XR, bool CW, bool ONE = false>
 static hipError_t launch_blk2(kh_ctx ctx, int G, ChainArgs& a, BlkBufs bf, const XrDev& xr) {
     static int blocks_per_cu = -1;
-    auto kern = k_mgs_chain_blk2<R2, MASKED, XR, CW>;
+    auto kern = k_mgs_chain_blk2<R2, MASKED, XR, CW, ONE>;
     if (blocks_per_cu < 0) {
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, 0);
@@ -70,7 +72,8 @@ int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t 
                     bool multi) {
     const int64_t n = V->n;
     int r2 = 0, G = 0, cwi = 0;
-    if (!ctx->chain_blk2 || !ctx->chain_configured || !chain_blk2_shape(ctx, n, &r2, &G, &cwi) || k + 3 > BLK_TABCOLS ||
+    if (!ctx->chain_blk2 || !ctx->chain_configured || !chain_blk2_shape(ctx, n, &r2, &G, &cwi, ctx->blk2_one >= (multi ? 1 : 2)) ||
+        k + 3 > BLK_TABCOLS ||
         ((n & 1) && (V->ld <= n || wld <= n)) || (!multi && ctx->blk2_refused_n == n)) {
         if (multi) return fail(KH_ERR_COMM, "blocked Gram-Schmidt with in-kernel cross-rank sums: a slab of %lld rows is not served "
                                             "here although the run's longest slab was found eligible", (long long)n);
@@ -152,7 +155,19 @@ int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t 
 #define KH_B2C(R, C) (multi ? (padded ? launch_blk2<R, false, true, C>(ctx, G, a, bf, xr) : launch_blk2<R, true, true, C>(ctx, G, a, bf, xr)) \
                             : (padded ? launch_blk2<R, false, false, C>(ctx, G, a, bf, xr) : launch_blk2<R, true, false, C>(ctx, G, a, bf, xr)))
 #define KH_B2(R) (cw ? KH_B2C(R, true) : KH_B2C(R, false))
-    e = r2 == 4 ? KH_B2(4) : (r2 == 5 ? KH_B2(5) : (r2 == 6 ? KH_B2(6) : KH_B2C(7, true)));
+#define KH_B2ONE(R) (multi ? (padded ? launch_blk2<R, false, true, true, true>(ctx, G, a, bf, xr) : launch_blk2<R, true, true, true, true>(ctx, G, a, bf, xr)) \
+                           : (padded ? launch_blk2<R, false, false, true, true>(ctx, G, a, bf, xr) : launch_blk2<R, true, false, true, true>(ctx, G, a, bf, xr)))
+    switch (r2) {
+        case 4: e = KH_B2(4); break;
+        case 5: e = KH_B2(5); break;
+        case 6: e = KH_B2(6); break;
+        case 7: e = KH_B2C(7, true); break;
+        case 8: e = KH_B2ONE(8); break;
+        case 9: e = KH_B2ONE(9); break;
+        case 10: e = KH_B2ONE(10); break;
+        default: e = KH_B2ONE(11); break;
+    }
+#undef KH_B2ONE
 #undef KH_B2C
 #undef KH_B2
     if (e != hipSuccess) {

@@ -108,6 +108,7 @@ struct kh_ctx_s {
     int chain_blk2 = 1;              // KRYPY_AMD_CHAIN_BLK2: the eight-wave blocked kernel (4 ... 6 rows per lane; on N ranks with the
                                      // cross-rank sums inside the launch)
     int blk2_cw = 1;                 // KRYPY_AMD_BLK2_CW: wave 0 of the eight-wave blocked kernel owns no rows where that shape fits (448 lanes with rows)
+    int blk2_one = 1;                // the one-block shapes of chain_blk2.h: 0 never, 1 on a communicator (default), 2 on one GPU too (KRYPY_AMD_BLK2_ONE)
     int gemv_rows = 0;               // rows per wave of k_gemv_dense (0: chosen by size)
     int blk2_cw_maxrows = 7;         // rows per lane up to which the communication-wave shape is used (KRYPY_AMD_BLK2_CW=2: 6, for A / B)
     int64_t n_chain_blk2 = 0;
@@ -323,7 +324,8 @@ static inline void chain_blk_touch(kh_ctx ctx, const void* v) {
 }
 hipError_t chain_blk_reset(kh_ctx ctx);
 // chain_blk2.hip: the eight-wave blocked kernel with the cross-rank stage
-bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out = nullptr);
+// one_slot: may the shapes with ONE block in registers (8 ... 11 rows per lane, up to 2.5 M rows) be offered
+bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out = nullptr, bool one_slot = false);
 int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount,
                     bool multi);
 // krylov_hip.hip: the epoch counter of the grid-wide sums brought back to 1 when it nears its wrap; <V[:, j0 .. j0+ncols), w> on the device

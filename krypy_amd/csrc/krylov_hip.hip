@@ -616,7 +616,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g)) ld = (int64_t)g * r2 * CH_BS * 2;
     if (n >= (1 << 12) && chain_geometry(ctx, n, &r2, &g, true)) ld = std::max(ld, (int64_t)g * r2 * CH_BS * 2);   // (one-XCD shape)
     int cw = 0;
-    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g, &cw))      // (chain_blk2.h: 4 ... 7 rows, 448 or 512 lanes with rows)
+    if (n >= (1 << 12) && chain_blk2_shape(ctx, n, &r2, &g, &cw, ctx->blk2_one >= 1))      // (chain_blk2.h: 4 ... 11 rows, 448 or 512 lanes with rows)
         ld = std::max(ld, (int64_t)g * r2 * (cw ? CH_BS - 64 : CH_BS) * 2);
     return ld == 0 ? 32 : ld;
 }
@@ -694,9 +694,9 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     // operator to be fused (Afuse) nothing is launched here, the caller runs the SpMV and comes back without it.
     {
         int r2b = 0, Gb = 0;
-        if (ctx->chain_blk2 && ctx->chain_blk && ctx->chain_small && r2 == 8 && !want_onex && B == V && dg == nullptr && !cplx && !presub &&
+        if (ctx->chain_blk2 && ctx->chain_blk && ctx->chain_small && (r2 == 8 || (r2 == 16 && ctx->blk2_one >= 2)) && !want_onex && B == V && dg == nullptr && !cplx && !presub &&
             sweeps == 1 && start == 0 && k + 1 >= KH_BLK_MIN_LINKS && (ctx->chain_debug == 0) && n != ctx->blk2_refused_n &&
-            chain_blk2_shape(ctx, n, &r2b, &Gb) && r2b > 4) {
+            chain_blk2_shape(ctx, n, &r2b, &Gb, nullptr, ctx->blk2_one >= 2) && r2b > 4) {
             if (Afuse != nullptr) return 0;
             const int rc = chain_blk2_step(ctx, V, w, wld, k, hdev, slot, hpin, hcount, false);
             if (rc != 0) {
@@ -1402,6 +1402,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         e = getenv("KRYPY_AMD_BLK2_CW");
         ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
         ctx->blk2_cw_maxrows = ctx->blk2_cw == 2 ? 6 : 7;
+        e = getenv("KRYPY_AMD_BLK2_ONE");
+        ctx->blk2_one = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_SPMV_WIN");
         ctx->spmv_win = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");
@@ -1532,6 +1534,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_small")) ctx->chain_small = value != 0;
     else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
+    else if (!strcmp(key, "chain_blk2_one")) { ctx->blk2_one = (int)value; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "gemv_rows")) ctx->gemv_rows = (int)value;       // rows per wave of the dense GEMV (0: by size; 1 / 2 / 4)
     else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
         ctx->blk2_cw = (int)value;
@@ -1608,6 +1611,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_blk2")) *value = ctx->chain_blk2;
     else if (!strcmp(key, "chain_blk2_cw")) *value = ctx->blk2_cw;
     else if (!strcmp(key, "gemv_rows")) *value = ctx->gemv_rows;
+    else if (!strcmp(key, "chain_blk2_one")) *value = ctx->blk2_one;
     else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;
@@ -2535,7 +2539,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
             if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
         int r2m = 0, gm = 0;
-        want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm) && k + 3 <= 4096;
+        want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm, nullptr, ctx->blk2_one >= 1) && k + 3 <= 4096;
     }
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
                             A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync && !want_blk2);

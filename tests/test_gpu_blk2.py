@@ -21,7 +21,8 @@ def _cycle(linsys, utils, ls, m=100, **kw):
         return e.solver
 
 
-@pytest.mark.parametrize("nx,ny,cw", [(4000, 313, 1), (1500, 1000, 1), (1201, 907, 1), (1250, 1270, 1), (1500, 1000, 2), (1201, 907, 0)])
+@pytest.mark.parametrize("nx,ny,cw", [(4000, 313, 1), (1500, 1000, 1), (1201, 907, 1), (1250, 1270, 1), (1500, 1000, 2), (1201, 907, 0),
+                                      (2001, 901, 12), (4000, 625, 12)])
 def test_one_gpu_long_short_vectors_against_the_per_column_kernels(hip, nx, ny, cw):
     """One GPU, 1.09 ... 1.59 M rows (5, 6 and 7 rows per lane; the first shape is the slab one of eight ranks holds of the
     benchmark problem): a whole GMRES(100) cycle through the blocked kernel - steps of eight links and more - against the
@@ -30,11 +31,15 @@ def test_one_gpu_long_short_vectors_against_the_per_column_kernels(hip, nx, ny, 
     stops that form at 6 rows (1.5 M rows then take the 512-lane form with 6 rows), cw = 0 is the 512-lane form throughout."""
     from krypy_amd import linsys, utils
 
-    hip.set("chain_blk2_cw", cw)
+    # cw = 12: the default shapes + the ones with ONE block in registers (8 ... 11 rows per lane, 1.6 ... 2.5 M rows) allowed on
+    # one GPU too (chain_blk2_one = 2; by default they serve a communicator's slabs only)
+    hip.set("chain_blk2_cw", 1 if cw == 12 else cw)
+    hip.set("chain_blk2_one", 2 if cw == 12 else 1)
     try:
         _one_gpu_case(hip, linsys, utils, nx, ny)
     finally:
         hip.set("chain_blk2_cw", 1)
+        hip.set("chain_blk2_one", 1)
 
 
 def _one_gpu_case(hip, linsys, utils, nx, ny):
@@ -111,13 +116,14 @@ def xr_ctx(hip):
     ctx.close()
 
 
-@pytest.mark.parametrize("nx,ny", [(30, 30), (90, 90), (301, 211), (1000, 700), (4000, 313), (1500, 1000)])
+@pytest.mark.parametrize("nx,ny", [(30, 30), (90, 90), (301, 211), (1000, 700), (4000, 313), (1500, 1000), (2001, 901), (4000, 625)])
 def test_cross_rank_sums_inside_the_launch_loopback(xr_ctx, nx, ny):
     """ortho='mgs' on the multi-rank path with the xr transport on: every Arnoldi step is SpMV + ONE launch whose
     grid-wide sums include the cross-rank stage (publish to every rank's mailbox, poll the own one, add in rank order) -
     no all-reduce call.  30 steps against the CPU oracle's MGS and against the one-reduction form of the same context
     (chain_blk2 = 0) at 1e-10 (H) / 1e-9 (basis); 900 rows (masked, one workgroup), 8,100, 63,511 (odd), 700,000 (4 rows per
-    lane), 1.25 M (5 rows: one of eight ranks' slab of the benchmark problem), 1.5 M (6 rows)."""
+    lane), 1.25 M (5 rows: one of eight ranks' slab of the benchmark problem), 1.5 M (7 rows), and - ONE block in registers - 1.8 M
+    (8 rows, odd and masked) and 2.5 M rows (11 rows: one of FOUR ranks' slab)."""
     from krypy_amd import utils
 
     ctx = xr_ctx

@@ -64,7 +64,7 @@ fallback)
   run "KRYPY_AMD_CHAIN_BLK=0 KRYPY_AMD_MGS_LOWSYNC=0 KRYPY_AMD_PROJ_REG=0 KRYPY_AMD_MINRES_CYCLE=0 KRYPY_AMD_CG_CYCLE=0 KRYPY_AMD_GMRES_CYCLE=0"
   run "KRYPY_AMD_CHAIN_SPMV=0 KRYPY_AMD_SPMV_DIA=0 KRYPY_AMD_CHAIN_LDS=0"
   run "KRYPY_AMD_CHAIN_PF=0 KRYPY_AMD_CHAIN_ONEX=0 KRYPY_AMD_CHAIN_SMALL=0 KRYPY_AMD_TAG_WAIT=0 KRYPY_AMD_LANCZOS_FUSED=0"
-  run "KRYPY_AMD_CG_STEP=0 KRYPY_AMD_SPMV_SPLIT=0 KRYPY_AMD_PROJ_PANEL=0 KRYPY_AMD_CGS_REVERSE=0 KRYPY_AMD_BLK_NX=0 KRYPY_AMD_XR=0 KRYPY_AMD_CHAIN_BLK2=0 KRYPY_AMD_XH=0 KRYPY_AMD_SPMV_WIN=0"
+  run "KRYPY_AMD_CG_STEP=0 KRYPY_AMD_SPMV_SPLIT=0 KRYPY_AMD_PROJ_PANEL=0 KRYPY_AMD_CGS_REVERSE=0 KRYPY_AMD_BLK_NX=0 KRYPY_AMD_XR=0 KRYPY_AMD_CHAIN_BLK2=0 KRYPY_AMD_XH=0 KRYPY_AMD_SPMV_WIN=0 KRYPY_AMD_BLK2_ONE=0"
   run "KRYPY_AMD_BLK2_CW=0"
   run "KRYPY_AMD_BLK2_CW=2"
   grep -c "^FAILED" gpurun_out/ev/fallback.log | sed 's/^/numeric FAILED lines in all switch sets: /' >> gpurun_out/ev/fallback.log
