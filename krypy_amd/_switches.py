@@ -48,10 +48,10 @@ SWITCHES = [
      "being a communication wave without rows (448 lanes with rows, 4 ... 7 rows per lane, up to 1.6 M rows: no register spills up to 6 "
      "rows, the total of a sum seen without waiting for the wave's own rows); 2: the communication wave up to 6 rows per lane, 512 lanes "
      "beyond (the A / B of the 7-row shape)"),
-    ("KRYPY_AMD_BLK2_ONE", "1", "kernel-path", "0",
-     "the eight-wave blocked kernel's shapes with ONE block of four columns in registers (8 ... 11 rows per lane, slabs of 1.6 ... 2.5 M "
-     "rows: a rank's share of the benchmark problem on four devices): 1 = on a communicator (the sums cross the ranks inside the "
-     "launch, the basis is read once where the panel forms read it twice), 2 = on one GPU too, 0 = never"),
+    ("KRYPY_AMD_BLK2_ONE", "2", "kernel-path", "0",
+     "the eight-wave blocked kernel's shapes with ONE block of four columns in registers (8 ... 11 rows per lane, vectors / slabs of "
+     "1.6 ... 2.5 M rows: a rank's share of the benchmark problem on four devices): 2 = wherever they fit, 1 = on a communicator only "
+     "(the sums cross the ranks inside the launch, the basis is read once where the panel forms read it twice), 0 = never"),
     ("KRYPY_AMD_BLK_ONEX_MAXN", "70000", "tuning", None,
      "vectors longer than this run the blocked kernel spread over the chip instead of on one XCD"),
     ("KRYPY_AMD_BLK_NX", "8", "kernel-path", "0",

@@ -108,7 +108,7 @@ struct kh_ctx_s {
     int chain_blk2 = 1;              // KRYPY_AMD_CHAIN_BLK2: the eight-wave blocked kernel (4 ... 6 rows per lane; on N ranks with the
                                      // cross-rank sums inside the launch)
     int blk2_cw = 1;                 // KRYPY_AMD_BLK2_CW: wave 0 of the eight-wave blocked kernel owns no rows where that shape fits (448 lanes with rows)
-    int blk2_one = 1;                // the one-block shapes of chain_blk2.h: 0 never, 1 on a communicator (default), 2 on one GPU too (KRYPY_AMD_BLK2_ONE)
+    int blk2_one = 2;                // the one-block shapes of chain_blk2.h: 0 never, 1 on a communicator only, 2 on one GPU too (default; KRYPY_AMD_BLK2_ONE)
     int gemv_rows = 0;               // rows per wave of k_gemv_dense (0: chosen by size)
     int blk2_cw_maxrows = 7;         // rows per lane up to which the communication-wave shape is used (KRYPY_AMD_BLK2_CW=2: 6, for A / B)
     int64_t n_chain_blk2 = 0;

@@ -689,7 +689,7 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     }
     if (cplx && 4 * G > 2 * CH_GMAX) return 0;      // grid_sum2: four granules per workgroup
     if ((n & 1) && (V->ld <= n || B->ld <= n || wld <= n || (P && P->ld <= n))) return 0;
-    // 1.05 M ... 1.57 M rows (8 rows per lane in the general geometry, 5 / 6 here), no preconditioner, a long chain: the
+    // 1.05 M ... 2.5 M rows (8 / 16 rows per lane in the general geometry, 5 ... 11 here), no preconditioner, a long chain: the
     // eight-wave blocked kernel (chain_blk2.h) - one grid-wide sum per four columns, columns read once.  It loads w: with the
     // operator to be fused (Afuse) nothing is launched here, the caller runs the SpMV and comes back without it.
     {
@@ -1403,7 +1403,7 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
         ctx->blk2_cw_maxrows = ctx->blk2_cw == 2 ? 6 : 7;
         e = getenv("KRYPY_AMD_BLK2_ONE");
-        ctx->blk2_one = (e == nullptr) ? 1 : atoi(e);
+        ctx->blk2_one = (e == nullptr) ? 2 : atoi(e);
         e = getenv("KRYPY_AMD_SPMV_WIN");
         ctx->spmv_win = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_PROJ_REG");

@@ -31,15 +31,13 @@ def test_one_gpu_long_short_vectors_against_the_per_column_kernels(hip, nx, ny, 
     stops that form at 6 rows (1.5 M rows then take the 512-lane form with 6 rows), cw = 0 is the 512-lane form throughout."""
     from krypy_amd import linsys, utils
 
-    # cw = 12: the default shapes + the ones with ONE block in registers (8 ... 11 rows per lane, 1.6 ... 2.5 M rows) allowed on
-    # one GPU too (chain_blk2_one = 2; by default they serve a communicator's slabs only)
+    # cw = 12: the default shapes at sizes where they are the ones with ONE block in registers (8 ... 11 rows per lane, 1.6 ... 2.5 M
+    # rows)
     hip.set("chain_blk2_cw", 1 if cw == 12 else cw)
-    hip.set("chain_blk2_one", 2 if cw == 12 else 1)
     try:
         _one_gpu_case(hip, linsys, utils, nx, ny)
     finally:
         hip.set("chain_blk2_cw", 1)
-        hip.set("chain_blk2_one", 1)
 
 
 def _one_gpu_case(hip, linsys, utils, nx, ny):
