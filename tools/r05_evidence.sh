@@ -25,6 +25,16 @@ bench)
   python bench.py > gpurun_out/ev/r05_bench.json 2> gpurun_out/ev/r05_bench.err
   tail -c 400 gpurun_out/ev/r05_bench.json
   ;;
+final)
+  # the short form for the last minutes of a round's GPU budget: kernel trace + PMC passes of the default (reference-order)
+  # bench command so that the traffic file carries the stamp of the final sources, then the line itself
+  bash tools/profile.sh r05_mgs --ortho mgs --other-modes none > gpurun_out/ev/profile_mgs.log 2>&1
+  python tools/summarize_prof.py gpurun_out/prof_r05_mgs profiles/r05_bench_mgs_chain.md
+  cp profiles/r05_bench_mgs_chain.md profiles/r05_bench_mgs_chain_traffic.json gpurun_out/ev/ 2>/dev/null
+  rm -rf gpurun_out/prof_r05_mgs/trace gpurun_out/prof_r05_mgs/pmc_*
+  python bench.py > gpurun_out/ev/r05_bench.json 2> gpurun_out/ev/r05_bench.err
+  tail -c 400 gpurun_out/ev/r05_bench.json
+  ;;
 configs)
   # kernel trace + PMC passes of each secondary configuration; every line of r05_configs.jsonl carries bytes_per_iteration, frac and
   # traffic_over_bytes (the last from the PMC passes: tools/profile_config.sh)
