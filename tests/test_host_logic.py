@@ -501,6 +501,71 @@ def test_blocked_one_ahead_recurrence_is_the_reference_loop():
         assert np.linalg.norm(w_upd - w) < 1e-12 * np.linalg.norm(w0), k
 
 
+def test_blk2_recurrence_on_row_slabs_is_the_reference_loop():
+    """The recurrence of k_mgs_chain_blk2 (chain_blk2.h; the two-block and the ONE-block shapes both run it) restated in NumPy on
+    THREE row slabs: per block of four columns the slabs' partial dots are added in rank order (the cross-rank stage), the
+    coefficients are corrected with the OWN block's Gram entries only, the four updates follow in the reference's order; the
+    dots of the next block are taken after the update.  The tail's sum carries the norm and the new column's table row (dots of
+    the last block's columns with the final w, over h).  In exact arithmetic that is the reference's sequential loop
+    (krypy/utils.py:1012-1045); here: a basis that is orthonormal only to 1e-4, every ragged length of the last block, and the
+    table row the step leaves behind is the Gram row the NEXT step's recurrence needs."""
+    import numpy as np
+
+    rng = np.random.default_rng(11)
+    n, bc = 300, 4
+    slabs = [slice(0, 90), slice(90, 217), slice(217, n)]
+
+    def xsum(parts):                      # rank-ordered sum of the slabs' contributions
+        t = 0.0
+        for p in parts:
+            t = t + p
+        return t
+
+    worst = 0.0
+    for total in (1, 3, 4, 5, 8, 9, 10, 11, 12, 23):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, total)))
+        V = Q + 1e-4 * rng.standard_normal((n, total))
+        w0 = rng.standard_normal(n)
+        # the reference's loop
+        w, ref_alpha = w0.copy(), np.zeros(total)
+        for j in range(total):
+            ref_alpha[j] = V[:, j] @ w
+            w = w - ref_alpha[j] * V[:, j]
+        ref_h = np.linalg.norm(w)
+        ref_v = w / ref_h
+        # the kernel's
+        G = V.T @ V                       # (only own-block entries are read below)
+        wk, alpha = w0.copy(), np.zeros(total)
+        for i in range((total + bc - 1) // bc):
+            cols = list(range(i * bc, min((i + 1) * bc, total)))
+            c = [xsum([V[s, j] @ wk[s] for s in slabs]) for j in cols]
+            a_blk = []
+            for l, j in enumerate(cols):
+                a = c[l]
+                for m in range(l):
+                    assert cols[m] // bc == j // bc
+                    a -= a_blk[m] * G[cols[m], j]
+                a_blk.append(a)
+                alpha[j] = a
+            for l, j in enumerate(cols):
+                wk = wk - a_blk[l] * V[:, j]
+        pnew = total % bc
+        last = list(range(total - pnew, total)) if pnew else []
+        tail = [xsum([wk[s] @ wk[s] for s in slabs])] + [xsum([V[s, m] @ wk[s] for s in slabs]) for m in last]
+        h = np.sqrt(tail[0])
+        vnew = wk / h
+        row = [t / h for t in tail[1:]]
+        scale = np.max(np.abs(ref_alpha))
+        worst = max(worst, np.max(np.abs(alpha - ref_alpha)) / scale, abs(h - ref_h) / ref_h, np.max(np.abs(vnew - ref_v)))
+        assert np.max(np.abs(alpha - ref_alpha)) < 1e-12 * scale, total
+        assert abs(h - ref_h) < 1e-12 * ref_h and np.max(np.abs(vnew - ref_v)) < 1e-12, total
+        # the row left behind = the new column against the earlier columns of ITS block (none when it opens a block)
+        assert len(row) == (total % bc)
+        for t, m in enumerate(last):
+            assert abs(row[t] - V[:, m] @ vnew) < 1e-14, (total, m)
+    print("blk2 restatement on three slabs against the reference loop: worst deviation %.1e" % worst)
+
+
 def test_enable_xr_is_all_or_nothing():
     """`dist.enable_xr`: whether the sums across the ranks run as mailbox kernels or as ncclAllReduce changes what a peer has to
     take part in, so it must come out the same on EVERY rank - whatever fails on whichever rank (the export, the attach, the
