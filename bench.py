@@ -301,7 +301,12 @@ def _launch(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC (RCCL between processes)
         procs.append(subprocess.Popen([sys.executable] + sys.argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    line = procs[0].stdout.read()          # rank 0 prints the one JSON line; EOF when it exits
+    # rank 0 prints the one JSON line; it is read on a thread of its own so that a rank that dies while rank 0 still waits
+    # for it (in the rendezvous, in a collective) is seen by the loop below, which then stops the others
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rcs = [None] * n
     deadline = None
     while any(rc is None for rc in rcs):
@@ -312,13 +317,15 @@ def _launch(args):
             # a rank failed (its peers would wait in a collective for ever), or rank 0 is done: give the others a
             # grace period, then stop them - by PID, these are our own children
             if deadline is None:
-                deadline = time.time() + 60.0
+                deadline = time.time() + (60.0 if all(rc in (None, 0) for rc in rcs) else 10.0)
             elif time.time() > deadline:
                 for r, p in enumerate(procs):
                     if rcs[r] is None:
                         p.kill()
                         rcs[r] = -9
         time.sleep(0.05)
+    reader.join(10.0)
+    line = got[0] if got else b""
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
     if bad:
         sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)

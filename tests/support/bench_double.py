@@ -15,6 +15,10 @@ if ROOT not in sys.path:
 
 
 def main():
+    # (a rank process that dies before the rendezvous, for the launcher's failed-rank test)
+    if os.environ.get("BENCH_DOUBLE_DIE_RANK") is not None and os.environ.get("RANK") == os.environ["BENCH_DOUBLE_DIE_RANK"]:
+        sys.stderr.write("bench_double: rank %s told to die\n" % os.environ["RANK"])
+        sys.exit(3)
     from krypy_amd import _hip
     from tests.support.numpy_context import NumpyContext
 

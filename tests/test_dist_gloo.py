@@ -361,6 +361,23 @@ def test_bench_gpus_n_reports_a_failed_rank():
     assert rc != 0 and lines == [] and "ranks failed" in err, (rc, lines, err[-800:])
 
 
+def test_bench_gpus_n_stops_the_others_when_one_rank_dies():
+    """ONE rank dies before the rendezvous while rank 0 waits there for it: the launcher must see the dead rank although rank 0
+    has not closed its stdout, stop the waiting ranks (its own children, by PID) and report - not sit in a read of rank 0's
+    pipe until the rendezvous' own ten-minute timeout."""
+    import time
+    os.environ["BENCH_DOUBLE_DIE_RANK"] = "1"
+    try:
+        t0 = time.time()
+        rc, lines, err = _bench_self_spawn(["--gpus", "2", "--steps", "1", "--warmup", "0", "--nx", "40", "--ny", "36",
+                                            "--restart", "12", "--no-roofline", "--no-cpu-baseline"], timeout=200)
+        took = time.time() - t0
+    finally:
+        del os.environ["BENCH_DOUBLE_DIE_RANK"]
+    assert rc != 0 and lines == [] and "ranks failed" in err and "(1, 3)" in err, (rc, lines, err[-800:])
+    assert took < 120.0, took
+
+
 def test_bench_sharded_path_under_an_external_launcher():
     """The same leg as a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`) starts it:
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment.  Every rank reports the same (max-over-ranks) time and
