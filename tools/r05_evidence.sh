@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 evidence on one MI355X box (through gpurun): tools/r05_evidence.sh <tests|bench|configs|small>
+# Round-5 evidence on one MI355X box (through gpurun): tools/r05_evidence.sh <tests|bench|final|configs|small|blk2|ranks|fallback|fuzz>
 # Everything lands under gpurun_out/ev/; the summaries that are judged are copied to profiles/ by hand afterwards.
 set -u
 WHAT=${1:-bench}
@@ -34,6 +34,47 @@ final)
   rm -rf gpurun_out/prof_r05_mgs/trace gpurun_out/prof_r05_mgs/pmc_*
   python bench.py > gpurun_out/ev/r05_bench.json 2> gpurun_out/ev/r05_bench.err
   tail -c 400 gpurun_out/ev/r05_bench.json
+  ;;
+blk2)
+  # the A / B lines of the eight-wave blocked kernel (profiles/r05_blk2_cw.log, r05_blk2_cw7.log, r05_blk2_one.log,
+  # r05_blk2_one_1gpu.log, r05_shard_loop.log were made by scratch scripts of this shape; this mode makes them again)
+  line() { python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config']
+print('$1: %.0f it/s (sums %s, halo %s)' % (d['value'], c.get('cross_rank_sums'), c.get('halo')))"; }
+  : > gpurun_out/ev/blk2_ab.log
+  for rep in 1 2; do
+    # one GPU: communication wave on / off / up to 6 rows, 1.12 ... 1.6 M rows
+    for cw in 1 0 2; do for ny in 280 313 330 375 400; do
+      KRYPY_AMD_BLK2_CW=$cw python bench.py --nx 4000 --ny $ny --ortho mgs --no-roofline --no-cpu-baseline --steps 10 --other-modes none 2>/dev/null \
+        | line "KRYPY_AMD_BLK2_CW=$cw: one GPU, 4000 x $ny, mgs" >> gpurun_out/ev/blk2_ab.log; done; done
+    # one GPU: the one-block shapes on (2) / on a communicator only (1), 1.68 ... 2.5 M rows
+    for one in 1 2; do for ny in 420 500 625; do
+      KRYPY_AMD_BLK2_ONE=$one python bench.py --nx 4000 --ny $ny --ortho mgs --no-roofline --no-cpu-baseline --steps 10 --other-modes none 2>/dev/null \
+        | line "one GPU, 4000 x $ny, KRYPY_AMD_BLK2_ONE=$one, mgs" >> gpurun_out/ev/blk2_ab.log; done; done
+    # one MIDDLE rank (sums through the own mailbox inside the blocked kernel, halo inside the SpMV's launch): N/8 and N/4 slabs
+    for ny in 313 450 500 625; do
+      for o in mgs cgs; do
+        python bench.py --force-sharded --loop-halo --nx 4000 --ny $ny --ortho $o --no-roofline --no-cpu-baseline --steps 10 --other-modes none 2>/dev/null \
+          | line "one middle rank, 4000 x $ny, $o" >> gpurun_out/ev/blk2_ab.log; done
+      KRYPY_AMD_BLK2_ONE=0 python bench.py --force-sharded --loop-halo --nx 4000 --ny $ny --ortho mgs --no-roofline --no-cpu-baseline --steps 10 --other-modes none 2>/dev/null \
+        | line "one middle rank, 4000 x $ny, KRYPY_AMD_BLK2_ONE=0, mgs" >> gpurun_out/ev/blk2_ab.log
+    done
+  done
+  cat gpurun_out/ev/blk2_ab.log
+  ;;
+ranks)
+  # N rank PROCESSES on the one device, no RCCL communicator (profiles/r05_ranks_on_one_gpu.log): the residual of every run against
+  # the one-rank run's
+  : > gpurun_out/ev/ranks_on_one_gpu.log
+  for n in 1 2 3 4 8; do
+    if [ $n = 1 ]; then X=""; else X="--gpus $n --share-devices --transport xr"; fi
+    python bench.py $X --nx 800 --ny 600 --ortho mgs --no-roofline --no-cpu-baseline --steps 2 --warmup 1 --other-modes none 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config']
+print('ranks %s on %s device(s): final relres %.15e, %.0f it/s (sums %s, halo %s)' % (c.get('ranks'), d['n_gpus'], c['final_relres'], d['value'], c.get('cross_rank_sums'), c.get('halo')))" >> gpurun_out/ev/ranks_on_one_gpu.log
+  done
+  cat gpurun_out/ev/ranks_on_one_gpu.log
   ;;
 configs)
   # kernel trace + PMC passes of each secondary configuration; every line of r05_configs.jsonl carries bytes_per_iteration, frac and
