@@ -22,6 +22,18 @@ def main():
     from krypy_amd import _hip
     from tests.support.numpy_context import NumpyContext
 
+    fail_at = os.environ.get("BENCH_DOUBLE_FAIL_MGS_AT")
+    if fail_at is not None:
+        # every rank's reference-order step fails at the same k (what a timed-out in-launch sum looks like from the host: an
+        # error on all ranks of the communicator) - for the test of `--ortho auto`'s way back to the panel form
+        orig = NumpyContext.arnoldi_step
+
+        def failing(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
+            if gs_mode == _hip.GS_MGS and k == int(fail_at):
+                raise _hip.BackendError("bench_double: the reference-order step was told to fail at k = %d" % k)
+            return orig(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+
+        NumpyContext.arnoldi_step = failing
     _hip._install_context_for_testing(NumpyContext())
     _hip.device_count = lambda: int(os.environ.get("BENCH_DOUBLE_DEVICES", "8"))
     import bench

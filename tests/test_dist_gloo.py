@@ -361,6 +361,30 @@ def test_bench_gpus_n_reports_a_failed_rank():
     assert rc != 0 and lines == [] and "ranks failed" in err, (rc, lines, err[-800:])
 
 
+def test_bench_ortho_auto_goes_back_to_the_panel_form_when_the_candidate_fails():
+    """`--ortho auto` on N > 1 ranks times one untimed cycle of `cgs` and of `mgs` and takes the faster - and the `mgs` candidate is
+    the one whose in-launch sums have never crossed a link between two GPUs.  When it fails (here: every rank's reference-order step
+    raises at k = 5, what a timed-out sum looks like from the host) the run must not lose its line: every rank goes back to the
+    panel form together, the line says so, and the timed cycles are the `cgs` ones of an undisturbed run."""
+    import json
+    os.environ["BENCH_DOUBLE_FAIL_MGS_AT"] = "5"
+    try:
+        rc, lines, err = _bench_self_spawn(["--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "40", "--ny", "36",
+                                            "--restart", "12", "--no-roofline", "--no-cpu-baseline"])
+    finally:
+        del os.environ["BENCH_DOUBLE_FAIL_MGS_AT"]
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24
+    auto = o["config"]["ortho_auto"]
+    assert auto["chosen"] == "cgs" and "ms_per_cycle" in auto["cgs"]
+    assert "told to fail at k = 5" in auto["mgs"]["error"] and "panel form" in auto["mgs"]["disabled"]
+    assert "ms_per_cycle" not in auto["mgs"]
+    want = _single_process_bench_residual(40, 36, 12)
+    assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
+
+
 def test_bench_gpus_n_stops_the_others_when_one_rank_dies():
     """ONE rank dies before the rendezvous while rank 0 waits there for it: the launcher must see the dead rank although rank 0
     has not closed its stdout, stop the waiting ranks (its own children, by PID) and report - not sit in a read of rank 0's
