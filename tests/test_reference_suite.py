@@ -1,0 +1,58 @@
+"""The REFERENCE'S OWN test-suite, run against krypy_amd (build container only: /root/reference/test is read where it lies).
+
+INTEGRATION.md section 1 says "switch the import".  This test does exactly that to the reference's tests: a pytest plugin
+(tests/support/reftests_plugin.py) makes ``import krypy`` resolve to krypy_amd - its host layer on the NumPy test double of the
+device library - and the unmodified files test_utils.py, test_linsys.py, test_deflation.py, test_recycling.py and
+test_convenience_wrappers.py (25,482 parametrised tests, all green on the reference itself under the same plugin with
+``REFTESTS_TARGET=reference``) are collected and run.  Expected: every test passes except those of the names SURVEY.md
+section 2 puts out of scope (the a-priori bound machinery: ``deflation.Arnoldifyer``, ``utils.gap``, ``Interval``, ``BoundCG``,
+``BoundMinres``, ``NormalizedRootsPolynomial``), which must fail with krypy_amd's descriptive NotImplementedError and nothing else.
+Nothing of the reference travels: on the GPU box this module skips; the device side of the same API is what tests -m gpu hold
+to the committed fixtures."""
+import os
+import subprocess
+import sys
+import xml.etree.ElementTree as ET
+
+import pytest
+
+from oracle import refshim
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(refshim.REFERENCE_ROOT, "test")),
+                                reason="reference tree /root/reference not present")
+
+OUT_OF_SCOPE = {"test_deflation::test_Arnoldifyer", "test_utils::test_gap", "test_utils::test_Interval", "test_utils::test_BoundCG",
+                "test_utils::test_BoundMinres", "test_utils::test_NormalizedRootsPolynomial"}
+
+
+def test_the_references_own_tests_pass_on_krypy_amd(tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_tests = os.path.join(refshim.REFERENCE_ROOT, "test")
+    xml = str(tmp_path / "reftests.xml")
+    env = dict(os.environ, REFTESTS_TARGET="krypy_amd", PYTHONDONTWRITEBYTECODE="1",       # (nothing is written under /root/reference)
+               PYTHONPATH=os.pathsep.join([root, ref_tests]))
+    workers = str(max(1, min(4, (os.cpu_count() or 2) // 2)))
+    p = subprocess.run([sys.executable, "-m", "pytest", ref_tests, "-q", "-p", "no:cacheprovider", "--rootdir", str(tmp_path),
+                        "-p", "tests.support.reftests_plugin", "-n", workers, "--junitxml", xml, "-W", "ignore"],
+                       cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
+    tail = p.stdout.decode()[-1500:]
+    assert os.path.exists(xml), tail
+    passed, failed, other = 0, {}, []
+    for tc in ET.parse(xml).getroot().iter("testcase"):
+        name = tc.get("classname") + "::" + tc.get("name").split("[")[0]
+        bad = tc.find("failure") if tc.find("failure") is not None else tc.find("error")
+        if tc.find("skipped") is not None:
+            other.append((name, "skipped"))
+        elif bad is None:
+            passed += 1
+        else:
+            msg = bad.get("message") or ""
+            failed[name] = failed.get(name, 0) + 1
+            if name not in OUT_OF_SCOPE or not msg.startswith("NotImplementedError: krypy_amd."):
+                other.append((name, msg[:200]))
+    print("the reference's own tests on krypy_amd: %d passed, %d failed (all out of scope: %s)"
+          % (passed, sum(failed.values()), dict(sorted(failed.items()))))
+    assert not other, other[:10]
+    assert set(failed) == OUT_OF_SCOPE, sorted(failed)
+    # test_linsys.py alone holds 20 k solver runs; the count guards against a collection that silently shrank
+    assert passed >= 25000 and passed + sum(failed.values()) >= 25400, (passed, failed, tail)
