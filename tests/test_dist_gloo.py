@@ -299,7 +299,7 @@ def _single_process_bench_residual(nx, ny, m, ortho="cgs"):
         _hip._install_context_for_testing(old)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_gpus_n_starts_its_own_ranks(world):
     """`python bench.py --gpus N` with a clean environment (what the driver runs for N = 1; what VERDICT r04 asked for
     N > 1): N rank processes are started by bench.py itself, exactly ONE JSON line comes back, it says n_gpus = N, and
