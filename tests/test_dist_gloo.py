@@ -450,16 +450,17 @@ def _bench5_worker(rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_config5_leg_on_n_ranks(world):
     """The config-5 leg of bench.py (z-slabs of the 3-D grid, plain GMRES to harvest Ritz vectors that stay sharded on
     the device, DeflatedGmres timed) on gloo ranks at a toy size: same JSON contract as config 2, every rank sees the
     same numbers, and those are the CPU oracle's (gmres -> Ritz vectors of smallest magnitude -> deflated_gmres;
     reference flow recycling/linsys.py:51-103, deflation.py:93-163).  world = 2: under an external launcher's
-    environment (all ranks' lines compared); world = 4: `bench.py --config 5 --gpus 4` starting its own ranks."""
-    if world == 4:
+    environment (all ranks' lines compared); world = 4 and 8 (BASELINE.json configs[4]'s partition: two-plane slabs here):
+    `bench.py --config 5 --gpus N` starting its own ranks."""
+    if world >= 4:
         import json
-        rc, lines, err = _bench_self_spawn(["--config", "5", "--gpus", "4", "--steps", "2", "--warmup", "1", "--nx", "12",
+        rc, lines, err = _bench_self_spawn(["--config", "5", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--nx", "12",
                                             "--ny", "10", "--nz", "16", "--restart", "30", "--defl", "5",
                                             "--no-cpu-baseline"])
         assert rc == 0 and len(lines) == 1, err[-3000:]
