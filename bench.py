@@ -116,10 +116,14 @@ def laplace3d(nx, ny, nz, z0=None, z1=None, chunk=8):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 5),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="BASELINE.json config: 2 = GMRES(100) on the 2-D Laplacian N = 10^7 (the metric; default), "
+                         "3 = MINRES + Jacobi on the same matrix (one MI355X; a step = one solve of --iters iterations), "
+                         "4 = CG on the dense SPD matrix n = 32768 (one MI355X; a step = one whole solve to tol 1e-8), "
                          "5 = DeflatedGmres with 16 recycled Ritz vectors on the 3-D 7-point Laplacian "
                          "500 x 500 x 400 (N = 10^8), z-slabs over the ranks")
+    ap.add_argument("--iters", type=int, default=200, help="config 3: MINRES iterations per step (SURVEY 8d: 200)")
+    ap.add_argument("--dense-n", type=int, default=32768, help="config 4: order of the dense SPD matrix")
     ap.add_argument("--nz", type=int, default=400, help="config 5: planes of the grid (nx, ny default to 500 there)")
     ap.add_argument("--defl", type=int, default=16, help="config 5: recycled Ritz vectors")
     ap.add_argument("--steps", type=int, default=8, help="timed GMRES(100) restart cycles")
@@ -309,10 +313,20 @@ def _launch(args):
     reader.start()
     rcs = [None] * n
     deadline = None
+    # the whole run is bounded: a collective that never returns (a link that never delivers) must end in a non-zero exit,
+    # not hold the driver until ITS timeout
+    overall = time.time() + float(os.environ.get("KRYPY_AMD_BENCH_DEADLINE_S", "1500"))
     while any(rc is None for rc in rcs):
         for r, p in enumerate(procs):
             if rcs[r] is None:
                 rcs[r] = p.poll()
+        if time.time() > overall:
+            sys.stderr.write("bench.py: the ranks did not finish within KRYPY_AMD_BENCH_DEADLINE_S; stopping them\n")
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.kill()
+                    rcs[r] = -9
+            break
         if any(rc not in (None, 0) for rc in rcs) or rcs[0] == 0:
             # a rank failed (its peers would wait in a collective for ever), or rank 0 is done: give the others a
             # grace period, then stop them - by PID, these are our own children
@@ -364,10 +378,138 @@ def _world(args):
     return rank, world, local_rank
 
 
+def _probe_sharded(ctx, dist, args, op, xr_on, run_one, xr_timeout_ms=10000):
+    """N > 1 ranks, --ortho auto: which Gram-Schmidt form over which transport is faster on THIS node is a property of its
+    links.  Candidates, one untimed pass of `run_one(ortho)` each, the max over the ranks decides, on every rank alike:
+
+      cgs / rccl   the panel form, two ncclAllReduce per step, halo as grouped ncclSend / ncclRecv (the only path that has no
+                   kernel of ours waiting for another GPU)
+      cgs / xr     the same with the sums (and a banded shard's halo) through the IPC mailboxes
+      mgs / xr     the reference order with the cross-rank sums INSIDE the launch: the blocked kernel up to 2.5 M rows per rank,
+                   the register-resident chain kernel beyond (the local basis is read once), else the one-reduction form
+      mgs / rccl   (no mailboxes) the one-reduction form / per-link all-reduces
+
+    EVERY rank runs the same sequence of host collectives whatever happened locally (a rank whose candidate
+    raised used to skip one and the star around rank 0 went off by one).  A candidate that fails over the mailboxes - its
+    in-launch sums have never run between two GPUs - takes the mailboxes off the table for the rest of the run, on every rank
+    together (the epochs may no longer agree).  Returns (ortho, transport, xr_on, report)."""
+    from krypy_amd import _hip
+    have_rccl = args.transport == "rccl"
+    cands = []
+    if have_rccl:
+        cands.append(("cgs", "rccl"))
+    if xr_on:
+        cands += [("cgs", "xr"), ("mgs", "xr")]
+    elif have_rccl:
+        cands.append(("mgs", "rccl"))
+    report = {"candidates": []}
+    state = {"xr_on": xr_on, "xr_usable": xr_on}
+
+    def set_transport(tr):
+        """sums (and the banded halo) through the mailboxes or through RCCL - every rank makes the same call"""
+        if not state["xr_usable"] or not hasattr(ctx, "set"):
+            return
+        want = tr == "xr"
+        ctx.set("xr", 1 if want else 0)
+        if hasattr(op, "halo_via"):
+            op.halo_via("in-launch" if want else "rccl")
+        state["xr_on"] = want
+
+    best = None
+    for ortho, tr in cands:
+        entry = {"ortho": ortho, "transport": tr}
+        report["candidates"].append(entry)
+        if tr == "xr" and not state["xr_usable"]:
+            entry["skipped"] = "the mailboxes were taken off after an earlier candidate failed"
+            continue
+        ok, d1, err = 1.0, 1e30, None
+        try:
+            set_transport(tr)
+            if tr == "xr" and hasattr(ctx, "set"):
+                ctx.set("xr_timeout_ms", int(xr_timeout_ms))
+            ctx.sync()
+            dist.barrier()
+            c0 = dict((k, ctx.get(k)) for k in ("n_chain_blk2", "n_chain_xr", "n_lowsync", "n_allreduce", "n_xr")) if hasattr(ctx, "get") else {}
+            t1 = time.perf_counter()
+            n_it = run_one(ortho)
+            ctx.sync()
+            d1 = time.perf_counter() - t1
+            if c0:
+                per = float(max(n_it, 1))
+                entry["per_iteration"] = {"allreduce_calls": (ctx.get("n_allreduce") - c0["n_allreduce"]) / per,
+                                          "mailbox_sums": (ctx.get("n_xr") - c0["n_xr"]) / per}
+                entry["kernels"] = {"blocked_in_launch_sums": ctx.get("n_chain_blk2") - c0["n_chain_blk2"],
+                                    "chain_in_launch_sums": ctx.get("n_chain_xr") - c0["n_chain_xr"],
+                                    "one_reduction_steps": ctx.get("n_lowsync") - c0["n_lowsync"]}
+        except _hip.BackendError as exc:
+            ok, err = 0.0, str(exc)[:300]
+        # ---- the same two collectives on every rank, whatever happened above ----
+        all_ok = dist.allreduce_min(ok) >= 1.0
+        dmax = dist.allreduce_max(d1 if ok else 1e30)
+        if err is not None:
+            entry["error"] = err
+        if all_ok:
+            entry["ms"] = dmax * 1e3
+            if best is None or dmax < best[0]:
+                best = (dmax, ortho, tr)
+        else:
+            entry["failed_on_some_rank"] = True
+            if tr == "xr" and state["xr_usable"]:
+                if not have_rccl:
+                    raise SystemExit("bench.py --transport xr: a candidate failed on some rank and there is no RCCL communicator to go "
+                                     "back to: %r" % (report,))
+                # off with the mailboxes, everywhere: blocked / chain kernels with in-launch sums, in-launch halo, mailbox sums
+                if hasattr(ctx, "set"):
+                    ctx.set("chain_blk2", 0)
+                    ctx.set("chain_xr", 0)
+                if hasattr(op, "halo_via"):
+                    op.halo_via("rccl")
+                if hasattr(ctx, "set"):
+                    ctx.set("xr", 0)
+                if hasattr(ctx, "xr_detach"):
+                    ctx.xr_detach()
+                state["xr_usable"] = state["xr_on"] = False
+                entry["disabled"] = "a rank failed: every rank back to ncclAllReduce / ncclSend / ncclRecv and the panel form"
+            else:
+                entry["disabled"] = "a rank failed: the candidate is not timed (every rank keeps the panel form over RCCL)"
+    if best is None:
+        raise SystemExit("bench.py: no Gram-Schmidt candidate ran on every rank: %r" % (report,))
+    set_transport(best[2])
+    if best[2] == "xr" and hasattr(ctx, "set"):
+        ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_BENCH_XR_TIMEOUT_S", "15")) * 1e3))
+    report["chosen"] = {"ortho": best[1], "transport": best[2]}
+    return best[1], best[2], state["xr_on"], report
+
+
+def _rank_table(dist, value):
+    """one double per rank, in rank order, on every rank"""
+    import struct
+    if dist is None:
+        return [float(value)]
+    return [struct.unpack("<d", x)[0] for x in dist.allgather_bytes(struct.pack("<d", float(value)))]
+
+
+def _spmv_us(ctx, opnd, n, reps=20):
+    """this rank's sharded (or plain) SpMV, microseconds per product by HIP events on the library's stream"""
+    X, Y = ctx.alloc(n, 1), ctx.alloc(n, 1)
+    X.upload(0, np.ones(n))
+    dm = opnd._device_matrix()
+    for _ in range(3):
+        ctx.apply(dm, X, 0, Y, 0, 1)
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.apply(dm, X, 0, Y, 0, 1)
+    return ctx.timer_stop() / reps * 1e3
+
+
 def _run():
     args = parse_args()
     if args.config == 5:
         return _run_config5(args)
+    if args.config in (3, 4):
+        if args.gpus != 1 or args.force_sharded:
+            raise SystemExit("bench.py --config %d: a one-GPU configuration (BASELINE.json: \"1 MI355X\")" % args.config)
+        return _run_config3(args) if args.config == 3 else _run_config4(args)
     rank, world, local_rank = _world(args)
     os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
 
@@ -451,72 +593,95 @@ def _run():
         if dist is not None:
             dist.barrier()
 
-    # ---- N > 1 ranks, --ortho auto: which Gram-Schmidt form is faster on THIS node is a property of its links - the panel
-    # form needs two sums across the ranks per step and reads the local basis twice; the reference order runs (xr transport
-    # on, slabs of up to 6 rows per lane) as the blocked kernel with one exchange per four columns INSIDE the launch and
-    # reads the basis once, else as the one-reduction form.  One untimed cycle of each, the max over the ranks decides - on
-    # every rank alike.  Both forms pass the 1e-10 parity tests.  A failure of the candidate (its in-launch sums have never
-    # run between two GPUs) must not cost the run its line: every rank then goes back to RCCL and the panel form, together.
+    # ---- N > 1 ranks, --ortho auto: one untimed cycle per (Gram-Schmidt form, transport) candidate, the max over the ranks
+    # decides, on every rank alike (_probe_sharded).  All forms pass the 1e-10 parity tests. ----
     ortho_timed = [ortho]
     auto_report = None
-    if auto_sharded and hasattr(ctx, "get"):
-        auto_report = {}
-        probe_ok = 1.0
-        for cand in ("cgs", "mgs"):
-            try:
-                if cand == "mgs" and xr_on:
-                    ctx.set("xr_timeout_ms", 10000)
-                barrier()
-                b2 = ctx.get("n_chain_blk2")
-                t1 = time.perf_counter()
-                run_cycles(1, None, ortho=cand)
-                ctx.sync()
-                d1 = time.perf_counter() - t1
-                auto_report[cand] = {"ms_per_cycle": dist.allreduce_max(d1) * 1e3,
-                                     "sums_inside_the_launch": bool(ctx.get("n_chain_blk2") > b2)}
-            except _hip.BackendError as exc:
-                probe_ok = 0.0
-                auto_report[cand] = {"error": str(exc)[:300]}
-            if cand == "mgs":
-                all_ok = dist.allreduce_min(probe_ok) >= 1.0
-                if not all_ok and args.transport == "xr":
-                    raise SystemExit("bench.py --transport xr: the reference-order candidate failed on some rank and there is no RCCL "
-                                     "communicator to go back to: %r" % (auto_report,))
-                if not all_ok:
-                    # some rank's candidate failed: the mailboxes' epochs may no longer agree - off with them, everywhere
-                    ctx.set("chain_blk2", 0)
-                    if hasattr(A_for_ls, "halo_through_rccl"):
-                        A_for_ls.halo_through_rccl()
-                    if xr_on:
-                        ctx.set("xr", 0)
-                        ctx.xr_detach()
-                        xr_on = False
-                    auto_report.setdefault("mgs", {})["disabled"] = "a rank failed: every rank back to ncclAllReduce and the panel form"
-                    auto_report["mgs"].pop("ms_per_cycle", None)
-                elif xr_on:
-                    ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_TIMEOUT_S", "60")) * 1e3))
-        if "ms_per_cycle" in auto_report.get("mgs", {}) and auto_report["mgs"]["ms_per_cycle"] < auto_report["cgs"]["ms_per_cycle"]:
-            ortho_timed[0] = "mgs"
-        ortho = ortho_timed[0]
+    transport_used = None if not sharded else ("xr" if xr_on else "rccl")
+    if auto_sharded:
+        def one_cycle(cand):
+            return len(run_cycles(1, None, ortho=cand).resnorms) - 1
+        ortho, transport_used, xr_on, auto_report = _probe_sharded(ctx, dist, args, A_for_ls, xr_on, one_cycle)
+        ortho_timed[0] = ortho
+        # (the per-form keys round 5's line carried, for whoever compares the two)
+        for c in auto_report["candidates"]:
+            e = auto_report.setdefault(c["ortho"], {})
+            if "ms" in c and c["ms"] < e.get("ms_per_cycle", 1e30):
+                e["ms_per_cycle"] = c["ms"]
+            for key in ("error", "disabled"):
+                if key in c:
+                    e[key] = c[key]
+        for form in ("cgs", "mgs"):
+            if "disabled" in auto_report.get(form, {}) and not any(
+                    c["ortho"] == form and "ms" in c for c in auto_report["candidates"]):
+                auto_report[form].pop("ms_per_cycle", None)
         auto_report["chosen"] = ortho
+        auto_report["chosen_transport"] = transport_used
 
-    x0 = None
-    sol = None
-    if args.warmup > 0:
-        sol = run_cycles(args.warmup, None)
-        x0 = sol.__dict__["_xk_dev"]
-    barrier()
-    del cycle_marks[:]
-    t0 = time.perf_counter()
-    sol = run_cycles(args.steps, x0)
-    ctx.sync()
-    dt = time.perf_counter() - t0
+    def timed_region():
+        x0_ = None
+        if args.warmup > 0:
+            x0_ = run_cycles(args.warmup, None).__dict__["_xk_dev"]
+        barrier()
+        del cycle_marks[:]
+        t0_ = time.perf_counter()
+        sol_ = run_cycles(args.steps, x0_)
+        ctx.sync()
+        return sol_, x0_, t0_, time.perf_counter() - t0_
+
+    # A failure INSIDE the timed region (a sum over the mailboxes that times out: KH_ERR_COMM after KRYPY_AMD_BENCH_XR_TIMEOUT_S,
+    # 15 s) must not cost the run its line where there is something to go back to: every rank reports whether its
+    # region completed - the same host collective on every rank - and if one did not, all of them switch to RCCL and the panel
+    # form together and the region is timed again, once.  The line then says so (`timed_region_fallback`).
+    region_fallback = None
+    ok, err = 1.0, None
+    try:
+        sol, x0, t0, dt = timed_region()
+    except _hip.BackendError as exc:
+        if not sharded:
+            raise
+        ok, err = 0.0, str(exc)[:300]
+    if sharded and dist.allreduce_min(ok) < 1.0:
+        if args.transport != "rccl" or (not xr_on and ortho_timed[0] == "cgs"):
+            raise SystemExit("bench.py: the timed region failed on some rank (%s) and there is no other path to go back to" % (err,))
+        region_fallback = {"reason": err or "another rank's timed region failed",
+                           "from": {"ortho": ortho_timed[0], "transport": transport_used}}
+        if hasattr(ctx, "set"):
+            ctx.set("chain_blk2", 0)
+            ctx.set("chain_xr", 0)
+        if hasattr(A_for_ls, "halo_via"):
+            A_for_ls.halo_via("rccl")
+        if xr_on:
+            ctx.set("xr", 0)
+            ctx.xr_detach()
+            xr_on = False
+        ortho = ortho_timed[0] = "cgs"
+        transport_used = "rccl"
+        sol, x0, t0, dt = timed_region()
     cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
     if dist is not None:
         dt = dist.allreduce_max(dt)
     n_iters = len(sol.resnorms) - 1
     assert n_iters == args.steps * m, (n_iters, args.steps, m)
     its = n_iters / dt
+
+    # ---- what a first run on real links needs to be read: per-rank SpMV time, sums per iteration and what carried them ----
+    shard_diag = None
+    if sharded:
+        keys = ("n_allreduce", "n_xr", "n_halo_exchange", "n_halo_xh", "n_chain_blk2", "n_chain_xr", "n_lowsync")
+        try:
+            c0 = dict((k, ctx.get(k)) for k in keys) if hasattr(ctx, "get") else {}
+            barrier()
+            one = run_cycles(1, x0)
+            ctx.sync()
+            per = float(max(len(one.resnorms) - 1, 1))
+            shard_diag = {"per_iteration": dict((k, (ctx.get(k) - c0[k]) / per) for k in c0)}
+            mine = _spmv_us(ctx, A_for_ls, ls.N) if hasattr(A_for_ls, "_device_matrix") else -1.0
+        except _hip.BackendError as exc:
+            shard_diag = {"error": str(exc)[:300]}
+            mine = -1.0
+        shard_diag["spmv_us_per_rank"] = _rank_table(dist, mine)
+        shard_diag["rows_per_rank"] = _rank_table(dist, ls.N)
 
     # ---- loss of orthogonality of one cycle's basis, ||V^T V - I||_F over all 101 columns (outside the timed
     # region): the evidence that the panel form the sharded runs default to is as good a basis as the
@@ -629,6 +794,11 @@ def _run():
                    "halo": None if not sharded else (("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl") +
                                                     (" (the slab is its own neighbour)" if args.loop_halo else "")),
                    "ortho_auto": auto_report,
+                   # a failure inside the timed region that every rank recovered from together (RCCL + the panel form), or null
+                   "timed_region_fallback": region_fallback,
+                   # N > 1 diagnostics (one extra untimed cycle): collectives per iteration by kind and which kernels served the
+                   # steps, every rank's SpMV time (HIP events) and slab length
+                   "sharded_diagnostics": shard_diag,
                    "final_relres": float(sol.resnorms[-1]), "cycle_ms": cycle_ms,
                    # guard against a slow first cycle / a box in a low power state: `value` is K cycles over their
                    # total time (the contract); the median cycle says what a typical one took
@@ -640,6 +810,18 @@ def _run():
     out.update(extra)
     if others:
         out["other_modes"] = others
+    if not sharded and os.environ.get("KRYPY_AMD_BENCH_SECONDARY", "1") != "0" and hasattr(ctx, "get"):
+        # one secondary configuration driver-timed in every round: BASELINE.json configs[2], MINRES + Jacobi
+        # on this very matrix, 2 x 200 iterations after one warm-up solve (< 2 s); `bench.py --config 3` is the full leg
+        try:
+            its3, dt3, n3, det3 = minres_jacobi_leg(ctx, A_for_ls, b, 200, 2, 1)
+            out["secondary"] = {"config3_minres_jacobi": {"iterations_per_s": its3, "iterations_timed": n3, "ms_per_iteration": dt3 / n3 * 1e3,
+                                                          "device_ms_per_iteration_hip_events": det3["device_ms_hip_events"] / n3,
+                                                          "lanczos_fused_launches": det3["lanczos_fused_launches"],
+                                                          "note": "BASELINE.json configs[2] on the timed run's matrix and right-hand side; "
+                                                                  "`python bench.py --config 3` carries its roofline and CPU baseline"}}
+        except Exception as exc:
+            out["secondary"] = {"config3_minres_jacobi": {"error": repr(exc)[:300]}}
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(A_for_ls, b, m, args.cpu_budget_s)
@@ -648,13 +830,266 @@ def _run():
     return out, rank, dist
 
 
+def _stamped_traffic(key, n=None):
+    """HBM-side bytes per launch of kernel `key` from a profiles/*_traffic.json of THIS source tree (tools/profile_config.sh
+    writes them from separate --pmc FETCH_SIZE / WRITE_SIZE passes; 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction).
+    None unless a file carries the stamp of the kernel sources that have just been timed."""
+    import glob
+    from krypy_amd import _bench
+    stamp = _bench.source_stamp()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            tj = json.load(open(fn))
+            if tj.get("source_stamp") != stamp or key not in tj:
+                continue
+            if n is not None and int(tj.get("n", n)) != int(n):
+                continue
+            e = tj[key]
+            return e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"], os.path.basename(fn)
+        except Exception:
+            continue
+    return None, None
+
+
+def _roof(kernel, bytes_per_launch, avg_launch_ms, traffic_key, n, bytes_source, note):
+    """The `roofline` object of a secondary configuration: algorithmic bytes per launch / the HIP-event launch time."""
+    from krypy_amd import _bench
+    ach = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+    traffic, tfile = _stamped_traffic(traffic_key, n)
+    r = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": traffic, "avg_launch_ms": avg_launch_ms, "bytes_per_launch": bytes_per_launch, "bytes_source": bytes_source,
+         "source_stamp": _bench.source_stamp(), "note": note}
+    if traffic is not None:
+        r["traffic_over_bytes"] = traffic / bytes_per_launch
+        r["traffic_source"] = "rocprofv3 PMC, separate passes: 2 x FETCH_SIZE + WRITE_SIZE, " + tfile
+    else:
+        r["traffic_source"] = "null: no profiles/*_traffic.json carries the stamp of these kernel sources for this kernel"
+    return r
+
+
+def minres_jacobi_leg(ctx, A, b, iters, steps, warmup):
+    """BASELINE.json configs[2] on an operator already built: MINRES (ortho='lanczos') with the Jacobi preconditioner
+    M = diag(A)^-1 (linsys.py:791-853), `steps` solves of `iters` iterations from x0 = 0 (the tolerance is not reached), after
+    `warmup` untimed ones.  Returns (iterations/s by the host clock, dict of details, roofline inputs)."""
+    import scipy.sparse as sp
+    from krypy_amd import linsys, utils
+    d = A.diagonal()
+    ls = linsys.LinearSystem(A, b, M=sp.diags(1.0 / d).tocsr(), Minv=sp.diags(d).tocsr(), self_adjoint=True)
+
+    def solve():
+        try:
+            return linsys.Minres(ls, ortho="lanczos", tol=1e-12, maxiter=iters)
+        except utils.ConvergenceError as e:
+            return e.solver
+    for _ in range(max(warmup, 1)):
+        solve()
+    ctx.sync()
+    f0, r0 = ctx.get("n_lanczos_fused"), ctx.get("n_minres_rides")
+    ctx.timer_start()
+    t0 = time.perf_counter()
+    n_it = 0
+    for _ in range(steps):
+        sol = solve()
+        n_it += len(sol.resnorms) - 1
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ev_ms = ctx.timer_stop()
+    fused, rides = ctx.get("n_lanczos_fused") - f0, ctx.get("n_minres_rides") - r0
+    return n_it / dt, dt, n_it, {"final_relres": float(sol.resnorms[-1]), "lanczos_fused_launches": fused,
+                                 "minres_updates_carried": rides, "device_ms_hip_events": ev_ms}
+
+
+def _run_config3(args):
+    """BASELINE.json configs[2]: the 2-D 5-pt Laplacian of config 2 (N = 10^7), MINRES + Jacobi M, one MI355X."""
+    os.environ.setdefault("KRYPY_AMD_DEVICE", "0")
+    from krypy_amd import _hip
+    if not os.path.exists(_hip.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    ctx = _hip.get_context()
+    nx, ny = args.nx, args.ny
+    N = nx * ny
+    A = laplace2d(nx, ny)
+    b = np.random.default_rng(0).standard_normal(N)
+    its, dt, n_it, det = minres_jacobi_leg(ctx, A, b, args.iters, args.steps, args.warmup)
+    assert n_it == args.steps * args.iters, (n_it, args.steps, args.iters)
+    fused = det["lanczos_fused_launches"] >= n_it - args.steps
+    # every datum once (lanczos.h): 5 diagonals 40 N + v_k 8 N + p_{k-1} 8 N | p_k 8 N + D 8 N | two stores 16 N = 88 N, and the
+    # MINRES recurrences of iteration k - 2 riding along: v, W0, W1, yk in, z and yk out = 48 N
+    bpl = (88.0 if fused else 104.0) * N + 48.0 * N
+    launches = max(det["lanczos_fused_launches"], 1) if fused else n_it
+    roof = _roof("k_lanczos_fused<40,5,JAC,MR>: one Lanczos step in three passes, the MINRES recurrences of iteration k-2 riding along"
+                 if fused else "per-kernel Lanczos + MINRES update path",
+                 bpl, det["device_ms_hip_events"] / launches, "k_lanczos_fused", N,
+                 "algorithmic bytes of one iteration, every datum once: 88 N (Lanczos launch: 5 diagonals of the banded copy, "
+                 "v_k, p_{k-1}, p_k, D, two stores) + 48 N (MINRES recurrences)",
+                 "avg_launch_ms = HIP-event time of the timed region (kh_timer_*, the library's stream) / launches of the fused "
+                 "kernel in it - the few other launches of a solve (initial residual, the final explicit residual) are inside, "
+                 "so this is an upper bound on the kernel's own duration; profiles/r06_config3.md has the kernel trace")
+    out = {
+        "metric": "MINRES+Jacobi iterations/sec, n=10^7 5-pt Laplacian fp64",
+        "value": its, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "MINRES (ortho=lanczos) + Jacobi M = diag(A)^-1, %d iterations per solve from x0 = 0, 2-D 5-pt "
+                               "Laplacian %dx%d CSR (N=%d, nnz=%d), b=rng(0) normal (BASELINE.json configs[2])"
+                               % (args.iters, nx, ny, N, A.nnz),
+                   "n": N, "iterations_timed": n_it, "parallelism": "1 GPU", "ranks": 1, **det},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = _cpu_baseline_minres(A, b, min(args.cpu_budget_s, 40.0))
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
+    return out, 0, None
+
+
+def _cpu_baseline_minres(A, b, budget_s):
+    """The CPU oracle's MINRES + Jacobi (oracle/krylov_ref.py: minres) on the same A and b: as many iterations as fit the
+    budget (an iteration costs the same whatever k: one SpMV + about twelve vector passes)."""
+    import scipy.sparse as sp
+    from oracle import krylov_ref as ref
+    d = A.diagonal()
+    M = sp.diags(1.0 / d).tocsr()
+    t0 = time.perf_counter()
+    ref.minres(A, b, tol=1e-30, maxiter=3, M=M)          # warm-up and a first estimate
+    per = (time.perf_counter() - t0) / 3.0
+    iters = int(max(5, min(200, budget_s / max(per, 1e-3))))
+    t0 = time.perf_counter()
+    res = ref.minres(A, b, tol=1e-30, maxiter=iters, M=M)
+    dt = time.perf_counter() - t0
+    done = len(res["resnorms"]) - 1
+    return {"value": done / dt, "unit": "iterations/s", "cores": _blas_threads() or 1, "kind": "port",
+            "sample": "%d MINRES + Jacobi iterations at N=%d with the NumPy/SciPy oracle (oracle/krylov_ref.py: minres), same A and b, "
+                      "%.1f s, set-up and the final explicit residual included; BLAS threads as NumPy picks them (%s), SciPy's "
+                      "csr_matvec is single-threaded" % (done, A.shape[0], dt, _blas_threads())}
+
+
+def _run_config4(args):
+    """BASELINE.json configs[3]: dense random SPD n = 32768 fp64, CG, the product A p as the row-per-wave GEMV kernel (the panel
+    A = G G^T is formed ON THE DEVICE by the FP64 MFMA kernel, k_gemm_dense_mfma, through kh_apply's panel path - the host never
+    multiplies).  A step = one whole solve to tol 1e-8 from x0 = 0 (linsys.py:593-689)."""
+    os.environ.setdefault("KRYPY_AMD_DEVICE", "0")
+    from krypy_amd import _hip, linsys, utils
+    if not os.path.exists(_hip.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    ctx = _hip.get_context()
+    n = args.dense_n
+    rng = np.random.default_rng(0)
+    t_setup = time.perf_counter()
+    G = rng.standard_normal((n, n))                 # the same stream as oracle/inputs.py: dense_spd_system (G first, then b)
+    b = rng.standard_normal(n)
+    # Y = G G^T: G as a dense operator applied to the block whose columns are the rows of G; the columns of the symmetric
+    # Y are the rows of the row-major operator A = Y / n + I (kh_dense_from_block) - all on the device
+    Gop = ctx.dense(G)
+    Gt = ctx.alloc(n, n, zero=False)
+    step = 2048
+    for c0 in range(0, n, step):
+        Gt.upload(c0, np.ascontiguousarray(G[c0:c0 + step].T))
+    del G
+    Y = ctx.alloc(n, n, zero=False)
+    ctx.sync()
+    t_mm = time.perf_counter()
+    ctx.apply(Gop, Gt, 0, Y, 0, n)
+    ctx.sync()
+    t_mm = time.perf_counter() - t_mm
+    del Gop, Gt
+    Aop = ctx.dense_from_block(Y, 0, n, 1.0 / n, 1.0)
+    del Y
+    import gc
+    gc.collect()
+    ctx._pool_flush()
+    t_setup = time.perf_counter() - t_setup
+    A = utils.DeviceOperator(Aop) if hasattr(utils, "DeviceOperator") else None
+    if A is None:
+        raise SystemExit("bench.py --config 4: krypy_amd.utils.DeviceOperator missing")
+    ls = linsys.LinearSystem(A, b, self_adjoint=True, positive_definite=True)
+
+    def solve():
+        return linsys.Cg(ls, tol=1e-8, maxiter=200)
+    for _ in range(max(args.warmup, 1)):
+        solve()
+    ctx.sync()
+    t0 = time.perf_counter()
+    n_it = 0
+    for _ in range(args.steps):
+        sol = solve()
+        n_it += sol.iter
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    its = n_it / dt
+    # the dominant kernel, timed by itself with HIP events on the library's stream: the GEMV of one CG iteration
+    X, Yv = ctx.upload(b), ctx.alloc(n, 1)
+    for _ in range(3):
+        ctx.apply(Aop, X, 0, Yv, 0, 1)
+    reps = 30
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.apply(Aop, X, 0, Yv, 0, 1)
+    gemv_ms = ctx.timer_stop() / reps
+    roof = _roof("k_gemv_dense (row-major GEMV, four rows per wave: one launch per CG iteration)", 8.0 * n * n + 16.0 * n, gemv_ms,
+                 "k_gemv_dense", n, "the matrix once (8 n^2) + x in, y out (16 n)",
+                 "avg_launch_ms = %d back-to-back launches between two HIP events on the library's stream (kh_timer_*); a CG "
+                 "iteration is this launch + two small fused vector launches (linsys.py:655-665)" % reps)
+    out = {
+        "metric": "CG iterations/sec, dense random SPD n=32768 fp64",
+        "value": its, "unit": "iterations/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "CG to tol 1e-8 from x0 = 0 on the dense SPD matrix A = G G^T / n + I, G = rng(0) normal (n=%d), "
+                               "b = the same stream's next n normals (BASELINE.json configs[3]); a step = one whole solve" % n,
+                   "n": n, "iterations_timed": n_it, "iterations_per_solve": sol.iter, "final_relres": float(sol.resnorms[-1]),
+                   "parallelism": "1 GPU", "ranks": 1,
+                   "setup_s": t_setup, "gg_t_on_device_s": t_mm,
+                   "gg_t_tflops": 2.0 * n * n * n / t_mm / 1e12,
+                   "setup_note": "A formed on the device: G uploaded once as an operator and once as a block, Y = G G^T by "
+                                 "k_gemm_dense_mfma (16 columns per launch, FP64 MFMA), A = Y^T / n + I by kh_dense_from_block; "
+                                 "sums taken in the MFMA kernel's order, i.e. A equals the NumPy matrix to rounding"},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = _cpu_baseline_cg(n, min(args.cpu_budget_s, 40.0))
+        except Exception as exc:
+            out["cpu_baseline"] = {"error": repr(exc)}
+    return out, 0, None
+
+
+def _cpu_baseline_cg(n, budget_s):
+    """The CPU oracle's CG (oracle/krylov_ref.py: cg) on a BOUNDED sample: the same construction at n_s = 8192 (the full
+    matrix costs a 70-TFLOP host dgemm before the first iteration), whole solves; an iteration is one dense GEMV, i.e.
+    n^2 flops and 8 n^2 bytes, so the rate at n is the measured one times (n_s / n)^2."""
+    from oracle import krylov_ref as ref
+    from oracle.inputs import dense_spd_system
+    ns = min(n, 8192)
+    A, b = dense_spd_system(ns)
+    ref.cg(A, b, tol=1e-8, maxiter=200)
+    t0 = time.perf_counter()
+    done, solves = 0, 0
+    while time.perf_counter() - t0 < budget_s / 4.0 or solves == 0:
+        res = ref.cg(A, b, tol=1e-8, maxiter=200)
+        done += len(res["resnorms"]) - 1
+        solves += 1
+    dt = time.perf_counter() - t0
+    scale = (float(ns) / n) ** 2
+    return {"value": done / dt * scale, "unit": "iterations/s", "cores": _blas_threads() or 1, "kind": "port",
+            "measured_at_sample_size": done / dt,
+            "sample": "%d whole CG solves (%d iterations, %.1f s) of the NumPy oracle (oracle/krylov_ref.py: cg) on the same "
+                      "construction at n = %d; `value` = that rate x (%d / %d)^2 (an iteration is one dense GEMV: 8 n^2 bytes), "
+                      "BLAS threads as NumPy picks them (%s)" % (solves, done, dt, ns, ns, n, _blas_threads())}
+
+
 def _run_config5(args):
     """BASELINE.json configs[4]: 3-D 7-point Laplacian on 500 x 500 x 400 points (N = 10^8, nnz = 698,700,000), rows in
     z-slabs over the ranks (400 / 8 = 50 planes = 12.5 M rows per GPU), b = rng(0) normal.  Solve 1: plain GMRES(m)
     (DeflatedGmres without U) to harvest the `defl` smallest-magnitude Ritz vectors ON THE DEVICE (every rank keeps its
     slab of them; the small eigenproblem is replicated host work); solve 2: DeflatedGmres(U, maxiter=m), timed - a
     *step* is one such solve of m iterations from x0 = 0 (reference flow: recycling/linsys.py:51-103,
-    deflation.py:93-163).  Same JSON contract as config 2; `scaling` is "strong" (the grid is fixed)."""
+    deflation.py:93-163).  Same JSON contract as config 2; `scaling` is "strong" (the grid is fixed).  On one GPU the whole
+    problem (N = 10^8: the basis 80.8 GB, the projector's four bases 51 GB, the operator 14 GB of the 288 GB) runs as it is."""
+    import gc
     rank, world, local_rank = _world(args)
     os.environ.setdefault("KRYPY_AMD_DEVICE", str(local_rank))
     sharded = world > 1 or args.force_sharded
@@ -679,9 +1114,12 @@ def _run_config5(args):
     plane = nx * ny
     N = plane * nz
     ortho = args.ortho
-    if ortho == "auto":
+    auto = ortho == "auto"
+    if auto:
         ortho = "cgs" if sharded else "mgs"
     b_rng = np.random.default_rng(0)
+    xr_on = False
+    t_setup = time.perf_counter()
     if sharded:
         from krypy_amd import dist as kdist
         if args.transport == "rccl":
@@ -692,8 +1130,14 @@ def _run_config5(args):
             raise SystemExit("bench.py --transport xr: the mailboxes did not come up on every rank, and there is no RCCL communicator")
         cuts = [(nz * p) // world for p in range(world + 1)]          # whole planes per rank
         z0, z1 = cuts[rank], cuts[rank + 1]
-        Aloc = laplace3d(nx, ny, nz, z0, z1)
-        op = kdist.ShardedCSROperator(Aloc, z0 * plane, N, ctx)
+        if args.loop_halo:
+            if not (args.force_sharded and world == 1):
+                raise SystemExit("bench.py --loop-halo: with --force-sharded on one rank")
+            Aloc = laplace3d(nx, ny, 3 * nz, nz, 2 * nz)
+            op = kdist.ShardedCSROperator(Aloc, nz * plane, 3 * N, ctx, self_loop=True)
+        else:
+            Aloc = laplace3d(nx, ny, nz, z0, z1)
+            op = kdist.ShardedCSROperator(Aloc, z0 * plane, N, ctx)
         del Aloc
         # every rank draws the same stream and keeps its slab (the right-hand side of the unsharded run)
         b = None
@@ -707,47 +1151,170 @@ def _run_config5(args):
         b = b_rng.standard_normal(N)
     nnz_global = 7 * N - 2 * (nx * ny + ny * nz + nx * nz)
     ls = linsys.LinearSystem(A_for_ls, b, self_adjoint=True)
+    t_setup = time.perf_counter() - t_setup
 
     def barrier():
         ctx.sync()
         if dist is not None:
             dist.barrier()
 
-    def solve(U):
+    mode = [ortho]
+
+    def solve(U, mode_=None):
         try:
-            return deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, ortho=ortho, store_arnoldi=U is None)
+            return deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=m, ortho=mode_ or mode[0], store_arnoldi=U is None)
         except utils.ConvergenceError as e:
             return e.solver
 
-    # solve 1 (untimed): harvest the Ritz vectors on the device
+    # solve 1 (untimed): harvest the Ritz vectors on the device.  (A solver and the operators it builds refer to each other:
+    # its 80 GB basis is garbage only to the cycle collector - collect before the next one is allocated.)
     s0 = solve(None)
     ritz = deflation.Ritz(s0)
     U = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:d])
     plain_relres = float(s0.resnorms[-1])
     ritz_values = np.sort(np.abs(ritz.values))[:d]
     del s0, ritz
-    for _ in range(args.warmup):
-        solve(U)
-    barrier()
-    cycle_marks = []
-    t0 = time.perf_counter()
-    n_iters = 0
-    for _ in range(args.steps):
-        s1 = solve(U)
-        n_iters += len(s1.resnorms) - 1
-        cycle_marks.append(time.perf_counter())
-    ctx.sync()
-    dt = time.perf_counter() - t0
+    gc.collect()
+
+    def one_solve(cand):
+        s_ = solve(U, cand)
+        n_ = len(s_.resnorms) - 1
+        del s_
+        gc.collect()
+        return n_
+
+    # --ortho auto: one untimed deflated solve per candidate, the faster one is timed (N ranks: per transport as well, the max
+    # over the ranks decides on every rank alike; a candidate that fails over the mailboxes sends every rank back to RCCL)
+    auto_report = None
+    transport_used = None if not sharded else ("xr" if xr_on else "rccl")
+    if auto and sharded:
+        ortho, transport_used, xr_on, auto_report = _probe_sharded(ctx, dist, args, A_for_ls, xr_on, one_solve)
+        mode[0] = ortho
+    elif auto:
+        auto_report = {"candidates": []}
+        best = None
+        for cand in ("mgs", "cgs"):
+            ctx.sync()
+            t1 = time.perf_counter()
+            one_solve(cand)
+            ctx.sync()
+            d1 = time.perf_counter() - t1
+            auto_report["candidates"].append({"ortho": cand, "ms": d1 * 1e3})
+            if best is None or d1 < best[0]:
+                best = (d1, cand)
+        ortho = mode[0] = best[1]
+        auto_report["chosen"] = {"ortho": ortho}
+
+    def timed_region():
+        for _ in range(args.warmup):
+            one_solve(None)
+        barrier()
+        marks = []
+        t0_ = time.perf_counter()
+        n_, last = 0, None
+        for _ in range(args.steps):
+            s1 = solve(U)
+            n_ += len(s1.resnorms) - 1
+            last = float(s1.resnorms[-1])
+            del s1
+            gc.collect()
+            marks.append(time.perf_counter())
+        ctx.sync()
+        return n_, last, t0_, marks, time.perf_counter() - t0_
+
+    region_fallback = None
+    ok, err = 1.0, None
+    try:
+        n_iters, deflated_relres, t0, cycle_marks, dt = timed_region()
+    except _hip.BackendError as exc:
+        if not sharded:
+            raise
+        ok, err = 0.0, str(exc)[:300]
+    if sharded and dist.allreduce_min(ok) < 1.0:
+        if args.transport != "rccl" or (not xr_on and mode[0] == "cgs"):
+            raise SystemExit("bench.py: the timed region failed on some rank (%s) and there is no other path to go back to" % (err,))
+        region_fallback = {"reason": err or "another rank's timed region failed", "from": {"ortho": mode[0], "transport": transport_used}}
+        if hasattr(ctx, "set"):
+            ctx.set("chain_blk2", 0)
+            ctx.set("chain_xr", 0)
+        if hasattr(A_for_ls, "halo_via"):
+            A_for_ls.halo_via("rccl")
+        if xr_on:
+            ctx.set("xr", 0)
+            ctx.xr_detach()
+            xr_on = False
+        ortho = mode[0] = "cgs"
+        transport_used = "rccl"
+        n_iters, deflated_relres, t0, cycle_marks, dt = timed_region()
     cycle_ms = [round((b_ - a_) * 1e3, 2) for a_, b_ in zip([t0] + cycle_marks[:-1], cycle_marks)]
     if dist is not None:
         dt = dist.allreduce_max(dt)
     assert n_iters == args.steps * m, (n_iters, args.steps, m)
     its = n_iters / dt
     nloc = ls.N
-    # bytes one deflated iteration has to move at least: the operator, the Gram-Schmidt columns once per
-    # use, the projector's two sweeps over the 2 d vectors (560 N for d = 16)
-    it_bytes = (12.0 * nnz_global + 4.0 * (N + 1) + 16.0 * N) + 16.0 * N * (m + 1) / 2.0 + 48.0 * N + \
-        (32.0 * d + 48.0) * N
+
+    shard_diag = None
+    if sharded:
+        keys = ("n_allreduce", "n_xr", "n_halo_exchange", "n_halo_xh", "n_chain_blk2", "n_chain_xr", "n_lowsync")
+        try:
+            c0 = dict((k, ctx.get(k)) for k in keys) if hasattr(ctx, "get") else {}
+            barrier()
+            per = float(max(one_solve(None), 1))
+            shard_diag = {"per_iteration": dict((k, (ctx.get(k) - c0[k]) / per) for k in c0)}
+            mine = _spmv_us(ctx, A_for_ls, nloc) if hasattr(ctx, "get") else -1.0
+        except _hip.BackendError as exc:
+            shard_diag = {"error": str(exc)[:300]}
+            mine = -1.0
+        shard_diag["spmv_us_per_rank"] = _rank_table(dist, mine)
+        shard_diag["rows_per_rank"] = _rank_table(dist, nloc)
+
+    # ---- per-kernel rooflines on this rank's slab (one rank; N ranks keep the whole-iteration average below: the
+    # micro-launches have no cross-rank stage) ----
+    # bytes one deflated iteration has to move at least on this rank: the operator (banded copy when there is one), w out
+    # and in again around the projector, the projector's two sweeps over its 2 d columns, every Gram-Schmidt column once
+    # per use of the form that ran, v_{k+1} out
+    dm = ls.A._device_matrix() if hasattr(ls.A, "_device_matrix") else None
+    nd = int(getattr(dm, "diagonals", 0) or 0)
+    op_bytes = (8.0 * nd * nloc + 16.0 * nloc) if nd else (12.0 * nnz_global / world + 4.0 * (nloc + 1) + 16.0 * nloc)
+    uses = 1.0 if (ortho == "mgs" and nloc <= 14680064) else 2.0          # register-resident chain: a column is read once
+    it_bytes = op_bytes + 32.0 * nloc + 32.0 * d * nloc + uses * 8.0 * nloc * (m + 1) / 2.0 + 8.0 * nloc
+    roof = {"bound": "hbm", "kernel": "whole deflated iteration (all kernels)", "achieved": it_bytes * its / 1e9, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": it_bytes * its / 1e9 / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": it_bytes,
+            "bytes_source": "algorithmic bytes of one deflated iteration on one rank, every datum once per use: operator %s, the "
+                            "projector's two sweeps over 2 x %d columns (32 d N), %s, w out / in around the projector, v_{k+1} out"
+                            % ("as its banded copy (8 nd N + 16 N)" if nd else "as CSR", d,
+                               "the Gram-Schmidt columns once (register-resident chain)" if uses == 1.0 else
+                               "the Gram-Schmidt columns twice (dots pass + update pass: w does not fit the register file, or the panel form)")}
+    extra = {}
+    if world == 1 and not args.no_roofline and hasattr(ctx, "bench_kernel"):
+        try:
+            from krypy_amd import _bench
+            gc.collect()
+            kroof, kextra = _bench.roofline(ctx, ls, ortho, HBM_PEAK_GBS, reps=20, m=m, solver_steps=False)
+            kernels = kextra.get("kernels", {})
+            # the projector, as the solver applies it (d columns, two sweeps): HIP events over 10 applications
+            pj_ms, pj_bytes, pj_name = _bench.projector_probe(ctx, nloc, d)
+            kernels[pj_name] = {"avg_ms": pj_ms, "compulsory_bytes": pj_bytes, "compulsory_gbs": pj_bytes / pj_ms / 1e6,
+                                "frac_compulsory": pj_bytes / pj_ms / 1e6 / HBM_PEAK_GBS}
+            # shares of an iteration: Gram-Schmidt ((m + 1) / 2 links or columns on average), projector, operator
+            gs_ms = kroof["avg_launch_ms"] * kroof.get("links_or_columns_per_iteration", (m + 1) / 2.0) / kroof.get("links_or_columns_per_launch", 1.0)
+            sp = kextra.get("spmv", {})
+            sp_ms = min([v["avg_ms"] for v in sp.values()] or [0.0]) if nd else max([v["avg_ms"] for v in sp.values()] or [0.0])
+            share = {"gram_schmidt_ms": gs_ms, "projector_ms": pj_ms, "operator_ms": sp_ms, "measured_iteration_ms": dt / n_iters * 1e3}
+            whole = roof
+            roof = dict(kroof)
+            if pj_ms > gs_ms:           # the projector dominates (short restart lengths): its roofline is the line's
+                roof.update(kernel=pj_name, achieved=pj_bytes / pj_ms / 1e6, frac=pj_bytes / pj_ms / 1e6 / HBM_PEAK_GBS,
+                            avg_launch_ms=pj_ms, bytes_per_launch=pj_bytes, traffic=None)
+            t_key = "k_proj" if pj_ms > gs_ms else kroof.get("traffic_key")
+            if t_key:
+                tr, tf = _stamped_traffic(t_key, nloc)
+                if tr is not None:
+                    roof["traffic"], roof["traffic_over_bytes"], roof["traffic_source"] = tr, tr / roof["bytes_per_launch"], "rocprofv3 PMC passes, " + tf
+            roof["iteration_shares_ms"] = share
+            extra = {"kernels": kernels, "whole_iteration": whole, "attainable": kextra.get("attainable"), "spmv": sp}
+        except Exception as exc:
+            extra = {"roofline_error": repr(exc)[:400]}
     out = {
         "metric": "DeflatedGmres iterations/sec, 3-D 7-pt Laplacian n=10^8 row-sharded, 16 recycled Ritz vectors, fp64",
         "value": its, "unit": "iterations/s", "n_gpus": int(os.environ.get("KRYPY_AMD_BENCH_DEVICES", world)), "steps": args.steps,
@@ -761,18 +1328,17 @@ def _run_config5(args):
                    "iterations_timed": n_iters,
                    "parallelism": "1 GPU" if not sharded else "z-slabs x%d (%s)" % (world, "RCCL" if args.transport == "rccl" else "mailboxes only"),
                    "ranks": world,
-                   "cross_rank_sums": None if not sharded else ("xr" if locals().get("xr_on") else "rccl"),
+                   "cross_rank_sums": None if not sharded else ("xr" if xr_on else "rccl"),
                    "halo": None if not sharded else (("in-launch" if getattr(A_for_ls, "halo_in_launch", False) else "rccl") +
                                                     (" (the slab is its own neighbour)" if args.loop_halo else "")),
-                   "plain_relres": plain_relres, "deflated_relres": float(s1.resnorms[-1]),
+                   "ortho_auto": auto_report, "timed_region_fallback": region_fallback, "sharded_diagnostics": shard_diag,
+                   "plain_relres": plain_relres, "deflated_relres": deflated_relres,
                    "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
+                   "operator_diagonals": nd, "setup_s": t_setup,
                    "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms))},
-        "roofline": {"bound": "hbm", "achieved": it_bytes / world * its / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": it_bytes / world * its / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                     "bytes_source": "SURVEY 8(d) algorithmic bytes of one deflated iteration per GPU (operator as CSR, "
-                                     "every basis column twice, projector 560 N for d = 16), whole-solve average - not "
-                                     "a per-kernel figure"},
+        "roofline": roof,
     }
+    out.update(extra)
     if rank == 0 and not sharded and not args.no_cpu_baseline:
         out["cpu_baseline"] = {"value": None, "note": "config 2 carries the CPU baseline (bench.py without --config)"}
     return out, rank, dist

@@ -157,6 +157,13 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
 /* dense row-major (C-ordered ndarray), leading dimension lda */
 int kh_dense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a, int64_t lda,
                     kh_mat* out);
+/* dense operator from a block already on the device: A = alpha X[:, col0 : col0 + n_rows]^T + beta I (row i of the
+ * operator = column col0 + i of X).  With Y = G G^T formed by kh_apply's panel path the columns of the symmetric Y are
+ * the rows of the row-major operator: BASELINE config 4's A = G G^T / n + I without a trip over the host
+ * ("build on device or in blocks"; the reference gets its ndarray through get_linearoperator,
+ * utils.py:241-259).  Synchronous. */
+int kh_dense_from_block(kh_ctx ctx, kh_vec X, int64_t col0, int64_t n_rows, double alpha, double beta,
+                        kh_mat* out);
 /* diagonal operator (Jacobi M / Minv given as scipy.sparse.diags) */
 int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out);
 int kh_mat_free(kh_mat A);

@@ -28,7 +28,7 @@ K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 _SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h", "chain_blk.h",
-            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip", "xr_dev.h", "chain_blk2.h", "chain_blk2.hip", "cycles.hip",
+            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip", "xr_dev.h", "chain_blk2.h", "chain_blk2.hip", "chain_xr.hip", "cycles.hip",
             "bench_abi.hip", "krylov_steps.h")
 
 
@@ -55,10 +55,10 @@ def chain_reread_fraction(n, ncu, lds=True):
     """Share of a column the LDS chain kernel requests a second time from memory (the rest of the second
     use comes from LDS and the register ring): NG*PB/R2 of chain.h's ChainShapeLds."""
     n2 = (n + 1) // 2
-    for r2 in (4, 8, 16, 24, 32, 40):
+    for r2 in (4, 8, 16, 24, 32, 40, 48, 56):
         g = -(-n2 // (r2 * 512))
         if g <= ncu and g <= 512:
-            if not lds:
+            if not lds or r2 > 40:
                 return r2, 1.0
             pb = 5 if r2 == 40 else (2 if r2 == 4 else 4)
             nb = r2 // pb
@@ -67,7 +67,31 @@ def chain_reread_fraction(n, ncu, lds=True):
     return 0, 1.0
 
 
-def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
+def projector_probe(ctx, n, d, reps=10):
+    """The deflation projector as a deflated Arnoldi step applies it (utils.py:604-627: d columns, two sweeps) on synthetic
+    bases of this length: (HIP-event ms per application, algorithmic bytes, kernel name).  One launch with z in registers
+    where the vector fits (proj_reg.h: 528 N for d = 16), else four launches per sweep (560 N)."""
+    rng = numpy.random.default_rng(3)
+    Wd, Vd = ctx.alloc(n, d), ctx.alloc(n, d)
+    col = rng.standard_normal(n) / numpy.sqrt(n)
+    for j in range(d):
+        Wd.upload(j, numpy.roll(col, j))
+        Vd.upload(j, numpy.roll(col, -j))
+    pj = ctx.proj_create(Wd, Vd, d, rng.standard_normal((d, d)) * 0.1, None, 2)
+    A, Z = ctx.upload(rng.standard_normal(n)), ctx.alloc(n, 1)
+    c0 = ctx.get("n_proj_reg")
+    ctx.proj_apply_complement(pj, A, 0, Z, 0, want_ya=True)
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.proj_apply_complement(pj, Z, 0, Z, 0)
+    ms = ctx.timer_stop() / reps
+    one = ctx.get("n_proj_reg") - c0 >= reps
+    nbytes = (32.0 * d + 16.0) * n if one else (32.0 * d + 48.0) * n
+    return ms, nbytes, ("k_proj_reg: the projector's two sweeps in one launch, z in registers (d = %d)" % d) if one else \
+        ("the projector as four launches per sweep (d = %d)" % d)
+
+
+def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100, solver_steps=True):
     """Returns (roofline dict of the dominant kernel, extra dict with the other kernels).  ``m``: the restart length
     of the timed solver (the solver's own launches are timed over k = 0 .. m-1)."""
     n = ls.N
@@ -147,7 +171,7 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
     solver = None
     solver_name = None
     Amat0 = ls.A._device_matrix() if hasattr(ls.A, "_device_matrix") else None
-    if (chain is not None and ortho in ("mgs",) and Amat0 is not None and Amat0.kind == "csr"
+    if (solver_steps and chain is not None and ortho in ("mgs",) and Amat0 is not None and Amat0.kind == "csr"
             and hasattr(ctx, "bench_arnoldi")):
         try:
             c0 = ctx.counters()
@@ -255,6 +279,8 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
         k, name, traffic_keys = kernels["k_gs_link<A_PART,T_DOT>"], "k_gs_link<A_PART,T_DOT>", ()
     ms = k["avg_ms"]
     comp = k["compulsory_bytes"]
+    per_launch = (m + 1) / 2.0 if (solver is not None and k is solver) else (CHAIN_LINKS if (chain is not None and k is chain) else
+                                                                             (16.0 if traffic_keys == ("k_cgs_dots", "k_cgs_update") or name.startswith("k_multidot") else 1.0))
     # `bytes_per_launch` = the ALGORITHMIC (compulsory) bytes of a launch - every datum once - and `frac` the
     # fraction of the peak they are moved at.  `traffic` = what the memory fabric was asked for, from the PMC passes
     # of this same command, attached only when the profile carries the stamp of the kernel sources that have just
@@ -283,7 +309,9 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100):
             "bytes_per_launch": comp,
             "bytes_source": "compulsory (algorithmic) bytes: every basis column once (8 N each), the operator's arrays once, "
                             "v_{k+1} out - SURVEY 8(d)'s per-unit figures with the column's second use NOT charged to HBM",
-            "source_stamp": stamp}
+            "source_stamp": stamp,
+            # Gram-Schmidt links (chain / link kernels) or columns (panel kernels) one timed launch (pair) serves
+            "links_or_columns_per_launch": per_launch, "traffic_key": traffic_keys[0] if len(traffic_keys) == 1 else None}
     if traffic is not None:
         # like with like: the solver key's traffic is the average over the steps k >= 1, so are the bytes under it
         roof["traffic_over_bytes"] = traffic / (k.get("compulsory_bytes_k_ge_1", comp) if traffic_keys == ("k_mgs_chain_solver",) else comp)

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "kh_csr_upload": [_H, _I64, _I64, _I64, _c_int32_p, _c_int32_p, _c_double_p,
                       ctypes.POINTER(_H)],
     "kh_dense_upload": [_H, _I64, _I64, _c_double_p, _I64, ctypes.POINTER(_H)],
+    "kh_dense_from_block": [_H, _H, _I64, _I64, ctypes.c_double, ctypes.c_double, ctypes.POINTER(_H)],
     "kh_diag_upload": [_H, _I64, _c_double_p, ctypes.POINTER(_H)],
     "kh_mat_free": [_H],
     "kh_mat_diagonals": [_H],
@@ -418,7 +419,9 @@ class Context(object):
     _POOL_PER_SHAPE = 2          # big blocks (a basis)
     _POOL_PER_SHAPE_SMALL = 12   # blocks below _POOL_SMALL_BYTES (single vectors, W pairs, panels):
     _POOL_SMALL_BYTES = 1 << 30  # a cycle allocates and drops about ten of them
-    _POOL_FRACTION = 0.35
+    _POOL_FRACTION = 0.6         # (0.35 until round 6: config 5 at N = 10^8 on one device - an 80.8 GB basis beside 34 GB of parked
+                                 #  projector blocks - fell over the cap and paid 4 x 0.86 s of hipMalloc per solve, 3.4 of 8.4 s;
+                                 #  an allocation that fails flushes the pool and is tried again, so a generous cap costs nothing)
 
     def _pool_take(self, n, ncols, zero=True):
         lst = self.__dict__.setdefault("_pool", {}).get((n, ncols))
@@ -628,6 +631,15 @@ class Context(object):
         _check(self._lib, self._with_memory(lambda: fn(self._h, a.shape[0], a.shape[1], _dptr(a), a.shape[1],
                                                        ctypes.byref(h))), "kh_dense_upload")
         return DeviceMatrix(self, h, "dense", a.shape, a.size, dt)
+
+    def dense_from_block(self, X, col0, nrows, alpha=1.0, beta=0.0):
+        """Dense operator alpha X[:, col0 : col0 + nrows]^T + beta I from a real block that is already on the device."""
+        if X.dtype != _F64:
+            raise BackendError("dense_from_block: a real block expected")
+        h = _H()
+        _check(self._lib, self._with_memory(lambda: self._lib.kh_dense_from_block(
+            self._h, X.handle, col0, nrows, float(alpha), float(beta), ctypes.byref(h))), "kh_dense_from_block")
+        return DeviceMatrix(self, h, "dense", (nrows, X.n), nrows * X.n, _F64)
 
     def diag(self, d, dtype=None):
         d = numpy.asarray(d)

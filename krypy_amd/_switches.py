@@ -109,7 +109,18 @@ SWITCHES = [
     ("KRYPY_AMD_BENCH_DEVICES", "unset", "bench", None,
      "set by `bench.py`'s own launcher for the rank processes it starts: the number of distinct devices the run uses (`n_gpus` of the line; "
      "differs from the number of ranks only in the `--share-devices` test mode)"),
-    ("KRYPY_AMD_BENCH_ORTHO", "auto", "bench", None, "`bench.py --ortho` default (`auto` = `mgs` on 1 GPU, `cgs` sharded)"),
+    ("KRYPY_AMD_BENCH_ORTHO", "auto", "bench", None,
+     "`bench.py --ortho` default (`auto` = `mgs` on 1 GPU; on N ranks one untimed cycle per (form, transport) candidate, the fastest "
+     "that ran on every rank is timed)"),
+    ("KRYPY_AMD_BENCH_SECONDARY", "1", "bench", None,
+     "0: the default `bench.py` line does not carry `secondary.config3_minres_jacobi` (MINRES + Jacobi on the timed run's matrix, "
+     "2 x 200 iterations after the timed region)"),
+    ("KRYPY_AMD_BENCH_XR_TIMEOUT_S", "15", "bench", None,
+     "seconds a cross-rank sum over the mailboxes may wait for a peer inside `bench.py`'s timed region before the run goes back to RCCL "
+     "and the panel form on every rank (`timed_region_fallback` of the line); the probe of the candidates uses 10 s"),
+    ("KRYPY_AMD_BENCH_DEADLINE_S", "1500", "bench", None,
+     "seconds after which `bench.py --gpus N`'s own launcher stops its rank processes and exits non-zero (a collective that never returns "
+     "must not hold the driver for ever)"),
     ("KRYPY_AMD_TEST_RLIMIT_GB", "96", "test", None,
      "cap (GB) on the host memory of the GPU test session (`RLIMIT_DATA`, set once the HIP context exists): a test asking for absurd "
      "memory dies with a `MemoryError` instead of taking the box down; 0: off"),

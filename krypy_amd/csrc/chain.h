@@ -84,6 +84,9 @@ struct ChainArgs {
     unsigned onex_target;
     unsigned* onex_ticket;     // zero when the launch begins
     unsigned* onex_clear;      // the ticket word of a launch far in the future: zeroed by this one
+    // N ranks (XR instantiations only: nobody else reads it): every grid-wide sum of the launch also crosses the ranks through
+    // the IPC-mapped mailboxes of xr.hip - inside the XCD leaders' hand-over (grid_sum<true>)
+    XrDev xr;
 #ifdef KH_CHAIN_TRACE
     unsigned long long* trace;   // diagnostic build only (make trace): [G][links][2 waves][8] 100 MHz stamps
 #endif
@@ -205,9 +208,15 @@ __device__ __forceinline__ GridRole grid_role(unsigned* xcc_leader, unsigned sta
 // fabric themselves (and 30 times fewer polls on the fabric while stragglers still stream).  The order of the
 // additions is the same in every leader: all workgroups get the same bits.  (More than 256 workgroups: every
 // workgroup sweeps, through LDS.)
+// XR (N ranks, chain_xr.hip): the sum also crosses the RANKS - an XCD leader that holds this device's total stores it into
+// every rank's mailbox (xr_dev.h: tagged system-scope stores; the eight leaders of a rank write the same bits to the same
+// slots - idempotent, no election), polls its own mailbox for the N contributions, adds them in rank order and hands THAT
+// total on through its XCD's L2: every workgroup of every rank gets the same bits.  `xepoch` tags the exchange.
+template <bool XR = false>
 __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned long long* gran,
                                            int G, int* err, double* smd, unsigned* smu, const GridRole role,
-                                           unsigned long long* xcc_res, unsigned long long* tr = nullptr) {
+                                           unsigned long long* xcc_res, unsigned long long* tr = nullptr,
+                                           const XrDev* xr = nullptr, unsigned xepoch = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NW = CH_BS / 64;
     // 1. workgroup partial (8 waves, fixed order)
@@ -250,12 +259,23 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
             typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
             u64x2 ab;
             unsigned spins = 0;
+            long long t0 = 0;
             while (true) {
                 asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(ab) : "v"(res) : "memory");
                 if ((unsigned)(ab.x >> 32) == epoch && (unsigned)(ab.y >> 32) == epoch) break;
                 if ((++spins & 4095u) == 0) {
                     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
-                    if (spins > (1u << 24)) {
+                    bool give_up = spins > (1u << 24);
+                    if constexpr (XR) {
+                        // (a peer rank may be late by far more than a workgroup of this launch ever is: by the clock, the
+                        // leader's own timeout + 2 s)
+                        if (xr->nranks > 0) {
+                            const long long now = (long long)wall_clock64();
+                            if (t0 == 0) t0 = now;
+                            give_up = now - t0 > xr->timeout_ticks + 200000000ll;
+                        }
+                    }
+                    if (give_up) {
                         __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
@@ -291,6 +311,19 @@ __device__ __forceinline__ double grid_sum(double part, unsigned epoch, unsigned
         double s = smd[NW];
 #pragma unroll
         for (int i = 1; i < NW; ++i) s += smd[NW + i];
+        if constexpr (XR) {
+            if (xr->nranks > 0) {      // 3b. the cross-rank stage (one lane; the workgroup takes the total from LDS)
+                if (tid == 0) {
+                    xr_put_all(xr->peer, xr->rank, xr->nranks, xepoch, 0, s);
+                    int bad = 0;
+                    const double t = xr_take_all(xr->peer[xr->rank], xr->nranks, xepoch, 0, xr->timeout_ticks, &bad);
+                    if (bad) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (2: a peer rank is missing)
+                    smd[2 * NW] = t;
+                }
+                __syncthreads();
+                s = smd[2 * NW];
+            }
+        }
         if (tid == 0) {      // 4. plain stores: the pair stays in this XCD's L2, where its other workgroups poll it
             const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
             const unsigned long long tag = (unsigned long long)epoch << 32;
@@ -717,9 +750,10 @@ __device__ __forceinline__ void chain_apply_banded(const ChainArgs& a, int64_t f
 // 256 CUs): the last WL rows of w live in LDS (8 KB per row and workgroup, each lane touches only its own
 // entries: no barrier), the first R2 - WL in registers as ever.  R2 = 48 / 56 (WL = 8 / 16) take N to
 // 12.58 M / 14.68 M per GPU with the same single launch per Arnoldi step and the same arithmetic.
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0, bool ONEX = false>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, int WL = 0, bool ONEX = false, bool XR = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
     static_assert(FND == 0 || !MASKED, "the fused operator exists for the padded kernels");
+    static_assert(!XR || (!CPLX && !ONEX), "the cross-rank stage exists for real vectors spread over the chip");
     constexpr int RW = R2 - WL;                   // rows of w in registers
     extern __shared__ __attribute__((aligned(16))) double2 wl[];   // [WL][CH_BS]
 #define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS + tid])
@@ -842,8 +876,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
                 onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
                 alpha = pv[0];
             } else {
+                const unsigned e_ = epoch++;
                 alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                       : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+                                       : grid_sum<XR>(acc0 + acc1, e_, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr, &a.xr,
+                                                      a.xr.epoch0 + (e_ - a.epoch0));
             }
             if (bid == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
@@ -908,7 +944,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain(ChainArgs a) {
         onex_sum<1>(pv, epoch++, a.gran, G, bid, a.err, smd);
         h2 = pv[0];
     } else {
-        h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+        const unsigned e_ = epoch++;
+        h2 = grid_sum<XR>(acc, e_, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr, &a.xr, a.xr.epoch0 + (e_ - a.epoch0));
     }
     const double h = sqrt(fabs(h2));
     if (bid == 0 && tid == 0) a.hdev[a.hnext] = h;
@@ -998,9 +1035,10 @@ struct ChainShapeLds {
     static constexpr size_t LDS_BYTES = (size_t)(LB * PB + WL) * CH_BS * sizeof(double2);
 };
 
-template <int R2, bool MASKED, bool CPLX = false, int FND = 0>
+template <int R2, bool MASKED, bool CPLX = false, int FND = 0, bool XR = false>
 __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
     static_assert(FND == 0 || !MASKED, "the fused operator exists for the padded kernels");
+    static_assert(!XR || !CPLX, "the cross-rank stage exists for real vectors");
     constexpr int PB = ChainShapeLds<R2, CPLX>::PB;
     constexpr int NB = ChainShapeLds<R2, CPLX>::NB;
     constexpr int LB = ChainShapeLds<R2, CPLX>::LB;
@@ -1127,8 +1165,10 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             alpha = grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res,
                              a.trace ? a.trace + (((size_t)blockIdx.x * total) + t) * 16 : nullptr);
 #else
+            const unsigned e_ = epoch++;
             alpha = (a.debug == 1) ? (acc0 + acc1) * 1e-30
-                                   : grid_sum(acc0 + acc1, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+                                   : grid_sum<XR>(acc0 + acc1, e_, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr, &a.xr,
+                                                  a.xr.epoch0 + (e_ - a.epoch0));
 #endif
             if (blockIdx.x == 0 && tid == 0) a.hdev[j] = (t < a.ncol ? 0.0 : a.hdev[j]) + alpha;
         }
@@ -1220,7 +1260,8 @@ __global__ __launch_bounds__(CH_BS) void k_mgs_chain_lds(ChainArgs a) {
             acc = fma(wr.y, wr.y, acc);
         }
     }
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
+    const unsigned en_ = epoch++;
+    const double h2 = grid_sum<XR>(acc, en_, a.gran, G, a.err, smd, smu, role, a.xcc_res, nullptr, &a.xr, a.xr.epoch0 + (en_ - a.epoch0));
     const double h = sqrt(fabs(h2));
     if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
     double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;

@@ -112,6 +112,11 @@ struct kh_ctx_s {
     int gemv_rows = 0;               // rows per wave of k_gemv_dense (0: chosen by size)
     int blk2_cw_maxrows = 7;         // rows per lane up to which the communication-wave shape is used (KRYPY_AMD_BLK2_CW=2: 6, for A / B)
     int64_t n_chain_blk2 = 0;
+    // N ranks, slabs beyond the blocked kernel's 2.5 M rows: the register-resident chain kernels with the cross-rank stage inside
+    // every grid-wide sum (chain_xr.hip; KRYPY_AMD_CHAIN_XR) - the local basis read once, no all-reduce call in the step
+    int chain_xr = 1;
+    int chain_xr_cus = 0;            // tests: the compute units the shape is chosen for (0: all; two processes share one device)
+    int64_t n_chain_xr = 0;
     int64_t blk2_refused_n = -1;
     int64_t n_blk_rowless = 0;       // blocked launches with workgroups without rows in front (chain_blk.h, BlkBufs::nx)
     int64_t blk_refused_n = -1;      // vector length whose blocked launch was refused (occupancy ...): not tried - nor its table rebuilt - again
@@ -328,6 +333,9 @@ hipError_t chain_blk_reset(kh_ctx ctx);
 bool chain_blk2_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, int* cw_out = nullptr, bool one_slot = false);
 int chain_blk2_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount,
                     bool multi);
+// chain_xr.hip: the register-resident chain kernels (16 ... 56 rows per lane) with the cross-rank stage in every sum
+bool chain_xr_shape(kh_ctx ctx, int64_t n, int* r2_out, int* g_out);
+int chain_xr_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k, double* hdev, int slot, double* hpin, int hcount);
 // krylov_hip.hip: the epoch counter of the grid-wide sums brought back to 1 when it nears its wrap; <V[:, j0 .. j0+ncols), w> on the device
 int chain_epoch_check(kh_ctx ctx);
 int dot_panel_raw(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* w, double* out_dev);

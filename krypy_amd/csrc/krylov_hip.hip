@@ -30,6 +30,10 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
+    // a refused allocation stays behind as the runtime's "last error": the host layer frees what it was merely holding on
+    // to and allocates again (_hip.py: _with_memory), and the next launch check (hipGetLastError) would report the stale
+    // "out of memory" of the attempt that was recovered from (seen at N = 10^8: config 5 on one device)
+    if (code == KH_ERR_NOMEM) (void)hipGetLastError();
     return code;
 }
 
@@ -1399,6 +1403,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK2");
         ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_XR");
+        ctx->chain_xr = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK2_CW");
         ctx->blk2_cw = (e == nullptr) ? 1 : atoi(e);
         ctx->blk2_cw_maxrows = ctx->blk2_cw == 2 ? 6 : 7;
@@ -1535,6 +1541,8 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_blk")) { ctx->chain_blk = value != 0; ctx->blk_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2_one")) { ctx->blk2_one = (int)value; ctx->blk2_refused_n = -1; }
+    else if (!strcmp(key, "chain_xr")) ctx->chain_xr = value != 0;
+    else if (!strcmp(key, "chain_xr_cus")) ctx->chain_xr_cus = (int)value;      // tests: shapes for this many compute units (0: all)
     else if (!strcmp(key, "gemv_rows")) ctx->gemv_rows = (int)value;       // rows per wave of the dense GEMV (0: by size; 1 / 2 / 4)
     else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
         ctx->blk2_cw = (int)value;
@@ -1613,6 +1621,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "gemv_rows")) *value = ctx->gemv_rows;
     else if (!strcmp(key, "chain_blk2_one")) *value = ctx->blk2_one;
     else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
+    else if (!strcmp(key, "chain_xr")) *value = ctx->chain_xr;
+    else if (!strcmp(key, "n_chain_xr")) *value = ctx->n_chain_xr;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;
     else if (!strcmp(key, "blk_nx")) *value = ctx->blk_nx;
@@ -2112,6 +2122,51 @@ int kh_dense_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, const double* a,
     return 0;
 }
 
+// A dense operator from a block that is already on the device: row i of the operator = column col0 + i of X, scaled, plus
+// beta on the diagonal - A = alpha X[:, col0 : col0 + nrows]^T + beta I.  What a symmetric product formed on the device
+// (Y = G G^T through kh_apply's panel path: the columns of Y ARE the rows of the row-major operator) needs to become the
+// operator of a solve without a trip over the host ("build on device").
+static __global__ void k_dense_from_block(int64_t n_rows, int64_t n_cols, const double* __restrict__ x, int64_t ldx,
+                                          double alpha, double beta, double* __restrict__ a, int64_t lda) {
+    const int64_t i = blockIdx.y;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_cols; j += (int64_t)gridDim.x * blockDim.x) {
+        const double v = alpha * x[i * ldx + j];
+        a[i * lda + j] = (i == j) ? v + beta : v;
+    }
+}
+
+int kh_dense_from_block(kh_ctx ctx, kh_vec X, int64_t col0, int64_t n_rows, double alpha, double beta, kh_mat* out) {
+    KH_ARG(ctx && X && out, "kh_dense_from_block: NULL argument");
+    KH_TRY(check_vec(X, col0, n_rows, "kh_dense_from_block(X)"));
+    KH_ARG(n_rows >= 1 && n_rows <= 65535, "kh_dense_from_block: 1 ... 65535 rows");
+    KH_HIP(hipSetDevice(ctx->device));
+    kh_mat A = new kh_mat_s();
+    A->ctx = ctx;
+    A->kind = KH_MAT_DENSE;
+    A->n_rows = n_rows;
+    A->n_cols = X->n;
+    A->lda = ((X->n + 1) / 2) * 2;
+    const size_t bytes = sizeof(double) * (size_t)A->lda * (size_t)n_rows;
+    hipError_t e = hipMalloc(&A->a, bytes);
+    if (e != hipSuccess) {
+        delete A;
+        return fail(KH_ERR_NOMEM, "kh_dense_from_block: hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
+    if (A->lda > A->n_cols) KH_HIP(hipMemsetAsync(A->a, 0, bytes, ctx->stream));
+    const unsigned gx = (unsigned)std::min<int64_t>((X->n + BS - 1) / BS, 64);
+    hipLaunchKernelGGL(k_dense_from_block, dim3(gx, (unsigned)n_rows), dim3(BS), 0, ctx->stream, n_rows, X->n, X->col(col0), X->ld,
+                       alpha, beta, A->a, A->lda);
+    hipError_t e2 = hipGetLastError();
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+    if (e2 != hipSuccess) {
+        (void)hipFree(A->a);
+        delete A;
+        return fail(KH_ERR_HIP, "kh_dense_from_block: %s", hipGetErrorString(e2));
+    }
+    *out = A;
+    return 0;
+}
+
 int kh_diag_upload(kh_ctx ctx, int64_t n, const double* d, kh_mat* out) {
     KH_ARG(ctx && out && (d || n == 0), "kh_diag_upload: NULL argument");
     KH_HIP(hipSetDevice(ctx->device));
@@ -2541,14 +2596,29 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         int r2m = 0, gm = 0;
         want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm, nullptr, ctx->blk2_one >= 1) && k + 3 <= 4096;
     }
+    // ... and beyond the blocked kernel's 2.5 M rows per rank: the register-resident chain kernels (16 ... 56 rows per lane, up
+    // to 14.68 M rows) with the cross-rank stage inside every grid-wide sum (chain_xr.hip) - one sum across the ranks per link,
+    // the local basis read ONCE where the one-reduction and panel forms read it twice.  Decided for the longest slab, like the
+    // other two; it takes the step in front of the one-reduction form (KRYPY_AMD_CHAIN_XR=0: that form / the panel kernels).
+    bool want_chain_xr = false;
+    if (!want_blk2 && kh_multi(ctx) && ctx->xr_on && ctx->chain_xr && ctx->chain_configured && gs_mode == KH_GS_MGS && sweeps == 1 &&
+        start == 0 && !presub && Md == nullptr) {
+        int64_t nmax = ctx->nranks > 1 ? 0 : n;
+        for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
+            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        int r2m = 0, gm = 0;
+        want_chain_xr = nmax >= n && chain_xr_shape(ctx, nmax, &r2m, &gm) && !((n & 1) && (V->ld <= n || W->ld <= n));
+    }
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
-                            A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync && !want_blk2);
+                            A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync && !want_blk2 && !want_chain_xr);
     // the H column accumulates over sweeps, so it starts from zero - except under the chain kernel, whose
     // first sweep assigns (one memset launch and its queue bubble less per step)
     // (nor under the single-sweep register-resident panel kernels, which write the entries directly)
     const bool want_cgs1 = (gs_mode == KH_GS_CGS && sweeps == 1 && ctx->chain_enabled);
     // (... nor under the blocked kernel with the cross-rank sums inside, which assigns every entry as well)
-    if (!want_chain && !want_cgs1 && !(want_blk2 && pd == 0)) KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
+    // (... nor under the chain kernels with the cross-rank stage: first sweep assigns, like on one GPU)
+    if (!want_chain && !want_cgs1 && !(want_blk2 && pd == 0) && !want_chain_xr)
+        KH_HIP(hipMemsetAsync(hdev, 0, sizeof(double) * (k + 2 + pd), ctx->stream));
     // 1. operator
     bool fused_chain = false;
     if (A != nullptr) {
@@ -2608,6 +2678,11 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     }
     if (!chained && want_blk2) {
         const int rc = chain_blk2_step(ctx, V, w, W->ld, k, hdev, slot, ctx->hslot_pin[slot], (int)(k + 2 + pd), true);
+        if (rc < 0) return rc;
+        chained = (rc == 1);
+    }
+    if (!chained && want_chain_xr) {
+        const int rc = chain_xr_step(ctx, V, w, W->ld, k, hdev, slot, ctx->hslot_pin[slot], (int)(k + 2 + pd));
         if (rc < 0) return rc;
         chained = (rc == 1);
     }
@@ -2798,7 +2873,7 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         // pattern of collectives the peers see)
         const int code = *ctx->chain_err_pin[slot];
         *ctx->chain_err_pin[slot] = 0;
-        return fail(KH_ERR_COMM, "a sum inside the blocked Gram-Schmidt kernel timed out on rank %d of %d (%s); no rank-local recovery on "
+        return fail(KH_ERR_COMM, "a sum inside the Gram-Schmidt kernel with in-launch cross-rank sums timed out on rank %d of %d (%s); no rank-local recovery on "
                                  "a communicator", ctx->rank, ctx->nranks, code == 2 ? "a peer rank's contribution did not arrive" :
                                  "a workgroup of the launch did not arrive");
     }

@@ -324,6 +324,7 @@ class ShardedCSROperator(utils.LinearOperator):
         dt = numpy.dtype(complex if numpy.dtype(A_local.dtype).kind == "c" else float)
         self._dmat = self._image(dt)
         self.halo_in_launch = False if dt.kind == "c" else self._xh_setup(self._dmat, table)
+        self._xh_ready = self.halo_in_launch           # (halo_via may switch it off and on again)
         super(ShardedCSROperator, self).__init__((nloc, nloc), dt, self._dot_host)
 
     def _image(self, dt):
@@ -404,9 +405,16 @@ class ShardedCSROperator(utils.LinearOperator):
     def halo_through_rccl(self):
         """Back to the grouped ``ncclSend`` / ``ncclRecv`` exchange (every rank must do the same: a launcher whose self-test
         of the mailboxes failed calls this on all of them)."""
-        if self.halo_in_launch:
-            self._ctx.xh_enable(self._dmat, False)
-            self.halo_in_launch = False
+        self.halo_via("rccl")
+
+    def halo_via(self, mode):
+        """``"rccl"``: the grouped ``ncclSend`` / ``ncclRecv`` exchange; ``"in-launch"``: back inside the banded SpMV's own
+        launch - only where ``_xh_setup`` had brought it up on every rank (the neighbours' granules stay mapped while it is
+        off).  EVERY rank must make the same call: a launcher that times its candidates over both transports does."""
+        want = (mode == "in-launch") and self._xh_ready
+        if want != self.halo_in_launch:
+            self._ctx.xh_enable(self._dmat, want)
+            self.halo_in_launch = want
 
     def _device_matrix(self, ctx=None, dtype=None):
         if dtype is not None and numpy.dtype(dtype).kind == "c":

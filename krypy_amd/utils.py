@@ -873,6 +873,38 @@ class MatrixLinearOperator(LinearOperator):
         return self._A.__repr__()
 
 
+class DeviceOperator(MatrixLinearOperator):
+    """An operator whose matrix is ALREADY on the device (a ``DeviceMatrix`` formed there, e.g. by
+    ``Context.dense_from_block``): there is no host image.  Everything a ``MatrixLinearOperator`` can do on
+    device blocks it can do; ``symmetric=True`` (the default) declares ``A == A^H`` so that the adjoint is the
+    operator itself (utils.py:1585-1602 builds the adjoint from the host matrix, which does not exist here)."""
+
+    def __init__(self, dmat, symmetric=True):
+        LinearOperator.__init__(self, dmat.shape, dmat.dtype, self._dot, self._dot_adj)
+        self._A = None
+        self._A_adj = None
+        self._dmats = {numpy.dtype(dmat.dtype).kind: dmat}
+        self._adj_op = None
+        self._symmetric = bool(symmetric)
+
+    def _device_matrix(self, ctx=None, dtype=None):
+        dm = self._dmats.get(_bdt(self.dtype, dtype).kind)
+        if dm is None:
+            raise LinearOperatorError("a device-only %s operator cannot be applied to %s blocks" % (self.dtype, dtype))
+        return dm
+
+    def _real_diag_image(self, ctx=None):
+        return None
+
+    def _dot_adj(self, X):
+        if not self._symmetric:
+            raise LinearOperatorError("no adjoint of a device-only operator that was not declared symmetric")
+        return self._dot(X)
+
+    def __repr__(self):
+        return "<DeviceOperator %dx%d %s on the device>" % (self.shape[0], self.shape[1], self.dtype)
+
+
 class Timer(list):
     """Measure execution time of multiple code blocks with ``with`` (utils.py:1289-1318)."""
 

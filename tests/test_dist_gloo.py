@@ -311,12 +311,20 @@ def test_bench_gpus_n_starts_its_own_ranks(world):
     assert len(lines) == 1, lines
     o = json.loads(lines[0])
     assert o["n_gpus"] == world and o["steps"] == 2 and o["warmup"] == 1 and o["unit"] == "iterations/s"
-    assert o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24
+    # (--ortho auto: one untimed cycle of each candidate, the faster one is timed - either may win on the double)
+    chosen = o["config"]["ortho"]
+    assert chosen in ("cgs", "mgs") and o["config"]["iterations_timed"] == 24
+    auto = o["config"]["ortho_auto"]
+    assert auto["chosen"] == chosen and auto["chosen_transport"] == "rccl"
+    assert [(c["ortho"], c["transport"]) for c in auto["candidates"]] == [("cgs", "rccl"), ("mgs", "rccl")]
+    assert all("ms" in c for c in auto["candidates"]) and o["config"]["timed_region_fallback"] is None
     assert o["config"]["parallelism"] == "row-sharded x%d (RCCL)" % world
     assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 24) < 1e-6
-    want = _single_process_bench_residual(40, 36, 12)
+    want = _single_process_bench_residual(40, 36, 12, ortho=chosen)
     assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
-    assert o["config"]["basis_orthogonality_fro"]["cgs"] < 1e-10
+    assert o["config"]["basis_orthogonality_fro"][chosen] < 1e-10
+    diag = o["config"]["sharded_diagnostics"]
+    assert len(diag["rows_per_rank"]) == world and sum(diag["rows_per_rank"]) == 40 * 36 and len(diag["spmv_us_per_rank"]) == world
 
 
 def test_bench_gpus_n_refuses_when_fewer_devices_are_visible():
@@ -424,7 +432,8 @@ def test_bench_sharded_path_under_an_external_launcher():
     assert o["n_gpus"] == world and o["config"]["iterations_timed"] == 24
     assert len({round(outs[r]["value"], 6) for r in outs}) == 1
     assert len({outs[r]["config"]["final_relres"] for r in outs}) == 1
-    want = _single_process_bench_residual(40, 36, 12)
+    assert len({outs[r]["config"]["ortho"] for r in outs}) == 1            # every rank timed the same candidate
+    want = _single_process_bench_residual(40, 36, 12, ortho=o["config"]["ortho"])
     assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
 
 
@@ -482,7 +491,8 @@ def test_bench_config5_leg_on_n_ranks(world):
     o = outs[0]
     assert o["n_gpus"] == world and o["steps"] == 2 and o["unit"] == "iterations/s" and o["scaling"] == "strong"
     assert o["config"]["iterations_timed"] == 60 and o["config"]["deflation_vectors"] == 5
-    assert o["config"]["parallelism"] == "z-slabs x%d (RCCL)" % world and o["config"]["ortho"] == "cgs"
+    assert o["config"]["parallelism"] == "z-slabs x%d (RCCL)" % world and o["config"]["ortho"] in ("cgs", "mgs")
+    assert o["config"]["ortho_auto"]["chosen"]["ortho"] == o["config"]["ortho"] and o["config"]["timed_region_fallback"] is None
     assert o["value"] > 0 and abs(o["ms_per_step"] * 2 / 1e3 * o["value"] - 60) < 1e-6
     for key in ("plain_relres", "deflated_relres"):
         assert len({outs[r]["config"][key] for r in outs}) == 1, key
