@@ -28,7 +28,7 @@ K_COPY, K_TRIAD, K_READ = 9, 10, 11
 CHAIN_LINKS = 64   # kh_bench_kernel runs the chain over 16 columns x 4 sweeps
 
 _SOURCES = ("chain.h", "kernels.h", "krylov_hip.hip", "kh_internal.h", "zpath.h", "comm.hip", "lanczos.h", "chain_blk.h",
-            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip", "xr_dev.h", "chain_blk2.h", "chain_blk2.hip", "chain_xr.hip", "cycles.hip",
+            "chain_blk.hip", "proj_reg.h", "proj_reg.hip", "xr.hip", "xr_dev.h", "chain_blk2.h", "chain_blk2.hip", "chain_xr.hip", "chain_long.h", "cycles.hip",
             "bench_abi.hip", "krylov_steps.h")
 
 
@@ -58,6 +58,9 @@ def chain_reread_fraction(n, ncu, lds=True):
     for r2 in (4, 8, 16, 24, 32, 40, 48, 56):
         g = -(-n2 // (r2 * 512))
         if g <= ncu and g <= 512:
+            if r2 == 48 and lds:
+                # chain_long.h: batches 0, 1 parked in LDS, batches 10, 11 still in the ring: 32 of 48 rows come back from memory
+                return r2, 32.0 / 48.0
             if not lds or r2 > 40:
                 return r2, 1.0
             pb = 5 if r2 == 40 else (2 if r2 == 4 else 4)
@@ -158,7 +161,7 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100, solve
         c1 = ctx.counters() if hasattr(ctx, "counters") else {}
         lds = c1.get("chain_lds", 0) > counters0.get("chain_lds", 0)
         r2, rr = chain_reread_fraction(n, int(info.get("compute_units", 256)), lds)
-        chain_name = "%s<%d> (64 links per launch)" % ("k_mgs_chain_lds" if lds else "k_mgs_chain", r2)
+        chain_name = "%s<%d> (64 links per launch)" % (("k_mgs_chain_long" if r2 == 48 else "k_mgs_chain_lds") if lds else "k_mgs_chain", r2)
         comp = 8.0 * n * CHAIN_LINKS + 16.0 * n
         chain = run(K_CHAIN, chain_name, comp, 8.0 * n * CHAIN_LINKS * (1.0 + rr) + 16.0 * n,
                     16.0 * n * CHAIN_LINKS + 16.0 * n)

@@ -43,6 +43,15 @@ SWITCHES = [
      "0: vectors of 5 / 6 rows per lane (1.05 M ... 1.57 M rows) keep the per-column ring kernel on one GPU, and on N ranks with the xr "
      "transport on `ortho='mgs'` keeps the one-reduction form (two cross-rank sums per step, the local basis read twice) instead of the "
      "eight-wave blocked kernel with the cross-rank sums INSIDE the launch (`csrc/chain_blk2.h`: the basis read once, no all-reduce call)"),
+    ("KRYPY_AMD_CHAIN_LONG", "1", "kernel-path", "0",
+     "0: 48 rows per lane (10.49 M ... 12.58 M rows per GPU / rank) keep `k_mgs_chain<48>` - both reads of every basis column from memory "
+     "- instead of `k_mgs_chain_long` (`csrc/chain_long.h`: two batches parked in LDS, the last two still in the register ring: 16 of 48 "
+     "rows never leave the chip between a column's dot and its update).  Same bits either way; counter `n_chain_long`"),
+    ("KRYPY_AMD_CHAIN_XR", "1", "kernel-path", "0",
+     "0: on N ranks with the xr transport on, slabs beyond the blocked kernel's 2.5 M rows keep the one-reduction form / the panel "
+     "kernels (the local basis read twice, two sums across the ranks per step) instead of the register-resident chain kernels with the "
+     "cross-rank stage inside every grid-wide sum (`csrc/chain_xr.hip`: 16 ... 56 rows per lane, up to 14.68 M rows per rank, the basis "
+     "read once, no all-reduce call; counter `n_chain_xr`)"),
     ("KRYPY_AMD_BLK2_CW", "1", "kernel-path", "0",
      "0: every wave of the eight-wave blocked kernel carries rows (512 lanes, 4 ... 6 rows per lane, up to 1.57 M rows) instead of wave 0 "
      "being a communication wave without rows (448 lanes with rows, 4 ... 7 rows per lane, up to 1.6 M rows: no register spills up to 6 "

@@ -18,6 +18,7 @@
 
 #include "kh_internal.h"
 #include "chain.h"
+#include "chain_long.h"
 
 namespace kh {
 
@@ -52,6 +53,23 @@ static hipError_t launch_xr_plain(kh_ctx ctx, int G, ChainArgs& a) {
         }
         int nb = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL(kern, dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+static hipError_t launch_xr_long(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = ChainShapeLong::LDS_BYTES;
+    auto kern = k_mgs_chain_long<0, true>;
+    if (blocks_per_cu < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, CH_BS, lds);
         if (e != hipSuccess) return e;
         blocks_per_cu = nb;
     }
@@ -142,7 +160,15 @@ int chain_xr_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k,
         case 24: e = use_lds ? KH_XL(24) : KH_XP(24, 0); break;
         case 32: e = use_lds ? launch_xr_lds<32, false>(ctx, G, a) : KH_XP(32, 0); break;
         case 40: e = use_lds ? launch_xr_lds<40, false>(ctx, G, a) : KH_XP(40, 0); break;
-        case 48: e = KH_XP(48, 8); break;
+        case 48:
+            e = (ctx->chain_long && padded) ? launch_xr_long(ctx, G, a) : hipErrorUnknown;
+            if (e != hipSuccess) {          // (switched off, an unpadded block, or the 128 KB of dynamic LDS refused: both reads from memory)
+                (void)hipGetLastError();
+                e = KH_XP(48, 8);
+            } else {
+                ctx->n_chain_long += 1;
+            }
+            break;
         default: e = KH_XP(56, 16); break;
     }
 #undef KH_XP

@@ -473,8 +473,9 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                                                     double* __restrict__ part_out,
                                                     int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0,
                                                     const int32_t* __restrict__ blkwin = nullptr, int wcap = 0) {
-    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products (WIN: + wcap entries of x)
+    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile + 4 products (WIN: + wcap entries of x)
     __shared__ double sm[8];
+    static_assert(ITEMS % 4 == 0, "a lane takes its entries in runs of four (16-byte index loads)");
     // a launch over a subset of the row blocks (interior / boundary rows of a shard, krylov_hip.hip): the
     // launch's blocks 0 .. blk_lo-1 are themselves, the others lie blk_skip further on
     int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -482,50 +483,80 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
     const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
     const int nz0 = indptr[r0], nz1 = indptr[r1];
     const int cnt = nz1 - nz0;
+    // Round 6: the index / value streams in runs of FOUR entries per lane - one 16-byte load of indices and two of values
+    // instead of four 4-byte and four 8-byte ones (a wave-wide 4-byte load is 256 B, two cache lines per instruction: the
+    // stream ran at 5.7 TB/s where 16-byte loads stream at 6.9).  The block's entries start wherever its first row does, so
+    // the runs start at the 4-aligned entry at or before it: up to three entries of the previous block in front and of the
+    // next one (or of the zeroed padding kh_csr_upload leaves behind the arrays) behind are multiplied as well and never
+    // summed.  The products of an entry and the order in which a row adds them are unchanged: the same bits.
+    const int base = nz0 & ~3;
+    const int cnta = nz1 - base;                     // entries from the aligned start (<= tile + 3)
     double acc = 0.0;
-    if (cnt <= tile) {
+    if (cnta <= tile) {        // (a single row of tile - 2 ... tile entries that starts off the alignment: the long-row path)
         if (cnt > 0) {
-            // all index/value loads first, then all gathers: ITEMS independent loads in flight per
-            // lane (clamped addresses instead of predicated loads, which would serialise)
-            int c[ITEMS];
-            double a[ITEMS];
+            typedef int i32x4_t __attribute__((ext_vector_type(4)));
+            constexpr int NCH = ITEMS / 4;
+            const i32x4_t* __restrict__ ip = reinterpret_cast<const i32x4_t*>(indices + base);
+            const double2* __restrict__ dp = reinterpret_cast<const double2*>(data + base);
+            const int lastch = (cnta - 1) >> 2;
+            i32x4_t c[NCH];
+            double2 a0[NCH], a1[NCH];
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const int t = threadIdx.x + i * BS;
-                const int tc = t < cnt ? t : cnt - 1;
+            for (int q = 0; q < NCH; ++q) {
+                const int ch = q * BS + threadIdx.x;
+                const int chc = ch < lastch ? ch : lastch;       // (clamped addresses instead of predicated loads, which would serialise)
                 // read-once streams: non-temporal, so that they do not push the x lines that the
                 // gathers below (and the neighbouring row blocks) need out of L2
-                c[i] = __builtin_nontemporal_load(indices + nz0 + tc);
-                a[i] = __builtin_nontemporal_load(data + nz0 + tc);
+                c[q] = __builtin_nontemporal_load(ip + chc);
+                a0[q] = ld_nt2(dp + 2 * chc);
+                a1[q] = ld_nt2(dp + 2 * chc + 1);
             }
             bool direct = true;
             if constexpr (WIN) {
                 const int cmin = blkwin[2 * bid], span = blkwin[2 * bid + 1];
                 if (span <= wcap) {                                  // (the same for the whole workgroup)
-                    double* __restrict__ xw = prod + tile;
+                    double* __restrict__ xw = prod + tile + 4;
                     for (int j = threadIdx.x; j < span; j += BS) xw[j] = x[cmin + j];
                     __syncthreads();
 #pragma unroll
-                    for (int i = 0; i < ITEMS; ++i) a[i] = a[i] * xw[c[i] - cmin];
+                    for (int q = 0; q < NCH; ++q) {
+                        // (an entry of a neighbouring block may lie outside this block's window: its product is never used)
+                        const unsigned j0 = (unsigned)(c[q].x - cmin), j1 = (unsigned)(c[q].y - cmin);
+                        const unsigned j2 = (unsigned)(c[q].z - cmin), j3 = (unsigned)(c[q].w - cmin);
+                        a0[q].x = a0[q].x * xw[j0 < (unsigned)span ? j0 : 0u];
+                        a0[q].y = a0[q].y * xw[j1 < (unsigned)span ? j1 : 0u];
+                        a1[q].x = a1[q].x * xw[j2 < (unsigned)span ? j2 : 0u];
+                        a1[q].y = a1[q].y * xw[j3 < (unsigned)span ? j3 : 0u];
+                    }
                     direct = false;
                 }
             }
             if (direct) {
 #pragma unroll
-                for (int i = 0; i < ITEMS; ++i) {
-                    const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
-                    a[i] = a[i] * xv;
+                for (int q = 0; q < NCH; ++q) {
+                    const double x0 = (c[q].x < nloc) ? x[c[q].x] : ghost[c[q].x - nloc];
+                    const double x1 = (c[q].y < nloc) ? x[c[q].y] : ghost[c[q].y - nloc];
+                    const double x2 = (c[q].z < nloc) ? x[c[q].z] : ghost[c[q].z - nloc];
+                    const double x3 = (c[q].w < nloc) ? x[c[q].w] : ghost[c[q].w - nloc];
+                    a0[q].x = a0[q].x * x0;
+                    a0[q].y = a0[q].y * x1;
+                    a1[q].x = a1[q].x * x2;
+                    a1[q].y = a1[q].y * x3;
                 }
             }
+            double2* __restrict__ prod2 = reinterpret_cast<double2*>(prod);
 #pragma unroll
-            for (int i = 0; i < ITEMS; ++i) {
-                const int t = threadIdx.x + i * BS;
-                if (t < cnt) prod[t] = a[i];
+            for (int q = 0; q < NCH; ++q) {
+                const int ch = q * BS + threadIdx.x;
+                if (ch <= lastch) {
+                    prod2[2 * ch] = a0[q];
+                    prod2[2 * ch + 1] = a1[q];
+                }
             }
         }
         __syncthreads();
         for (int r = r0 + threadIdx.x; r < r1; r += BS) {
-            const int p0 = indptr[r] - nz0, p1 = indptr[r + 1] - nz0;
+            const int p0 = indptr[r] - base, p1 = indptr[r + 1] - base;
             double s = 0.0;
             for (int p = p0; p < p1; ++p) s += prod[p];
             if (EPI == EPI_RES) {

@@ -114,6 +114,9 @@ struct kh_ctx_s {
     int64_t n_chain_blk2 = 0;
     // N ranks, slabs beyond the blocked kernel's 2.5 M rows: the register-resident chain kernels with the cross-rank stage inside
     // every grid-wide sum (chain_xr.hip; KRYPY_AMD_CHAIN_XR) - the local basis read once, no all-reduce call in the step
+    int chain_long = 1;              // KRYPY_AMD_CHAIN_LONG: 48 rows per lane take k_mgs_chain_long (chain_long.h: a third of every column
+                                     // stays on the chip between its dot and its update) instead of k_mgs_chain<48> (both reads from memory)
+    int64_t n_chain_long = 0;
     int chain_xr = 1;
     int chain_xr_cus = 0;            // tests: the compute units the shape is chosen for (0: all; two processes share one device)
     int64_t n_chain_xr = 0;

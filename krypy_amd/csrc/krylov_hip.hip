@@ -11,6 +11,7 @@
 
 #include "kernels.h"
 #include "chain.h"
+#include "chain_long.h"
 #include "lanczos.h"
 #include "krylov_steps.h"
 #include <stdlib.h>
@@ -240,11 +241,19 @@ struct SpmvRange {
 
 template <int EPI, int ITEMS>
 static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux, const SpmvRange& rg) {
-    const size_t lds = (size_t)A->tile * sizeof(double);
+    const size_t lds = (size_t)(A->tile + 4) * sizeof(double);      // (+ 4: the runs of four entries start at an aligned entry)
     const int grid = rg.grid < 0 ? A->nblk : rg.grid;
     if (grid == 0) return;
     if (ctx->spmv_win && A->win_cap > 0 && A->blkwin != nullptr && A->nrecv_prev + A->nrecv_next == 0) {
         // (no ghost columns: a window is a run of x itself)
+        // tile 4096 + a 4096-entry window is 64 KB + 32 B: above what a kernel gets without asking
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_stream<EPI, ITEMS, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 4 + 4096) * sizeof(double)));
+            (void)hipGetLastError();
+            attr_done = true;
+        }
         hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS, true>), dim3(grid), dim3(BS), lds + (size_t)A->win_cap * sizeof(double),
                            ctx->stream, A->indptr, A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
                            aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, A->blkwin, A->win_cap);
@@ -470,6 +479,25 @@ static hipError_t launch_chain_lds(kh_ctx ctx, int G, ChainArgs& a) {
     }
     if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
     hipLaunchKernelGGL((k_mgs_chain_lds<R2, MASKED, CPLX, FND>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
+    return hipGetLastError();
+}
+
+// 48 rows per lane with a third of every column kept on the chip between its two uses (chain_long.h)
+template <int FND>
+static hipError_t launch_chain_long(kh_ctx ctx, int G, ChainArgs& a) {
+    static int blocks_per_cu = -1;
+    constexpr size_t lds = ChainShapeLong::LDS_BYTES;
+    if (blocks_per_cu < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mgs_chain_long<FND, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        int nb = 0;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_mgs_chain_long<FND, false>, CH_BS, lds);
+        if (e != hipSuccess) return e;
+        blocks_per_cu = nb;
+    }
+    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
+    hipLaunchKernelGGL((k_mgs_chain_long<FND, false>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
     return hipGetLastError();
 }
 
@@ -766,6 +794,9 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     bool use_lds = lds_env && !lds_failed && B == V && dg == nullptr && (a.debug == 0 || a.debug == 4) &&
                    (padded || r2 <= 24) && r2 <= 40;     // (48 / 56 rows: LDS holds a part of w itself)
     if (r2 > 40 && cplx) return 0;
+    // 48 rows per lane, no preconditioner, padded blocks: a third of every column stays on the chip between its two uses
+    static thread_local bool long_failed = false;
+    bool use_long = ctx->chain_long && !long_failed && r2 == 48 && B == V && dg == nullptr && !cplx && padded && (a.debug == 0 || a.debug == 4);
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
@@ -981,7 +1012,15 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
                 }
                 break;
             }
-            if (r2 == 48) e = (a.offs.nd == 5) ? launch_chain<48, false, false, 5, 8>(ctx, G, a) : launch_chain<48, false, false, 7, 8>(ctx, G, a);
+            if (r2 == 48 && use_long) {
+                e = (a.offs.nd == 5) ? launch_chain_long<5>(ctx, G, a) : launch_chain_long<7>(ctx, G, a);
+                if (e != hipSuccess) {       // (e.g. the 128 KB of dynamic LDS were refused: the kernel with both reads from memory)
+                    (void)hipGetLastError();
+                    long_failed = true;
+                    use_long = false;
+                    e = (a.offs.nd == 5) ? launch_chain<48, false, false, 5, 8>(ctx, G, a) : launch_chain<48, false, false, 7, 8>(ctx, G, a);
+                }
+            } else if (r2 == 48) e = (a.offs.nd == 5) ? launch_chain<48, false, false, 5, 8>(ctx, G, a) : launch_chain<48, false, false, 7, 8>(ctx, G, a);
             else if (r2 == 40) e = (a.offs.nd == 5) ? KH_FUSED(40, 5) : KH_FUSED(40, 7);
             else if (r2 == 32) e = (a.offs.nd == 5) ? KH_FUSED(32, 5) : KH_FUSED(32, 7);
             else if (r2 == 24) e = (a.offs.nd == 5) ? KH_FUSED(24, 5) : KH_FUSED(24, 7);
@@ -1000,6 +1039,15 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
         else if (r2 == 24) e = KH_CHAIN(24);
         else if (r2 == 32) e = KH_CHAIN(32);
         else if (r2 == 40) e = KH_CHAIN(40);
+        else if (r2 == 48 && use_long) {
+            e = launch_chain_long<0>(ctx, G, a);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                long_failed = true;
+                use_long = false;
+                e = launch_chain<48, false, false, 0, 8>(ctx, G, a);
+            }
+        }
         else if (r2 == 48) e = padded ? launch_chain<48, false, false, 0, 8>(ctx, G, a) : launch_chain<48, true, false, 0, 8>(ctx, G, a);
         else e = padded ? launch_chain<56, false, false, 0, 16>(ctx, G, a) : launch_chain<56, true, false, 0, 16>(ctx, G, a);
         if (e == hipSuccess || !use_lds) break;
@@ -1020,7 +1068,8 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     }
     if (a.debug == 4) ctx->chain_fault = 0;
     ctx->n_chain += 1;
-    ctx->n_chain_lds += use_lds ? 1 : 0;
+    ctx->n_chain_lds += (use_lds || use_long) ? 1 : 0;
+    ctx->n_chain_long += use_long ? 1 : 0;
     ctx->n_chain_pf += use_pf ? 1 : 0;
     ctx->n_chain_fused += fused ? 1 : 0;
     ctx->chain_epoch += (unsigned)(a.ncol * a.sweeps + 1);   // one grid reduction per link (complex: both parts in it) + the norm
@@ -1403,6 +1452,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_BLK2");
         ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_CHAIN_LONG");
+        ctx->chain_long = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_XR");
         ctx->chain_xr = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK2_CW");
@@ -1542,6 +1593,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_blk2")) { ctx->chain_blk2 = value != 0; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "chain_blk2_one")) { ctx->blk2_one = (int)value; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "chain_xr")) ctx->chain_xr = value != 0;
+    else if (!strcmp(key, "chain_long")) ctx->chain_long = value != 0;
     else if (!strcmp(key, "chain_xr_cus")) ctx->chain_xr_cus = (int)value;      // tests: shapes for this many compute units (0: all)
     else if (!strcmp(key, "gemv_rows")) ctx->gemv_rows = (int)value;       // rows per wave of the dense GEMV (0: by size; 1 / 2 / 4)
     else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
@@ -1622,6 +1674,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_blk2_one")) *value = ctx->blk2_one;
     else if (!strcmp(key, "n_chain_blk2")) *value = ctx->n_chain_blk2;
     else if (!strcmp(key, "chain_xr")) *value = ctx->chain_xr;
+    else if (!strcmp(key, "chain_long")) *value = ctx->chain_long;
+    else if (!strcmp(key, "n_chain_long")) *value = ctx->n_chain_long;
     else if (!strcmp(key, "n_chain_xr")) *value = ctx->n_chain_xr;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
     else if (!strcmp(key, "n_blk_rowless")) *value = ctx->n_blk_rowless;
@@ -1835,7 +1889,7 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
         int64_t acc = 0;
         while (r_end < n_rows && (r_end - r) < max_rows) {
             const int64_t nz = (int64_t)indptr[r_end + 1] - indptr[r_end];
-            if (acc + nz > tile) break;
+            if (acc + nz > tile - 3) break;      // (- 3: k_spmv_stream's runs of four start at the aligned entry at or before the block's first)
             acc += nz;
             ++r_end;
         }
@@ -2042,8 +2096,12 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     // any failure from here on releases what has been allocated so far (kh_mat_free takes a partial handle)
     auto body = [&]() -> int {
         KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
-        KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-        KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        // (eight zeroed entries behind the arrays: k_spmv_stream reads its index / value streams in aligned runs of four, the
+        // last of which may reach up to three entries beyond nnz)
+        KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * (nnz + 8)));
+        KH_HIP(hipMalloc(&A->data, sizeof(double) * (nnz + 8)));
+        KH_HIP(hipMemset(A->indices + nnz, 0, sizeof(int32_t) * 8));
+        KH_HIP(hipMemset(A->data + nnz, 0, sizeof(double) * 8));
         KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
         std::vector<int> offs;
         const bool banded = detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs);
@@ -2607,7 +2665,10 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
             if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
         int r2m = 0, gm = 0;
-        want_chain_xr = nmax >= n && chain_xr_shape(ctx, nmax, &r2m, &gm) && !((n & 1) && (V->ld <= n || W->ld <= n));
+        // (a slab that fills less than half the compute units at 16 rows per lane - under 2.1 M rows - belongs to the blocked
+        // kernel; with that switched off it keeps the one-reduction form rather than a chain on a handful of workgroups)
+        want_chain_xr = nmax >= n && chain_xr_shape(ctx, nmax, &r2m, &gm) && (ctx->chain_xr_cus > 0 || 2 * gm >= ctx->ncu) &&
+                        !((n & 1) && (V->ld <= n || W->ld <= n));
     }
     const bool fuse_dot0 = (A != nullptr && A->kind == KH_MAT_CSR && !presub && gs_mode == KH_GS_MGS &&
                             A->nblk > 0 && !want_chain && proj == nullptr && !want_lowsync && !want_blk2 && !want_chain_xr);

@@ -83,6 +83,25 @@ def main():
         sc = linsys.RestartedGmres(linsys.LinearSystem(op, bc[r0:r1]), maxiter=40, max_restarts=40, tol=1e-9, ortho=ortho)
         res["coupled_%s_resnorms" % ortho] = np.array(sc.resnorms)
         res["coupled_%s_x" % ortho] = sc.xk[:, 0].copy()
+    # 2c. slabs beyond the blocked kernel's range: the register-resident chain kernels with the cross-rank stage inside every
+    # grid-wide sum (csrc/chain_xr.hip).  Two processes share this device, so the shapes are chosen for FOUR compute units
+    # (kh_ctx_set "chain_xr_cus"): 24 rows per lane at 90,000 / 87,000 rows, 48 (the last 8 rows of w in LDS) at 184,900 / 180,600
+    ctx.set("chain_xr_cus", 4)
+    ctx.set("chain_blk2", 0)
+    for tag, nxx in (("24", 300), ("48", 430)):
+        Ax, bx = block(rank, nxx)
+        nmax = int(rdv.allreduce_max(float(Ax.shape[0])))
+        ctx.set("lowsync_rows", (int(Ax.shape[0]) << 32) | nmax)
+        c0 = ctx.get("n_chain_xr")
+        try:
+            sx = linsys.RestartedGmres(linsys.LinearSystem(Ax, bx), maxiter=30, max_restarts=5, tol=1e-9, ortho="mgs")
+        except utils.ConvergenceError as e:
+            sx = e.solver
+        res["chainxr_%s_resnorms" % tag] = np.array(sx.resnorms)
+        res["chainxr_%s_x" % tag] = sx.xk[:, 0].copy()
+        res["chainxr_%s_launches" % tag] = ctx.get("n_chain_xr") - c0
+    ctx.set("chain_xr_cus", 0)
+    ctx.set("chain_blk2", 1)
     res["n_halo_xh"], res["n_halo_exchange"] = ctx.get("n_halo_xh"), ctx.get("n_halo_exchange")
     res["n_xr"], res["n_xr_fused"], res["panels_checked"] = ctx.get("n_xr"), ctx.get("n_xr_fused"), checked
     res["n_chain_blk2"] = ctx.get("n_chain_blk2")

@@ -171,5 +171,26 @@ def test_two_processes_sum_through_ipc_mailboxes(hip, placement):
     expect_kernel(int(r[0]["n_xr_fused"]) > 100, "the panel form took the fused reduce-and-exchange kernel")
     expect_kernel(int(r[0]["n_chain_blk2"]) == int(r[1]["n_chain_blk2"]) and int(r[0]["n_chain_blk2"]) > 30,
                   "the reference order took the blocked kernel with the cross-rank sums inside the launch: %r" % ((int(r[0]["n_chain_blk2"]), int(r[1]["n_chain_blk2"])),))
+    # slabs beyond the blocked kernel's range: the chain kernels with the cross-rank stage (24 and 48 rows per lane), two
+    # processes' launches exchanging every link's sum - against ONE process solving the block-diagonal system
+    from krypy_amd import utils
+    for tag, nxx in (("24", 300), ("48", 430)):
+        (X0, y0), (X1, y1) = block(0, nxx), block(1, nxx)
+        Ax, bx = sp.block_diag([X0, X1]).tocsr(), np.concatenate([y0, y1])
+        try:
+            s = linsys.RestartedGmres(linsys.LinearSystem(Ax, bx), maxiter=30, max_restarts=5, tol=1e-9, ortho="mgs")
+        except utils.ConvergenceError as e:
+            s = e.solver
+        want = np.array(s.resnorms)
+        for k in range(2):
+            got = r[k]["chainxr_%s_resnorms" % tag]
+            assert len(got) == len(want), (tag, k, len(got), len(want))
+            assert np.max(np.abs(got[:31] - want[:31]) / want[:31]) < 1e-10, (tag, k)
+            assert np.max(np.abs(got - want) / want) < 1e-6, (tag, k)
+        assert np.array_equal(r[0]["chainxr_%s_resnorms" % tag], r[1]["chainxr_%s_resnorms" % tag])
+        x = np.concatenate([r[0]["chainxr_%s_x" % tag], r[1]["chainxr_%s_x" % tag]])
+        assert np.linalg.norm(x - s.xk[:, 0]) < 1e-7 * np.linalg.norm(s.xk)
+        expect_kernel(int(r[0]["chainxr_%s_launches" % tag]) == int(r[1]["chainxr_%s_launches" % tag]) == len(want) - 1,
+                      "every step of the %s-row solves took the chain kernel with the cross-rank stage: %r" % (tag, (int(r[0]["chainxr_%s_launches" % tag]), len(want) - 1)))
     # the peer that did not arrive: rank 0's sum ended in an error that says so
     assert open(os.path.join(out, "rank0.done")).read().strip() == "1"
