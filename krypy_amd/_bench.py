@@ -259,6 +259,26 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100, solve
         for v in spmv.values():
             if attainable:
                 v["frac_of_attainable"] = v["achieved_gbs"] / attainable
+        # what a kernel trace of this command reproduces: the per-dispatch average of a stamped profile of these sources
+        # (tools/summarize_prof.py).  It sits a few per cent ABOVE avg_ms: a dispatch timed by itself includes its own ramp
+        # and drain, which back-to-back launches between two HIP events overlap with their neighbours'
+        stamp_ = source_stamp()
+        for fn in sorted(traffic_files or [], reverse=True):
+            try:
+                import json
+                tj = json.load(open(fn))
+                if tj.get("source_stamp") != stamp_ or int(tj.get("n", n)) != n or "kernel_trace_avg_us" not in tj:
+                    continue
+                for name, v in spmv.items():
+                    key = "k_spmv_dia" if name.startswith("k_spmv_dia") else "k_spmv_stream"
+                    if key in tj["kernel_trace_avg_us"]:
+                        us = tj["kernel_trace_avg_us"][key]["avg_us"]
+                        v["kernel_trace_avg_ms"] = us / 1e3
+                        v["frac_kernel_trace"] = _gbs(v["moved_bytes"], us / 1e3) / peak_gbs
+                        v["kernel_trace_source"] = os.path.basename(fn)
+                break
+            except Exception:
+                continue
         extra["spmv"] = spmv
         if nd and counters0.get("chain_fused", 0) > 0:
             extra["spmv_in_solver"] = ("fused: the GMRES / Lanczos steps of this run computed A v_k in the prologue of the "

@@ -69,7 +69,8 @@ constexpr int BLK_BC = KH_BLK_BC_CFG;         // basis columns per block
 constexpr int BLK_NSLOT = KH_BLK_NSLOT_CFG;   // blocks of columns in registers
 constexpr int BLK_NVMAX = 8;                  // values per sum (the block's BC coefficients; the norm + BC - 1 table entries)
 constexpr int BLK_NVS = 16;                   // granule PAIRS reserved per workgroup and parity (256 B records)
-constexpr int BLK_TABCOLS = 4096;             // basis columns the Gram table has rows for (BLK_BC entries each)
+constexpr int BLK_TABCOLS = KH_BLK_TABCOLS;   // basis columns the Gram table has rows for (BLK_BC entries each); the eligibility tests
+                                              // of krylov_hip.hip use the same constant (a literal 4096 stood there)
 #ifndef BLK_GS_CFG
 #define BLK_GS_CFG 32
 #endif

@@ -161,7 +161,7 @@ int chain_xr_step(kh_ctx ctx, kh_vec V, const double* w, int64_t wld, int64_t k,
         case 32: e = use_lds ? launch_xr_lds<32, false>(ctx, G, a) : KH_XP(32, 0); break;
         case 40: e = use_lds ? launch_xr_lds<40, false>(ctx, G, a) : KH_XP(40, 0); break;
         case 48:
-            e = (ctx->chain_long && padded) ? launch_xr_long(ctx, G, a) : hipErrorUnknown;
+            e = (ctx->chain_long && ctx->chain_lds && padded) ? launch_xr_long(ctx, G, a) : hipErrorUnknown;
             if (e != hipSuccess) {          // (switched off, an unpadded block, or the 128 KB of dynamic LDS refused: both reads from memory)
                 (void)hipGetLastError();
                 e = KH_XP(48, 8);

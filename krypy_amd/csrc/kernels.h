@@ -460,11 +460,21 @@ __device__ __forceinline__ int xcd_unmap(int lb, int nblk) {
 // fills a 128-byte line for 8 bytes of x - on a matrix with entries at random places of a band that is ten times the bytes of
 // the matrix itself between L2 and the compute units (273 us as is, 95 us without the gather).  Same products in
 // the same order: the same bits.
+// Round 6 (0.66 of peak in the kernel trace against the banded kernel's 0.72): what a workgroup does
+// BESIDES streaming is latency in line with the stream, paid 24,400 times at N = 10^7 -
+//   * its row range and entry range came from two DEPENDENT pairs of loads (rowblk[bid], then indptr[r0], indptr[r1]) before
+//     the first stream load could be issued: now ONE table of (first row, first entry) pairs (rowblk2);
+//   * after the barrier every row's indptr[r], indptr[r + 1] were global loads in front of the row's sum: now requested with
+//     the stream loads, before the barrier, and held in registers (a block has at most 4 rows per lane).
+// Neither moved the product on the stencil matrix (148-152 us on one box before and after, kernel trace 157-159 us), nor did
+// reading the index / value streams in aligned runs of four entries per lane (16-byte loads: 147-162 us; EXPERIMENTS.md) - the
+// kernel's rate is not set by the width of its loads or by these latencies.  The table of pairs and the early requests stay
+// (fewer dependent loads, no cost), the runs of four do not.
 template <int EPI, int ITEMS, bool WIN = false>
 __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
                                                     const double* __restrict__ data,
-                                                    const int32_t* __restrict__ rowblk, int nblk,
+                                                    const int2* __restrict__ rowblk2, int nblk,
                                                     int tile, int64_t nloc,
                                                     const double* __restrict__ x,
                                                     const double* __restrict__ ghost,
@@ -473,98 +483,85 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
                                                     double* __restrict__ part_out,
                                                     int blk_lo = 0x7fffffff, int blk_skip = 0, int part_off = 0,
                                                     const int32_t* __restrict__ blkwin = nullptr, int wcap = 0) {
-    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile + 4 products (WIN: + wcap entries of x)
+    extern __shared__ __attribute__((aligned(16))) double prod[];   // tile == ITEMS * BS products (WIN: + wcap entries of x)
     __shared__ double sm[8];
-    static_assert(ITEMS % 4 == 0, "a lane takes its entries in runs of four (16-byte index loads)");
     // a launch over a subset of the row blocks (interior / boundary rows of a shard, krylov_hip.hip): the
     // launch's blocks 0 .. blk_lo-1 are themselves, the others lie blk_skip further on
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     bid = bid < blk_lo ? bid : bid + blk_skip;
-    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
-    const int nz0 = indptr[r0], nz1 = indptr[r1];
+    const int2 b0 = rowblk2[bid], b1 = rowblk2[bid + 1];
+    const int r0 = b0.x, r1 = b1.x;
+    const int nz0 = b0.y, nz1 = b1.y;
     const int cnt = nz1 - nz0;
-    // Round 6: the index / value streams in runs of FOUR entries per lane - one 16-byte load of indices and two of values
-    // instead of four 4-byte and four 8-byte ones (a wave-wide 4-byte load is 256 B, two cache lines per instruction: the
-    // stream ran at 5.7 TB/s where 16-byte loads stream at 6.9).  The block's entries start wherever its first row does, so
-    // the runs start at the 4-aligned entry at or before it: up to three entries of the previous block in front and of the
-    // next one (or of the zeroed padding kh_csr_upload leaves behind the arrays) behind are multiplied as well and never
-    // summed.  The products of an entry and the order in which a row adds them are unchanged: the same bits.
-    const int base = nz0 & ~3;
-    const int cnta = nz1 - base;                     // entries from the aligned start (<= tile + 3)
     double acc = 0.0;
-    if (cnta <= tile) {        // (a single row of tile - 2 ... tile entries that starts off the alignment: the long-row path)
-        if (cnt > 0) {
-            typedef int i32x4_t __attribute__((ext_vector_type(4)));
-            constexpr int NCH = ITEMS / 4;
-            const i32x4_t* __restrict__ ip = reinterpret_cast<const i32x4_t*>(indices + base);
-            const double2* __restrict__ dp = reinterpret_cast<const double2*>(data + base);
-            const int lastch = (cnta - 1) >> 2;
-            i32x4_t c[NCH];
-            double2 a0[NCH], a1[NCH];
+    if (cnt <= tile) {
+        // this lane's rows: r0 + tid + j * BS, their entry ranges requested now, used behind the barrier
+        constexpr int MAXR = 4;                      // build_rowblocks: at most 4 rows per lane
+        const int nrows = r1 - r0;
+        int q0[MAXR], q1[MAXR];
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int ch = q * BS + threadIdx.x;
-                const int chc = ch < lastch ? ch : lastch;       // (clamped addresses instead of predicated loads, which would serialise)
+        for (int j = 0; j < MAXR; ++j) {
+            if (j * BS < nrows) {                    // (the same for the whole workgroup)
+                const int r = r0 + j * BS + (int)threadIdx.x;
+                const int rc = r < r1 ? r : r1 - 1;
+                q0[j] = indptr[rc];
+                q1[j] = indptr[rc + 1];
+            }
+        }
+        if (cnt > 0) {
+            // all index/value loads first, then all gathers: ITEMS independent loads in flight per
+            // lane (clamped addresses instead of predicated loads, which would serialise)
+            int c[ITEMS];
+            double a[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                const int tc = t < cnt ? t : cnt - 1;
                 // read-once streams: non-temporal, so that they do not push the x lines that the
                 // gathers below (and the neighbouring row blocks) need out of L2
-                c[q] = __builtin_nontemporal_load(ip + chc);
-                a0[q] = ld_nt2(dp + 2 * chc);
-                a1[q] = ld_nt2(dp + 2 * chc + 1);
+                c[i] = __builtin_nontemporal_load(indices + nz0 + tc);
+                a[i] = __builtin_nontemporal_load(data + nz0 + tc);
             }
             bool direct = true;
             if constexpr (WIN) {
                 const int cmin = blkwin[2 * bid], span = blkwin[2 * bid + 1];
                 if (span <= wcap) {                                  // (the same for the whole workgroup)
-                    double* __restrict__ xw = prod + tile + 4;
+                    double* __restrict__ xw = prod + tile;
                     for (int j = threadIdx.x; j < span; j += BS) xw[j] = x[cmin + j];
                     __syncthreads();
 #pragma unroll
-                    for (int q = 0; q < NCH; ++q) {
-                        // (an entry of a neighbouring block may lie outside this block's window: its product is never used)
-                        const unsigned j0 = (unsigned)(c[q].x - cmin), j1 = (unsigned)(c[q].y - cmin);
-                        const unsigned j2 = (unsigned)(c[q].z - cmin), j3 = (unsigned)(c[q].w - cmin);
-                        a0[q].x = a0[q].x * xw[j0 < (unsigned)span ? j0 : 0u];
-                        a0[q].y = a0[q].y * xw[j1 < (unsigned)span ? j1 : 0u];
-                        a1[q].x = a1[q].x * xw[j2 < (unsigned)span ? j2 : 0u];
-                        a1[q].y = a1[q].y * xw[j3 < (unsigned)span ? j3 : 0u];
-                    }
+                    for (int i = 0; i < ITEMS; ++i) a[i] = a[i] * xw[c[i] - cmin];
                     direct = false;
                 }
             }
             if (direct) {
 #pragma unroll
-                for (int q = 0; q < NCH; ++q) {
-                    const double x0 = (c[q].x < nloc) ? x[c[q].x] : ghost[c[q].x - nloc];
-                    const double x1 = (c[q].y < nloc) ? x[c[q].y] : ghost[c[q].y - nloc];
-                    const double x2 = (c[q].z < nloc) ? x[c[q].z] : ghost[c[q].z - nloc];
-                    const double x3 = (c[q].w < nloc) ? x[c[q].w] : ghost[c[q].w - nloc];
-                    a0[q].x = a0[q].x * x0;
-                    a0[q].y = a0[q].y * x1;
-                    a1[q].x = a1[q].x * x2;
-                    a1[q].y = a1[q].y * x3;
+                for (int i = 0; i < ITEMS; ++i) {
+                    const double xv = (c[i] < nloc) ? x[c[i]] : ghost[c[i] - nloc];
+                    a[i] = a[i] * xv;
                 }
             }
-            double2* __restrict__ prod2 = reinterpret_cast<double2*>(prod);
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int ch = q * BS + threadIdx.x;
-                if (ch <= lastch) {
-                    prod2[2 * ch] = a0[q];
-                    prod2[2 * ch + 1] = a1[q];
-                }
+            for (int i = 0; i < ITEMS; ++i) {
+                const int t = threadIdx.x + i * BS;
+                if (t < cnt) prod[t] = a[i];
             }
         }
         __syncthreads();
-        for (int r = r0 + threadIdx.x; r < r1; r += BS) {
-            const int p0 = indptr[r] - base, p1 = indptr[r + 1] - base;
-            double s = 0.0;
-            for (int p = p0; p < p1; ++p) s += prod[p];
-            if (EPI == EPI_RES) {
-                s = aux[r] - s;
-                acc = fma(s, s, acc);
+#pragma unroll
+        for (int j = 0; j < MAXR; ++j) {
+            const int r = r0 + j * BS + (int)threadIdx.x;
+            if (j * BS < nrows && r < r1) {
+                const int p0 = q0[j] - nz0, p1 = q1[j] - nz0;
+                double s = 0.0;
+                for (int p = p0; p < p1; ++p) s += prod[p];
+                if (EPI == EPI_RES) {
+                    s = aux[r] - s;
+                    acc = fma(s, s, acc);
+                }
+                st_nt(y + r, s);
+                if (EPI == EPI_DOT) acc = fma(aux[r], s, acc);
             }
-            st_nt(y + r, s);
-            if (EPI == EPI_DOT) acc = fma(aux[r], s, acc);
         }
     } else {  // one long row
         double s = 0.0;

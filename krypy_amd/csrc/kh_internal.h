@@ -242,6 +242,7 @@ struct kh_mat_s {
     int32_t* indices = nullptr;
     double* data = nullptr;
     int32_t* rowblk = nullptr;  // row-block boundaries of the CSR-stream kernel
+    int2* rowblk2 = nullptr;    // [nblk + 1] (first row, first entry) of every row block: what k_spmv_stream needs from ONE load
     int32_t* blkwin = nullptr;  // [nblk][cmin, span]: the columns a row block touches (k_spmv_stream<.., WIN>)
     int win_cap = 0;            // LDS window (entries of x) of that kernel for this operator; 0: not worth it
     int nblk = 0;
@@ -324,6 +325,7 @@ bool chain_blk_shape_ok(int r2, int G, const ChainArgs& a, int fnd);
 #define KH_BLK_BC_CFG 4
 #endif
 constexpr int KH_BLK_BC = KH_BLK_BC_CFG;   // (= BLK_BC of chain_blk.h) columns per block
+constexpr int KH_BLK_TABCOLS = 4096;       // (= BLK_TABCOLS of chain_blk.h: static_assert there) basis columns the Gram table has rows for
 constexpr int KH_BLK_TW = 2 * KH_BLK_BC;   // (= BLK_TW) entries per row of the Gram table: the block before the column's, then its own
 // an entry point writes to block v: the Gram table of an Arnoldi sequence on it (chain_blk.hip) is no longer vouched for
 static inline void chain_blk_touch(kh_ctx ctx, const void* v) {

@@ -241,27 +241,27 @@ struct SpmvRange {
 
 template <int EPI, int ITEMS>
 static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, const double* aux, const SpmvRange& rg) {
-    const size_t lds = (size_t)(A->tile + 4) * sizeof(double);      // (+ 4: the runs of four entries start at an aligned entry)
+    const size_t lds = (size_t)A->tile * sizeof(double);
     const int grid = rg.grid < 0 ? A->nblk : rg.grid;
     if (grid == 0) return;
     if (ctx->spmv_win && A->win_cap > 0 && A->blkwin != nullptr && A->nrecv_prev + A->nrecv_next == 0) {
         // (no ghost columns: a window is a run of x itself)
-        // tile 4096 + a 4096-entry window is 64 KB + 32 B: above what a kernel gets without asking
+        // tile 4096 + a 4096-entry window is 64 KB (+ the 64 B of static LDS): above what a kernel gets without asking
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_spmv_stream<EPI, ITEMS, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 4 + 4096) * sizeof(double)));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4096 + 4096) * sizeof(double)));
             (void)hipGetLastError();
             attr_done = true;
         }
         hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS, true>), dim3(grid), dim3(BS), lds + (size_t)A->win_cap * sizeof(double),
-                           ctx->stream, A->indptr, A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
+                           ctx->stream, A->indptr, A->indices, A->data, A->rowblk2, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
                            aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, A->blkwin, A->win_cap);
         ctx->n_spmv_win += 1;
         return;
     }
     hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(grid), dim3(BS), lds, ctx->stream, A->indptr,
-                       A->indices, A->data, A->rowblk, A->nblk, A->tile,
+                       A->indices, A->data, A->rowblk2, A->nblk, A->tile,
                        A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part, rg.blk_lo, rg.blk_skip,
                        rg.part_off);
 }
@@ -657,7 +657,7 @@ static int64_t padded_ld(kh_ctx ctx, int64_t n) {
 // true when the step goes to the blocked kernel (which has no operator prologue yet)
 static inline bool blk_takes_step(kh_ctx ctx, const ChainArgs& a, int r2) {
     return ctx->chain_blk && r2 == 4 && !a.presub && a.sweeps == 1 && a.col0 == 0 && a.ncol >= KH_BLK_MIN_LINKS &&
-           a.ncol + 2 <= 4096 && !kh_multi(ctx);
+           a.ncol + 2 <= KH_BLK_TABCOLS && !kh_multi(ctx);
 }
 
 // returns 1 if the chain was launched, 0 if this step is not eligible (caller uses the link
@@ -796,7 +796,7 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     if (r2 > 40 && cplx) return 0;
     // 48 rows per lane, no preconditioner, padded blocks: a third of every column stays on the chip between its two uses
     static thread_local bool long_failed = false;
-    bool use_long = ctx->chain_long && !long_failed && r2 == 48 && B == V && dg == nullptr && !cplx && padded && (a.debug == 0 || a.debug == 4);
+    bool use_long = ctx->chain_long && ctx->chain_lds && !long_failed && r2 == 48 && B == V && dg == nullptr && !cplx && padded && (a.debug == 0 || a.debug == 4);
     // fused operator: the padded real kernels with 16 ... 40 rows per lane (N > 2.1 M) have that prologue
     bool fused = false;
     if (Afuse != nullptr) {
@@ -1889,7 +1889,7 @@ static int build_rowblocks(const int32_t* indptr, int64_t n_rows, int tile,
         int64_t acc = 0;
         while (r_end < n_rows && (r_end - r) < max_rows) {
             const int64_t nz = (int64_t)indptr[r_end + 1] - indptr[r_end];
-            if (acc + nz > tile - 3) break;      // (- 3: k_spmv_stream's runs of four start at the aligned entry at or before the block's first)
+            if (acc + nz > tile) break;
             acc += nz;
             ++r_end;
         }
@@ -2096,12 +2096,8 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
     // any failure from here on releases what has been allocated so far (kh_mat_free takes a partial handle)
     auto body = [&]() -> int {
         KH_HIP(hipMalloc(&A->indptr, sizeof(int32_t) * (n_rows + 1)));
-        // (eight zeroed entries behind the arrays: k_spmv_stream reads its index / value streams in aligned runs of four, the
-        // last of which may reach up to three entries beyond nnz)
-        KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * (nnz + 8)));
-        KH_HIP(hipMalloc(&A->data, sizeof(double) * (nnz + 8)));
-        KH_HIP(hipMemset(A->indices + nnz, 0, sizeof(int32_t) * 8));
-        KH_HIP(hipMemset(A->data + nnz, 0, sizeof(double) * 8));
+        KH_HIP(hipMalloc(&A->indices, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+        KH_HIP(hipMalloc(&A->data, sizeof(double) * std::max<int64_t>(nnz, 1)));
         KH_HIP(hipMalloc(&A->rowblk, sizeof(int32_t) * blk.size()));
         std::vector<int> offs;
         const bool banded = detect_dia(n_rows, n_cols, nnz, indptr, indices, data, offs);
@@ -2113,6 +2109,12 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
             KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
         }
         KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
+        {
+            std::vector<int2> blk2(blk.size());
+            for (size_t i = 0; i < blk.size(); ++i) blk2[i] = make_int2(blk[i], indptr[blk[i]]);
+            KH_HIP(hipMalloc(&A->rowblk2, sizeof(int2) * blk2.size()));
+            KH_HIP(hipMemcpy(A->rowblk2, blk2.data(), sizeof(int2) * blk2.size(), hipMemcpyHostToDevice));
+        }
         if (banded) KH_TRY(build_dia(ctx, A, offs));
         // the columns every row block touches (k_spmv_stream<.., WIN>): where nine blocks in ten fit an LDS window of at most
         // SPMV_WIN_CAP entries of x, the operator's launches carry a window as wide as the widest of those
@@ -2254,6 +2256,7 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->indices);
     (void)hipFree(A->data);
     (void)hipFree(A->rowblk);
+    (void)hipFree(A->rowblk2);
     (void)hipFree(A->blkwin);
     (void)hipFree(A->part);
     (void)hipFree(A->dia);
@@ -2652,7 +2655,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
         for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
             if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
         int r2m = 0, gm = 0;
-        want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm, nullptr, ctx->blk2_one >= 1) && k + 3 <= 4096;
+        want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm, nullptr, ctx->blk2_one >= 1) && k + 3 <= KH_BLK_TABCOLS;
     }
     // ... and beyond the blocked kernel's 2.5 M rows per rank: the register-resident chain kernels (16 ... 56 rows per lane, up
     // to 14.68 M rows) with the cross-rank stage inside every grid-wide sum (chain_xr.hip) - one sum across the ranks per link,

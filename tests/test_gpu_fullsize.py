@@ -347,6 +347,67 @@ def test_config5_slab_at_its_stated_size_through_the_sharded_path(hip):
         ctx.close()
 
 
+def test_config5_at_its_stated_size_on_one_device(hip):
+    """BASELINE.json configs[4] at N = 10^8 (500 x 500 x 400, nnz = 698,700,000) as ONE device holds it - the N = 1 point of
+    config 5's curve (/root/reference/krypy/deflation.py:93-163, recycling/linsys.py:51-103): the int32 CSR index arithmetic
+    within a factor three of its limit (the last rows' products against the host's), plain GMRES(40) -> 16 Ritz vectors on the
+    device -> DeflatedGmres(40): the deflation identity E = <U, A U>, an orthogonal basis, U orthogonal to the deflated basis,
+    the deflated residual below the plain one, and which kernels served a vector eight times the register file.  Sizes the
+    oracle cannot reach in seconds: properties, not a comparison (the flow itself is pinned at 2.2 M rows against the
+    reference's fixture above)."""
+    import gc
+    import time
+    import bench
+    from krypy_amd import deflation, linsys, utils
+
+    t0 = time.perf_counter()
+    A = bench.laplace3d(500, 500, 400)
+    N = A.shape[0]
+    assert N == 100_000_000 and A.nnz == 698_700_000 and A.indices.dtype == np.int32
+    b = np.random.default_rng(0).standard_normal(N)
+    ls = linsys.LinearSystem(A, b, self_adjoint=True)
+    dm = ls.A._device_matrix()
+    # the operator at both ends of the index range, bit for bit against SciPy (rows 0 .. 999 and the last 1000)
+    x = np.random.default_rng(1).standard_normal(N)
+    X, Y = hip.upload(x), hip.alloc(N, 1)
+    hip.apply(dm, X, 0, Y, 0, 1)
+    head, tail = Y.get(0, 0, 1000), Y.get(0, N - 1000, 1000)
+    assert np.array_equal(head, A[:1000].dot(x)) and np.array_equal(tail, A[N - 1000:].dot(x))
+    del X, Y
+    chain0 = hip.counters()["chain"]
+
+    def solve(U=None):
+        try:
+            return deflation.DeflatedGmres(ls, U=U, tol=1e-12, maxiter=40, store_arnoldi=True, ortho="mgs")
+        except utils.ConvergenceError as e:
+            return e.solver
+    s0 = solve()
+    ritz = deflation.Ritz(s0)
+    Ud = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:16])
+    r0 = np.array(s0.resnorms)
+    del s0, ritz
+    gc.collect()
+    pr0 = hip.get("n_proj_reg")
+    s1 = solve(Ud)
+    r1 = np.array(s1.resnorms)
+    assert len(r0) == len(r1) == 41 and r1[-1] < r0[-1]
+    U, AU = s1.projection._Ud, s1.projection._AUd
+    E = hip.gemm_tn(U, 0, 16, AU, 0, 16)
+    assert np.linalg.norm(E - s1.E) < 1e-10 * np.linalg.norm(E)
+    n = s1.H.shape[1]
+    G = hip.gemm_tn(s1.arnoldi._V, 0, n + 1, s1.arnoldi._V, 0, n + 1)
+    assert np.linalg.norm(G - np.eye(n + 1)) < 1e-11
+    assert np.linalg.norm(hip.gemm_tn(U, 0, 16, s1.arnoldi._V, 0, n)) < 1e-9
+    expect_kernel(dm.diagonals == 7, "the banded copy of the 7-point operator exists at 698.7 M entries: %r" % (dm.diagonals,))
+    expect_kernel(hip.counters()["chain"] == chain0 and hip.get("n_proj_reg") == pr0,
+                  "a vector eight times the register file: per-column kernels and the four-launch projector, no register-resident launch")
+    del s1, U, AU, Ud
+    gc.collect()
+    hip._pool_flush()
+    took = time.perf_counter() - t0
+    assert took < 240.0, "the full-size config-5 test took %.0f s" % took
+
+
 def test_bench_config5_leg_one_rank_slab(hip):
     """bench.py --config 5 as a rank of the 8-GPU run sees it: the 500 x 500 x 50 slab (12.5 M rows) through the sharded
     code path on a 1-rank RCCL communicator (--force-sharded), plain GMRES(100) -> 16 Ritz vectors on the device ->
@@ -369,6 +430,15 @@ def test_bench_config5_leg_one_rank_slab(hip):
     c = o["config"]
     assert o["n_gpus"] == 1 and o["unit"] == "iterations/s" and o["dtype"] == "f64" and o["scaling"] == "strong"
     assert c["n"] == 12_500_000 and c["rows_per_gpu"] == 12_500_000 and c["iterations_timed"] == 200
-    assert c["ortho"] == "cgs" and c["deflation_vectors"] == 16
+    # --ortho auto: one untimed solve per (form, transport) candidate, the fastest that ran is timed - with the mailboxes on in
+    # loopback the reference order runs as the chain kernel with the cross-rank stage inside its sums (csrc/chain_xr.hip)
+    auto = c["ortho_auto"]
+    assert c["ortho"] in ("cgs", "mgs") and c["deflation_vectors"] == 16 and auto["chosen"]["ortho"] == c["ortho"]
+    assert all("ms" in cand for cand in auto["candidates"]) and c["timed_region_fallback"] is None
+    mgs_xr = [cand for cand in auto["candidates"] if (cand["ortho"], cand["transport"]) == ("mgs", "xr")]
+    # (a deflated step: the projector's sums - four launches per sweep on N ranks - go through the mailboxes as calls)
+    expect_kernel(len(mgs_xr) == 1 and mgs_xr[0]["kernels"]["chain_in_launch_sums"] >= 100 and
+                  mgs_xr[0]["per_iteration"]["allreduce_calls"] < 10,
+                  "the reference-order candidate over the mailboxes took the chain kernel with the stage: %r" % (mgs_xr,))
     assert c["deflated_relres"] < c["plain_relres"] < 1.0
     assert o["value"] > 50 and 0 < o["roofline"]["frac"] < 1

@@ -92,7 +92,9 @@ def test_bench_two_ranks_share_the_one_gpu_through_the_mailboxes(hip):
         assert c["cross_rank_sums"] == "xr" and c["halo"] == "in-launch" and c["iterations_timed"] == 80
         res[ortho] = two
     assert res["auto"]["config"]["ortho"] in ("cgs", "mgs") and set(res["auto"]["config"]["ortho_auto"]) >= {"cgs", "mgs", "chosen"}
-    assert res["auto"]["config"]["ortho_auto"]["mgs"]["sums_inside_the_launch"] is True
+    cands = res["auto"]["config"]["ortho_auto"]["candidates"]
+    assert [(c_["ortho"], c_["transport"]) for c_ in cands] == [("cgs", "xr"), ("mgs", "xr")] and all("ms" in c_ for c_ in cands)
+    assert cands[1]["kernels"]["blocked_in_launch_sums"] > 0 and cands[1]["per_iteration"]["allreduce_calls"] < 1.0
     for ortho in ("cgs", "mgs"):
         rc, lines, err = _bench(["--gpus", "1", "--ortho", ortho] + common)
         assert rc == 0 and len(lines) == 1, err[-3000:]

@@ -33,11 +33,14 @@ def main(src, dst):
     if os.path.exists(bj):
         try:
             b = json.loads(open(bj).read().strip().splitlines()[-1])
+            extra_args = " ".join(sys.argv[3:])
             lines += ["Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d "
-                      "--no-cpu-baseline --ortho %s --other-modes none` (tools/profile.sh) on one MI355X." % (b["steps"], b["warmup"], b["config"]["ortho"]),
-                      "", "bench.py under the profiler: **%.1f iterations/s** (%.1f ms per GMRES(100) cycle); "
+                      "--no-cpu-baseline %s` (tools/profile.sh) on one MI355X; workload: %s" % (
+                          b["steps"], b["warmup"], extra_args or ("--ortho %s --other-modes none" % b["config"].get("ortho")),
+                          b["config"].get("workload", "")),
+                      "", "bench.py under the profiler: **%.1f %s** (%.1f ms per step); "
                       "live HIP-event average of the dominant kernel `%s`: **%.3f us**." % (
-                          b["value"], b["ms_per_step"], b["roofline"]["kernel"],
+                          b["value"], b["unit"], b["ms_per_step"], b["roofline"]["kernel"],
                           b["roofline"]["avg_launch_ms"] * 1e3), ""]
         except Exception as exc:  # pragma: no cover
             lines += ["(bench json unreadable: %r)" % exc, ""]
@@ -128,6 +131,25 @@ def main(src, dst):
                            "launches_averaged": len(f),
                            "note": "the %d %s between the harness' k_bench_marker launches = bench.py's kh_bench_kernel launches; "
                                    "FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % (len(f), what)}
+        # kernels of the secondary configurations' legs (bench.py --config 3 / 4 / 5): every launch of the run
+        for key, pat in (("k_lanczos_fused", "%k_lanczos_fused%"), ("k_gemv_dense", "%k_gemv_dense%"), ("k_proj", "%k_proj_reg%")):
+            f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and name like '%s'" % pat)
+            w = q(wdb, "select counter_value from pmc_events where counter_name='WRITE_SIZE' and name like '%s'" % pat)
+            if f and w:
+                tj[key] = {"hbm_read_bytes_per_launch": 2 * sum(x[0] for x in f) / len(f) * 1024,
+                           "hbm_write_bytes_per_launch": sum(x[0] for x in w) / len(w) * 1024, "launches_averaged": len(f),
+                           "note": "all %d launches of the run; FETCH_SIZE doubled (gfx950 correction), separate --pmc passes" % len(f)}
+        # per-dispatch durations of the stand-alone SpMV kernels (the plain instantiations, EPI = 0: bench.py's back-to-back
+        # launches and nothing else) - what a kernel trace reproduces of the line's SpMV figures (the HIP-event
+        # average of back-to-back launches sits below the per-dispatch average, whose every sample includes the kernel's own
+        # ramp and drain)
+        kt = {}
+        for key, pat in (("k_spmv_dia", "%k_spmv_dia<0,%"), ("k_spmv_stream", "%k_spmv_stream<0,%")):
+            d = q(tdb, "select end - start from kernels where name like '%s'" % pat)
+            if d:
+                kt[key] = {"avg_us": sum(x[0] for x in d) / len(d) / 1e3, "launches": len(d)}
+        if kt:
+            tj["kernel_trace_avg_us"] = kt
         # the solver's own instantiation of the chain kernel (operator in the prologue: a template argument FND > 0),
         # every launch of the run - whole cycles k = 1 .. m-1 of the solver and of kh_bench_arnoldi alike
         f = q(fdb, "select counter_value from pmc_events where counter_name='FETCH_SIZE' and " + SOLVER_CHAIN)
