@@ -127,6 +127,12 @@ int kh_mat_xh_enable(kh_ctx ctx, kh_mat A, int on);
  * matrix' column indices must address [local rows | ghosts from prev | ghosts from next]. */
 int kh_mat_set_halo(kh_ctx ctx, kh_mat A, int64_t nsend_prev, int64_t nsend_next,
                     int64_t nrecv_prev, int64_t nrecv_next);
+/* The LONGEST slab of the run this shard belongs to (every rank passes the same number).  Kernel choices of an Arnoldi step that
+ * change the PATTERN of sums across the ranks - the one-reduction form, the blocked and the chain kernels with the sums inside
+ * their launch - are made for it, so that every rank decides alike whatever the length of its own slab; keyed on the operator
+ * (steps without an operator: kh_ctx_set "lowsync_rows" by local length).  New component: the reference is
+ * single-process. */
+int kh_mat_set_rows_max(kh_mat A, int64_t rows_max);
 /* diagnostic: write the nrecv_prev + nrecv_next ghost entries directly (what the halo exchange would
  * deliver); lets a single process check a shard's SpMV against the global operator */
 int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count);

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "kh_mat_xh_attach": [_H, _H, ctypes.c_char_p, _I64, _I64, ctypes.c_char_p, _I64, _INT],
     "kh_mat_xh_enable": [_H, _H, _INT],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
+    "kh_mat_set_rows_max": [_H, _I64],
     "kh_mat_set_ghost": [_H, _c_double_p, _I64],
     "kh_mat_get_ghost": [_H, _c_double_p, _I64],
     "kh_vec_alloc": [_H, _I64, _I64, ctypes.POINTER(_H)],
@@ -583,6 +584,10 @@ class Context(object):
         out = numpy.empty(2 * count if cplx else count, dtype=numpy.float64)
         _check(self._lib, self._lib.kh_mat_get_ghost(A.handle, _dptr(out), out.size), "kh_mat_get_ghost")
         return out.view(numpy.complex128) if cplx else out
+
+    def set_rows_max(self, A, rows_max):
+        """The longest slab of the run a sharded operator belongs to (``kh_mat_set_rows_max``: every rank the same number)."""
+        _check(self._lib, self._lib.kh_mat_set_rows_max(A.handle, int(rows_max)), "kh_mat_set_rows_max")
 
     def set_halo(self, A, nsend_prev, nsend_next, nrecv_prev, nrecv_next):
         _check(self._lib, self._lib.kh_mat_set_halo(self._h, A.handle, nsend_prev, nsend_next,

@@ -460,21 +460,15 @@ __device__ __forceinline__ int xcd_unmap(int lb, int nblk) {
 // fills a 128-byte line for 8 bytes of x - on a matrix with entries at random places of a band that is ten times the bytes of
 // the matrix itself between L2 and the compute units (273 us as is, 95 us without the gather).  Same products in
 // the same order: the same bits.
-// Round 6 (0.66 of peak in the kernel trace against the banded kernel's 0.72): what a workgroup does
-// BESIDES streaming is latency in line with the stream, paid 24,400 times at N = 10^7 -
-//   * its row range and entry range came from two DEPENDENT pairs of loads (rowblk[bid], then indptr[r0], indptr[r1]) before
-//     the first stream load could be issued: now ONE table of (first row, first entry) pairs (rowblk2);
-//   * after the barrier every row's indptr[r], indptr[r + 1] were global loads in front of the row's sum: now requested with
-//     the stream loads, before the barrier, and held in registers (a block has at most 4 rows per lane).
-// Neither moved the product on the stencil matrix (148-152 us on one box before and after, kernel trace 157-159 us), nor did
-// reading the index / value streams in aligned runs of four entries per lane (16-byte loads: 147-162 us; EXPERIMENTS.md) - the
-// kernel's rate is not set by the width of its loads or by these latencies.  The table of pairs and the early requests stay
-// (fewer dependent loads, no cost), the runs of four do not.
+// (Round 6 tried three things on this kernel - ONE table of (first row, first entry) pairs instead of rowblk[bid] -> indptr[r0],
+// indptr[r1]; every lane's indptr[r], indptr[r + 1] requested with the stream loads instead of behind the barrier; the index /
+// value streams in aligned runs of four entries per lane - all bit-identical, all SLOWER on the stencil matrix: 146 us against
+// 137-138 for this form on the same boxes (EXPERIMENTS.md).  This is round 5's kernel.)
 template <int EPI, int ITEMS, bool WIN = false>
 __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ indptr,
                                                     const int32_t* __restrict__ indices,
                                                     const double* __restrict__ data,
-                                                    const int2* __restrict__ rowblk2, int nblk,
+                                                    const int32_t* __restrict__ rowblk, int nblk,
                                                     int tile, int64_t nloc,
                                                     const double* __restrict__ x,
                                                     const double* __restrict__ ghost,
@@ -489,25 +483,11 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
     // launch's blocks 0 .. blk_lo-1 are themselves, the others lie blk_skip further on
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     bid = bid < blk_lo ? bid : bid + blk_skip;
-    const int2 b0 = rowblk2[bid], b1 = rowblk2[bid + 1];
-    const int r0 = b0.x, r1 = b1.x;
-    const int nz0 = b0.y, nz1 = b1.y;
+    const int r0 = rowblk[bid], r1 = rowblk[bid + 1];
+    const int nz0 = indptr[r0], nz1 = indptr[r1];
     const int cnt = nz1 - nz0;
     double acc = 0.0;
     if (cnt <= tile) {
-        // this lane's rows: r0 + tid + j * BS, their entry ranges requested now, used behind the barrier
-        constexpr int MAXR = 4;                      // build_rowblocks: at most 4 rows per lane
-        const int nrows = r1 - r0;
-        int q0[MAXR], q1[MAXR];
-#pragma unroll
-        for (int j = 0; j < MAXR; ++j) {
-            if (j * BS < nrows) {                    // (the same for the whole workgroup)
-                const int r = r0 + j * BS + (int)threadIdx.x;
-                const int rc = r < r1 ? r : r1 - 1;
-                q0[j] = indptr[rc];
-                q1[j] = indptr[rc + 1];
-            }
-        }
         if (cnt > 0) {
             // all index/value loads first, then all gathers: ITEMS independent loads in flight per
             // lane (clamped addresses instead of predicated loads, which would serialise)
@@ -548,20 +528,16 @@ __global__ __launch_bounds__(BS) void k_spmv_stream(const int32_t* __restrict__ 
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MAXR; ++j) {
-            const int r = r0 + j * BS + (int)threadIdx.x;
-            if (j * BS < nrows && r < r1) {
-                const int p0 = q0[j] - nz0, p1 = q1[j] - nz0;
-                double s = 0.0;
-                for (int p = p0; p < p1; ++p) s += prod[p];
-                if (EPI == EPI_RES) {
-                    s = aux[r] - s;
-                    acc = fma(s, s, acc);
-                }
-                st_nt(y + r, s);
-                if (EPI == EPI_DOT) acc = fma(aux[r], s, acc);
+        for (int r = r0 + threadIdx.x; r < r1; r += BS) {
+            const int p0 = indptr[r] - nz0, p1 = indptr[r + 1] - nz0;
+            double s = 0.0;
+            for (int p = p0; p < p1; ++p) s += prod[p];
+            if (EPI == EPI_RES) {
+                s = aux[r] - s;
+                acc = fma(s, s, acc);
             }
+            st_nt(y + r, s);
+            if (EPI == EPI_DOT) acc = fma(aux[r], s, acc);
         }
     } else {  // one long row
         double s = 0.0;

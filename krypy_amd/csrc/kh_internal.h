@@ -242,7 +242,8 @@ struct kh_mat_s {
     int32_t* indices = nullptr;
     double* data = nullptr;
     int32_t* rowblk = nullptr;  // row-block boundaries of the CSR-stream kernel
-    int2* rowblk2 = nullptr;    // [nblk + 1] (first row, first entry) of every row block: what k_spmv_stream needs from ONE load
+    int64_t rows_max = 0;       // a block-row shard: the LONGEST slab of the run (kh_mat_set_rows_max; 0: not announced) - kernel choices
+                                // that change the pattern of cross-rank sums are made for it, so that every rank decides alike
     int32_t* blkwin = nullptr;  // [nblk][cmin, span]: the columns a row block touches (k_spmv_stream<.., WIN>)
     int win_cap = 0;            // LDS window (entries of x) of that kernel for this operator; 0: not worth it
     int nblk = 0;

@@ -255,13 +255,13 @@ static void launch_spmv_items(kh_ctx ctx, kh_mat A, const double* x, double* y, 
             attr_done = true;
         }
         hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS, true>), dim3(grid), dim3(BS), lds + (size_t)A->win_cap * sizeof(double),
-                           ctx->stream, A->indptr, A->indices, A->data, A->rowblk2, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
+                           ctx->stream, A->indptr, A->indices, A->data, A->rowblk, A->nblk, A->tile, A->n_cols, x, A->ghost, y,
                            aux, A->part, rg.blk_lo, rg.blk_skip, rg.part_off, A->blkwin, A->win_cap);
         ctx->n_spmv_win += 1;
         return;
     }
     hipLaunchKernelGGL((k_spmv_stream<EPI, ITEMS>), dim3(grid), dim3(BS), lds, ctx->stream, A->indptr,
-                       A->indices, A->data, A->rowblk2, A->nblk, A->tile,
+                       A->indices, A->data, A->rowblk, A->nblk, A->tile,
                        A->n_cols - A->nrecv_prev - A->nrecv_next, x, A->ghost, y, aux, A->part, rg.blk_lo, rg.blk_skip,
                        rg.part_off);
 }
@@ -1262,7 +1262,20 @@ static __global__ void k_ls_put_column(double* gt, int j, const double* vals) {
 // device, update pass.  Returns 1 when done (norm partials in SLOT_NRM, *nrm_count of them), 0 when not eligible.
 // The Gram table (ctx->ls_tab) belongs to ONE Arnoldi sequence, like the blocked kernel's: (ls_V, ls_next) name the
 // basis block and the step that finds columns 0 .. k-1 of it valid; any other step rebuilds them from the basis first.
-static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
+// The LONGEST slab of the run for a step on local vectors of length n: what the operator of the step was told
+// (kh_mat_set_rows_max: keyed on the operator, ADVICE r05 - two sharded operators of equal local length but different longest
+// slabs used to share one entry of the context's table, and the last announcement won), else the context's table by local
+// length (kh_ctx_set "lowsync_rows": steps without an operator), else 0 = unknown.
+static int64_t longest_slab(kh_ctx ctx, kh_mat A, int64_t n) {
+    if (ctx->nranks <= 1) return n;
+    if (A != nullptr && A->rows_max > 0) return A->rows_max;
+    int64_t nmax = 0;
+    for (int i = 0; i < 4; ++i)
+        if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+    return nmax;
+}
+
+static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k, kh_mat A = nullptr) {
     if (!ctx->mgs_lowsync || !ctx->chain_configured || k + 1 > LS_MAXCOL) return false;
     const int64_t n = V->n;
     int r2 = 0, G = 0;
@@ -1271,9 +1284,7 @@ static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
     // host layer has announced for vectors of this local length (krypy_amd/dist.py: kh_ctx_set "lowsync_rows"); without
     // that announcement the per-link path - the same on every rank - is taken
     if (ctx->nranks > 1) {
-        int64_t nmax = 0;
-        for (int i = 0; i < 4; ++i)
-            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        const int64_t nmax = longest_slab(ctx, A, n);
         int r2m = 0, Gm = 0;
         if (nmax < n || !chain_geometry(ctx, nmax, &r2m, &Gm) || r2m > 24) return false;
     }
@@ -1284,8 +1295,8 @@ static bool lowsync_eligible(kh_ctx ctx, kh_vec V, int64_t wld, int64_t k) {
 }
 
 static int try_lowsync_mgs(kh_ctx ctx, kh_vec V, double* w, int64_t wld, int64_t k, bool multi, double* hdev, double* coef,
-                           int* nrm_count) {
-    if (!lowsync_eligible(ctx, V, wld, k)) return 0;
+                           int* nrm_count, kh_mat A = nullptr) {
+    if (!lowsync_eligible(ctx, V, wld, k, A)) return 0;
     const int64_t n = V->n;
     int r2 = 0, G = 0;
     chain_geometry(ctx, n, &r2, &G);
@@ -2042,6 +2053,12 @@ int dia_rebuild_for_halo(kh_ctx ctx, kh_mat A) {
 }  // namespace kh
 }  // extern "C++"
 
+int kh_mat_set_rows_max(kh_mat A, int64_t rows_max) {
+    KH_ARG(A != nullptr && rows_max >= 0, "kh_mat_set_rows_max: NULL / negative");
+    A->rows_max = rows_max;
+    return 0;
+}
+
 int kh_mat_set_ghost(kh_mat A, const double* values, int64_t count) {
     KH_ARG(A && (values || count == 0), "kh_mat_set_ghost: NULL");
     KH_ARG((A->kind == KH_MAT_CSR && count == A->nrecv_prev + A->nrecv_next) ||
@@ -2109,12 +2126,6 @@ int kh_csr_upload(kh_ctx ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const
             KH_HIP(hipMemcpy(A->data, data, sizeof(double) * nnz, hipMemcpyHostToDevice));
         }
         KH_HIP(hipMemcpy(A->rowblk, blk.data(), sizeof(int32_t) * blk.size(), hipMemcpyHostToDevice));
-        {
-            std::vector<int2> blk2(blk.size());
-            for (size_t i = 0; i < blk.size(); ++i) blk2[i] = make_int2(blk[i], indptr[blk[i]]);
-            KH_HIP(hipMalloc(&A->rowblk2, sizeof(int2) * blk2.size()));
-            KH_HIP(hipMemcpy(A->rowblk2, blk2.data(), sizeof(int2) * blk2.size(), hipMemcpyHostToDevice));
-        }
         if (banded) KH_TRY(build_dia(ctx, A, offs));
         // the columns every row block touches (k_spmv_stream<.., WIN>): where nine blocks in ten fit an LDS window of at most
         // SPMV_WIN_CAP entries of x, the operator's launches carry a window as wide as the widest of those
@@ -2256,7 +2267,6 @@ int kh_mat_free(kh_mat A) {
     (void)hipFree(A->indices);
     (void)hipFree(A->data);
     (void)hipFree(A->rowblk);
-    (void)hipFree(A->rowblk2);
     (void)hipFree(A->blkwin);
     (void)hipFree(A->part);
     (void)hipFree(A->dia);
@@ -2644,16 +2654,14 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
                              chain_geometry(ctx, n, &cr2, &cg));
     // N ranks, reference order: all coefficients of the step from one pass and ONE all-reduce (try_lowsync_mgs below)
     const bool want_lowsync = (kh_multi(ctx) && gs_mode == KH_GS_MGS && sweeps == 1 && start == 0 && !presub && Md == nullptr &&
-                               lowsync_eligible(ctx, V, W->ld, k));
+                               lowsync_eligible(ctx, V, W->ld, k, A));
     // ... or, with the xr transport on and slabs of up to 6 rows per lane: the blocked kernel with the cross-rank sums INSIDE the
     // launch (chain_blk2.h) - the local basis is read once, no all-reduce call in the step.  Eligibility is decided for the
     // longest slab of the run (like the one-reduction form's), so every rank decides alike; from there on a refusal is an error.
     bool want_blk2 = false;
     if (kh_multi(ctx) && ctx->xr_on && ctx->chain_blk2 && ctx->chain_configured && gs_mode == KH_GS_MGS && sweeps == 1 && start == 0 &&
         !presub && Md == nullptr) {
-        int64_t nmax = ctx->nranks > 1 ? 0 : n;
-        for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
-            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        const int64_t nmax = longest_slab(ctx, A, n);
         int r2m = 0, gm = 0;
         want_blk2 = nmax >= n && chain_blk2_shape(ctx, nmax, &r2m, &gm, nullptr, ctx->blk2_one >= 1) && k + 3 <= KH_BLK_TABCOLS;
     }
@@ -2664,9 +2672,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     bool want_chain_xr = false;
     if (!want_blk2 && kh_multi(ctx) && ctx->xr_on && ctx->chain_xr && ctx->chain_configured && gs_mode == KH_GS_MGS && sweeps == 1 &&
         start == 0 && !presub && Md == nullptr) {
-        int64_t nmax = ctx->nranks > 1 ? 0 : n;
-        for (int i = 0; i < 4 && ctx->nranks > 1; ++i)
-            if (ctx->ls_rows_local[i] == n) nmax = ctx->ls_rows_max[i];
+        const int64_t nmax = longest_slab(ctx, A, n);
         int r2m = 0, gm = 0;
         // (a slab that fills less than half the compute units at 16 rows per lane - under 2.1 M rows - belongs to the blocked
         // kernel; with that switched off it keeps the one-reduction form rather than a chain on a handful of workgroups)
@@ -2752,7 +2758,7 @@ int kh_arnoldi_step_begin(kh_ctx ctx, kh_mat A, kh_proj proj, kh_mat Md, kh_vec 
     }
     bool lowsync = false;
     if (!chained && want_lowsync) {
-        const int rc = try_lowsync_mgs(ctx, V, w, W->ld, k, multi, hdev, ctx->scal + SC_COEF, &nrm_count);
+        const int rc = try_lowsync_mgs(ctx, V, w, W->ld, k, multi, hdev, ctx->scal + SC_COEF, &nrm_count, A);
         if (rc < 0) return rc;
         lowsync = (rc == 1);
     }

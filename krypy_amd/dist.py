@@ -311,8 +311,9 @@ class ShardedCSROperator(utils.LinearOperator):
             nsend_prev, nsend_next = nrn, nrp         # what goes to the previous slab is ITS "next" ghost region
         # the LONGEST slab of the run: kernel choices that change the pattern of all-reduces (the one-reduction form of
         # reference-order Gram-Schmidt) must come out the same on every rank, so they are made for that length
+        self._rows_max = int(table[2::3].max())
         if hasattr(ctx, "set") and ctx.nranks > 1:
-            ctx.set("lowsync_rows", (int(nloc) << 32) | int(table[2::3].max()))
+            ctx.set("lowsync_rows", (int(nloc) << 32) | self._rows_max)
         if nsend_prev > nloc or nsend_next > nloc:
             raise utils.ArgumentError("halo wider than the local slab: use fewer ranks")
         self._A_local = A_local
@@ -333,6 +334,8 @@ class ShardedCSROperator(utils.LinearOperator):
         if dm is None:
             dm = self._ctx.csr(self._A_local, n_cols=self._A_local.shape[1], dtype=dt)
             self._ctx.set_halo(dm, *self.halo)
+            if hasattr(self._ctx, "set_rows_max"):      # (the operator carries the run's longest slab: ADVICE r05)
+                self._ctx.set_rows_max(dm, self._rows_max)
             self._dmats[kind] = dm
         return dm
 
