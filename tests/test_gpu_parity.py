@@ -1318,3 +1318,41 @@ def test_dense_gemv_rows_per_wave_same_bits(hip, n_rows, n_cols):
     assert np.allclose(got[1], A.dot(x), rtol=1e-12, atol=1e-11 * np.abs(A).max() * np.abs(x).max() * n_cols)
     for rows in (2, 4, 0):
         assert np.array_equal(got[rows], got[1]), rows
+
+
+def test_dense_operator_formed_on_the_device(hip, golden):
+    """bench.py --config 4 forms A = G G^T / n + I on the device (kh_apply's panel path on the FP64 matrix cores, then
+    kh_dense_from_block) and hands it to the solvers as a utils.DeviceOperator - no host image.  At n = 512 (1,100 at the
+    second size: not a multiple of the panel width): the operator's entries against NumPy's to rounding, its products
+    against A x, and CG through it against the reference's fixture (krypy/linsys.py:593-689; cg_dense_n512: the same
+    iteration count, residual history and iterate)."""
+    from krypy_amd import linsys, utils
+
+    for n in (512, 1100):
+        rng = np.random.default_rng(0)
+        G = rng.standard_normal((n, n))
+        b = rng.standard_normal(n)
+        A = G.dot(G.T) / n + np.eye(n)
+        Gop = hip.dense(G)
+        Gt = hip.upload(np.ascontiguousarray(G.T))
+        Y = hip.alloc(n, n)
+        hip.apply(Gop, Gt, 0, Y, 0, n)
+        Aop = hip.dense_from_block(Y, 0, n, 1.0 / n, 1.0)
+        op = utils.DeviceOperator(Aop)
+        # the entries: apply to the identity, block by block
+        E = hip.upload(np.eye(n))
+        Z = hip.alloc(n, n)
+        hip.apply(Aop, E, 0, Z, 0, n)
+        got = Z.download()
+        assert np.max(np.abs(got - A)) < 1e-13 * np.max(np.abs(A)) * 10
+        x = rng.standard_normal((n, 3))
+        assert np.allclose(op.dot(x), A.dot(x), rtol=1e-12, atol=1e-12)
+        assert np.allclose(op.adj.dot(x), A.dot(x), rtol=1e-12, atol=1e-12)
+        ls = linsys.LinearSystem(op, b, self_adjoint=True, positive_definite=True)
+        s = linsys.Cg(ls, tol=1e-8, maxiter=200)
+        assert np.linalg.norm(A.dot(s.xk[:, 0]) - b) <= 1.0001e-8 * np.linalg.norm(b)
+        if n == 512:
+            g = golden("cg_dense_n512")
+            assert s.iter == int(g["iter"])
+            assert np.max(np.abs(np.array(s.resnorms) - g["resnorms"]) / g["resnorms"]) < 1e-9
+            assert np.linalg.norm(s.xk[:, 0] - g["xk"]) < 1e-10 * np.linalg.norm(g["xk"])
