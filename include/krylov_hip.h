@@ -121,6 +121,9 @@ int kh_mat_xh_export(kh_ctx ctx, kh_mat A, unsigned char handle[64]);
 int kh_mat_xh_attach(kh_ctx ctx, kh_mat A, const unsigned char* prev, int64_t prev_ng, int64_t prev_off, const unsigned char* next,
                      int64_t next_ng, int self_loop);
 int kh_mat_xh_enable(kh_ctx ctx, kh_mat A, int on);
+/* unmap the neighbours' granules again (every rank, when the collective decision about the in-launch halo is "off" after
+ * some ranks had attached): a later kh_mat_xh_attach starts from scratch.  New component. */
+int kh_mat_xh_detach(kh_ctx ctx, kh_mat A);
 /* describe the halo of a block-row-sharded matrix: this rank sends `nsend_*` of its first/last
  * local rows to the previous/next rank and receives as many ghost entries from them.  After
  * this call kh_apply() on `A` exchanges halos (ncclSend/ncclRecv) before the local SpMV; the

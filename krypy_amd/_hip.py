@@ -67,6 +67,7 @@ _SIGNATURES = {
     "kh_mat_xh_export": [_H, _H, ctypes.c_char_p],
     "kh_mat_xh_attach": [_H, _H, ctypes.c_char_p, _I64, _I64, ctypes.c_char_p, _I64, _INT],
     "kh_mat_xh_enable": [_H, _H, _INT],
+    "kh_mat_xh_detach": [_H, _H],
     "kh_mat_set_halo": [_H, _H, _I64, _I64, _I64, _I64],
     "kh_mat_set_rows_max": [_H, _I64],
     "kh_mat_set_ghost": [_H, _c_double_p, _I64],
@@ -556,6 +557,9 @@ class Context(object):
     def xh_attach(self, A, prev, prev_ng, prev_off, next_, next_ng, self_loop=False):
         _check(self._lib, self._lib.kh_mat_xh_attach(self._h, A.handle, prev, int(prev_ng), int(prev_off), next_, int(next_ng),
                                                       1 if self_loop else 0), "kh_mat_xh_attach")
+
+    def xh_detach(self, A):
+        _check(self._lib, self._lib.kh_mat_xh_detach(self._h, A.handle), "kh_mat_xh_detach")
 
     def xh_enable(self, A, on=True):
         _check(self._lib, self._lib.kh_mat_xh_enable(self._h, A.handle, 1 if on else 0), "kh_mat_xh_enable")

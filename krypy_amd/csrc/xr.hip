@@ -276,6 +276,22 @@ int kh_mat_xh_enable(kh_ctx ctx, kh_mat A, int on) {
     return 0;
 }
 
+// the neighbours' granules unmapped again (the own box stays until kh_mat_free: a neighbour may still have it mapped): what the
+// host layer calls on EVERY rank when the collective decision about the in-launch halo comes out "off" after some ranks had
+// attached already - so that a later attempt does not find the operator "already attached" 
+int kh_mat_xh_detach(kh_ctx ctx, kh_mat A) {
+    KH_ARG(ctx && A, "kh_mat_xh_detach: NULL");
+    A->xh_on = 0;
+    if (!A->xh_self) {
+        if (A->xh_prev != nullptr) (void)hipIpcCloseMemHandle(A->xh_prev);
+        if (A->xh_next != nullptr) (void)hipIpcCloseMemHandle(A->xh_next);
+        (void)hipGetLastError();
+    }
+    A->xh_prev = A->xh_next = nullptr;
+    A->xh_self = 0;
+    return 0;
+}
+
 int kh_xr_export(kh_ctx ctx, unsigned char handle[64]) {
     KH_ARG(ctx && handle, "kh_xr_export: NULL");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");

@@ -229,11 +229,11 @@ def enable_xr(ctx, rdv, rank=None, world=None):
         for t, count in enumerate((1, 37, 512, 700, 5, 1, 1, 64)):
             def contrib(r):
                 return numpy.random.default_rng(1000 * t + r).standard_normal(count)
-            want = contrib(0)
+            expect = contrib(0)
             for r in range(1, world):
-                want = want + contrib(r)                      # rank order, like the kernel
+                expect = expect + contrib(r)                  # rank order, like the kernel
             got = ctx.allreduce_host(contrib(rank))
-            if not numpy.array_equal(got, want):
+            if not numpy.array_equal(got, expect):
                 good = 0.0
     except _hip.BackendError:
         good = 0.0
@@ -379,6 +379,8 @@ class ShardedCSROperator(utils.LinearOperator):
         except _hip.BackendError:
             ok = 0.0
         if ctx.allreduce_host(numpy.array([1.0 - ok]))[0] > 0.0:
+            if ok and hasattr(ctx, "xh_detach"):          # (some rank could not attach: the ranks that did let go again)
+                ctx.xh_detach(dm)
             return False
         ctx.xh_enable(dm, True)
         # one application with a known answer before anything depends on it, under a short timeout: x = 1 on every rank, so
@@ -402,6 +404,8 @@ class ShardedCSROperator(utils.LinearOperator):
             ctx.set("xr_timeout_ms", int(float(os.environ.get("KRYPY_AMD_XR_TIMEOUT_S", "60")) * 1e3))
         if ctx.allreduce_host(numpy.array([1.0 - good]))[0] > 0.0:
             ctx.xh_enable(dm, False)
+            if hasattr(ctx, "xh_detach"):
+                ctx.xh_detach(dm)
             return False
         return True
 

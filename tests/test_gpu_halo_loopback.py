@@ -143,6 +143,17 @@ def test_halo_inside_the_spmv_launch(loop_ctx, kind):
     ctx.apply(Ad, X, 0, Y, 0, 1)
     assert np.array_equal(Y.download()[:, 0], want)
     expect_kernel(ctx.get("n_halo_exchange") == e0 + 1, "back on the RCCL exchange")
+    # detached (what every rank does when the collective decision comes out "off" after some had attached) and attached again:
+    # the exchange is back inside the launch, the same bits
+    ctx.xh_detach(Ad)
+    with pytest.raises(Exception):
+        ctx.xh_enable(Ad, True)                 # (nothing attached: refused)
+    ctx.xh_attach(Ad, None, 0, 0, None, 0, self_loop=True)
+    ctx.xh_enable(Ad, True)
+    x1 = ctx.get("n_halo_xh")
+    ctx.apply(Ad, X, 0, Y, 0, 1)
+    assert np.array_equal(Y.download()[:, 0], want)
+    expect_kernel(ctx.get("n_halo_xh") == x1 + 1, "in the launch again after detach + attach")
 
 
 @pytest.mark.parametrize("kind", ["lap2d", "random"])
