@@ -117,6 +117,7 @@ struct kh_ctx_s {
     int chain_long = 1;              // KRYPY_AMD_CHAIN_LONG: 48 rows per lane take k_mgs_chain_long (chain_long.h: a third of every column
                                      // stays on the chip between its dot and its update) instead of k_mgs_chain<48> (both reads from memory)
     int64_t n_chain_long = 0;
+    int64_t n_zspmv_dia = 0;         // products of a banded complex operator through its diagonal-major copy (zpath.h: k_zspmv_dia)
     int chain_xr = 1;
     int chain_xr_cus = 0;            // tests: the compute units the shape is chosen for (0: all; two processes share one device)
     int64_t n_chain_xr = 0;

@@ -2,6 +2,8 @@
 edge sizes, mixed shapes, bit-level agreement of the complex CSR SpMV with SciPy, and the complex
 Arnoldi step against NumPy.  The solver-level complex parity cases run from tests/test_gpu_parity.py
 (tests/parity_cases_complex.py)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -392,7 +394,7 @@ def test_complex_operator_fused_into_the_chain_prologue(hip, shape):
     assert np.linalg.norm(A.dot(Vf[:, :m]) - Vf.dot(Hf)) < 1e-12 * np.linalg.norm(Hf)
 
 
-@pytest.mark.parametrize("nx,ny", [(1300, 1000), (2500, 2000)])
+@pytest.mark.parametrize("nx,ny", [(1300, 1000), (1700, 1500), (2200, 1800), (2500, 2000)])
 def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
     """A complex HERMITIAN banded operator (D^H L D with a diagonal of phases D): the Lanczos step of complex MINRES -
     operator, pre-subtraction of H[k,k-1] v_{k-1} (a real coefficient), one Gram-Schmidt link, norm, store - is ONE launch
@@ -414,6 +416,7 @@ def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
         hip.set("chain_spmv", fused)
         try:
             before = hip.counters()
+            lz0, zd0 = hip.get("n_lanczos_fused"), hip.get("n_zspmv_dia")
             V, W = hip.alloc(n, m + 1, dtype=complex), hip.alloc(n, 2, dtype=complex)
             V.upload(0, (v / np.linalg.norm(v)).reshape(-1, 1))
             H = np.zeros((m + 1, m), dtype=complex)
@@ -425,6 +428,12 @@ def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
                     H[k - 1, k] = H[k, k - 1]
             c = hip.counters()
             expect_kernel(c["chain_fused"] - before["chain_fused"] == (m if fused else 0), "c[\"chain_fused\"] - before[\"chain_fused\"] == (m if fused else 0): %r" % ((fused, c),))
+            # (round 6: the fused step is the complex three-pass kernel, lanczos.h: k_zlanczos_fused - 16, 24, 32 and 40 rows
+            # per lane here; the separate launches take the banded complex SpMV, zpath.h: k_zspmv_dia)
+            lz_on = os.environ.get("KRYPY_AMD_LANCZOS_FUSED", "1") != "0"
+            expect_kernel(hip.get("n_lanczos_fused") - lz0 == (m if (fused and lz_on) else 0),
+                          "three-pass launches: %r" % ((fused, hip.get("n_lanczos_fused") - lz0),))
+            expect_kernel(fused or hip.get("n_zspmv_dia") - zd0 == m, "banded complex SpMV launches: %r" % (hip.get("n_zspmv_dia") - zd0,))
             out.append((H, V.download()))
             del V, W
         finally:
