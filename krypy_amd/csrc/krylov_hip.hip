@@ -608,27 +608,6 @@ static hipError_t launch_lanczos(kh_ctx ctx, int G, ChainArgs& a, const MinresJo
     return hipGetLastError();
 }
 
-// ... for complex vectors (lanczos.h: k_zlanczos_fused; no preconditioner, no MINRES job)
-template <int R2, int FND>
-static hipError_t launch_zlanczos(kh_ctx ctx, int G, ChainArgs& a) {
-    static int blocks_per_cu = -1;
-    constexpr size_t lds = ZLanczosShape<R2>::LDS_BYTES;
-    if (blocks_per_cu < 0) {
-        if (lds > 0) {
-            hipError_t e0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_zlanczos_fused<R2, FND>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e0 != hipSuccess) return e0;
-        }
-        int nb = 0;
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_zlanczos_fused<R2, FND>, CH_BS, lds);
-        if (e != hipSuccess) return e;
-        blocks_per_cu = nb;
-    }
-    if ((int64_t)blocks_per_cu * ctx->ncu < G) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((k_zlanczos_fused<R2, FND>), dim3(G), dim3(CH_BS), lds, ctx->stream, a);
-    return hipGetLastError();
-}
-
 // rows-per-workgroup (= template R2) and grid of the chain kernel for vectors of length n
 bool chain_geometry(kh_ctx ctx, int64_t n, int* r2_out, int* g_out, bool onex) {
     if (n < 2) return false;
@@ -864,33 +843,6 @@ int try_chain(kh_ctx ctx, kh_vec V, kh_vec B, const double* w, int64_t wld, cons
     // and cost what they save (17.4 vs 16.3 us per link at N = 10^7)
     const bool use_pf = use_lds && ctx->chain_pf && (r2 <= 24 || (ctx->chain_pf == 2 && r2 <= 40));   // (2: measurement)
 #define KH_CHAIN(R) (use_lds ? (use_pf ? KH_CHAIN_PF(R) : KH_CHAIN_LDS(R)) : KH_CHAIN_PLAIN(R))
-    // ... the same for complex vectors (16 ... 40 rows per lane: where the complex operator has its prologue)
-    if (fused && cplx && r2 >= 16 && r2 <= 40 && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && a.debug != 1 && a.debug != 2) {
-        if (!presub) {                 // no previous column: subtract 0 * (some valid column)
-            a.bprev = B->col(k);
-            a.h_km1 = 0.0;
-            a.h_km1_dev = nullptr;
-        }
-#define KH_ZLZ(R) ((a.offs.nd == 5) ? launch_zlanczos<R, 5>(ctx, G, a) : launch_zlanczos<R, 7>(ctx, G, a))
-        if (r2 == 40) e = KH_ZLZ(40);
-        else if (r2 == 32) e = KH_ZLZ(32);
-        else if (r2 == 24) e = KH_ZLZ(24);
-        else e = KH_ZLZ(16);
-#undef KH_ZLZ
-        if (e == hipSuccess) {
-            if (a.debug == 4) ctx->chain_fault = 0;
-            ctx->n_chain += 1;
-            ctx->n_chain_fused += 1;
-            ctx->n_lanczos_fused += 1;
-            ctx->chain_epoch += 2u;          // the coefficient's (two values in one round) and the norm's grid-wide sums
-            if (hpin == nullptr)
-                KH_HIP(hipMemcpyAsync(ctx->chain_err_pin[slot], ctx->chain_err, sizeof(int), hipMemcpyDeviceToHost,
-                                      ctx->stream));
-            { ctx->wait_tag[slot] = a.donepin != nullptr; return 1; }
-        }
-        (void)hipGetLastError();             // e.g. the dynamic LDS was refused: the general complex chain kernel below
-        if (!presub) a.bprev = nullptr;
-    }
     // a step with ONE Gram-Schmidt link (Lanczos / MINRES, the first Arnoldi step): three passes instead of six
     if (fused && !cplx && r2 <= 40 && ctx->lanczos_fused && a.ncol == 1 && a.sweeps == 1 && (dg == nullptr || P != nullptr)) {
         if (!presub) {                 // no previous column: subtract 0 * (some valid column)

@@ -252,153 +252,10 @@ __global__ __launch_bounds__(CH_BS) void k_lanczos_fused(ChainArgs a, MinresJob 
 #undef W_GET
 }
 
-// ------------------------------------------------------------------------------------------
-// The same three passes for COMPLEX (c128) vectors (round 6; Hermitian MINRES on complex data, linsys.py:791-853 with
-// utils.py:999-1045): a complex N-vector is a real block of 2N doubles, one double2 row per entry, so geometry and padding
-// are the chain kernels'.  Pass 1 computes (A v_k)_r from the diagonal-major copy of (re, im) pairs exactly as
-// chain_apply_banded_z does (NumPy's product formula, sums from (0, 0) in ascending offset order, empty slots skipped),
-// subtracts h_{k-1,k} v_{k-1}[r] (a REAL coefficient: the previous step's norm) and feeds conj(v_k[r]) w_r into the two
-// accumulators of the complex dot at once; one two-value grid-wide sum; pass 2 is the complex update w -= alpha v_k with
-// |w|^2 in the same sweep; one sum; pass 3 stores v_{k+1} = w / h.  Every floating-point operation and the order of every
-// sum are those of k_mgs_chain_lds<R2, false, true, FND> with presub: H and the basis come out bit for bit
-// (tests/test_gpu_complex.py::test_complex_lanczos_step_with_the_operator_in_the_prologue compares both with the separate
-// launches).  No preconditioner and no MINRES job here (the complex recurrences stay a launch of their own).
-// ------------------------------------------------------------------------------------------
-template <int R2>
-struct ZLanczosShape {
-    static constexpr int WL = (R2 == 40) ? 8 : 0;                     // rows of w in LDS (160 + the operator's temporaries do not fit)
-    static constexpr size_t LDS_BYTES = (size_t)WL * CH_BS * sizeof(double2);
-};
-
-template <int R2, int FND>
-__global__ __launch_bounds__(CH_BS) void k_zlanczos_fused(ChainArgs a) {
-    constexpr int WL = ZLanczosShape<R2>::WL;
-    constexpr int RW = R2 - WL;
-    extern __shared__ __attribute__((aligned(16))) double2 zlsm[];   // [WL rows of w][CH_BS]
-    const int tid = threadIdx.x;
-    double2* const wl = zlsm + tid;
-#define W_GET(r) (((r) < RW) ? w[((r) < RW) ? (r) : 0] : wl[((r) - RW) * CH_BS])
-#define W_PUT(r, val)                                   \
-    do {                                                \
-        if ((r) < RW) w[((r) < RW) ? (r) : 0] = (val);  \
-        else wl[((r) - RW) * CH_BS] = (val);            \
-    } while (0)
-    __shared__ double smd[4 * (CH_BS / 64)];
-    __shared__ unsigned smu[2 * CH_GMAX];
-    __shared__ int slead;
-    const int G = gridDim.x;
-    const GridRole role = grid_role(a.xcc_leader, a.epoch0, &slead);
-    const int64_t first = (int64_t)blockIdx.x * a.chunk2 + tid;
-    const int64_t left = a.n2 - first;
-    const int rem = (int)(left < 0 ? 0 : (left > a.chunk2 ? a.chunk2 : left));
-    double2 w[RW];
-    unsigned epoch = a.epoch0;
-    if (a.debug == 4 && tid == 0) __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // tests: a faked timeout
-    // ---- pass 1: w = A v_k - h_{k-1,k} v_{k-1}, conj(v_k) . w ----
-    double acc0 = 0.0, acc1 = 0.0;
-    {
-        const double hk = (a.h_km1_dev != nullptr) ? a.h_km1_dev[0] : a.h_km1;
-        const double2* __restrict__ xk = reinterpret_cast<const double2*>(a.xk);
-        const double2* __restrict__ dia = reinterpret_cast<const double2*>(a.dia);
-        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(a.bprev);
-        const double2* __restrict__ v2 = reinterpret_cast<const double2*>(a.V + a.col0 * a.ld);
-        const int64_t last = a.n_last;           // last complex row
-        int64_t fb = first;
-#pragma unroll
-        for (int r = 0; r < R2; ++r) {
-            const int64_t row = fb + (int64_t)r * CH_BS;
-            double2 av[FND], xv[FND];
-#pragma unroll
-            for (int d = 0; d < FND; ++d) {
-                av[d] = ld_nt2(dia + (int64_t)d * a.dia_ld + row);
-                int64_t c = row + a.offs.off[d];
-                c = c < 0 ? 0 : (c > last ? last : c);
-                xv[d] = xk[c];
-            }
-            const double2 vv = v2[row];              // (the line the operator's centre entry came from)
-            const double2 pp = p2[row];
-            double sx = 0.0, sy = 0.0;
-#pragma unroll
-            for (int d = 0; d < FND; ++d) {
-                const double px = av[d].x * xv[d].x - av[d].y * xv[d].y;
-                const double py = av[d].x * xv[d].y + av[d].y * xv[d].x;
-                const bool on = (av[d].x != 0.0) || (av[d].y != 0.0);
-                sx = on ? sx + px : sx;
-                sy = on ? sy + py : sy;
-            }
-            double2 t;
-            t.x = sx - hk * pp.x;
-            t.y = sy - hk * pp.y;
-            W_PUT(r, t);
-            // conj(v) * w: acc0 = re, acc1 = im (k_mgs_chain's order)
-            acc0 = fma(vv.x, t.x, acc0);
-            acc0 = fma(vv.y, t.y, acc0);
-            acc1 = fma(vv.x, t.y, acc1);
-            acc1 = fma(-vv.y, t.x, acc1);
-            if ((r & 1) == 1) asm volatile("" : "+v"(fb) : : "memory");      // two rows of loads in flight
-        }
-    }
-    // ---- pass 2: w -= alpha v_k, |w|^2; a two-deep ring of PB2 rows, its first batch in flight across the sum ----
-    constexpr int PB2 = 4, NB2 = R2 / PB2;
-    static_assert(NB2 * PB2 == R2, "rows per lane are a multiple of four");
-    const double2* __restrict__ b2 = reinterpret_cast<const double2*>(a.B + a.col0 * a.ld) + first;
-    double2 rp[2][PB2];
-#pragma unroll
-    for (int i = 0; i < PB2; ++i) rp[0][i] = ld_nt2(b2 + (int64_t)i * CH_BS);
-    CH_ISSUE_FENCE();
-    double alpha = acc0, alpha_i = acc1;
-    grid_sum2(alpha, alpha_i, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-    if (blockIdx.x == 0 && tid == 0) {
-        a.hdev[2 * a.col0] = 0.0 + alpha;
-        a.hdev[2 * a.col0 + 1] = 0.0 + alpha_i;
-    }
-    if (a.debug == 4) alpha *= 0.5;      // ... that leaves garbage behind
-    double acc = 0.0;
-#pragma unroll
-    for (int b = 0; b < NB2; ++b) {
-        if (b + 1 < NB2) {
-#pragma unroll
-            for (int i = 0; i < PB2; ++i) rp[(b + 1) & 1][i] = ld_nt2(b2 + (int64_t)((b + 1) * PB2 + i) * CH_BS);
-        }
-        CH_ISSUE_FENCE();
-#pragma unroll
-        for (int i = 0; i < PB2; ++i) {
-            const int r = b * PB2 + i;
-            const double2 p = rp[b & 1][i];
-            double2 wr = W_GET(r);
-            const double tr = alpha * p.x - alpha_i * p.y;      // (alpha + i alpha_i) * (p.x + i p.y), NumPy's formula
-            const double ti = alpha * p.y + alpha_i * p.x;
-            wr.x = wr.x - tr;
-            wr.y = wr.y - ti;
-            W_PUT(r, wr);
-            acc = fma(wr.x, wr.x, acc);
-            acc = fma(wr.y, wr.y, acc);
-        }
-    }
-    // ---- pass 3: v_{k+1} = w / h ----
-    const double h2 = grid_sum(acc, epoch++, a.gran, G, a.err, smd, smu, role, a.xcc_res);
-    const double h = sqrt(fabs(h2));
-    if (blockIdx.x == 0 && tid == 0) a.hdev[a.hnext] = h;
-    double2* __restrict__ vn2 = reinterpret_cast<double2*>(a.vnext) + first;
-#pragma unroll
-    for (int r = 0; r < R2; ++r) {
-        if (r * CH_BS < rem) {
-            const double2 wr = W_GET(r);
-            double2 o;
-            o.x = wr.x / h;
-            o.y = wr.y / h;
-            st_nt2(vn2 + (int64_t)r * CH_BS, o);
-        }
-    }
-    if (blockIdx.x == 0 && a.hpin != nullptr) {
-        __syncthreads();          // the H entries were written by thread 0 of this workgroup
-        for (int i = tid; i < a.hcount; i += CH_BS)
-            a.hpin[i] = __hip_atomic_load(a.hdev + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) *a.errpin = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        CH_SIGNAL_DONE(a);
-    }
-#undef W_PUT
-#undef W_GET
-}
+// (Round 6 built the same three passes for complex (c128) vectors - k_zlanczos_fused<R2, FND>: chain_apply_banded_z's products,
+// the real pre-subtraction and conj(v_k) w in pass 1, the complex update and |w|^2 in pass 2, the store in pass 3; bit for bit
+// the complex chain kernel's H and basis at 16 ... 40 rows per lane, no spilled registers - and measured it on complex Hermitian
+// MINRES at N = 5 * 10^6: 3,980-4,120 it/s with two rows of loads in flight, 4,226-4,237 with four, against 4,242-4,275 for the
+// general complex chain kernel with the operator in its prologue.  No gain: not kept (EXPERIMENTS.md).)
 
 }  // namespace kh

@@ -416,7 +416,7 @@ def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
         hip.set("chain_spmv", fused)
         try:
             before = hip.counters()
-            lz0, zd0 = hip.get("n_lanczos_fused"), hip.get("n_zspmv_dia")
+            zd0 = hip.get("n_zspmv_dia")
             V, W = hip.alloc(n, m + 1, dtype=complex), hip.alloc(n, 2, dtype=complex)
             V.upload(0, (v / np.linalg.norm(v)).reshape(-1, 1))
             H = np.zeros((m + 1, m), dtype=complex)
@@ -428,11 +428,7 @@ def test_complex_lanczos_step_with_the_operator_in_the_prologue(hip, nx, ny):
                     H[k - 1, k] = H[k, k - 1]
             c = hip.counters()
             expect_kernel(c["chain_fused"] - before["chain_fused"] == (m if fused else 0), "c[\"chain_fused\"] - before[\"chain_fused\"] == (m if fused else 0): %r" % ((fused, c),))
-            # (round 6: the fused step is the complex three-pass kernel, lanczos.h: k_zlanczos_fused - 16, 24, 32 and 40 rows
-            # per lane here; the separate launches take the banded complex SpMV, zpath.h: k_zspmv_dia)
-            lz_on = os.environ.get("KRYPY_AMD_LANCZOS_FUSED", "1") != "0"
-            expect_kernel(hip.get("n_lanczos_fused") - lz0 == (m if (fused and lz_on) else 0),
-                          "three-pass launches: %r" % ((fused, hip.get("n_lanczos_fused") - lz0),))
+            # (round 6: the separate launches take the banded complex SpMV, zpath.h: k_zspmv_dia)
             expect_kernel(fused or hip.get("n_zspmv_dia") - zd0 == m, "banded complex SpMV launches: %r" % (hip.get("n_zspmv_dia") - zd0,))
             out.append((H, V.download()))
             del V, W
