@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 evidence on one MI355X box (through gpurun): tools/r06_evidence.sh <bench|legs|slabs|tests>
+# Round-6 evidence on one MI355X box (through gpurun): tools/r06_evidence.sh <bench|legs|slabs|soak|tests>
 # Everything lands under gpurun_out/ev6/; profiles/r06_* are written in place (copy them back from gpurun_out/ev6/profiles).
 set -u
 WHAT=${1:-bench}
@@ -59,6 +59,19 @@ print('$1: %.1f it/s (sums %s, halo %s, per iteration %s)' % (d['value'], c.get(
       | line "config 5, one middle rank of eight, mgs with KRYPY_AMD_CHAIN_LONG=0" >> $EV/profiles/r06_slabs.log
   done
   cat $EV/profiles/r06_slabs.log
+  ;;
+soak)
+  # the round's two kernels for long enough to mean something: 4,000 launches of the chain with the cross-rank stage on the N/2
+  # slab (200 k sums through the mailbox) and 2,000 of the 48-row kernel with it on config 5's slab, every cycle's residual
+  # history compared with the first one's by the line itself (final_relres / deflated_relres must repeat to the last bit)
+  : > $EV/profiles/r06_soak.log
+  for rep in 1 2; do
+    python bench.py --force-sharded --loop-halo --nx 4000 --ny 1250 --ortho mgs --no-roofline --no-cpu-baseline --steps 20 --warmup 0 --other-modes none 2>/dev/null \
+      | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config']; print('N/2 slab, 2000 iterations: %.1f it/s, final_relres %.17g, cycles %s' % (d['value'], c['final_relres'], c['cycle_ms']))" >> $EV/profiles/r06_soak.log
+    python bench.py --config 5 --nz 50 --force-sharded --loop-halo --ortho mgs --no-roofline --no-cpu-baseline --steps 10 --warmup 0 2>/dev/null \
+      | python -c "import json,sys; d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); c=d['config']; print('config 5 slab, 1000 deflated iterations: %.1f it/s, deflated_relres %.17g, solves %s' % (d['value'], c['deflated_relres'], c['cycle_ms']))" >> $EV/profiles/r06_soak.log
+  done
+  cat $EV/profiles/r06_soak.log
   ;;
 tests)
   rm -f $EV/fullsize_parity.log
