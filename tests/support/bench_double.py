@@ -34,6 +34,21 @@ def main():
             return orig(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
 
         NumpyContext.arnoldi_step = failing
+    fail_after = os.environ.get("BENCH_DOUBLE_FAIL_MGS_AFTER")
+    if fail_after is not None:
+        # every rank's reference-order steps start failing after the same number of calls - a sum over the mailboxes that times out
+        # INSIDE the timed region (the probe, if any, has passed by then): for the test of the timed region's way back to the panel form
+        orig2 = NumpyContext.arnoldi_step
+        calls = [0]
+
+        def failing2(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1=0.0):
+            if gs_mode == _hip.GS_MGS:
+                calls[0] += 1
+                if calls[0] > int(fail_after):
+                    raise _hip.BackendError("bench_double: reference-order step %d of this process was told to fail" % calls[0])
+            return orig2(self, A, Md, V, P, W, wcol, k, start, sweeps, gs_mode, h_km1)
+
+        NumpyContext.arnoldi_step = failing2
     _hip._install_context_for_testing(NumpyContext())
     _hip.device_count = lambda: int(os.environ.get("BENCH_DOUBLE_DEVICES", "8"))
     import bench

@@ -393,6 +393,32 @@ def test_bench_ortho_auto_goes_back_to_the_panel_form_when_the_candidate_fails()
     assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
 
 
+def test_bench_timed_region_falls_back_to_the_panel_form_together():
+    """A failure INSIDE the timed region (what a sum over the mailboxes that times out looks like from the host -
+    an error on every rank of the communicator, here from the 20th reference-order step on, i.e. in the second cycle of the region)
+    must not cost the run its line where there is something to go back to: every rank reports through the same host collective, all
+    of them switch to the panel form over RCCL, the region is timed again, and the line says so.  Bounded: well under a minute."""
+    import json
+    import time
+    os.environ["BENCH_DOUBLE_FAIL_MGS_AFTER"] = "20"
+    try:
+        t0 = time.time()
+        rc, lines, err = _bench_self_spawn(["--gpus", "2", "--steps", "2", "--warmup", "1", "--nx", "40", "--ny", "36", "--restart", "12",
+                                            "--ortho", "mgs", "--no-roofline", "--no-cpu-baseline", "--other-modes", "none"])
+        took = time.time() - t0
+    finally:
+        del os.environ["BENCH_DOUBLE_FAIL_MGS_AFTER"]
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    o = json.loads(lines[0])
+    fb = o["config"]["timed_region_fallback"]
+    assert fb is not None and fb["from"] == {"ortho": "mgs", "transport": "rccl"} and "told to fail" in fb["reason"]
+    assert o["config"]["ortho"] == "cgs" and o["config"]["iterations_timed"] == 24 and o["n_gpus"] == 2
+    want = _single_process_bench_residual(40, 36, 12, ortho="cgs")
+    assert abs(want - o["config"]["final_relres"]) <= 1e-9 * want
+    assert took < 120.0, took
+
+
 def test_bench_gpus_n_stops_the_others_when_one_rank_dies():
     """ONE rank dies before the rendezvous while rank 0 waits there for it: the launcher must see the dead rank although rank 0
     has not closed its stdout, stop the waiting ranks (its own children, by PID) and report - not sit in a read of rank 0's
