@@ -784,6 +784,14 @@ def _run():
                                "b=rng(0) normal, x0=0, tol=1e-8 (BASELINE.json configs[1])"
                                % (m, nx, ny, N, nnz_global),
                    "n": N, "ortho": ortho, "restart": m, "iterations_timed": n_iters,
+                   # CSR in, DIA streamed: the operator arrives as SciPy's CSR arrays and is uploaded as they are; the
+                   # banded structure is detected at upload and the solver's steps stream a diagonal-major copy built on the device
+                   # (8 B per slot, no index stream; bit-identical products).  The CSR kernel north_star names is timed beside it:
+                   # `spmv` (stand-alone) and `other_modes["mgs, general CSR SpMV kernel + chain kernel ..."]` (the whole run).
+                   "operator_format": (("CSR in (int32 indptr / indices, fp64 data, as SciPy holds them); the timed iterations stream the "
+                                        "diagonal-major copy of the %d diagonals built at upload" % ls.A._device_matrix().diagonals)
+                                       if (hasattr(ls.A, "_device_matrix") and getattr(ls.A._device_matrix(), "diagonals", 0)) else
+                                       "CSR in, CSR streamed (k_spmv_stream)"),
                    "parallelism": "1 GPU" if not sharded else "row-sharded x%d (%s)" % (world, "RCCL" if args.transport == "rccl" else "mailboxes only"),
                    "ranks": world,
                    # sums across the ranks: "xr" = one kernel of system-scope stores into the peers' IPC-mapped mailboxes
