@@ -127,6 +127,9 @@ SWITCHES = [
     ("KRYPY_AMD_BENCH_XR_TIMEOUT_S", "15", "bench", None,
      "seconds a cross-rank sum over the mailboxes may wait for a peer inside `bench.py`'s timed region before the run goes back to RCCL "
      "and the panel form on every rank (`timed_region_fallback` of the line); the probe of the candidates uses 10 s"),
+    ("KRYPY_AMD_BENCH_FAULT", "0", "test", None,
+     "1: a sharded `bench.py` run fakes a timed-out in-launch sum in the first launch of its timed region (`kh_ctx_set \"chain_fault\"`): "
+     "the test of the timed region's way back to RCCL and the panel form on the real context (`tests/test_gpu_multirank.py`)"),
     ("KRYPY_AMD_BENCH_DEADLINE_S", "1500", "bench", None,
      "seconds after which `bench.py --gpus N`'s own launcher stops its rank processes and exits non-zero (a collective that never returns "
      "must not hold the driver for ever)"),

@@ -126,6 +126,36 @@ def test_bench_one_rank_as_a_middle_slab_with_itself_as_neighbour(hip):
     assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
 
 
+def test_bench_timed_region_fallback_on_the_real_context(hip):
+    """A failure INSIDE the timed region of a sharded run (here faked: the first launch with in-launch sums of the region
+    reports a timed-out sum, `KRYPY_AMD_BENCH_FAULT=1`; on a communicator that is KH_ERR_COMM, never a rank-local recovery)
+    must not cost the run its line: the mailboxes are detached, the halo goes back to ncclSend / ncclRecv, the panel form over
+    ncclAllReduce is timed instead - on the REAL context (the CPU suite runs the same logic on the double) - and the line says
+    so; the residual is the one of a plain `--ortho cgs` run over RCCL."""
+    common = ["--force-sharded", "--steps", "2", "--warmup", "1", "--nx", "4000", "--ny", "700", "--restart", "30",
+              "--no-cpu-baseline", "--no-roofline", "--other-modes", "none"]
+    os.environ["KRYPY_AMD_BENCH_FAULT"] = "1"
+    try:
+        rc, lines, err = _bench(common + ["--ortho", "mgs"])
+    finally:
+        del os.environ["KRYPY_AMD_BENCH_FAULT"]
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    a = json.loads(lines[0])
+    fb = a["config"]["timed_region_fallback"]
+    assert fb is not None and fb["from"] == {"ortho": "mgs", "transport": "xr"} and "timed out" in fb["reason"], fb
+    assert a["config"]["ortho"] == "cgs" and a["config"]["cross_rank_sums"] == "rccl" and a["config"]["halo"].startswith("rccl")
+    assert a["config"]["iterations_timed"] == 60 and a["config"]["sharded_diagnostics"]["per_iteration"]["n_xr"] == 0
+    os.environ["KRYPY_AMD_XR"] = "0"
+    try:
+        rc, lines, err = _bench(common + ["--ortho", "cgs"])
+    finally:
+        del os.environ["KRYPY_AMD_XR"]
+    assert rc == 0 and len(lines) == 1, err[-3000:]
+    b = json.loads(lines[0])
+    r1, r2 = a["config"]["final_relres"], b["config"]["final_relres"]
+    assert abs(r1 - r2) <= 1e-9 * r1, (r1, r2)
+
+
 def test_bench_config5_two_ranks_share_the_one_gpu(hip):
     """BASELINE.json configs[4]'s flow (harvest of the Ritz vectors on the device, DeflatedGmres with them:
     /root/reference/krypy/recycling/linsys.py:51-103, deflation.py:93-163) on TWO rank processes, z-slabs of the 3-D
