@@ -2943,7 +2943,20 @@ int kh_arnoldi_step_end(kh_ctx ctx, int slot, int64_t count, double* hcol_out) {
         // out - a workgroup of this launch, a peer rank - re-running the step HERE alone on other kernels would change the
         // pattern of collectives the peers see)
         const int code = *ctx->chain_err_pin[slot];
-        *ctx->chain_err_pin[slot] = 0;
+        // The caller gives this Arnoldi sequence up.  The steps begun behind the failed one (look-ahead) ran with the same error
+        // word set and copied it into THEIR slots: wait for them, then clear the device's word and every slot's copy, and forget
+        // the Gram tables those launches may have written garbage rows into - whatever the caller does next on this context
+        // (bench.py: every rank back to RCCL and the panel form, together) must not find a stale "timed out" in a slot it
+        // re-uses (a panel step does not write its slot's word: it would report the aborted look-ahead step's).
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipMemset(ctx->chain_err, 0, sizeof(int));
+        for (int s2 = 0; s2 < KH_NSLOT; ++s2) {
+            *ctx->chain_err_pin[s2] = 0;
+            ctx->wait_tag[s2] = false;
+            if (s2 != slot) ctx->step[s2].kind = 0;
+        }
+        ctx->blk_next = -1;
+        ctx->ls_next = -1;
         return fail(KH_ERR_COMM, "a sum inside the Gram-Schmidt kernel with in-launch cross-rank sums timed out on rank %d of %d (%s); no rank-local recovery on "
                                  "a communicator", ctx->rank, ctx->nranks, code == 2 ? "a peer rank's contribution did not arrive" :
                                  "a workgroup of the launch did not arrive");
