@@ -190,7 +190,9 @@ int kh_apply(kh_ctx ctx, kh_mat A, kh_vec X, int64_t xcol, kh_vec Y, int64_t yco
 /* out[j] = <V[:, j0+j], W[:, wcol]>, j < ncols   (numpy.dot(X.T.conj(), Y), utils.py:183) */
 int kh_dot_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, kh_vec W, int64_t wcol,
                  double* out);
-/* out (row-major nx*ny) = X[:, x0:x0+nx]^T Y[:, y0:y0+ny] */
+/* out (row-major nx*ny) = X[:, x0:x0+nx]^T Y[:, y0:y0+ny]   (utils.inner with a block on both sides, utils.py:160-193).
+ * ny >= 2: 16 x 16 tiles on the FP64 matrix cores, both blocks read once per tile (k_gram_mfma; kh_ctx_set "gram_mfma" 0 /
+ * KRYPY_AMD_GRAM_MFMA=0: one kh_dot_panel per column of Y).  Either way a fixed summation order: the same bits from run to run. */
 int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y0, int64_t ny,
                double* out);
 /* W[:, wcol] -= sum_j h[j] * V[:, j0+j], applied left to right, multiply then subtract

@@ -419,6 +419,8 @@ class Context(object):
     # blocks are parked (at most _POOL_PER_SHAPE per shape, _POOL_FRACTION of device memory in
     # total) and handed out again zero-filled, which is what kh_vec_alloc guarantees. ----
     _POOL_PER_SHAPE = 2          # big blocks (a basis)
+    _POOL_PER_SHAPE_MEDIUM = 6   # blocks below _POOL_MEDIUM_BYTES: a deflated solve holds U, AU and the projector's two bases of one
+    _POOL_MEDIUM_BYTES = 8 << 30 # shape (N x 16: 1.6 GB at config 5's slab) - with two parked, the next solve allocated two afresh
     _POOL_PER_SHAPE_SMALL = 12   # blocks below _POOL_SMALL_BYTES (single vectors, W pairs, panels):
     _POOL_SMALL_BYTES = 1 << 30  # a cycle allocates and drops about ten of them
     _POOL_FRACTION = 0.6         # (0.35 until round 6: config 5 at N = 10^8 on one device - an 80.8 GB basis beside 34 GB of parked
@@ -445,7 +447,8 @@ class Context(object):
                 self._pool_cap = 0
         nbytes = 8 * n * max(ncols, 1)
         lst = pool.setdefault((n, ncols), [])
-        cap = self._POOL_PER_SHAPE_SMALL if nbytes < self._POOL_SMALL_BYTES else self._POOL_PER_SHAPE
+        cap = (self._POOL_PER_SHAPE_SMALL if nbytes < self._POOL_SMALL_BYTES
+               else self._POOL_PER_SHAPE_MEDIUM if nbytes < self._POOL_MEDIUM_BYTES else self._POOL_PER_SHAPE)
         if len(lst) < cap and self._pool_bytes + nbytes <= self._pool_cap:
             lst.append(h)
             self._pool_bytes += nbytes

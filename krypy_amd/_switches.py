@@ -47,6 +47,11 @@ SWITCHES = [
      "0: 48 rows per lane (10.49 M ... 12.58 M rows per GPU / rank) keep `k_mgs_chain<48>` - both reads of every basis column from memory "
      "- instead of `k_mgs_chain_long` (`csrc/chain_long.h`: two batches parked in LDS, the last two still in the register ring: 16 of 48 "
      "rows never leave the chip between a column's dot and its update).  Same bits either way; counter `n_chain_long`"),
+    ("KRYPY_AMD_GRAM_MFMA", "1", "kernel-path", "0",
+     "0: an inner product with a block on both sides (`kh_gemm_tn` with two or more columns on the right: `<W, V>` of the deflation "
+     "projector's set-up, `<U, AU>`, the Ritz set-up's `<V, AU>`) keeps one `k_multidot` launch and one host round trip per column of "
+     "the right block - the left block read once PER column - instead of `k_gram_mfma` (`csrc/kernels.h`: both blocks read once per "
+     "16 x 16 tile, FP64 matrix cores).  Another summation order, the same bits from run to run; counter `n_gram_mfma`"),
     ("KRYPY_AMD_CHAIN_XR", "1", "kernel-path", "0",
      "0: on N ranks with the xr transport on, slabs beyond the blocked kernel's 2.5 M rows keep the one-reduction form / the panel "
      "kernels (the local basis read twice, two sums across the ranks per step) instead of the register-resident chain kernels with the "

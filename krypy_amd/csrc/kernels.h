@@ -1035,6 +1035,66 @@ __global__ __launch_bounds__(BS) void k_gemm_dense_mfma(int64_t n_rows, int64_t 
 }
 
 // ------------------------------------------------------------------------------------------
+// X^T Y for two tall blocks of up to 16 columns each on the FP64 matrix cores: utils.inner with a block on both sides
+// (utils.py:160-193 - <W, V> of Projection.__init__, <U, AU>, <V, AU> of the Ritz set-up).  The per-column form
+// (k_multidot, one launch and one host round trip per column of Y) reads X once PER COLUMN of Y: 272 column reads for a
+// 16 x 16 product; here both blocks are read once (32).  A wave takes chunks of 64 rows; lane (c, q) loads the rows
+// r0 + 8 i + 2 q, + 1 (i = 0 .. 7) of column c of X and of Y - the four lanes of a column read 64 contiguous bytes per
+// instruction - and feeds them to 16 MFMAs whose k index only has to agree between the two operands (the layouts of
+// k_gemm_dense_mfma above).  Per workgroup the four waves' tiles are added in wave order and stored to
+// part[e * pstride + blockIdx.x], e = 16 i + j; k_reduce_partials adds the workgroups in index order: the same bits from run to
+// run, another summation order than k_multidot's (parity with the oracle at 1e-10 like every other sum, tests/test_gpu_gram.py).
+// ------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(BS) void k_gram_mfma(int64_t n, const double* __restrict__ X, int64_t ldx, int nx,
+                                                         const double* __restrict__ Y, int64_t ldy, int ny,
+                                                         double* __restrict__ part, int pstride) {
+    __shared__ double sm[BS / 64][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const bool xok = c < nx, yok = c < ny;
+    const double* __restrict__ xc = X + (int64_t)(xok ? c : 0) * ldx;
+    const double* __restrict__ yc = Y + (int64_t)(yok ? c : 0) * ldy;
+    v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int64_t nchunk = n >> 6;
+    const int64_t nw = (int64_t)gridDim.x * (BS / 64);
+    const int64_t me = (int64_t)blockIdx.x * (BS / 64) + wave;
+    for (int64_t ch = me; ch < nchunk; ch += nw) {
+        const int64_t r0 = (ch << 6) + 2 * q;
+        double2 xv[8], yv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = ld_nt2(reinterpret_cast<const double2*>(xc + r0 + 8 * i));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) yv[i] = ld_nt2(reinterpret_cast<const double2*>(yc + r0 + 8 * i));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xok ? xv[i].x : 0.0, yok ? yv[i].x : 0.0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xok ? xv[i].y : 0.0, yok ? yv[i].y : 0.0, acc, 0, 0, 0);
+        }
+    }
+    if ((n & 63) != 0 && me == nchunk % nw) {      // the last, partial chunk: guarded scalar loads, one wave
+        const int64_t r0 = nchunk << 6;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t row = r0 + 8 * i + 2 * q + h;
+                const bool ok = row < n;
+                const double ax = (ok && xok) ? xc[row] : 0.0;
+                const double bx = (ok && yok) ? yc[row] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bx, acc, 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sm[wave][(q + 4 * r) * 16 + c] = acc[r];      // D: row = q + 4 reg, column = c
+    __syncthreads();
+    double s = sm[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < BS / 64; ++w) s += sm[w][threadIdx.x];
+    part[(int64_t)threadIdx.x * pstride + blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
 // Attainable-bandwidth probes for bench.py ("measure the attainable ceiling on the box with
 // a device triad/copy kernel"): plain 16-byte grid-stride streams, non-temporal loads, no reuse.
 // ------------------------------------------------------------------------------------------

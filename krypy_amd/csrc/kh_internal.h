@@ -12,7 +12,8 @@ namespace kh {
 
 constexpr int BS = 256;          // threads per workgroup of every vector kernel (4 wave64)
 constexpr int MAXC = 16;         // widest column panel one multidot / multiaxpy launch handles
-constexpr int NB_MAX = 4096;     // upper bound of the reduction grid
+constexpr int NB_MAX = 4096;
+constexpr int KH_GRAM_NB = 1024; // workgroups of k_gram_mfma (kernels.h)     // upper bound of the reduction grid
 constexpr int SCAL_CAP = 8192;   // device scalar slots (panel coefficients, norms)
 #define KH_NSLOT 4               // Arnoldi steps that may be in flight (H-column slots)
 #define KH_CHAIN_REARM_STEPS 100  // clean per-column steps after which a timed-out chain family is tried again
@@ -117,6 +118,10 @@ struct kh_ctx_s {
     int chain_long = 1;              // KRYPY_AMD_CHAIN_LONG: 48 rows per lane take k_mgs_chain_long (chain_long.h: a third of every column
                                      // stays on the chip between its dot and its update) instead of k_mgs_chain<48> (both reads from memory)
     int64_t n_chain_long = 0;
+    int gram_mfma = 1;               // KRYPY_AMD_GRAM_MFMA: kh_gemm_tn with 2 ... columns on the right takes k_gram_mfma (both blocks read
+                                     // once per 16 x 16 tile) instead of one k_multidot launch and one host round trip per column
+    int64_t n_gram_mfma = 0;         // 16 x 16 tiles computed by it
+    double* gram_part = nullptr;     // [256][KH_GRAM_NB] workgroup partials of k_gram_mfma (allocated at first use)
     int64_t n_zspmv_dia = 0;         // products of a banded complex operator through its diagonal-major copy (zpath.h: k_zspmv_dia)
     int chain_xr = 1;
     int chain_xr_cus = 0;            // tests: the compute units the shape is chosen for (0: all; two processes share one device)

@@ -1465,6 +1465,8 @@ int kh_ctx_create(int device, kh_ctx* out) {
         ctx->chain_blk2 = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_LONG");
         ctx->chain_long = (e == nullptr) ? 1 : atoi(e);
+        e = getenv("KRYPY_AMD_GRAM_MFMA");
+        ctx->gram_mfma = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_CHAIN_XR");
         ctx->chain_xr = (e == nullptr) ? 1 : atoi(e);
         e = getenv("KRYPY_AMD_BLK2_CW");
@@ -1531,6 +1533,7 @@ int kh_ctx_destroy(kh_ctx ctx) {
         if (ctx->done_pin[s]) (void)hipHostFree(ctx->done_pin[s]);
     }
     (void)hipFree(ctx->part);
+    if (ctx->gram_part) (void)hipFree(ctx->gram_part);
     (void)hipFree(ctx->scal);
     (void)hipHostFree(ctx->hpin);
     (void)hipEventDestroy(ctx->ev0);
@@ -1605,6 +1608,7 @@ int kh_ctx_set(kh_ctx ctx, const char* key, int64_t value) {
     else if (!strcmp(key, "chain_blk2_one")) { ctx->blk2_one = (int)value; ctx->blk2_refused_n = -1; }
     else if (!strcmp(key, "chain_xr")) ctx->chain_xr = value != 0;
     else if (!strcmp(key, "chain_long")) ctx->chain_long = value != 0;
+    else if (!strcmp(key, "gram_mfma")) ctx->gram_mfma = value != 0;
     else if (!strcmp(key, "chain_xr_cus")) ctx->chain_xr_cus = (int)value;      // tests: shapes for this many compute units (0: all)
     else if (!strcmp(key, "gemv_rows")) ctx->gemv_rows = (int)value;       // rows per wave of the dense GEMV (0: by size; 1 / 2 / 4)
     else if (!strcmp(key, "chain_blk2_cw")) {       // 1: a communication wave, 4 ... 7 rows; 2: the same up to 6 rows; 0: 512 lanes with rows
@@ -1687,6 +1691,8 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "chain_xr")) *value = ctx->chain_xr;
     else if (!strcmp(key, "chain_long")) *value = ctx->chain_long;
     else if (!strcmp(key, "n_chain_long")) *value = ctx->n_chain_long;
+    else if (!strcmp(key, "gram_mfma")) *value = ctx->gram_mfma;
+    else if (!strcmp(key, "n_gram_mfma")) *value = ctx->n_gram_mfma;
     else if (!strcmp(key, "n_zspmv_dia")) *value = ctx->n_zspmv_dia;
     else if (!strcmp(key, "n_chain_xr")) *value = ctx->n_chain_xr;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
@@ -2449,6 +2455,31 @@ int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y
     KH_TRY(check_vec(Y, y0, ny, "kh_gemm_tn(Y)"));
     KH_ARG(X->n == Y->n, "kh_gemm_tn: length mismatch");
     KH_ARG(nx <= 1024, "kh_gemm_tn: at most 1024 rows");
+    if (ctx->gram_mfma && ny >= 2 && nx >= 1 && (X->ld & 1) == 0 && (Y->ld & 1) == 0) {
+        // both blocks read once per 16 x 16 tile of the product (k_gram_mfma); on N ranks one all-reduce per tile - every rank
+        // decides alike (shapes and the switch only)
+        if (ctx->gram_part == nullptr) KH_HIP(hipMalloc(&ctx->gram_part, sizeof(double) * 256 * (size_t)KH_GRAM_NB));
+        const int G = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(KH_GRAM_NB, ctx->ncu * 4), (X->n + 255) / 256));
+        double* dev = ctx->scal + SC_COEF;
+        double tile[256];
+        for (int64_t j0 = 0; j0 < ny; j0 += 16) {
+            const int tj = (int)std::min<int64_t>(16, ny - j0);
+            for (int64_t i0 = 0; i0 < nx; i0 += 16) {
+                const int ti = (int)std::min<int64_t>(16, nx - i0);
+                hipLaunchKernelGGL(k_gram_mfma, dim3(G), dim3(BS), 0, ctx->stream, X->n, X->col(x0 + i0), X->ld, ti,
+                                   Y->col(y0 + j0), Y->ld, tj, ctx->gram_part, KH_GRAM_NB);
+                KH_HIP(hipGetLastError());
+                hipLaunchKernelGGL(k_reduce_partials, dim3(256), dim3(BS), 0, ctx->stream, ctx->gram_part, G, KH_GRAM_NB, dev, 0);
+                KH_HIP(hipGetLastError());
+                if (kh_multi(ctx)) KH_TRY(comm_allreduce_dev(ctx, dev, 256));
+                KH_TRY(fetch_scalars(ctx, dev, 256, tile));
+                for (int i = 0; i < ti; ++i)
+                    for (int j = 0; j < tj; ++j) out[(i0 + i) * ny + (j0 + j)] = tile[i * 16 + j];
+                ctx->n_gram_mfma += 1;
+            }
+        }
+        return 0;
+    }
     std::vector<double> colbuf((size_t)std::max<int64_t>(nx, 1));
     for (int64_t j = 0; j < ny; ++j) {
         KH_TRY(kh_dot_panel(ctx, X, x0, nx, Y, y0 + j, colbuf.data()));

@@ -1648,13 +1648,17 @@ def _qr_mgs_fused(Q, reorthos):
     return R
 
 
-def _qr_mgs_dev(Q, ip_B, reorthos):
-    """In-place modified Gram-Schmidt of the device block ``Q`` (utils.py:694-707)."""
+def _qr_mgs_dev(Q, ip_B, reorthos, source=None):
+    """In-place modified Gram-Schmidt of the device block ``Q`` (utils.py:694-707).  ``source``: a device block that still
+    holds the columns ``Q`` was copied from (utils.qr's input) - the fused path's way back when it meets a dependent column;
+    without one a copy of ``Q`` is kept for that."""
     ctx = Q.ctx
     k = Q.ncols
     if (ip_B is None or isinstance(ip_B, IdentityLinearOperator)) and k > 1 and hasattr(ctx, "arnoldi_step"):
-        keep = ctx.alloc(Q.n, k, dtype=Q.dtype)
-        keep.copy_from(0, Q, 0, k)
+        keep = source
+        if keep is None:
+            keep = ctx.alloc(Q.n, k, dtype=Q.dtype, zero=False)
+            keep.copy_from(0, Q, 0, k)
         R = _qr_mgs_fused(Q, reorthos)
         if R is not None:
             return R
@@ -1687,11 +1691,11 @@ def qr(X, ip_B=None, reorthos=1):
     if ip_B is None and not on_device and X.shape[1] > 0:
         return scipy.linalg.qr(X, mode="economic")
     if on_device:
-        Q = X.ctx.alloc(X.n, X.ncols, dtype=X.dtype)
+        Q = X.ctx.alloc(X.n, X.ncols, dtype=X.dtype, zero=False)      # (every column is written by the copy, padding included)
         Q.copy_from(0, X, 0, X.ncols)
     else:
         Q = _hip.get_context().upload(numpy.asarray(X))
-    R = _qr_mgs_dev(Q, ip_B, reorthos)
+    R = _qr_mgs_dev(Q, ip_B, reorthos, source=X if on_device else None)
     if on_device:
         return Q, R
     return numpy.ascontiguousarray(Q.download()), R

@@ -104,7 +104,7 @@ fallback)
   # recorded, and reported at teardown only after the test body - all numeric comparisons - has passed.  So in this log a
   # line "ERROR ... KERNEL-PATH EXPECTATION (all numeric comparisons of this test passed)" is a counter that is false by
   # construction under the switch; a line "FAILED ..." would be a numeric comparison that failed on the fallback path.
-  F="tests/test_gpu_parity.py tests/test_gpu_complex.py tests/test_gpu_blocked.py tests/test_gpu_halo_loopback.py tests/test_gpu_xr.py tests/test_gpu_blk2.py tests/test_gpu_chain_xr.py"
+  F="tests/test_gpu_parity.py tests/test_gpu_complex.py tests/test_gpu_blocked.py tests/test_gpu_halo_loopback.py tests/test_gpu_xr.py tests/test_gpu_blk2.py tests/test_gpu_chain_xr.py tests/test_gpu_gram.py"
   : > gpurun_out/ev/fallback.log
   run() { echo "## $1" >> gpurun_out/ev/fallback.log; env $1 python -m pytest $F -q -rfE -p no:cacheprovider 2>&1 | grep -E "^FAILED|^ERROR|passed|failed|error" | cut -c1-420 >> gpurun_out/ev/fallback.log; echo >> gpurun_out/ev/fallback.log; }
   if [ -n "${2:-}" ]; then          # tools/r05_evidence.sh fallback "<switch set>": that one set only
@@ -118,7 +118,7 @@ fallback)
   run "KRYPY_AMD_CG_STEP=0 KRYPY_AMD_SPMV_SPLIT=0 KRYPY_AMD_PROJ_PANEL=0 KRYPY_AMD_CGS_REVERSE=0 KRYPY_AMD_BLK_NX=0 KRYPY_AMD_XR=0 KRYPY_AMD_CHAIN_BLK2=0 KRYPY_AMD_XH=0 KRYPY_AMD_SPMV_WIN=0 KRYPY_AMD_BLK2_ONE=0"
   run "KRYPY_AMD_BLK2_CW=0"
   run "KRYPY_AMD_BLK2_CW=2"
-  run "KRYPY_AMD_CHAIN_XR=0 KRYPY_AMD_CHAIN_LONG=0"
+  run "KRYPY_AMD_CHAIN_XR=0 KRYPY_AMD_CHAIN_LONG=0 KRYPY_AMD_GRAM_MFMA=0"
   grep -c "^FAILED" gpurun_out/ev/fallback.log | sed 's/^/numeric FAILED lines in all switch sets: /' >> gpurun_out/ev/fallback.log
   cat gpurun_out/ev/fallback.log
   ;;
