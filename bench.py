@@ -902,8 +902,9 @@ def minres_jacobi_leg(ctx, A, b, iters, steps, warmup):
     f0, r0 = ctx.get("n_lanczos_fused"), ctx.get("n_minres_rides")
     ctx.timer_start()
     t0 = time.perf_counter()
-    n_it = 0
+    n_it, sol = 0, None
     for _ in range(steps):
+        sol = None          # (the previous solver's blocks go back to the pool BEFORE the next one allocates: no second set)
         sol = solve()
         n_it += len(sol.resnorms) - 1
     ctx.sync()
