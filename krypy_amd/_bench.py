@@ -246,7 +246,10 @@ def roofline(ctx, ls, ortho, peak_gbs, reps=60, traffic_files=None, m=100, solve
                 "avg_ms": ms, "moved_bytes": moved, "achieved_gbs": _gbs(moved, ms), "frac": _gbs(moved, ms) / peak_gbs,
                 "csr_equivalent_gbs_side_number": _gbs(csr_bytes, ms),
                 "note": "diagonal-major copy: 8 B per slot, no index stream; bytes = 8 nd N + 16 N (PMC: equal)"}
-        if hasattr(ctx, "set"):
+        # (a block-row shard whose halo travels inside the banded kernel's launch has no CSR form of the exchange to time:
+        # kh_apply refuses it - every rank alike, but the refusal used to cost the N > 1 line its whole roofline object)
+        sharded_in_launch = bool(getattr(ls.A, "halo_in_launch", False))
+        if hasattr(ctx, "set") and not sharded_in_launch:
             ctx.set("spmv_dia", 0)
             try:
                 ms = time_spmv()
