@@ -200,7 +200,9 @@ int kh_gemm_tn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t nx, kh_vec Y, int64_t y
 int kh_axpy_panel(kh_ctx ctx, kh_vec V, int64_t j0, int64_t ncols, const double* h, kh_vec W,
                   int64_t wcol);
 /* Y[:, y0:y0+nc] = beta*Y[:, ...] + alpha * X[:, x0:x0+k] @ C  with C (k x nc) row-major.
- * (V[:, :k].dot(yy) linsys.py:947;  V.dot(c) utils.py:549;  Ritz.get_vectors deflation.py:845) */
+ * (V[:, :k].dot(yy) linsys.py:947;  V.dot(c) utils.py:549;  Ritz.get_vectors deflation.py:845)
+ * nc = 1: one k_multiaxpy pass, additions left to right.  nc = 2 ... 16: the block is read ONCE for all output columns on the FP64
+ * matrix cores (k_panel_gemm_mfma, passes of 64 columns; kh_ctx_set "gram_mfma" 0: one pass over the block per output column). */
 int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int64_t nc,
                double alpha, double beta, kh_vec Y, int64_t y0);
 /* out = ||W[:, wcol]||_2   (numpy.linalg.norm(x, 2), utils.py:226) */

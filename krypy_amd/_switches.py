@@ -51,7 +51,9 @@ SWITCHES = [
      "0: an inner product with a block on both sides (`kh_gemm_tn` with two or more columns on the right: `<W, V>` of the deflation "
      "projector's set-up, `<U, AU>`, the Ritz set-up's `<V, AU>`) keeps one `k_multidot` launch and one host round trip per column of "
      "the right block - the left block read once PER column - instead of `k_gram_mfma` (`csrc/kernels.h`: both blocks read once per "
-     "16 x 16 tile, FP64 matrix cores).  Another summation order, the same bits from run to run; counter `n_gram_mfma`"),
+     "16 x 16 tile, FP64 matrix cores), and a block times a small matrix with 2 ... 16 output columns (`kh_gemm_nn`: the Ritz vectors "
+     "`[V_n, U] @ coeffs`) keeps one `k_multiaxpy` pass over the block per output column instead of `k_panel_gemm_mfma` (the block "
+     "read once).  Another summation order, the same bits from run to run; counters `n_gram_mfma`, `n_panel_gemm`"),
     ("KRYPY_AMD_CHAIN_XR", "1", "kernel-path", "0",
      "0: on N ranks with the xr transport on, slabs beyond the blocked kernel's 2.5 M rows keep the one-reduction form / the panel "
      "kernels (the local basis read twice, two sums across the ranks per step) instead of the register-resident chain kernels with the "

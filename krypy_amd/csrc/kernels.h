@@ -1095,6 +1095,87 @@ static __global__ __launch_bounds__(BS) void k_gram_mfma(int64_t n, const double
 }
 
 // ------------------------------------------------------------------------------------------
+// A tall block times a small matrix on the FP64 matrix cores: Y[:, 0:nc] = beta Y + X[:, 0:k] C, nc = 2 ... 16 - the Ritz
+// vectors [V_n, U] @ coeffs (deflation.py:840-847), utils.py:1618's V @ Ur.  The per-column form (k_multiaxpy, one pass over all
+// of X per OUTPUT column) read the basis nc times; here it is read once.  Another summation order than k_multiaxpy's left-to-right
+// fold (1e-13 against it, tests/test_gpu_gram.py); one output column (the x update of every solver) keeps k_multiaxpy and its bits.
+// Y[:, 0:nc] = beta * Y[:, 0:nc] + X[:, 0:k] C   (C: k x 16 in LDS order, rows beyond nc zero) on the FP64 matrix cores.
+// A wave takes tiles of 32 rows: lane (r, q) loads the row PAIR (2 r, 2 r + 1) of basis column i0 + q as one 16-byte load (the
+// sixteen lanes of a column read 256 contiguous bytes) - .x feeds the MFMA of the even rows, .y the one of the odd rows; the B
+// operand is C[i0 + q][c] from LDS.  D: column c = l & 15, row t = (l >> 4) + 4 reg of the even / odd half: stored as the pair
+// (even, odd) = rows 2 t, 2 t + 1 of output column c, 16 bytes per lane.
+template <int RT, int BETA>      // RT tiles of 32 rows per wave and pass; BETA 0: Y not read, 1: Y += , 2: runtime beta
+__global__ __launch_bounds__(BS) void k_panel_gemm_mfma(int64_t n, const double* __restrict__ X, int64_t ldx, int k,
+                                                         const double* __restrict__ Cdev, int nc, double beta,
+                                                         double* __restrict__ Y, int64_t ldy) {
+    extern __shared__ double csm[];              // [kpad][16]
+    const int kpad = (k + 3) & ~3;
+    for (int i = threadIdx.x; i < kpad * 16; i += BS) {
+        const int row = i >> 4, c = i & 15;
+        csm[i] = (row < k && c < nc) ? Cdev[row * nc + c] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int64_t ntile = (n + 31) >> 5;
+    const int64_t nw = (int64_t)gridDim.x * (BS / 64);
+    const int64_t n2 = (n + 1) >> 1;             // row pairs (the padding behind n is zero and stays zero: 0 * C)
+    for (int64_t t0 = ((int64_t)blockIdx.x * (BS / 64) + wave) * RT; t0 < ntile; t0 += nw * RT) {
+        v4f64 ae[RT], ao[RT];
+        const double2* __restrict__ xp[RT];
+        bool ok[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            ae[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            ao[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            const int64_t pair = ((t0 + t) << 4) + r;          // row pair of this lane
+            ok[t] = pair < n2;
+            xp[t] = reinterpret_cast<const double2*>(X + (int64_t)q * ldx) + (ok[t] ? pair : 0);
+        }
+        const int64_t cstep = 2 * ldx;                          // four columns on, in double2 units
+        for (int i0 = 0; i0 < kpad; i0 += 8) {
+            double2 xa[RT], xb[RT];
+            const bool two = i0 + 4 < kpad;
+            const bool va = i0 + q < k, vb = two && (i0 + 4 + q < k);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                xa[t] = (ok[t] && va) ? ld_nt2(xp[t]) : make_double2(0.0, 0.0);
+                xb[t] = (ok[t] && vb) ? ld_nt2(xp[t] + cstep) : make_double2(0.0, 0.0);
+                xp[t] += 2 * cstep;
+            }
+            const double ba = csm[(i0 + q) * 16 + r];
+            const double bb = two ? csm[(i0 + 4 + q) * 16 + r] : 0.0;
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                ae[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].x, ba, ae[t], 0, 0, 0);
+                ao[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[t].y, ba, ao[t], 0, 0, 0);
+                ae[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[t].x, bb, ae[t], 0, 0, 0);
+                ao[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(xb[t].y, bb, ao[t], 0, 0, 0);
+            }
+        }
+        if (r < nc) {
+            double2* __restrict__ yc = reinterpret_cast<double2*>(Y + (int64_t)r * ldy);
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int64_t pair = ((t0 + t) << 4) + q + 4 * g;
+                    if (pair < n2) {
+                        double2 v = make_double2(ae[t][g], ao[t][g]);
+                        if (BETA != 0) {
+                            const double2 y = yc[pair];
+                            const double b = BETA == 1 ? 1.0 : beta;
+                            v.x += b * y.x;
+                            v.y += b * y.y;
+                        }
+                        yc[pair] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Attainable-bandwidth probes for bench.py ("measure the attainable ceiling on the box with
 // a device triad/copy kernel"): plain 16-byte grid-stride streams, non-temporal loads, no reuse.
 // ------------------------------------------------------------------------------------------

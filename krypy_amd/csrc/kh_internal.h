@@ -121,6 +121,7 @@ struct kh_ctx_s {
     int gram_mfma = 1;               // KRYPY_AMD_GRAM_MFMA: kh_gemm_tn with 2 ... columns on the right takes k_gram_mfma (both blocks read
                                      // once per 16 x 16 tile) instead of one k_multidot launch and one host round trip per column
     int64_t n_gram_mfma = 0;         // 16 x 16 tiles computed by it
+    int64_t n_panel_gemm = 0;        // passes of k_panel_gemm_mfma (kh_gemm_nn with 2 ... 16 output columns; the same switch)
     double* gram_part = nullptr;     // [256][KH_GRAM_NB] workgroup partials of k_gram_mfma (allocated at first use)
     int64_t n_zspmv_dia = 0;         // products of a banded complex operator through its diagonal-major copy (zpath.h: k_zspmv_dia)
     int chain_xr = 1;

@@ -1693,6 +1693,7 @@ int kh_ctx_get(kh_ctx ctx, const char* key, int64_t* value) {
     else if (!strcmp(key, "n_chain_long")) *value = ctx->n_chain_long;
     else if (!strcmp(key, "gram_mfma")) *value = ctx->gram_mfma;
     else if (!strcmp(key, "n_gram_mfma")) *value = ctx->n_gram_mfma;
+    else if (!strcmp(key, "n_panel_gemm")) *value = ctx->n_panel_gemm;
     else if (!strcmp(key, "n_zspmv_dia")) *value = ctx->n_zspmv_dia;
     else if (!strcmp(key, "n_chain_xr")) *value = ctx->n_chain_xr;
     else if (!strcmp(key, "n_blk_rebuild")) *value = ctx->n_blk_rebuild;
@@ -2511,6 +2512,34 @@ int kh_gemm_nn(kh_ctx ctx, kh_vec X, int64_t x0, int64_t k, const double* C, int
     KH_ARG(X->n == Y->n, "kh_gemm_nn: length mismatch");
     KH_ARG(X != Y, "kh_gemm_nn: X and Y must be different blocks");
     chain_blk_touch(ctx, Y);
+    if (ctx->gram_mfma && nc >= 2 && nc <= 16 && k >= 1 && (X->ld & 1) == 0 && (Y->ld & 1) == 0) {
+        // the block read once for all nc output columns (k_panel_gemm_mfma), in passes of 64 columns of X (the coefficients
+        // of a pass: 64 x nc <= 1024 staged doubles, 8 KB of LDS)
+        constexpr int64_t KP = 64;
+        double* devc = ctx->scal + SC_COEF;
+        std::vector<double> cpass((size_t)(KP * nc));
+        const int G = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->ncu * 4, (X->n + 255) / 256));
+        for (int64_t i0 = 0; i0 < k; i0 += KP) {
+            const int kk = (int)std::min(KP, k - i0);
+            for (int i = 0; i < kk; ++i)
+                for (int64_t c = 0; c < nc; ++c) cpass[(size_t)(i * nc + c)] = alpha * C[(i0 + i) * nc + c];
+            KH_TRY(push_scalars(ctx, cpass.data(), (int64_t)kk * nc, devc));
+            const size_t lds = sizeof(double) * 16 * (size_t)((kk + 3) & ~3);
+            const double b = i0 == 0 ? beta : 1.0;
+            if (b == 0.0)
+                hipLaunchKernelGGL((k_panel_gemm_mfma<2, 0>), dim3(G), dim3(BS), lds, ctx->stream, X->n, X->col(x0 + i0), X->ld, kk,
+                                   devc, (int)nc, 0.0, Y->col(y0), Y->ld);
+            else if (b == 1.0)
+                hipLaunchKernelGGL((k_panel_gemm_mfma<2, 1>), dim3(G), dim3(BS), lds, ctx->stream, X->n, X->col(x0 + i0), X->ld, kk,
+                                   devc, (int)nc, 1.0, Y->col(y0), Y->ld);
+            else
+                hipLaunchKernelGGL((k_panel_gemm_mfma<2, 2>), dim3(G), dim3(BS), lds, ctx->stream, X->n, X->col(x0 + i0), X->ld, kk,
+                                   devc, (int)nc, b, Y->col(y0), Y->ld);
+            KH_HIP(hipGetLastError());
+            ctx->n_panel_gemm += 1;
+        }
+        return 0;
+    }
     constexpr int64_t KMAX = 1024;      // coefficients staged per pass (SC_COEF region of the device scalars)
     std::vector<double> coef((size_t)std::max<int64_t>(std::min(k, KMAX), 1));
     double* dev = ctx->scal + SC_COEF;

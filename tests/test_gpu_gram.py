@@ -5,7 +5,9 @@ Projection.__init__ (utils.py:478-520), <U, AU> and <V, AU> of the deflated solv
 * against NumPy at every tile shape (full, partial, one column on the left, several tiles on both sides), row counts around
   the 64-row chunk (0 ... 63 rows of tail, fewer rows than one chunk), sub-blocks at column offsets, a block with itself;
 * against the per-column kernels (the switch off) at 1e-13, and the same bits from run to run;
-* a deflated solve through it against the CPU oracle."""
+* a deflated solve through it against the CPU oracle;
+* the other block product of the set-up, a block times a small matrix (kh_gemm_nn with 2 ... 16 output columns: k_panel_gemm_mfma),
+  against NumPy and against the per-column kernel."""
 import numpy as np
 import pytest
 
@@ -85,3 +87,55 @@ def test_deflated_solve_through_it_against_the_oracle(hip):
     got, want = np.array(d.resnorms), np.array(o.resnorms)
     assert len(got) == len(want) and np.max(np.abs(got - want) / want) < 1e-9
     expect_kernel(used >= 1, "the set-up's block inner products took k_gram_mfma: %d tiles" % used)
+
+
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 1000, 4096 + 63, 100_003, 3_000_001])
+@pytest.mark.parametrize("k,nc", [(116, 16), (5, 2), (1, 3), (64, 16), (65, 7), (130, 16)])
+def test_block_times_a_small_matrix_against_numpy(hip, n, k, nc):
+    """kh_gemm_nn with 2 ... 16 output columns (k_panel_gemm_mfma: the Ritz vectors [V_n, U] @ coeffs,
+    /root/reference/krypy/deflation.py:840-847): Y = beta Y + alpha X C against NumPy for beta = 0, 1 and 0.5, one to three
+    passes of 64 columns, tails of 0 ... 31 rows, and against the per-column kernel (the switch off) at 1e-13."""
+    if n >= 1_000_000 and k > 70:
+        pytest.skip("the large case runs the one-pass shapes")
+    rng = np.random.default_rng(n + k)
+    X = rng.standard_normal((n, k + 2))
+    C = rng.standard_normal((k, nc))
+    Y0 = rng.standard_normal((n, nc + 1))
+    Xd = hip.upload(X)
+    scale = np.abs(X[:, 1:k + 1]).dot(np.abs(C)) + np.abs(Y0[:, 1:]) + 1e-300
+    for alpha, beta in ((1.0, 0.0), (-0.75, 1.0), (2.0, 0.5)):
+        Yd = hip.upload(Y0)
+        p0 = hip.get("n_panel_gemm")
+        hip.gemm_nn(Xd, 1, k, C, alpha, beta, Yd, 1)
+        passes = hip.get("n_panel_gemm") - p0
+        got = Yd.download()
+        want = beta * Y0[:, 1:] + alpha * X[:, 1:k + 1].dot(C)
+        assert np.array_equal(got[:, 0], Y0[:, 0]), "the column in front of the output is untouched"
+        assert np.max(np.abs(got[:, 1:] - want) / scale) < 1e-14 * max(4.0, np.sqrt(k))
+        was = hip.get("gram_mfma")
+        hip.set("gram_mfma", 0)
+        try:
+            Yc = hip.upload(Y0)
+            hip.gemm_nn(Xd, 1, k, C, alpha, beta, Yc, 1)
+        finally:
+            hip.set("gram_mfma", was)
+        assert np.max(np.abs(got[:, 1:] - Yc.download()[:, 1:]) / scale) < 1e-13
+        expect_kernel(passes == (k + 63) // 64, "passes of k_panel_gemm_mfma: %d" % passes)
+
+
+def test_one_output_column_keeps_the_per_column_kernel(hip):
+    """The x update of every solver (V[:, :k] @ y, linsys.py:941-949) has one output column: k_multiaxpy and its bits."""
+    n, k = 50_001, 40
+    rng = np.random.default_rng(9)
+    X, c = rng.standard_normal((n, k)), rng.standard_normal(k)
+    Xd, Yd, Zd = hip.upload(X), hip.alloc(n, 1), hip.alloc(n, 1)
+    p0 = hip.get("n_panel_gemm")
+    hip.gemm_nn(Xd, 0, k, c, 1.0, 0.0, Yd, 0)
+    assert hip.get("n_panel_gemm") == p0
+    was = hip.get("gram_mfma")
+    hip.set("gram_mfma", 0)
+    try:
+        hip.gemm_nn(Xd, 0, k, c, 1.0, 0.0, Zd, 0)
+    finally:
+        hip.set("gram_mfma", was)
+    assert np.array_equal(Yd.download(), Zd.download())
