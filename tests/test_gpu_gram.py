@@ -139,3 +139,32 @@ def test_one_output_column_keeps_the_per_column_kernel(hip):
     finally:
         hip.set("gram_mfma", was)
     assert np.array_equal(Yd.download(), Zd.download())
+
+
+def test_qr_of_a_device_block_with_a_dependent_column_goes_back_to_its_input(hip):
+    """utils.qr (/root/reference/krypy/utils.py:680-707) on a DEVICE block keeps no spare copy: when the fused factorisation meets a
+    dependent column (R[i, i] < 1e-15) it starts again from the input block, which is still there - the result is the host
+    path's (the reference's guard: the column is left unnormalised), and the input is untouched."""
+    from krypy_amd import utils
+
+    n = 5000
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((n, 5))
+    X[:, 3] = X[:, 1]                    # column 3 is column 1: R[3, 3] = 0
+    ipI = utils.IdentityLinearOperator((n, n))
+    Xd = hip.upload(X)
+    Qd, Rd = utils.qr(Xd, ip_B=ipI, reorthos=1)
+    Qh, Rh = utils.qr(X, ip_B=ipI, reorthos=1)
+    assert np.array_equal(Xd.download(), X), "the input block is not written"
+    assert abs(Rd[3, 3]) < 1e-12 and abs(Rh[3, 3]) < 1e-12
+    assert np.max(np.abs(Rd - Rh)) < 1e-12 * np.max(np.abs(Rh))
+    Q = Qd.download()
+    assert np.max(np.abs(Q - Qh)) < 1e-10
+    keep = [0, 1, 2, 4]
+    assert np.linalg.norm(Q[:, keep].T.dot(Q[:, keep]) - np.eye(4)) < 1e-12
+    # and an independent block through the fused path: Q R = X, orthonormal columns
+    X2 = rng.standard_normal((n, 6))
+    Q2, R2 = utils.qr(hip.upload(X2), ip_B=ipI, reorthos=1)
+    Q2 = Q2.download()
+    assert np.linalg.norm(Q2.dot(R2) - X2) < 1e-12 * np.linalg.norm(X2)
+    assert np.linalg.norm(Q2.T.dot(Q2) - np.eye(6)) < 1e-13
