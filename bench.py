@@ -1185,8 +1185,12 @@ def _run_config5(args):
     # solve 1 (untimed): harvest the Ritz vectors on the device.  (A solver and the operators it builds refer to each other:
     # its 80 GB basis is garbage only to the cycle collector - collect before the next one is allocated.)
     s0 = solve(None)
+    ctx.sync()
+    t_ritz = time.perf_counter()
     ritz = deflation.Ritz(s0)
     U = ritz._get_vectors_dev(np.argsort(np.abs(ritz.values))[:d])
+    ctx.sync()
+    t_ritz = time.perf_counter() - t_ritz
     plain_relres = float(s0.resnorms[-1])
     ritz_values = np.sort(np.abs(ritz.values))[:d]
     del s0, ritz
@@ -1358,6 +1362,8 @@ def _run_config5(args):
                    "ortho_auto": auto_report, "timed_region_fallback": region_fallback, "sharded_diagnostics": shard_diag,
                    "plain_relres": plain_relres, "deflated_relres": deflated_relres,
                    "smallest_ritz_values": [float(v) for v in ritz_values[:4]],
+                   "ritz_harvest_ms": t_ritz * 1e3,      # deflation.Ritz + the vectors [V_n, U] @ coeffs (deflation.py:738-847), untimed
+
                    "operator_diagonals": nd, "setup_s": t_setup,
                    "cycle_ms": cycle_ms, "median_cycle_ms": float(np.median(cycle_ms)),
                    "host_gc_ms_per_solve": [round(g, 2) for g in gc_ms]},
